@@ -1,0 +1,94 @@
+"""ctypes loader of libarks_hip.so (the C ABI declared in include/arks_hip.h).
+
+Fails loudly: a missing library is an ImportError-like RuntimeError, never a silent fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "lib", "libarks_hip.so")
+
+
+class ArksError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        L = lib()
+        msg = L.arks_strerror(status).decode()
+        extra = L.arks_last_error_string().decode()
+        super().__init__(f"{what}: {msg}" + (f" ({extra})" if extra else ""))
+
+
+class BuildStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("total_kmers", "null_kmers", "recorded", "collisions", "removed_dup", "unique",
+                 "short_ends")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class MapStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("total_valid", "bad", "found", "recorded", "dups", "reads_pass", "reads_fail",
+                 "windows")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+MAP_STATS_FIELDS = [n for n, _ in MapStats._fields_]
+
+# name -> (restype, argtypes): every symbol include/arks_hip.h declares
+_VP, _I, _I64, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
+SYMBOLS = {
+    "arks_abi_version": (_I, []),
+    "arks_strerror": (C.c_char_p, [_I]),
+    "arks_last_error_string": (C.c_char_p, []),
+    "arks_device_count": (_I, []),
+    "arks_key_bytes": (_I, [_I]),
+    "arks_index_build": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, C.POINTER(BuildStats)]),
+    "arks_index_free": (_I, [_VP]),
+    "arks_index_k": (_I, [_VP]),
+    "arks_index_size": (_I64, [_VP]),
+    "arks_index_device_bytes": (_I64, [_VP]),
+    "arks_index_export": (_I, [_VP, _VP, _VP]),
+    "arks_end_cutoff": (_I, [_I, _I, _I, C.POINTER(_I)]),
+    "arks_word_offsets": (_I, [_VP, _I64, _VP]),
+    "arks_pack_reads_device": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _I, _VP]),
+    "arks_pack_reads_host": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
+    "arks_map_reads_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
+    "arks_map_reads": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _VP, C.POINTER(MapStats)]),
+    "arks_imap_create": (_I, [C.POINTER(_VP), _I64, _I]),
+    "arks_imap_free": (_I, [_VP]),
+    "arks_imap_size": (_I64, [_VP]),
+    "arks_imap_export": (_I, [_VP, _VP]),
+    "arks_pair_gate_device": (_I, [_VP, _VP, _I64, _VP, _I, _VP]),
+    "arks_pairs_device": (_I, [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _I, _VP]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _PATH
+
+
+def lib():
+    """the loaded library; raises RuntimeError when it has not been built"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise RuntimeError(
+                f"{_PATH} is missing: build it with `python -m arcs_amd.build` "
+                "(hipcc --offload-arch=gfx950); arcs_amd has no CPU fallback")
+        L = C.CDLL(_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError when the ABI and the header disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise ArksError(status, what)

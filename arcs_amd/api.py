@@ -1,0 +1,277 @@
+"""Host-side helpers over the C ABI (include/arks_hip.h) for tests, bench.py and the multi-GPU
+driver.  torch is used only as the owner of device memory and streams; every computation happens
+in libarks_hip.so.  Names follow the reference (contig ends, conreci, reads, pairs, barcodes)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BuildStats, MapStats, check, lib
+
+
+def device_count():
+    """number of visible gfx950 devices (0 on a machine without an MI355X)"""
+    return lib().arks_device_count()
+
+
+def key_bytes(k):
+    return lib().arks_key_bytes(k)
+
+
+def end_cutoff(length, min_size=500, end_length=30000):
+    """getContigKmers' head/tail split (Arcs/Arcs.cpp:1056,1072-1074); None = contig skipped"""
+    c = C.c_int(0)
+    return c.value if lib().arks_end_cutoff(length, min_size, end_length, C.byref(c)) else None
+
+
+def contig_ends(contigs, min_size=500, end_length=30000):
+    """end strings in conreci order: end i <-> conreci i + 1 (Arcs/Arcs.cpp:1057-1091)"""
+    ends = []
+    for s in contigs:
+        c = end_cutoff(len(s), min_size, end_length)
+        if c is None:
+            continue
+        ends.append(s[:c])
+        ends.append(s[len(s) - c:])
+    return ends
+
+
+def _concat(seqs):
+    """list of str/bytes -> (uint8 array, uint64 offsets, uint32 lens)"""
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    lens = np.fromiter((len(b) for b in bs), dtype=np.uint32, count=len(bs))
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    data = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(data), offsets, lens
+
+
+def word_offsets(lens):
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    out = np.zeros(len(lens) + 1, dtype=np.uint64)
+    check(lib().arks_word_offsets(lens.ctypes.data, len(lens), out.ctypes.data), "arks_word_offsets")
+    return out
+
+
+def pack_reads_host(seqs):
+    """arks_pack_reads_host over a list of sequences -> dict of numpy arrays"""
+    data, offsets, lens = _concat(seqs)
+    woff = word_offsets(lens)
+    total = int(woff[-1])
+    codes = np.zeros(total + 4, dtype=np.uint64)
+    nmask = np.zeros(total + 4, dtype=np.uint32)
+    cls = np.zeros(max(len(lens), 1), dtype=np.uint8)
+    if len(lens):
+        pad = np.concatenate([data, np.zeros(1, np.uint8)])
+        check(lib().arks_pack_reads_host(pad.ctypes.data, offsets.ctypes.data, lens.ctypes.data,
+                                         woff.ctypes.data, len(lens), codes.ctypes.data,
+                                         nmask.ctypes.data, cls.ctypes.data),
+              "arks_pack_reads_host")
+    return {"codes": codes, "nmask": nmask, "word_off": woff, "lens": lens,
+            "read_class": cls[:len(lens)]}
+
+
+class ArksIndex:
+    """Device-resident contig-end k-mer index: ContigKMap (Arcs/Arcs.h:158) built the way
+    getContigKmers/mapKmers do (Arcs/Arcs.cpp:869-929, 1021-1129)."""
+
+    def __init__(self, handle, k, device, stats):
+        self._h = handle
+        self.k = k
+        self.device = device
+        self.build_stats = stats
+
+    @classmethod
+    def build(cls, ends, k, device=0, want_stats=True):
+        data, offsets, lens = _concat(ends)
+        data = np.concatenate([data, np.zeros(1, np.uint8)])
+        h = C.c_void_p()
+        st = BuildStats()
+        rc = lib().arks_index_build(C.byref(h), k, data.ctypes.data, offsets.ctypes.data,
+                                    lens.ctypes.data, len(lens), device,
+                                    C.byref(st) if want_stats else None)
+        check(rc, "arks_index_build")
+        return cls(h, k, device, st.as_dict() if want_stats else None)
+
+    def close(self):
+        if self._h:
+            lib().arks_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return lib().arks_index_size(self._h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def device_bytes(self):
+        return lib().arks_index_device_bytes(self._h)
+
+    def export(self):
+        """(keys uint8[n, key_bytes] in the reference's byte order, vals int32[n])"""
+        n = len(self)
+        kb = key_bytes(self.k)
+        keys = np.zeros((max(n, 1), kb), dtype=np.uint8)
+        vals = np.zeros(max(n, 1), dtype=np.int32)
+        check(lib().arks_index_export(self._h, keys.ctypes.data, vals.ctypes.data),
+              "arks_index_export")
+        return keys[:n], vals[:n]
+
+    def map_reads(self, reads, j_index, want_stats=False):
+        """bestContig (Arcs/Arcs.cpp:939-1014) of every read; host in, host out"""
+        data, offsets, lens = _concat(reads)
+        data = np.concatenate([data, np.zeros(1, np.uint8)])
+        out = np.zeros(max(len(lens), 1), dtype=np.int32)
+        st = MapStats()
+        check(lib().arks_map_reads(self._h, data.ctypes.data, offsets.ctypes.data, lens.ctypes.data,
+                                   len(lens), float(j_index), out.ctypes.data,
+                                   C.byref(st) if want_stats else None), "arks_map_reads")
+        out = out[:len(lens)]
+        return (out, st.as_dict()) if want_stats else out
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr(device):
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class PackedReads:
+    """A batch of reads resident in HBM in the packed layout of include/arks_hip.h."""
+
+    def __init__(self, codes, nmask, word_off, lens, read_class, device):
+        self.codes, self.nmask, self.word_off, self.lens = codes, nmask, word_off, lens
+        self.read_class = read_class
+        self.device = device
+
+    @property
+    def n_reads(self):
+        return int(self.lens.numel())
+
+    def windows(self, k):
+        """sum over reads of max(0, len - k + 1): the unit of the throughput metric"""
+        torch = _torch()
+        return int(torch.clamp(self.lens.to(torch.int64) - (k - 1), min=0).sum().item())
+
+    @classmethod
+    def from_ascii(cls, seqs, device=0):
+        """upload ASCII reads and pack them on the device (arks_pack_reads_device)"""
+        data, offsets, lens = _concat(seqs)
+        return cls.from_arrays(data, offsets, lens, device)
+
+    @classmethod
+    def from_arrays(cls, data, offsets, lens, device=0):
+        torch = _torch()
+        dev = torch.device("cuda", device)
+        woff = word_offsets(lens)
+        total = int(woff[-1])
+        n = len(lens)
+        d_ascii = torch.from_numpy(np.concatenate([data, np.zeros(64, np.uint8)])).to(dev)
+        d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+        d_lens = torch.from_numpy(lens.view(np.int32)).to(dev)
+        d_woff = torch.from_numpy(woff.view(np.int64)).to(dev)
+        codes = torch.zeros(total + 4, dtype=torch.int64, device=dev)
+        nmask = torch.zeros(total + 4, dtype=torch.int32, device=dev)
+        rclass = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+        check(lib().arks_pack_reads_device(d_ascii.data_ptr(), d_off.data_ptr(), d_lens.data_ptr(),
+                                           d_woff.data_ptr(), n, codes.data_ptr(),
+                                           nmask.data_ptr(), rclass.data_ptr(), device,
+                                           _stream_ptr(device)), "arks_pack_reads_device")
+        torch.cuda.synchronize(device)
+        return cls(codes, nmask, d_woff, d_lens, rclass[:n], device)
+
+    @classmethod
+    def from_host_packed(cls, packed, device=0):
+        """upload the output of pack_reads_host"""
+        torch = _torch()
+        dev = torch.device("cuda", device)
+        return cls(torch.from_numpy(packed["codes"].view(np.int64)).to(dev),
+                   torch.from_numpy(packed["nmask"].view(np.int32)).to(dev),
+                   torch.from_numpy(packed["word_off"].view(np.int64)).to(dev),
+                   torch.from_numpy(packed["lens"].view(np.int32)).to(dev),
+                   torch.from_numpy(packed["read_class"]).to(dev), device)
+
+
+def map_reads_packed(index, reads, j_index, eval_mask=None, stats=None, out=None):
+    """arks_map_reads_device on the current torch stream.  stats: optional int64[8] device tensor
+    that the counters of arks_map_stats are added to.  Returns the int32 conreci tensor."""
+    torch = _torch()
+    n = reads.n_reads
+    if out is None:
+        out = torch.empty(max(n, 1), dtype=torch.int32, device=reads.codes.device)
+    check(lib().arks_map_reads_device(
+        index.handle, reads.codes.data_ptr(), reads.nmask.data_ptr(), reads.word_off.data_ptr(),
+        reads.lens.data_ptr(), eval_mask.data_ptr() if eval_mask is not None else None, n,
+        float(j_index), out.data_ptr(), stats.data_ptr() if stats is not None else None,
+        _stream_ptr(reads.device)), "arks_map_reads_device")
+    return out[:n]
+
+
+class ImapAccumulator:
+    """Device accumulator of IndexMap (Arcs/Arcs.h:108-113) as (barcode id, conreci) -> count."""
+
+    def __init__(self, capacity_entries, device=0):
+        h = C.c_void_p()
+        check(lib().arks_imap_create(C.byref(h), capacity_entries, device), "arks_imap_create")
+        self._h = h
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            lib().arks_imap_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def triples(self):
+        """uint32[n, 3] (barcode id, conreci, count) sorted by (barcode id, conreci)"""
+        n = lib().arks_imap_size(self._h)
+        if n < 0:
+            raise _lib.ArksError(int(-n), "arks_imap_size")
+        out = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        check(lib().arks_imap_export(self._h, out.ctypes.data), "arks_imap_export")
+        return out[:n]
+
+
+def map_pairs_packed(index, reads, j_index, pair_ok=None, barcode_id=None, imap=None,
+                     stats=None, stored=None):
+    """The per-pair flow of chromiumRead (Arcs/Arcs.cpp:1264-1292) for a resident batch whose
+    reads 2p, 2p+1 are mates: gate -> bestContig of both mates -> pair rule -> imap update.
+    Returns (conreci int32[n_reads], pair int32[n_pairs])."""
+    torch = _torch()
+    dev = reads.codes.device
+    n_pairs = reads.n_reads // 2
+    sp = _stream_ptr(reads.device)
+    ev = torch.empty(max(2 * n_pairs, 1), dtype=torch.uint8, device=dev)
+    check(lib().arks_pair_gate_device(pair_ok.data_ptr() if pair_ok is not None else None,
+                                      reads.read_class.data_ptr(), n_pairs, ev.data_ptr(),
+                                      reads.device, sp), "arks_pair_gate_device")
+    conreci = map_reads_packed(index, reads, j_index, eval_mask=ev, stats=stats)
+    pair = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=dev)
+    check(lib().arks_pairs_device(conreci.data_ptr(),
+                                  pair_ok.data_ptr() if pair_ok is not None else None,
+                                  barcode_id.data_ptr() if barcode_id is not None else None,
+                                  n_pairs, pair.data_ptr(), imap.handle if imap is not None else None,
+                                  stored.data_ptr() if stored is not None else None,
+                                  reads.device, sp), "arks_pairs_device")
+    return conreci, pair[:n_pairs]

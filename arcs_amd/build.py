@@ -1,0 +1,36 @@
+"""Builds arcs_amd/lib/libarks_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SOURCES = [os.path.join(HERE, "csrc", f) for f in ("arks_kernels.hip", "arks_capi.hip")]
+HEADERS = [os.path.join(HERE, "csrc", f) for f in ("arks_device.hpp", "arks_kernels.hpp")] + \
+          [os.path.join(ROOT, "include", "arks_hip.h")]
+OUT = os.path.join(HERE, "lib", "libarks_hip.so")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+           *SOURCES, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

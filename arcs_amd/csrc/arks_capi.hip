@@ -1,0 +1,816 @@
+// arks_capi.hip -- the C ABI of libarks_hip.so (include/arks_hip.h) over the kernels of
+// arks_kernels.hip.  No CPU fallback exists: without a gfx950 device every compute entry point
+// returns ARKS_ERR_NO_DEVICE.
+#include "arks_hip.h"
+#include "arks_kernels.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace arks;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int
+fail_hip(hipError_t e, const char* what)
+{
+	g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+	(void)hipGetLastError(); // clear the sticky launch error, if any
+	return e == hipErrorOutOfMemory ? ARKS_ERR_OOM : ARKS_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                                                              \
+	do {                                                                                           \
+		hipError_t e_ = (expr);                                                                    \
+		if (e_ != hipSuccess) {                                                                    \
+			rc = fail_hip(e_, #expr);                                                              \
+			goto done;                                                                             \
+		}                                                                                          \
+	} while (0)
+
+bool
+device_is_gfx950(int dev)
+{
+	hipDeviceProp_t p;
+	if (hipGetDeviceProperties(&p, dev) != hipSuccess)
+		return false;
+	return std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+int
+check_k(int k)
+{
+	if (k <= 3 || k == 6 || k == 10)
+		return ARKS_ERR_BAD_K;
+	if (k > ARKS_MAX_K)
+		return ARKS_ERR_K_UNSUPPORTED;
+	return ARKS_OK;
+}
+
+// RAII device buffer for temporaries
+struct DevBuf
+{
+	void* p = nullptr;
+	~DevBuf()
+	{
+		if (p)
+			(void)hipFree(p);
+	}
+	hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+	template <typename T>
+	T* as() const
+	{
+		return static_cast<T*>(p);
+	}
+};
+
+struct DeviceGuard
+{
+	int prev = -1;
+	explicit DeviceGuard(int dev)
+	{
+		(void)hipGetDevice(&prev);
+		if (prev != dev)
+			(void)hipSetDevice(dev);
+		else
+			prev = -1;
+	}
+	~DeviceGuard()
+	{
+		if (prev >= 0)
+			(void)hipSetDevice(prev);
+	}
+};
+
+} // namespace
+
+struct arks_index
+{
+	int k = 0;
+	int kw = 0;
+	int device = 0;
+	int n_cu = 256;
+	KeyGeom geom;
+	TableView table{ nullptr, 0 };
+	int64_t n_keys = 0;
+	// redo queue of the map kernel (indices of reads that need the slow path)
+	mutable u32* queue = nullptr;
+	mutable u32* queue_count = nullptr;
+	mutable int64_t queue_cap = 0;
+};
+
+struct arks_imap
+{
+	int device = 0;
+	u64* keys = nullptr;
+	u32* counts = nullptr;
+	u32* overflow = nullptr;
+	u64 cap = 0;
+};
+
+extern "C" {
+
+int
+arks_abi_version(void)
+{
+	return ARKS_ABI_VERSION;
+}
+
+const char*
+arks_strerror(int status)
+{
+	switch (status) {
+	case ARKS_OK: return "ok";
+	case ARKS_ERR_BAD_K: return "k-mer size must be > 3 (and not 6 or 10)";
+	case ARKS_ERR_K_UNSUPPORTED: return "k-mer size above ARKS_MAX_K";
+	case ARKS_ERR_OOM: return "out of memory";
+	case ARKS_ERR_HIP: return "HIP runtime error";
+	case ARKS_ERR_NO_DEVICE: return "no gfx950 (MI355X) device available";
+	case ARKS_ERR_BAD_ARG: return "bad argument";
+	case ARKS_ERR_FULL: return "accumulator table full";
+	default: return "unknown status";
+	}
+}
+
+const char*
+arks_last_error_string(void)
+{
+	return g_last_error.c_str();
+}
+
+int
+arks_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		(void)hipGetLastError();
+		return 0;
+	}
+	int ok = 0;
+	for (int d = 0; d < n; ++d)
+		ok += device_is_gfx950(d);
+	return ok;
+}
+
+int
+arks_key_bytes(int k)
+{
+	return k / 4 + ((k % 4) ? 1 : 0);
+}
+
+int
+arks_end_cutoff(int len, int min_size, int end_length, int* cutoff)
+{
+	if (len < min_size)
+		return 0;
+	int c = end_length;
+	if (c == 0 || len <= c * 2)
+		c = len / 2;
+	if (cutoff)
+		*cutoff = c;
+	return 1;
+}
+
+int
+arks_word_offsets(const uint32_t* h_lens, int64_t n, uint64_t* h_word_off)
+{
+	if (n < 0 || (n > 0 && (!h_lens || !h_word_off)) || !h_word_off)
+		return ARKS_ERR_BAD_ARG;
+	uint64_t acc = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		h_word_off[i] = acc;
+		acc += ((uint64_t)h_lens[i] + 31) / 32;
+	}
+	h_word_off[n] = acc;
+	return ARKS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* packing                                                                                        */
+/* ---------------------------------------------------------------------------------------------- */
+
+static int
+require_device(int device)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+		(void)hipGetLastError();
+		g_last_error = "no HIP device visible";
+		return ARKS_ERR_NO_DEVICE;
+	}
+	if (device < 0 || device >= n)
+		return ARKS_ERR_BAD_ARG;
+	if (!device_is_gfx950(device)) {
+		g_last_error = "device is not gfx950";
+		return ARKS_ERR_NO_DEVICE;
+	}
+	return ARKS_OK;
+}
+
+int
+arks_pack_reads_device(
+    const uint8_t* d_ascii,
+    const uint64_t* d_offsets,
+    const uint32_t* d_lens,
+    const uint64_t* d_word_off,
+    int64_t n_reads,
+    uint64_t* d_codes,
+    uint32_t* d_nmask,
+    uint8_t* d_read_class,
+    int device,
+    void* stream)
+{
+	if (n_reads < 0)
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads == 0)
+		return ARKS_OK;
+	if (!d_ascii || !d_offsets || !d_lens || !d_word_off || !d_codes || !d_nmask)
+		return ARKS_ERR_BAD_ARG;
+	int rc = require_device(device);
+	if (rc != ARKS_OK)
+		return rc;
+	DeviceGuard guard(device);
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	DevBuf ncount, other;
+	u64 total_words = 0;
+	HIP_TRY(hipMemcpyAsync(&total_words, d_word_off + n_reads, sizeof(u64), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (d_read_class) {
+		HIP_TRY(ncount.alloc(sizeof(u32) * (size_t)n_reads));
+		HIP_TRY(other.alloc(sizeof(u32) * (size_t)n_reads));
+		HIP_TRY(hipMemsetAsync(ncount.p, 0, sizeof(u32) * (size_t)n_reads, st));
+		HIP_TRY(hipMemsetAsync(other.p, 0, sizeof(u32) * (size_t)n_reads, st));
+	}
+	HIP_TRY(launch_pack(
+	    d_ascii, (const u64*)d_offsets, d_lens, (const u64*)d_word_off, (long)n_reads, total_words,
+	    (u64*)d_codes, d_nmask, ncount.as<u32>(), other.as<u32>(), st));
+	if (d_read_class) {
+		HIP_TRY(launch_read_class(d_lens, ncount.as<u32>(), other.as<u32>(), (long)n_reads, d_read_class, st));
+		HIP_TRY(hipStreamSynchronize(st)); // temporaries are freed on return
+	}
+done:
+	return rc;
+}
+
+int
+arks_pack_reads_host(
+    const char* h_ascii,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    const uint64_t* h_word_off,
+    int64_t n_reads,
+    uint64_t* h_codes,
+    uint32_t* h_nmask,
+    uint8_t* h_read_class)
+{
+	if (n_reads < 0)
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads == 0)
+		return ARKS_OK;
+	if (!h_ascii || !h_offsets || !h_lens || !h_word_off || !h_codes || !h_nmask)
+		return ARKS_ERR_BAD_ARG;
+	static uint8_t cls[256];
+	static bool ready = false;
+	if (!ready) {
+		std::memset(cls, 5, sizeof cls);
+		cls['A'] = cls['a'] = 0;
+		cls['C'] = cls['c'] = 1;
+		cls['G'] = cls['g'] = 2;
+		cls['T'] = cls['t'] = 3;
+		cls['N'] = cls['n'] = 4;
+		ready = true;
+	}
+	for (int64_t r = 0; r < n_reads; ++r) {
+		const unsigned char* s = reinterpret_cast<const unsigned char*>(h_ascii) + h_offsets[r];
+		const uint32_t len = h_lens[r];
+		uint64_t* cw = h_codes + h_word_off[r];
+		uint32_t* mw = h_nmask + h_word_off[r];
+		const uint64_t nw = ((uint64_t)len + 31) / 32;
+		uint32_t nn = 0, other = 0;
+		for (uint64_t w = 0; w < nw; ++w) {
+			uint64_t c = 0;
+			uint32_t m = 0;
+			const uint32_t n = std::min<uint32_t>(32, len - (uint32_t)(w * 32));
+			for (uint32_t i = 0; i < n; ++i) {
+				const uint32_t x = cls[s[w * 32 + i]];
+				c |= (uint64_t)(x < 4 ? x : 0) << (62 - 2 * i);
+				m |= (uint32_t)(x >= 4) << (31 - i);
+				nn += x == 4;
+				other |= x == 5;
+			}
+			cw[w] = c;
+			mw[w] = m;
+		}
+		if (h_read_class) { // checkReadSequence, Arcs/Arcs.cpp:366-389
+			const double ar = (double)nn / (double)len;
+			h_read_class[r] = (other == 0 && !(ar > 0.02)) ? 1 : 0;
+		}
+	}
+	return ARKS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* index                                                                                          */
+/* ---------------------------------------------------------------------------------------------- */
+
+int
+arks_index_build(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int device,
+    arks_build_stats* stats)
+{
+	if (!out || n_ends < 0 || (n_ends > 0 && (!h_bases || !h_offsets || !h_lens)))
+		return ARKS_ERR_BAD_ARG;
+	*out = nullptr;
+	int rc = check_k(k);
+	if (rc != ARKS_OK)
+		return rc;
+	rc = require_device(device);
+	if (rc != ARKS_OK)
+		return rc;
+	DeviceGuard guard(device);
+
+	arks_index* idx = new (std::nothrow) arks_index;
+	if (!idx)
+		return ARKS_ERR_OOM;
+	idx->k = k;
+	idx->kw = key_words_for_k(k);
+	idx->device = device;
+	idx->geom = make_geom(k, idx->kw);
+	{
+		hipDeviceProp_t p;
+		if (hipGetDeviceProperties(&p, device) == hipSuccess)
+			idx->n_cu = p.multiProcessorCount;
+	}
+
+	hipStream_t st = nullptr;
+	std::vector<uint64_t> word_off((size_t)n_ends + 1, 0);
+	// contiguous copy of the end strings (they may be scattered in the caller's buffer)
+	uint64_t total_bases = 0;
+	for (int64_t e = 0; e < n_ends; ++e)
+		total_bases += h_lens[e];
+	std::vector<uint64_t> offs((size_t)n_ends + 1, 0);
+	DevBuf d_ascii, d_offs, d_lens, d_woff, d_codes, d_nmask, d_visited, d_counters;
+	u64 total_words = 0, counters[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	u64 visited_total = 0;
+
+	arks_word_offsets(h_lens, n_ends, word_off.data());
+	total_words = word_off[(size_t)n_ends];
+	{
+		uint64_t acc = 0;
+		for (int64_t e = 0; e < n_ends; ++e) {
+			offs[(size_t)e] = acc;
+			acc += h_lens[e];
+		}
+		offs[(size_t)n_ends] = acc;
+	}
+	HIP_TRY(d_ascii.alloc(total_bases + 64));
+	for (int64_t e = 0; e < n_ends; ++e) // one copy per end: the source need not be contiguous
+		if (h_lens[e])
+			HIP_TRY(hipMemcpy(
+			    d_ascii.as<char>() + offs[(size_t)e], h_bases + h_offsets[e], h_lens[e],
+			    hipMemcpyHostToDevice));
+	HIP_TRY(d_offs.alloc(sizeof(u64) * ((size_t)n_ends + 1)));
+	HIP_TRY(d_lens.alloc(sizeof(u32) * ((size_t)n_ends + 1)));
+	HIP_TRY(d_woff.alloc(sizeof(u64) * ((size_t)n_ends + 1)));
+	HIP_TRY(hipMemcpy(d_offs.p, offs.data(), sizeof(u64) * ((size_t)n_ends + 1), hipMemcpyHostToDevice));
+	if (n_ends)
+		HIP_TRY(hipMemcpy(d_lens.p, h_lens, sizeof(u32) * (size_t)n_ends, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_woff.p, word_off.data(), sizeof(u64) * ((size_t)n_ends + 1), hipMemcpyHostToDevice));
+	HIP_TRY(d_codes.alloc(sizeof(u64) * (total_words + ARKS_PAD_WORDS)));
+	HIP_TRY(d_nmask.alloc(sizeof(u32) * (total_words + ARKS_PAD_WORDS)));
+	HIP_TRY(d_visited.alloc(sizeof(u32) * (total_words + ARKS_PAD_WORDS)));
+	HIP_TRY(d_counters.alloc(sizeof(counters)));
+	HIP_TRY(hipMemsetAsync(d_codes.p, 0, sizeof(u64) * (total_words + ARKS_PAD_WORDS), st));
+	HIP_TRY(hipMemsetAsync(d_nmask.p, 0, sizeof(u32) * (total_words + ARKS_PAD_WORDS), st));
+	HIP_TRY(hipMemsetAsync(d_visited.p, 0, sizeof(u32) * (total_words + ARKS_PAD_WORDS), st));
+	HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
+
+	HIP_TRY(launch_pack(
+	    d_ascii.as<uint8_t>(), d_offs.as<u64>(), d_lens.as<u32>(), d_woff.as<u64>(), (long)n_ends,
+	    total_words, d_codes.as<u64>(), d_nmask.as<u32>(), nullptr, nullptr, st));
+	HIP_TRY(launch_visit(
+	    d_nmask.as<u32>(), d_woff.as<u64>(), d_lens.as<u32>(), (long)n_ends, k, d_visited.as<u32>(),
+	    d_counters.as<u64>(), st));
+	HIP_TRY(launch_popcount(d_visited.as<u32>(), total_words, d_counters.as<u64>() + 6, st));
+	HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	visited_total = counters[6];
+
+	// capacity: load factor <= 0.5 over the visited windows (an upper bound of the distinct keys)
+	idx->table.cap = std::max<u64>(1024, visited_total * 2 + 64);
+	{
+		void* p = nullptr;
+		HIP_TRY(hipMalloc(&p, idx->table.cap * kSlotWords * sizeof(u64)));
+		idx->table.slots = static_cast<u64*>(p);
+	}
+	HIP_TRY(hipMemsetAsync(idx->table.slots, 0, idx->table.cap * kSlotWords * sizeof(u64), st));
+	HIP_TRY(launch_insert(
+	    idx->kw, d_codes.as<u64>(), d_visited.as<u32>(), d_woff.as<u64>(), (long)n_ends, total_words,
+	    idx->geom, idx->table, d_counters.as<u64>(), st));
+	if (stats)
+		HIP_TRY(launch_build_stats(
+		    idx->kw, d_codes.as<u64>(), d_visited.as<u32>(), d_woff.as<u64>(), (long)n_ends,
+		    total_words, idx->geom, idx->table, d_counters.as<u64>(), st));
+	HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	idx->n_keys = (int64_t)counters[2];
+	if (stats) {
+		stats->total_kmers = visited_total;
+		stats->null_kmers = counters[0];
+		stats->short_ends = counters[1];
+		stats->recorded = counters[2];
+		stats->collisions = visited_total - counters[2];
+		stats->removed_dup = visited_total - counters[4];
+		stats->unique = counters[5];
+	}
+	{
+		void* p = nullptr;
+		HIP_TRY(hipMalloc(&p, sizeof(u32)));
+		idx->queue_count = static_cast<u32*>(p);
+	}
+	*out = idx;
+	idx = nullptr;
+done:
+	if (idx)
+		arks_index_free(idx);
+	return rc;
+}
+
+int
+arks_index_free(arks_index* idx)
+{
+	if (!idx)
+		return ARKS_OK;
+	DeviceGuard guard(idx->device);
+	if (idx->table.slots)
+		(void)hipFree(idx->table.slots);
+	if (idx->queue)
+		(void)hipFree(idx->queue);
+	if (idx->queue_count)
+		(void)hipFree(idx->queue_count);
+	delete idx;
+	return ARKS_OK;
+}
+
+int
+arks_index_k(const arks_index* idx)
+{
+	return idx ? idx->k : 0;
+}
+
+int64_t
+arks_index_size(const arks_index* idx)
+{
+	return idx ? idx->n_keys : 0;
+}
+
+int64_t
+arks_index_device_bytes(const arks_index* idx)
+{
+	if (!idx)
+		return 0;
+	return (int64_t)(idx->table.cap * kSlotWords * sizeof(u64)) + idx->queue_cap * (int64_t)sizeof(u32);
+}
+
+int
+arks_index_export(const arks_index* idx, unsigned char* h_keys, int32_t* h_vals)
+{
+	if (!idx || !h_keys || !h_vals)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(idx->device);
+	int rc = ARKS_OK;
+	const int kb = arks_key_bytes(idx->k);
+	std::vector<u64> host;
+	try {
+		host.resize(idx->table.cap * kSlotWords);
+	} catch (const std::bad_alloc&) {
+		return ARKS_ERR_OOM;
+	}
+	int64_t n = 0;
+	HIP_TRY(hipMemcpy(host.data(), idx->table.slots, host.size() * sizeof(u64), hipMemcpyDeviceToHost));
+	for (u64 s = 0; s < idx->table.cap && n < idx->n_keys; ++s) {
+		const u64* slot = host.data() + s * kSlotWords;
+		const u32 st = (u32)slot[3];
+		if (st == kEmpty)
+			continue;
+		unsigned char* kout = h_keys + (size_t)n * (size_t)kb;
+		for (int b = 0; b < kb; ++b)
+			kout[b] = (unsigned char)(slot[b >> 3] >> (56 - 8 * (b & 7)));
+		h_vals[n++] = (int32_t)(st - 1u);
+	}
+done:
+	return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* mapping                                                                                        */
+/* ---------------------------------------------------------------------------------------------- */
+
+static int
+ensure_queue(const arks_index* idx, int64_t n_reads)
+{
+	if (idx->queue_cap >= n_reads)
+		return ARKS_OK;
+	if (idx->queue) {
+		(void)hipDeviceSynchronize();
+		(void)hipFree(idx->queue);
+		idx->queue = nullptr;
+		idx->queue_cap = 0;
+	}
+	void* p = nullptr;
+	const int64_t cap = n_reads + n_reads / 4 + 1024;
+	hipError_t e = hipMalloc(&p, sizeof(u32) * (size_t)cap);
+	if (e != hipSuccess)
+		return fail_hip(e, "hipMalloc(redo queue)");
+	idx->queue = static_cast<u32*>(p);
+	idx->queue_cap = cap;
+	return ARKS_OK;
+}
+
+int
+arks_map_reads_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream)
+{
+	if (!idx || n_reads < 0 || n_reads > 0xFFFFFFFFll)
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads == 0)
+		return ARKS_OK;
+	if (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_out_conreci)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(idx->device);
+	int rc = ensure_queue(idx, n_reads);
+	if (rc != ARKS_OK)
+		return rc;
+	HIP_TRY(launch_map_reads(
+	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads,
+	    j_index, idx->geom, idx->table, d_out_conreci, reinterpret_cast<u64*>(d_stats), idx->queue,
+	    idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+int
+arks_map_reads(
+    const arks_index* idx,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_reads,
+    double j_index,
+    int32_t* h_out_conreci,
+    arks_map_stats* stats)
+{
+	if (!idx || n_reads < 0)
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads == 0)
+		return ARKS_OK;
+	if (!h_bases || !h_offsets || !h_lens || !h_out_conreci)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(idx->device);
+	int rc = ARKS_OK;
+	hipStream_t st = nullptr;
+	std::vector<uint64_t> word_off((size_t)n_reads + 1), offs((size_t)n_reads + 1);
+	arks_word_offsets(h_lens, n_reads, word_off.data());
+	const u64 total_words = word_off[(size_t)n_reads];
+	uint64_t total_bases = 0;
+	for (int64_t r = 0; r < n_reads; ++r) {
+		offs[(size_t)r] = total_bases;
+		total_bases += h_lens[r];
+	}
+	offs[(size_t)n_reads] = total_bases;
+	std::vector<char> staged;
+	try {
+		staged.resize(total_bases + 64);
+	} catch (const std::bad_alloc&) {
+		return ARKS_ERR_OOM;
+	}
+	for (int64_t r = 0; r < n_reads; ++r)
+		std::memcpy(staged.data() + offs[(size_t)r], h_bases + h_offsets[r], h_lens[r]);
+	DevBuf d_ascii, d_offs, d_lens, d_woff, d_codes, d_nmask, d_out, d_st;
+	arks_map_stats zero;
+	std::memset(&zero, 0, sizeof zero);
+	HIP_TRY(d_ascii.alloc(total_bases + 64));
+	HIP_TRY(d_offs.alloc(sizeof(u64) * ((size_t)n_reads + 1)));
+	HIP_TRY(d_lens.alloc(sizeof(u32) * (size_t)n_reads));
+	HIP_TRY(d_woff.alloc(sizeof(u64) * ((size_t)n_reads + 1)));
+	HIP_TRY(d_codes.alloc(sizeof(u64) * (total_words + ARKS_PAD_WORDS)));
+	HIP_TRY(d_nmask.alloc(sizeof(u32) * (total_words + ARKS_PAD_WORDS)));
+	HIP_TRY(d_out.alloc(sizeof(int32_t) * (size_t)n_reads));
+	HIP_TRY(d_st.alloc(sizeof(arks_map_stats)));
+	HIP_TRY(hipMemcpy(d_ascii.p, staged.data(), total_bases, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_offs.p, offs.data(), sizeof(u64) * ((size_t)n_reads + 1), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_lens.p, h_lens, sizeof(u32) * (size_t)n_reads, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_woff.p, word_off.data(), sizeof(u64) * ((size_t)n_reads + 1), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemsetAsync(d_codes.p, 0, sizeof(u64) * (total_words + ARKS_PAD_WORDS), st));
+	HIP_TRY(hipMemsetAsync(d_nmask.p, 0, sizeof(u32) * (total_words + ARKS_PAD_WORDS), st));
+	HIP_TRY(hipMemcpy(d_st.p, &zero, sizeof zero, hipMemcpyHostToDevice));
+	HIP_TRY(launch_pack(
+	    d_ascii.as<uint8_t>(), d_offs.as<u64>(), d_lens.as<u32>(), d_woff.as<u64>(), (long)n_reads,
+	    total_words, d_codes.as<u64>(), d_nmask.as<u32>(), nullptr, nullptr, st));
+	rc = arks_map_reads_device(
+	    idx, d_codes.as<uint64_t>(), d_nmask.as<u32>(), d_woff.as<uint64_t>(), d_lens.as<u32>(), nullptr,
+	    n_reads, j_index, d_out.as<int32_t>(), stats ? d_st.as<arks_map_stats>() : nullptr, st);
+	if (rc != ARKS_OK)
+		goto done;
+	HIP_TRY(hipMemcpy(h_out_conreci, d_out.p, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost));
+	if (stats) {
+		arks_map_stats got;
+		HIP_TRY(hipMemcpy(&got, d_st.p, sizeof got, hipMemcpyDeviceToHost));
+		stats->total_valid += got.total_valid;
+		stats->bad += got.bad;
+		stats->found += got.found;
+		stats->recorded += got.recorded;
+		stats->dups += got.dups;
+		stats->reads_pass += got.reads_pass;
+		stats->reads_fail += got.reads_fail;
+		stats->windows += got.windows;
+	}
+done:
+	return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* pairs and the IndexMap accumulator                                                             */
+/* ---------------------------------------------------------------------------------------------- */
+
+int
+arks_imap_create(arks_imap** out, int64_t capacity_entries, int device)
+{
+	if (!out || capacity_entries <= 0)
+		return ARKS_ERR_BAD_ARG;
+	*out = nullptr;
+	int rc = require_device(device);
+	if (rc != ARKS_OK)
+		return rc;
+	DeviceGuard guard(device);
+	arks_imap* m = new (std::nothrow) arks_imap;
+	if (!m)
+		return ARKS_ERR_OOM;
+	m->device = device;
+	m->cap = (u64)capacity_entries * 2 + 64; // load factor <= 0.5
+	void* p = nullptr;
+	HIP_TRY(hipMalloc(&p, m->cap * sizeof(u64)));
+	m->keys = static_cast<u64*>(p);
+	HIP_TRY(hipMalloc(&p, m->cap * sizeof(u32)));
+	m->counts = static_cast<u32*>(p);
+	HIP_TRY(hipMalloc(&p, sizeof(u32)));
+	m->overflow = static_cast<u32*>(p);
+	HIP_TRY(hipMemset(m->keys, 0, m->cap * sizeof(u64)));
+	HIP_TRY(hipMemset(m->counts, 0, m->cap * sizeof(u32)));
+	HIP_TRY(hipMemset(m->overflow, 0, sizeof(u32)));
+	*out = m;
+	m = nullptr;
+done:
+	if (m)
+		arks_imap_free(m);
+	return rc;
+}
+
+int
+arks_imap_free(arks_imap* m)
+{
+	if (!m)
+		return ARKS_OK;
+	DeviceGuard guard(m->device);
+	if (m->keys)
+		(void)hipFree(m->keys);
+	if (m->counts)
+		(void)hipFree(m->counts);
+	if (m->overflow)
+		(void)hipFree(m->overflow);
+	delete m;
+	return ARKS_OK;
+}
+
+static int
+imap_download(const arks_imap* m, std::vector<std::pair<u64, u32>>& ent)
+{
+	int rc = ARKS_OK;
+	std::vector<u64> keys;
+	std::vector<u32> counts;
+	u32 overflow = 0;
+	try {
+		keys.resize(m->cap);
+		counts.resize(m->cap);
+	} catch (const std::bad_alloc&) {
+		return ARKS_ERR_OOM;
+	}
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(&overflow, m->overflow, sizeof(u32), hipMemcpyDeviceToHost));
+	if (overflow)
+		return ARKS_ERR_FULL;
+	HIP_TRY(hipMemcpy(keys.data(), m->keys, m->cap * sizeof(u64), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(counts.data(), m->counts, m->cap * sizeof(u32), hipMemcpyDeviceToHost));
+	for (u64 s = 0; s < m->cap; ++s)
+		if (keys[s] != 0)
+			ent.emplace_back(keys[s], counts[s]);
+	std::sort(ent.begin(), ent.end());
+done:
+	return rc;
+}
+
+int64_t
+arks_imap_size(const arks_imap* m)
+{
+	if (!m)
+		return 0;
+	DeviceGuard guard(m->device);
+	std::vector<std::pair<u64, u32>> ent;
+	const int rc = imap_download(m, ent);
+	return rc == ARKS_OK ? (int64_t)ent.size() : -(int64_t)rc;
+}
+
+int
+arks_imap_export(const arks_imap* m, uint32_t* h_triples)
+{
+	if (!m || !h_triples)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(m->device);
+	std::vector<std::pair<u64, u32>> ent;
+	const int rc = imap_download(m, ent);
+	if (rc != ARKS_OK)
+		return rc;
+	for (size_t i = 0; i < ent.size(); ++i) {
+		h_triples[3 * i + 0] = (uint32_t)(ent[i].first >> 32);
+		h_triples[3 * i + 1] = (uint32_t)ent[i].first;
+		h_triples[3 * i + 2] = ent[i].second;
+	}
+	return ARKS_OK;
+}
+
+int
+arks_pair_gate_device(
+    const uint8_t* d_pair_ok,
+    const uint8_t* d_read_class,
+    int64_t n_pairs,
+    uint8_t* d_eval,
+    int device,
+    void* stream)
+{
+	if (n_pairs < 0)
+		return ARKS_ERR_BAD_ARG;
+	if (n_pairs == 0)
+		return ARKS_OK;
+	if (!d_read_class || !d_eval)
+		return ARKS_ERR_BAD_ARG;
+	int rc = require_device(device);
+	if (rc != ARKS_OK)
+		return rc;
+	DeviceGuard guard(device);
+	HIP_TRY(launch_pair_gate(d_pair_ok, d_read_class, (long)n_pairs, d_eval, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+int
+arks_pairs_device(
+    const int32_t* d_conreci,
+    const uint8_t* d_pair_ok,
+    const uint32_t* d_barcode_id,
+    int64_t n_pairs,
+    int32_t* d_out_pair,
+    arks_imap* imap,
+    uint64_t* d_stored,
+    int device,
+    void* stream)
+{
+	if (n_pairs < 0)
+		return ARKS_ERR_BAD_ARG;
+	if (n_pairs == 0)
+		return ARKS_OK;
+	if (!d_conreci || (imap && !d_barcode_id))
+		return ARKS_ERR_BAD_ARG;
+	int rc = require_device(device);
+	if (rc != ARKS_OK)
+		return rc;
+	DeviceGuard guard(device);
+	HIP_TRY(launch_pairs(
+	    d_conreci, d_pair_ok, d_barcode_id, (long)n_pairs, d_out_pair, imap ? imap->keys : nullptr,
+	    imap ? imap->counts : nullptr, imap ? imap->cap : 0, imap ? imap->overflow : nullptr,
+	    (u64*)d_stored, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+} /* extern "C" */

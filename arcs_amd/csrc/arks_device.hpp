@@ -1,0 +1,318 @@
+// arks_device.hpp -- device-side k-mer primitives shared by every kernel of libarks_hip (gfx950).
+//
+// A k-mer key is the reference's packed key (Common/ReadsProcessor.cpp:376-535: 4 bases per byte,
+// first base in bits 7:6, zero padded) viewed as KW big-endian 64-bit words: w[0] holds bases
+// 0..31 with base 0 in bits 63:62.  Lexicographic byte order == unsigned word order, so
+// "the smaller of forward / reverse complement" (ReadsProcessor.cpp:427,464) is a word compare.
+// Reads and contig ends are stored in exactly this bit order (include/arks_hip.h, "Packed read
+// layout"), which makes a window's forward key a funnel-shifted bit-field of the stream -- no
+// per-base work, no rolling state, any lane can produce any window.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace arks {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int kMaxKW = 3; // 64-bit words per key: k <= 32 * KW
+
+template <int KW>
+struct Key
+{
+	u64 w[KW];
+};
+
+// Byte geometry of a k-mer, Common/ReadsProcessor.cpp:20-37, plus the word masks the kernels use.
+struct KeyGeom
+{
+	int k;
+	int full;     // k / 4
+	int hang;     // k % 4
+	int half;     // ceil(k / 8)
+	int nbytes;   // full + (hang != 0)
+	int rc_shift; // 64*KW - 2k: left shift that re-aligns a reversed key
+	u64 mask[kMaxKW]; // valid bits of word j of a left-aligned 2k-bit key
+};
+
+inline KeyGeom
+make_geom(int k, int kw)
+{
+	KeyGeom g;
+	g.k = k;
+	g.full = k / 4;
+	g.hang = k % 4;
+	g.half = k / 8 + ((k % 8) ? 1 : 0);
+	g.nbytes = g.full + (g.hang ? 1 : 0);
+	g.rc_shift = 64 * kw - 2 * k;
+	for (int j = 0; j < kMaxKW; ++j) {
+		int bits = 2 * k - 64 * j;
+		if (bits <= 0)
+			g.mask[j] = 0;
+		else if (bits >= 64)
+			g.mask[j] = ~0ull;
+		else
+			g.mask[j] = ~(~0ull >> bits);
+	}
+	return g;
+}
+
+inline int
+key_words_for_k(int k)
+{
+	return k <= 64 ? 2 : 3; // KW = 2 serves every k <= 64 (w[1] == 0 when k <= 32)
+}
+
+// (a:b) << s, upper 64 bits; s in [0, 63]
+__device__ __forceinline__ u64
+funnel_l(u64 a, u64 b, int s)
+{
+	return (a << s) | ((b >> 1) >> (63 - s));
+}
+
+// reverse the order of the 32 two-bit groups of x
+__device__ __forceinline__ u64
+rev_groups(u64 x)
+{
+	u64 t = __brevll(x);
+	return ((t >> 1) & 0x5555555555555555ull) | ((t & 0x5555555555555555ull) << 1);
+}
+
+template <int KW>
+__device__ __forceinline__ bool
+key_less(const Key<KW>& a, const Key<KW>& b)
+{
+	bool lt = false, decided = false;
+#pragma unroll
+	for (int j = 0; j < KW; ++j) {
+		bool ne = a.w[j] != b.w[j];
+		lt = (!decided && ne) ? (a.w[j] < b.w[j]) : lt;
+		decided = decided || ne;
+	}
+	return lt;
+}
+
+template <int KW>
+__device__ __forceinline__ bool
+key_eq(const Key<KW>& a, const Key<KW>& b)
+{
+	bool eq = true;
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		eq = eq && (a.w[j] == b.w[j]);
+	return eq;
+}
+
+// Forward key of the window that starts `p` bases after word `wbase` of a packed stream.
+template <int KW>
+__device__ __forceinline__ Key<KW>
+window_key(const u64* __restrict__ codes, u64 wbase, int p, const KeyGeom& g)
+{
+	const u64* src = codes + wbase + (u64)(p >> 5);
+	const int s = (p & 31) * 2;
+	u64 w[KW + 1];
+#pragma unroll
+	for (int j = 0; j <= KW; ++j)
+		w[j] = src[j];
+	Key<KW> f;
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		f.w[j] = funnel_l(w[j], w[j + 1], s) & g.mask[j];
+	return f;
+}
+
+// True iff any of the k bases of the window is flagged in the N-mask (=> NULL k-mer,
+// ReadsProcessor.cpp:397-421; the reference validates every base of the window on every branch).
+template <int KW>
+__device__ __forceinline__ bool
+window_has_invalid(const u32* __restrict__ nmask, u64 wbase, int p, int k)
+{
+	const u32* src = nmask + wbase + (u64)(p >> 5);
+	const int t = p & 31, e = t + k; // bit range [t, e) relative to src[0]
+	u32 any = 0;
+#pragma unroll
+	for (int j = 0; j <= KW; ++j) {
+		int lo = t - 32 * j, hi = e - 32 * j;
+		lo = lo < 0 ? 0 : lo;
+		hi = hi > 32 ? 32 : hi;
+		if (lo < hi) {
+			u32 m = (0xFFFFFFFFu >> lo) & ~(hi == 32 ? 0u : (0xFFFFFFFFu >> hi));
+			any |= src[j] & m;
+		}
+	}
+	return any != 0;
+}
+
+// Reverse complement of a left-aligned 2k-bit key.
+template <int KW>
+__device__ __forceinline__ Key<KW>
+key_revcomp(const Key<KW>& f, const KeyGeom& g)
+{
+	u64 r[KW + 1];
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		r[j] = rev_groups(f.w[KW - 1 - j]); // reversed sequence, right-aligned in 64*KW bits
+	r[KW] = 0;
+	const int ws = g.rc_shift >> 6, bs = g.rc_shift & 63;
+	Key<KW> out;
+#pragma unroll
+	for (int j = 0; j < KW; ++j) {
+		u64 a = 0, b = 0;
+#pragma unroll
+		for (int t = 0; t <= KW; ++t) { // static indices only: r[] stays in registers
+			a = (t == j + ws) ? r[t] : a;
+			b = (t == j + ws + 1) ? r[t] : b;
+		}
+		out.w[j] = ~funnel_l(a, b, bs) & g.mask[j];
+	}
+	return out;
+}
+
+template <int KW>
+__device__ __forceinline__ u32
+key_base(const Key<KW>& f, int i)
+{
+	u64 w = 0;
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		w = ((i >> 5) == j) ? f.w[j] : w;
+	return (u32)(w >> (62 - 2 * (i & 31))) & 3u;
+}
+
+template <int KW>
+__device__ __forceinline__ void
+key_or_byte(Key<KW>& o, int b, u32 v)
+{
+	const u64 x = (u64)(v & 0xFFu) << (56 - 8 * (b & 7));
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		o.w[j] |= ((b >> 3) == j) ? x : 0ull;
+}
+
+// The key the reference produces for a reverse-complement palindrome (forward == revcomp), its
+// damaged branch Common/ReadsProcessor.cpp:503-534: the first `half` bytes are the forward bytes,
+// byte `half` stays 0, later full bytes are refilled from a cursor that advances 3 bases per byte,
+// and a hanging last byte keeps only one base.  Rare path (4^-(k/2) of random windows).
+template <int KW>
+__device__ __forceinline__ Key<KW>
+key_palindrome_quirk(const Key<KW>& f, const KeyGeom& g)
+{
+	Key<KW> o;
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		o.w[j] = 0;
+	for (int b = 0; b < g.half; ++b) {
+		u32 v = (key_base(f, 4 * b) << 6) | (key_base(f, 4 * b + 1) << 4) |
+		        (key_base(f, 4 * b + 2) << 2) | key_base(f, 4 * b + 3);
+		key_or_byte(o, b, v);
+	}
+	int idx = 4 * g.half;
+	for (int b = g.half + 1; b < g.full; ++b) {
+		u32 v = (key_base(f, idx) << 6) | (key_base(f, idx + 1) << 4) | (key_base(f, idx + 2) << 2) |
+		        key_base(f, idx + 3);
+		key_or_byte(o, b, v);
+		idx += 3;
+	}
+	if (g.hang) {
+		int last = g.k - 1;
+		u32 v = key_base(f, last) << 6;
+		for (; idx < last; --last)
+			v = ((v << 2) & 0xFFu) | (key_base(f, last) << 6);
+		key_or_byte(o, g.full, v);
+	}
+	return o;
+}
+
+// The reference key (prepSeq + getStr) of a window whose forward key is f and that has no invalid
+// base: min(forward, revcomp), or the palindrome quirk when they are equal.
+template <int KW>
+__device__ __forceinline__ Key<KW>
+reference_key(const Key<KW>& f, const KeyGeom& g)
+{
+	const Key<KW> r = key_revcomp(f, g);
+	Key<KW> c;
+	const bool lt = key_less(f, r);
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		c.w[j] = lt ? f.w[j] : r.w[j];
+	if (key_eq(f, r))
+		c = key_palindrome_quirk(f, g);
+	return c;
+}
+
+// 64-bit mix of a key; the table position is free to use any hash because the path's results
+// depend only on exact key equality (Arcs/Arcs.h:153-156), not on CityHash64 (Arcs/Arcs.h:150).
+template <int KW>
+__device__ __forceinline__ u64
+key_hash(const Key<KW>& c)
+{
+	u64 h = c.w[0] * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+	for (int j = 1; j < KW; ++j) {
+		h = (h << 31) | (h >> 33);
+		h ^= c.w[j] * 0xC2B2AE3D27D4EB4Full;
+	}
+	h ^= h >> 32;
+	h *= 0xD6E8FEB86659FD93ull;
+	h ^= h >> 29;
+	return h;
+}
+
+__device__ __forceinline__ u64
+mulhi64(u64 a, u64 b)
+{
+	return __umul64hi(a, b);
+}
+
+// ---- the contig k-mer table ------------------------------------------------------------------
+// Open addressing, linear probing.  One slot = 4 x u64 (32 B, two per 64-B line):
+//   [0, KW)   key words
+//   [3]       low 32 bits: state (0 = empty, 0xFFFFFFFF = being written, else value + 1)
+//             high 32 bits: smallest contig-end index that visited the key (build statistics)
+constexpr int kSlotWords = 4;
+constexpr u32 kEmpty = 0u;
+constexpr u32 kLocked = 0xFFFFFFFFu;
+
+struct TableView
+{
+	u64* slots;
+	u64 cap;
+};
+
+template <int KW>
+__device__ __forceinline__ Key<KW>
+slot_key(const u64* slot)
+{
+	Key<KW> s;
+	if (KW == 2) {
+		const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(slot);
+		s.w[0] = v.x;
+		s.w[KW - 1] = v.y;
+	} else {
+#pragma unroll
+		for (int j = 0; j < KW; ++j)
+			s.w[j] = slot[j];
+	}
+	return s;
+}
+
+// value of key c, or -1 when absent (read-only phase: no slot is locked any more)
+template <int KW>
+__device__ __forceinline__ int
+table_lookup(const TableView& t, const Key<KW>& c)
+{
+	u64 s = mulhi64(key_hash(c), t.cap);
+	for (;;) {
+		const u64* slot = t.slots + s * kSlotWords;
+		const u32 st = *reinterpret_cast<const u32*>(slot + 3);
+		if (st == kEmpty)
+			return -1;
+		if (key_eq(slot_key<KW>(slot), c))
+			return (int)(st - 1u);
+		s = (s + 1 == t.cap) ? 0 : s + 1;
+	}
+}
+
+} // namespace arks

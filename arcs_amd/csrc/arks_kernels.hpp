@@ -1,0 +1,33 @@
+// arks_kernels.hpp -- host-visible launchers of the kernels in arks_kernels.hip.
+#pragma once
+
+#include "arks_device.hpp"
+
+namespace arks {
+
+hipError_t launch_pack(
+    const uint8_t* ascii, const u64* offsets, const u32* lens, const u64* word_off, long n_seqs,
+    u64 total_words, u64* codes, u32* nmask, u32* n_count, u32* other, hipStream_t st);
+hipError_t launch_read_class(
+    const u32* lens, const u32* n_count, const u32* other, long n, uint8_t* out, hipStream_t st);
+hipError_t launch_visit(
+    const u32* nmask, const u64* word_off, const u32* lens, long n_ends, int k, u32* visited,
+    u64* counters, hipStream_t st);
+hipError_t launch_popcount(const u32* words, u64 n, u64* out, hipStream_t st);
+hipError_t launch_insert(
+    int kw, const u64* codes, const u32* visited, const u64* word_off, long n_ends, u64 total_words,
+    const KeyGeom& g, TableView t, u64* counters, hipStream_t st);
+hipError_t launch_build_stats(
+    int kw, const u64* codes, const u32* visited, const u64* word_off, long n_ends, u64 total_words,
+    const KeyGeom& g, TableView t, u64* counters, hipStream_t st);
+hipError_t launch_map_reads(
+    int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens,
+    const uint8_t* eval, long n_reads, double j_index, const KeyGeom& g, TableView t, int* out,
+    u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st);
+hipError_t launch_pair_gate(
+    const uint8_t* pair_ok, const uint8_t* read_class, long n_pairs, uint8_t* eval, hipStream_t st);
+hipError_t launch_pairs(
+    const int* conreci, const uint8_t* pair_ok, const u32* barcode_id, long n_pairs, int* out_pair,
+    u64* imap_keys, u32* imap_counts, u64 imap_cap, u32* imap_overflow, u64* stored, hipStream_t st);
+
+} // namespace arks

@@ -1,0 +1,232 @@
+/*
+ * arks_hip.h -- C ABI of libarks_hip.so: the MI355X (gfx950) implementation of ARCS's ARKS-mode
+ * read -> contig-end k-mer mapping path.
+ *
+ * The reference (bcgsc/arcs v1.2.8) has no plugin/FFI seam for this path; the seams are the plain
+ * C++ functions of Arcs/Arcs.cpp that runArcs() calls (Arcs.cpp:1897,1902).  Each entry point
+ * below names the reference function it replaces.  All arguments are plain pointers and sizes;
+ * no C++ or torch types cross this boundary; no exception and no abort() crosses it either --
+ * every function returns an ARKS_* status code (the reference prints a message and exit(1)s; the
+ * host CLI maps codes back to those messages).
+ *
+ * Conventions
+ *   - "end e" (0-based) of an index build <-> contig-end index `conreci` = e + 1
+ *     (Arcs.cpp:1057-1058: head of the n-th valid contig = 2n-1, tail = 2n; 0 = "null contig").
+ *   - h_ pointers are host memory, d_ pointers are device (HIP) memory on the index's device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Device entry points
+ *     are asynchronous on that stream; host entry points return after their results are valid.
+ *   - Handles are thread-compatible, not thread-safe (one in-flight call per handle/stream), like
+ *     the per-thread ReadsProcessor of Arcs.cpp:1152-1156.
+ *
+ * Packed read layout (what the kernels consume; produced by arks_pack_* below)
+ *   - codes: uint64 words, 32 bases per word, MSB first (base 0 of a word in bits 63:62), A=0 C=1
+ *     G=2 T=3 (case-insensitive), anything else 0.  Read r starts at word d_word_off[r] and owns
+ *     ceil(len/32) words; unused tail bits are 0.  The array must be followed by >= 4 readable
+ *     padding words.  These are exactly the bytes of the reference's packed k-mer
+ *     (Common/ReadsProcessor.cpp:376-535) so a window's key is a bit-field of the stream.
+ *   - nmask: uint32 words, 1 bit per base, same indexing (bit 31 = base 0 of the word); 1 = the
+ *     character was not one of ACGTacgt (such a window is the NULL k-mer, ReadsProcessor.cpp:400).
+ */
+#ifndef ARKS_HIP_H
+#define ARKS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARKS_ABI_VERSION 1
+
+/* status codes */
+#define ARKS_OK 0
+#define ARKS_ERR_BAD_K 1        /* k <= 3 (ReadsProcessor.cpp:25 assert) or k in {6,10} (reference UB) */
+#define ARKS_ERR_K_UNSUPPORTED 2 /* k > ARKS_MAX_K */
+#define ARKS_ERR_OOM 3          /* host or device allocation failed */
+#define ARKS_ERR_HIP 4          /* a HIP runtime call / kernel launch failed (arks_last_error_string) */
+#define ARKS_ERR_NO_DEVICE 5    /* no usable gfx950 device: the product has no CPU fallback */
+#define ARKS_ERR_BAD_ARG 6      /* NULL pointer, negative count, ... */
+#define ARKS_ERR_READ_TOO_LONG 7 /* a read has more than ARKS_MAX_WINDOWS k-mer windows */
+#define ARKS_ERR_FULL 8         /* accumulator table full */
+
+#define ARKS_MAX_K 96
+#define ARKS_MAX_WINDOWS 256 /* windows per read handled by the per-read vote (len - k + 1) */
+
+int arks_abi_version(void);
+const char* arks_strerror(int status);
+/* text of the last HIP error seen by the calling thread (empty string when none) */
+const char* arks_last_error_string(void);
+/* number of visible HIP devices whose architecture is gfx950; 0 when there is none */
+int arks_device_count(void);
+/* bytes of one packed key, Common/ReadsProcessor.cpp:20-37 (k=60 -> 15) */
+int arks_key_bytes(int k);
+
+/* ---- counters -------------------------------------------------------------------------------- */
+
+/* index-build counters printed by getContigKmers under -v, Arcs/Arcs.cpp:1107-1128
+ * (64-bit here; the CLI narrows to the reference's 32-bit unsigned for printing). */
+typedef struct
+{
+	uint64_t total_kmers; /* "Total number of Kmers"      sum of mapKmers() returns :1087,1093 */
+	uint64_t null_kmers;  /* "Number Null Kmers"          s_numbadkmers        :924 */
+	uint64_t recorded;    /* "Number Kmers Recorded"      s_numkmersmapped     :919 */
+	uint64_t collisions;  /* "Number Kmer Collisions"     s_numkmercollisions  :915 */
+	uint64_t removed_dup; /* "Number Times Kmers Removed" s_numkmersremdup     :909 */
+	uint64_t unique;      /* "Number of unique kmers"     s_uniquedraftkmers   :911,918 */
+	uint64_t short_ends;  /* ends shorter than k (the warning of :877-882), no k-mers added */
+} arks_build_stats;
+
+/* read-mapping counters printed by chromiumRead under -v, Arcs/Arcs.cpp:1329-1340 */
+typedef struct
+{
+	uint64_t total_valid; /* s_totalnumckmers :966 */
+	uint64_t bad;         /* s_numbadckmers   :991 */
+	uint64_t found;       /* s_numckmersfound :987 */
+	uint64_t recorded;    /* s_numckmersrec   :977 */
+	uint64_t dups;        /* s_ckmersasdups   :980 */
+	uint64_t reads_pass;  /* s_numreadspassingjaccard :1007 */
+	uint64_t reads_fail;  /* s_numreadsfailjaccard    :1011 */
+	uint64_t windows;     /* sum of totalnumkmers :962 -- the unit of the throughput metric */
+} arks_map_stats;
+
+/* ---- the contig k-mer index ------------------------------------------------------------------ */
+
+/* Opaque device-resident replacement of `ARCS::ContigKMap kmap` (Arcs/Arcs.h:158) together with
+ * the ReadsProcessor(k) geometry (Arcs.cpp:1044-1045). */
+typedef struct arks_index arks_index;
+
+/* Replaces getContigKmers' loop over mapKmers (Arcs/Arcs.cpp:869-929, 1084-1091): k-merizes every
+ * end string (ASCII, h_bases + h_offsets[e], h_lens[e] characters) with the reference's visit rule
+ * (a NULL k-mer jumps k positions, :922-925) and records key -> (e+1), or 0 once a key has been
+ * seen from two different ends.  The caller does the head/tail split (arks_end_cutoff).
+ * stats may be NULL (skips the extra pass that the "removed" counter needs). */
+int arks_index_build(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int device,
+    arks_build_stats* stats);
+
+int arks_index_free(arks_index* idx);
+int arks_index_k(const arks_index* idx);
+/* number of distinct keys (== kmap.size()) */
+int64_t arks_index_size(const arks_index* idx);
+/* device bytes held by the index */
+int64_t arks_index_device_bytes(const arks_index* idx);
+/* Copies every (key, value) to host: h_keys = size * arks_key_bytes(k) bytes in the reference's
+ * byte order (what ReadsProcessor::getStr returns), h_vals = size int32.  Order unspecified. */
+int arks_index_export(const arks_index* idx, unsigned char* h_keys, int32_t* h_vals);
+
+/* The head/tail split of getContigKmers, Arcs/Arcs.cpp:1056,1072-1074.  Returns 1 and the length
+ * of both end substrings in *cutoff, or 0 when the contig is skipped (len < min_size). */
+int arks_end_cutoff(int len, int min_size, int end_length, int* cutoff);
+
+/* ---- packing --------------------------------------------------------------------------------- */
+
+/* Words of packed storage for n sequences: h_word_off[i] = first word of sequence i,
+ * h_word_off[n] = total words (add ARKS_PAD_WORDS when allocating). */
+#define ARKS_PAD_WORDS 4
+int arks_word_offsets(const uint32_t* h_lens, int64_t n, uint64_t* h_word_off);
+
+/* ASCII -> packed, on the device.  d_read_class[r] (may be NULL) receives what
+ * checkReadSequence (Arcs/Arcs.cpp:366-389) decides for read r: 1 = accepted (only ACGTN,
+ * N fraction <= 0.02), 0 = rejected. */
+int arks_pack_reads_device(
+    const uint8_t* d_ascii,
+    const uint64_t* d_offsets,
+    const uint32_t* d_lens,
+    const uint64_t* d_word_off,
+    int64_t n_reads,
+    uint64_t* d_codes,
+    uint32_t* d_nmask,
+    uint8_t* d_read_class,
+    int device,
+    void* stream);
+
+/* The same packing on the host (for ingest threads that ship 3 bits/base over PCIe instead of 8). */
+int arks_pack_reads_host(
+    const char* h_ascii,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    const uint64_t* h_word_off,
+    int64_t n_reads,
+    uint64_t* h_codes,
+    uint32_t* h_nmask,
+    uint8_t* h_read_class);
+
+/* ---- read mapping ---------------------------------------------------------------------------- */
+
+/* Replaces bestContig (Arcs/Arcs.cpp:939-1014) for a batch of packed reads resident on the device:
+ * d_out_conreci[r] = the contig end whose k-mers dominate read r (count/total > j_index, ties to
+ * the smallest index, total counts NULL windows too) or 0.  d_eval (may be NULL = all) selects the
+ * reads bestContig is called for (Arcs.cpp:1268); the others get 0 and touch no counter.
+ * d_stats (may be NULL) points to one arks_map_stats in device memory that is ADDED to. */
+int arks_map_reads_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream);
+
+/* Host convenience over the above (pack + map + copy back); mirrors calling bestContig on every
+ * read of the batch.  stats may be NULL. */
+int arks_map_reads(
+    const arks_index* idx,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_reads,
+    double j_index,
+    int32_t* h_out_conreci,
+    arks_map_stats* stats);
+
+/* ---- pairs and the IndexMap ------------------------------------------------------------------ */
+
+/* Device accumulator for `IndexMap imap` (Arcs/Arcs.h:108-113) as (barcode id, conreci) -> count;
+ * the caller keeps the barcode string <-> id dictionary. */
+typedef struct arks_imap arks_imap;
+int arks_imap_create(arks_imap** out, int64_t capacity_entries, int device);
+int arks_imap_free(arks_imap* m);
+int64_t arks_imap_size(const arks_imap* m);
+/* h_triples = size * 3 uint32 (barcode id, conreci, count), sorted by (barcode id, conreci). */
+int arks_imap_export(const arks_imap* m, uint32_t* h_triples);
+
+/* The gate of chromiumRead, Arcs/Arcs.cpp:1264-1268: d_eval[2p] = d_eval[2p+1] =
+ * pair_ok[p] && class[2p] && class[2p+1]  (goodmult is always true, :1267). */
+int arks_pair_gate_device(
+    const uint8_t* d_pair_ok,
+    const uint8_t* d_read_class,
+    int64_t n_pairs,
+    uint8_t* d_eval,
+    int device,
+    void* stream);
+
+/* The pair rule of chromiumRead, Arcs/Arcs.cpp:1280-1292: reads 2p, 2p+1 are mates;
+ * d_out_pair[p] = c1 if (c1 != 0 && c1 == c2) else 0; for stored pairs with d_pair_ok[p] != 0
+ * (NULL = all) imap[(d_barcode_id[p], c1)]++ (imap and d_barcode_id may both be NULL).
+ * d_stored (may be NULL) points to one uint64 on the device that is ADDED to. */
+int arks_pairs_device(
+    const int32_t* d_conreci,
+    const uint8_t* d_pair_ok,
+    const uint32_t* d_barcode_id,
+    int64_t n_pairs,
+    int32_t* d_out_pair,
+    arks_imap* imap,
+    uint64_t* d_stored,
+    int device,
+    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARKS_HIP_H */

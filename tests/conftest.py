@@ -1,0 +1,74 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+
+
+def read_fasta(path):
+    seqs, name, cur = [], None, []
+    with open(path) as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                if name is not None:
+                    seqs.append((name, "".join(cur)))
+                name, cur = line[1:].split()[0], []
+            else:
+                cur.append(line)
+    if name is not None:
+        seqs.append((name, "".join(cur)))
+    return seqs
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """the CPU oracle (test infrastructure), built on demand with gcc"""
+    from oracle import pyoracle
+    pyoracle.build_oracle()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def demo_contigs():
+    return read_fasta(os.path.join(GOLDEN, "arks_test-demo.test_scaffolds.fa"))
+
+
+@pytest.fixture(scope="session")
+def golden_keys():
+    return json.load(open(os.path.join(GOLDEN, "keys.json")))
+
+
+@pytest.fixture(scope="session")
+def golden_demo_index():
+    return json.load(open(os.path.join(GOLDEN, "demo_index.json")))
+
+
+@pytest.fixture(scope="session")
+def golden_mini():
+    return json.load(open(os.path.join(GOLDEN, "mini.json")))
+
+
+@pytest.fixture(scope="session")
+def arks():
+    """the product library; GPU tests fail (not skip) when it is missing"""
+    import arcs_amd
+    arcs_amd.lib()
+    return arcs_amd
+
+
+@pytest.fixture(scope="session")
+def gpu(arks):
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test on a machine without a GPU"
+    assert arks.device_count() >= 1, "no gfx950 device visible to libarks_hip"
+    return 0

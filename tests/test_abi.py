@@ -1,0 +1,113 @@
+"""CPU-side checks of the drop-in boundary: libarks_hip.so loads, exports every symbol that
+include/arks_hip.h declares, refuses to compute without a gfx950 device (no CPU fallback), and its
+host-side helpers (packing, word offsets, end cut-off) agree with the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "arks_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(arks_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_library_agree(arks):
+    from arcs_amd import _lib
+    names = header_functions()
+    assert len(names) >= 20
+    assert sorted(_lib.SYMBOLS) == names  # the ctypes table binds exactly the declared ABI
+    out = subprocess.check_output(["nm", "-D", "--defined-only", arks.lib_path()]).decode()
+    exported = set(re.findall(r" T (arks_[a-z0-9_]+)", out))
+    assert set(names) <= exported
+    assert arks.lib().arks_abi_version() == 1
+
+
+def test_library_has_gfx950_code_object(arks):
+    """the .so carries a gfx950 code object (what the GPU box will load)"""
+    data = open(arks.lib_path(), "rb").read()
+    assert b"gfx950" in data
+
+
+def test_key_bytes_and_cutoff(arks, oracle):
+    for k in range(4, 97):
+        assert arks.key_bytes(k) == oracle.key_bytes(k)
+    for L in (0, 499, 500, 501, 59999, 60000, 60001, 61001, 1000000):
+        for e in (0, 1000, 30000):
+            assert arks.end_cutoff(L, 500, e) == oracle.end_cutoff(L, 500, e)
+    s = ["A" * 499, "C" * 501, "G" * 70000]
+    assert arks.contig_ends(s) == oracle.contig_ends(s)
+
+
+def _py_pack(seq):
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    nw = (len(seq) + 31) // 32
+    codes = [0] * nw
+    mask = [0] * nw
+    for i, ch in enumerate(seq):
+        c = code.get(ch.upper())
+        if c is None:
+            mask[i // 32] |= 1 << (31 - i % 32)
+        else:
+            codes[i // 32] |= c << (62 - 2 * (i % 32))
+    return codes, mask
+
+
+def test_host_packer(arks, oracle):
+    rng = np.random.Generator(np.random.PCG64(1))
+    seqs = ["", "A", "ACGT" * 8, "ACGT" * 8 + "T", "acgtnNRyx-" * 7]
+    for _ in range(30):
+        L = int(rng.integers(1, 400))
+        seqs.append("".join(rng.choice(list("ACGTacgtNn.R"), size=L,
+                                       p=np.array([20] * 8 + [1, 1, 1, 1]) / 164.0)))
+    p = arks.pack_reads_host(seqs)
+    assert p["word_off"][0] == 0
+    for i, s in enumerate(seqs):
+        w0, w1 = int(p["word_off"][i]), int(p["word_off"][i + 1])
+        assert w1 - w0 == (len(s) + 31) // 32
+        codes, mask = _py_pack(s)
+        assert [int(x) for x in p["codes"][w0:w1]] == codes
+        assert [int(x) for x in p["nmask"][w0:w1]] == mask
+        if len(s):
+            assert bool(p["read_class"][i]) == oracle.check_read_sequence(s), s
+    # the packed code words ARE the reference key bytes: window 0 of a 32-mer == word 0
+    s = "".join(rng.choice(list("ACGT"), size=64))
+    p = arks.pack_reads_host([s])
+    k32 = int(p["codes"][0]).to_bytes(8, "big")
+    fw = oracle.key(s[:32] + "T" * 0, 0, 32)
+    rc = s[:32][::-1].translate(str.maketrans("ACGT", "TGCA"))
+    assert fw == min(k32, int(arks.pack_reads_host([rc])["codes"][0]).to_bytes(8, "big"))
+
+
+def test_no_device_is_loud(arks):
+    """without a gfx950 device the compute entry points return ARKS_ERR_NO_DEVICE -- there is no
+    CPU path inside the product"""
+    if arks.device_count() > 0:
+        pytest.skip("a gfx950 device is present")
+    with pytest.raises(arks.ArksError) as e:
+        arks.ArksIndex.build(["ACGT" * 100], 20)
+    assert e.value.status == 5
+    L = arks.lib()
+    h = C.c_void_p()
+    assert L.arks_imap_create(C.byref(h), 16, 0) == 5
+    assert L.arks_index_build(C.byref(h), 3, None, None, None, 0, 0, None) == 1   # bad k first
+    assert L.arks_index_build(C.byref(h), 10, None, None, None, 0, 0, None) == 1
+    assert L.arks_index_build(C.byref(h), 97, None, None, None, 0, 0, None) == 2
+    assert b"gfx950" in L.arks_strerror(5)
+
+
+def test_product_does_not_reach_into_oracle():
+    """the package and the C ABI never import, link or call anything under oracle/"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "arcs_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower() or f == "synth.py", os.path.join(dirpath, f)
+    out = subprocess.check_output(["ldd", os.path.join(ROOT, "arcs_amd", "lib", "libarks_hip.so")]).decode()
+    assert "arks_oracle" not in out and "arks_ref" not in out
