@@ -80,6 +80,14 @@ def lib():
             raise RuntimeError(
                 f"{_PATH} is missing: build it with `python -m arcs_amd.build` "
                 "(hipcc --offload-arch=gfx950); arcs_amd has no CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 /
+        # libhsa-runtime64.so.1, and a second copy (ROCm's, which libarks_hip.so is linked to)
+        # cannot open the device once the first has.  Importing torch first makes the dynamic
+        # loader satisfy libarks_hip's DT_NEEDED sonames with the copies torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError when the ABI and the header disagree
