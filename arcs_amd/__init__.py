@@ -6,7 +6,7 @@ multi-GPU driver; there is no CPU fallback -- on a machine without the built lib
 gfx950 device every compute call raises.
 """
 from ._lib import ArksError, lib, lib_path  # noqa: F401
-from .api import (ArksIndex, ImapAccumulator, PackedReads, contig_ends, device_count,  # noqa: F401
+from .api import (ArksIndex, ImapAccumulator, PackedReads, PairStep, contig_ends, device_count,  # noqa: F401
                   end_cutoff, key_bytes, map_pairs_packed, map_reads_packed, pack_reads_host)
 
 __all__ = ["ArksError", "ArksIndex", "ImapAccumulator", "PackedReads", "contig_ends",

@@ -193,6 +193,27 @@ class PackedReads:
         return cls(codes, nmask, d_woff, d_lens, rclass[:n], device)
 
     @classmethod
+    def from_arrays_device(cls, d_ascii, d_offsets, d_lens, device=0):
+        """pack ASCII reads that already live on the device (torch uint8 / int64 / int32)"""
+        torch = _torch()
+        dev = torch.device("cuda", device)
+        n = int(d_lens.numel())
+        woff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        woff[1:] = torch.cumsum((d_lens.to(torch.int64) + 31) // 32, 0)
+        total = int(woff[-1].item())
+        pad = torch.zeros(64, dtype=torch.uint8, device=dev)
+        d_ascii = torch.cat([d_ascii, pad])
+        codes = torch.zeros(total + 4, dtype=torch.int64, device=dev)
+        nmask = torch.zeros(total + 4, dtype=torch.int32, device=dev)
+        rclass = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+        check(lib().arks_pack_reads_device(d_ascii.data_ptr(), d_offsets.data_ptr(), d_lens.data_ptr(),
+                                           woff.data_ptr(), n, codes.data_ptr(), nmask.data_ptr(),
+                                           rclass.data_ptr(), device, _stream_ptr(device)),
+              "arks_pack_reads_device")
+        torch.cuda.synchronize(device)
+        return cls(codes, nmask, woff, d_lens.contiguous(), rclass[:n], device)
+
+    @classmethod
     def from_host_packed(cls, packed, device=0):
         """upload the output of pack_reads_host"""
         torch = _torch()
@@ -275,3 +296,38 @@ def map_pairs_packed(index, reads, j_index, pair_ok=None, barcode_id=None, imap=
                                   stored.data_ptr() if stored is not None else None,
                                   reads.device, sp), "arks_pairs_device")
     return conreci, pair[:n_pairs]
+
+
+class PairStep:
+    """One pass of the hot path over a resident batch with every buffer preallocated (what
+    bench.py times): pair gate -> map_reads -> pair rule + imap update."""
+
+    def __init__(self, index, reads, j_index, pair_ok=None, barcode_id=None, imap=None):
+        torch = _torch()
+        dev = reads.codes.device
+        self.index, self.reads, self.j = index, reads, float(j_index)
+        self.pair_ok, self.barcode_id, self.imap = pair_ok, barcode_id, imap
+        self.n_pairs = reads.n_reads // 2
+        self.eval = torch.empty(max(2 * self.n_pairs, 1), dtype=torch.uint8, device=dev)
+        self.conreci = torch.empty(max(reads.n_reads, 1), dtype=torch.int32, device=dev)
+        self.pair = torch.empty(max(self.n_pairs, 1), dtype=torch.int32, device=dev)
+
+    def run(self, stats=None, stored=None, map_events=None):
+        L = lib()
+        r = self.reads
+        sp = _stream_ptr(r.device)
+        check(L.arks_pair_gate_device(self.pair_ok.data_ptr() if self.pair_ok is not None else None,
+                                      r.read_class.data_ptr(), self.n_pairs, self.eval.data_ptr(),
+                                      r.device, sp), "arks_pair_gate_device")
+        if map_events is not None:
+            map_events[0].record()
+        map_reads_packed(self.index, r, self.j, eval_mask=self.eval, stats=stats, out=self.conreci)
+        if map_events is not None:
+            map_events[1].record()
+        check(L.arks_pairs_device(self.conreci.data_ptr(),
+                                  self.pair_ok.data_ptr() if self.pair_ok is not None else None,
+                                  self.barcode_id.data_ptr() if self.barcode_id is not None else None,
+                                  self.n_pairs, self.pair.data_ptr(),
+                                  self.imap.handle if self.imap is not None else None,
+                                  stored.data_ptr() if stored is not None else None, r.device, sp),
+              "arks_pairs_device")
