@@ -50,6 +50,7 @@ SYMBOLS = {
     "arks_index_k": (_I, [_VP]),
     "arks_index_size": (_I64, [_VP]),
     "arks_index_device_bytes": (_I64, [_VP]),
+    "arks_index_kind": (_I, [_VP]),
     "arks_index_export": (_I, [_VP, _VP, _VP]),
     "arks_end_cutoff": (_I, [_I, _I, _I, C.POINTER(_I)]),
     "arks_word_offsets": (_I, [_VP, _I64, _VP]),

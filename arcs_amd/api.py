@@ -112,6 +112,11 @@ class ArksIndex:
         return self._h
 
     @property
+    def kind(self):
+        """0 = hash table, 1 = locality index"""
+        return lib().arks_index_kind(self._h)
+
+    @property
     def device_bytes(self):
         return lib().arks_index_device_bytes(self._h)
 

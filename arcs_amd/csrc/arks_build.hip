@@ -1,0 +1,910 @@
+// arks_build.hip -- index-build kernels of libarks_hip (gfx950 / CDNA4, wave64).
+//
+//   K0  pack_kernel           ASCII -> 2-bit codes + N-mask (+ checkReadSequence class)
+//   K1  visit_kernel          the reference's index-build visit rule (i += k on a NULL k-mer)
+//   K2  insert_kernel         owner-or-0 insertion of every visited contig-end k-mer
+//   K2s build_stats_kernel    second pass for the "removed" counter
+//   K3  map_reads_kernel      per read: window keys -> table probe -> vote   (the hot kernel)
+//   K4  pair_gate_kernel / pairs_kernel   pair rule + (barcode, contig end) accumulation
+//
+// Reference behaviour restated (never its code): Arcs/Arcs.cpp:869-929 (mapKmers), :939-1014
+// (bestContig), :1264-1292 (pair rule), :366-389 (checkReadSequence),
+// Common/ReadsProcessor.cpp:376-535 (prepSeq).
+#include "arks_kernels.hpp"
+
+namespace arks {
+
+// ------------------------------------------------------------------------------------------------
+// K0: packing.  One thread per 32-base word.
+// ------------------------------------------------------------------------------------------------
+// class of an input byte: 0..3 = A C G T (either case), 4 = N/n, 5 = anything else
+// (prepSeq's LUTs accept exactly ACGTacgt, Common/ReadsProcessor.cpp:39-317; checkReadSequence
+// upper-cases first, Arcs/Arcs.cpp:373)
+__device__ __forceinline__ u32
+base_class(u32 ch)
+{
+	const u32 c = (ch >= 'a' && ch <= 'z') ? ch - 32u : ch;
+	u32 r = 5;
+	r = (c == 'A') ? 0u : r;
+	r = (c == 'C') ? 1u : r;
+	r = (c == 'G') ? 2u : r;
+	r = (c == 'T') ? 3u : r;
+	r = (c == 'N') ? 4u : r;
+	return r;
+}
+
+__global__ void
+pack_kernel(
+    const uint8_t* __restrict__ ascii,
+    const u64* __restrict__ offsets,
+    const u32* __restrict__ lens,
+    const u64* __restrict__ word_off,
+    long n_seqs,
+    u64 total_words,
+    u64* __restrict__ codes,
+    u32* __restrict__ nmask,
+    u32* __restrict__ seq_n_count,  // per sequence: number of N/n (may be NULL)
+    u32* __restrict__ seq_other)    // per sequence: != 0 if any byte outside ACGTN (may be NULL)
+{
+	const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= total_words)
+		return;
+	// sequence that owns word w: last r with word_off[r] <= w
+	long lo = 0, hi = n_seqs - 1;
+	while (lo < hi) {
+		const long mid = (lo + hi + 1) >> 1;
+		if (word_off[mid] <= w)
+			lo = mid;
+		else
+			hi = mid - 1;
+	}
+	const long r = lo;
+	const u64 first = (w - word_off[r]) * 32ull;
+	const u32 len = lens[r];
+	if (first >= len) { // zero-length sequence sharing an offset, or padding
+		codes[w] = 0;
+		nmask[w] = 0;
+		return;
+	}
+	const uint8_t* src = ascii + offsets[r] + first;
+	const u32 n = (len - first) < 32u ? (u32)(len - first) : 32u;
+	u64 c = 0;
+	u32 m = 0, nn = 0, other = 0;
+	for (u32 i = 0; i < n; ++i) {
+		const u32 cls = base_class(src[i]);
+		c |= (u64)(cls < 4u ? cls : 0u) << (62 - 2 * i);
+		m |= (cls >= 4u ? 1u : 0u) << (31 - i);
+		nn += cls == 4u;
+		other |= cls == 5u;
+	}
+	codes[w] = c;
+	nmask[w] = m;
+	if (seq_n_count && nn)
+		atomicAdd(seq_n_count + r, nn);
+	if (seq_other && other)
+		atomicOr(seq_other + r, 1u);
+}
+
+// checkReadSequence, Arcs/Arcs.cpp:366-389: only ACGTN, and (double)N / (double)len <= 0.02
+__global__ void
+read_class_kernel(
+    const u32* __restrict__ lens,
+    const u32* __restrict__ seq_n_count,
+    const u32* __restrict__ seq_other,
+    long n,
+    uint8_t* __restrict__ out)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n)
+		return;
+	const double ar = (double)seq_n_count[r] / (double)lens[r]; // 0/0 = NaN -> "> 0.02" false
+	out[r] = (seq_other[r] == 0 && !(ar > 0.02)) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: visit rule of mapKmers (Arcs/Arcs.cpp:887-926).  One thread per contig end: walks the
+// end's N-mask; a valid window is visited and i advances by 1, a NULL window makes i jump by k
+// (so valid windows inside the jumped span are NOT indexed).  Emits a bit per visited start.
+// ------------------------------------------------------------------------------------------------
+// first position >= from (relative to the end's first base) whose N-mask bit is set, or len
+__device__ inline int
+next_invalid(const u32* __restrict__ nm, int from, int len)
+{
+	int w = from >> 5;
+	const int nw = (len + 31) >> 5;
+	if (w >= nw)
+		return len;
+	u32 bits = nm[w] & (0xFFFFFFFFu >> (from & 31));
+	while (bits == 0) {
+		if (++w >= nw)
+			return len;
+		bits = nm[w];
+	}
+	const int pos = (w << 5) + __clz((int)bits);
+	return pos < len ? pos : len;
+}
+
+__global__ void
+visit_kernel(
+    const u32* __restrict__ nmask,
+    const u64* __restrict__ word_off,
+    const u32* __restrict__ lens,
+    long n_ends,
+    int k,
+    u32* __restrict__ visited, // zero-initialised, same indexing as nmask
+    u64* __restrict__ counters) // [0] += null k-mers, [1] += ends shorter than k
+{
+	const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n_ends)
+		return;
+	const int len = (int)lens[e];
+	if (len < k) { // Arcs.cpp:877-882
+		atomicAdd(counters + 1, 1ull);
+		return;
+	}
+	const u32* nm = nmask + word_off[e];
+	u32* vis = visited + word_off[e];
+	const int last = len - k; // last window start
+	u64 nulls = 0;
+	int i = 0;
+	int nb = next_invalid(nm, 0, len);
+	while (i <= last) {
+		if (nb >= i + k) {
+			// windows i .. min(nb - k, last) are all valid: visited consecutively
+			int e2 = nb - k;
+			e2 = e2 > last ? last : e2;
+			for (int p = i; p <= e2;) { // set bits [p, e2] a word at a time
+				const int w = p >> 5, b = p & 31;
+				int n = 32 - b;
+				n = (e2 - p + 1) < n ? (e2 - p + 1) : n;
+				const u32 m = (n == 32) ? 0xFFFFFFFFu : (((1u << n) - 1u) << (32 - b - n));
+				vis[w] |= m; // this thread owns the end's words
+				p += n;
+			}
+			i = e2 + 1;
+		} else {
+			nulls++;
+			i += k; // Arcs.cpp:923
+			if (nb < i)
+				nb = next_invalid(nm, i, len);
+		}
+	}
+	if (nulls)
+		atomicAdd(counters + 0, nulls);
+}
+
+__global__ void
+popcount_kernel(const u32* __restrict__ words, u64 n, u64* __restrict__ out)
+{
+	u64 acc = 0;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+		acc += (u64)__popc(words[i]);
+	for (int off = 32; off > 0; off >>= 1)
+		acc += __shfl_down(acc, off);
+	if ((threadIdx.x & 63) == 0 && acc)
+		atomicAdd(out, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: insertion.  One thread per visited window.  State word protocol (agent scope):
+//   EMPTY -CAS-> LOCKED (winner writes the key) -release-> value+1 ; equal key from another end
+//   turns value+1 into 0+1 (once, counted).  The owner-or-0 rule is commutative, so the result is
+//   independent of execution order, unlike the serial loop of Arcs.cpp:903-920 it replaces.
+// ------------------------------------------------------------------------------------------------
+template <int KW>
+__global__ void
+insert_kernel(
+    const u64* __restrict__ codes,
+    const u32* __restrict__ visited,
+    const u64* __restrict__ word_off, // n_ends + 1 entries
+    long n_ends,
+    u64 total_words,
+    KeyGeom g,
+    TableView t,
+    u64* __restrict__ counters) // [2] += new keys, [3] += keys that lost their unique owner
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x; // global base position
+	const u64 w = pos >> 5;
+	bool active = w < total_words;
+	if (active)
+		active = (visited[w] >> (31 - (pos & 31))) & 1u;
+	u32 n_new = 0, n_lost = 0, owner = 0;
+	Key<KW> c;
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		c.w[j] = 0;
+	u64 s = 0;
+	if (active) {
+		long lo = 0, hi = n_ends - 1; // end that owns word w
+		while (lo < hi) {
+			const long mid = (lo + hi + 1) >> 1;
+			if (word_off[mid] <= w)
+				lo = mid;
+			else
+				hi = mid - 1;
+		}
+		owner = (u32)lo + 1u; // conreci
+		c = reference_key(window_key_at<KW>(codes, pos, g), g);
+		s = mulhi64(key_hash(c), t.cap);
+	}
+	// The loop's trip count is wave-uniform (ballot): a lane that has finished idles inside the
+	// loop until its whole wave has.  With a per-lane exit the compiler is free to sink the
+	// winner's key/state stores to the loop exit, which a SIMT machine reaches only after every
+	// lane has left the loop -- while the wave-mates polling the locked slot never would.
+	bool done = !active;
+	while (__ballot(!done) != 0) {
+		if (!done) {
+			u64* slot = t.slots + s * kSlotWords;
+			u32* state = reinterpret_cast<u32*>(slot + 3);
+			u32* minown = state + 1;
+			u32 st = __hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+			if (st == kEmpty) {
+				u32 expect = kEmpty;
+				if (__hip_atomic_compare_exchange_strong(
+				        state, &expect, kLocked, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+				        __HIP_MEMORY_SCOPE_AGENT)) {
+#pragma unroll
+					for (int j = 0; j < KW; ++j)
+						__hip_atomic_store(slot + j, c.w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(minown, owner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(state, owner + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					n_new = 1;
+					done = true;
+				}
+				// lost the race: look at the same slot again
+			} else if (st != kLocked) {
+				Key<KW> sk;
+#pragma unroll
+				for (int j = 0; j < KW; ++j)
+					sk.w[j] = __hip_atomic_load(slot + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (key_eq(sk, c)) {
+					__hip_atomic_fetch_min(minown, owner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					while (st != owner + 1u && st != 1u) { // seen from a different end -> 0
+						u32 expect = st;
+						if (__hip_atomic_compare_exchange_strong(
+						        state, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+						        __HIP_MEMORY_SCOPE_AGENT)) {
+							n_lost = 1;
+							break;
+						}
+						st = expect;
+					}
+					done = true;
+				} else
+					s = (s + 1 == t.cap) ? 0 : s + 1;
+			}
+			// st == kLocked: the writer is mid-flight -- poll the same slot again
+		}
+	}
+	// wave-level reduction of the two counters
+	const u64 b_new = __ballot(n_new), b_lost = __ballot(n_lost);
+	if ((threadIdx.x & 63) == 0) {
+		if (b_new)
+			atomicAdd(counters + 2, (u64)__popcll(b_new));
+		if (b_lost)
+			atomicAdd(counters + 3, (u64)__popcll(b_lost));
+	}
+}
+
+// K2s: counts the visits whose end is the smallest end that visited the key; the reference's
+// "removed" counter (Arcs.cpp:909, order dependent in the serial loop, ends in ascending order) is
+// total visits minus that count.
+template <int KW>
+__global__ void
+build_stats_kernel(
+    const u64* __restrict__ codes,
+    const u32* __restrict__ visited,
+    const u64* __restrict__ word_off,
+    long n_ends,
+    u64 total_words,
+    KeyGeom g,
+    TableView t,
+    u64* __restrict__ counters) // [4] += visits by the key's smallest end
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 w = pos >> 5;
+	bool active = w < total_words;
+	if (active)
+		active = (visited[w] >> (31 - (pos & 31))) & 1u;
+	u32 hit = 0;
+	if (active) {
+		long lo = 0, hi = n_ends - 1;
+		while (lo < hi) {
+			const long mid = (lo + hi + 1) >> 1;
+			if (word_off[mid] <= w)
+				lo = mid;
+			else
+				hi = mid - 1;
+		}
+		const u32 owner = (u32)lo + 1u;
+		const u64 wbase = word_off[lo];
+		const int p = (int)(pos - wbase * 32ull);
+		const Key<KW> c = reference_key(window_key<KW>(codes, wbase, p, g), g);
+		u64 s = mulhi64(key_hash(c), t.cap);
+		for (;;) {
+			const u64* slot = t.slots + s * kSlotWords;
+			const u64 meta = slot[3];
+			if ((u32)meta == kEmpty)
+				break; // cannot happen for a visited window
+			if (key_eq(slot_key<KW>(slot), c)) {
+				hit = (u32)(meta >> 32) == owner;
+				break;
+			}
+			s = (s + 1 == t.cap) ? 0 : s + 1;
+		}
+	}
+	const u64 b = __ballot(hit);
+	if ((threadIdx.x & 63) == 0 && b)
+		atomicAdd(counters + 4, (u64)__popcll(b));
+}
+
+// number of slots whose value is a real contig end (state >= 2): "unique kmers"
+__global__ void
+count_unique_kernel(TableView t, u64* __restrict__ out)
+{
+	u64 acc = 0;
+	for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < t.cap; s += (u64)gridDim.x * blockDim.x)
+		acc += (u32)t.slots[s * kSlotWords + 3] >= 2u;
+	for (int off = 32; off > 0; off >>= 1)
+		acc += __shfl_down(acc, off);
+	if ((threadIdx.x & 63) == 0 && acc)
+		atomicAdd(out, acc);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Locality index ("B", arks_device.hpp) -- build kernels.  All run once per index, one thread per
+// text position unless noted; bitmaps share the indexing of `visited`.
+// ------------------------------------------------------------------------------------------------
+
+// contig-end index of every 32-base word (0 in the front / back padding)
+__global__ void
+word_owner_kernel(const u64* __restrict__ word_off, long n_ends, u64 total_words, u32* __restrict__ owner)
+{
+	const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= total_words)
+		return;
+	u32 o = 0;
+	if (n_ends > 0 && w >= word_off[0] && w < word_off[n_ends]) {
+		long lo = 0, hi = n_ends - 1;
+		while (lo < hi) {
+			const long mid = (lo + hi + 1) >> 1;
+			if (word_off[mid] <= w)
+				lo = mid;
+			else
+				hi = mid - 1;
+		}
+		o = (u32)lo + 1u;
+	}
+	owner[w] = o;
+}
+
+// Is the regular (non-palindromic) reference key c the quirk image of the palindrome that its own
+// first half spells?  (Only such keys can be hit by a palindromic query, see DESIGN.md.)
+template <int KW>
+__device__ __forceinline__ bool
+is_quirk_image(const Key<KW>& c, const KeyGeom& g)
+{
+	if (g.k & 1)
+		return false;
+	// byte `half` of a quirk key is 0 (ReadsProcessor.cpp:505: the byte is skipped)
+	u64 wsel = 0;
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		wsel = ((g.half >> 3) == j) ? c.w[j] : wsel;
+	if (((wsel >> (56 - 8 * (g.half & 7))) & 0xFFull) != 0)
+		return false;
+	// Q = first k/2 bases of c followed by their reverse complement
+	const int hb = g.k; // bits of the first half: 2 * (k/2)
+	Key<KW> h, lowmask;
+#pragma unroll
+	for (int j = 0; j < KW; ++j) {
+		const int bits = hb - 64 * j;
+		const u64 m = bits <= 0 ? 0ull : (bits >= 64 ? ~0ull : ~(~0ull >> bits));
+		h.w[j] = c.w[j] & m;
+		lowmask.w[j] = g.mask[j] & ~m;
+	}
+	const Key<KW> rh = key_revcomp(h, g); // T..T followed by revcomp(first half)
+	Key<KW> q;
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		q.w[j] = h.w[j] | (rh.w[j] & lowmask.w[j]);
+	return key_eq(key_palindrome_quirk(q, g), c);
+}
+
+// per visited window: ambiguity bit (value 0 in the full table), palindrome / quirk-image bits,
+// and the positions of its minimizer (all ties)
+template <int KW>
+__global__ void
+bmark_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ visited, u64 total_words, KeyGeom g,
+    TableView full, int w, u32* __restrict__ ambig, u32* __restrict__ is_min,
+    u32* __restrict__ is_pal, u32* __restrict__ is_img)
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 word = pos >> 5;
+	if (word >= total_words)
+		return;
+	const u32 bit = 1u << (31 - (u32)(pos & 31));
+	if (!(visited[word] & bit))
+		return;
+	const Key<KW> f = window_key_at<KW>(codes, pos, g);
+	const Key<KW> r = key_revcomp(f, g);
+	const bool pal = key_eq(f, r);
+	Key<KW> c;
+	const bool lt = key_less(f, r);
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		c.w[j] = lt ? f.w[j] : r.w[j];
+	if (pal)
+		c = key_palindrome_quirk(f, g);
+	if (table_lookup<KW>(full, c) == 0)
+		atomicOr(ambig + word, bit);
+	if (pal)
+		atomicOr(is_pal + word, bit);
+	else if (is_quirk_image(c, g))
+		atomicOr(is_img + word, bit);
+	u32 min_h;
+	int off;
+	window_minimizer(codes, pos, w, min_h, off);
+	for (int o = off; o < w; ++o) {
+		const u32 mf = mmer_fw(codes, pos + (u64)o);
+		const u32 mr = mmer_rc(mf);
+		if (mmer_order(mf < mr ? mf : mr) == min_h) {
+			const u64 q = pos + (u64)o;
+			atomicOr(is_min + (q >> 5), 1u << (31 - (u32)(q & 31)));
+		}
+	}
+}
+
+// ---- minimizer occurrence counts: open-addressed u32 key (cm | 0x80000000) -> u32 counter -------
+constexpr u32 kCntForced = 0x80000000u; // heavy by decree (quirk-image minimizers)
+constexpr u32 kCntMarker = 0x40000000u; // the HEAVY marker entry has been written to mtab
+constexpr u32 kCntMask = 0x3FFFFFFFu;
+
+__device__ inline u32*
+ctab_slot(u32* __restrict__ keys, u32* __restrict__ cnts, u64 cap, u32 cm, bool insert)
+{
+	const u32 key = cm | 0x80000000u;
+	u64 s = mtab_home(cm, cap);
+	for (;;) {
+		u32 cur = __hip_atomic_load(keys + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (cur == 0) {
+			if (!insert)
+				return nullptr;
+			u32 expect = 0;
+			if (__hip_atomic_compare_exchange_strong(
+			        keys + s, &expect, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+				cur = key;
+			else
+				cur = expect;
+		}
+		if (cur == key)
+			return cnts + s;
+		s = (s + 1 == cap) ? 0 : s + 1;
+	}
+}
+
+__global__ void
+bcount_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ is_min, u64 total_words,
+    u32* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap)
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 word = pos >> 5;
+	if (word >= total_words || !((is_min[word] >> (31 - (u32)(pos & 31))) & 1u))
+		return;
+	const u32 mf = mmer_fw(codes, pos);
+	const u32 mr = mmer_rc(mf);
+	atomicAdd(ctab_slot(ckeys, ccnts, ccap, mf < mr ? mf : mr, true), 1u);
+}
+
+// 15-mer at offset o of a key (rare paths only)
+template <int KW>
+__device__ inline u32
+key_mmer(const Key<KW>& x, int o)
+{
+	u32 m = 0;
+	for (int i = 0; i < kM; ++i)
+		m = (m << 2) | key_base(x, o + i);
+	return m;
+}
+
+// For every indexed palindrome Q: the sequence X' that spells its quirk key K'(Q).  A regular query
+// whose canonical k-mer is X' must find K' -- which is not in the text -- so the minimizer of X' is
+// decreed heavy: such queries then consult the fallback table, where K' lives.
+// PHASE 0: decree (count table); PHASE 1: write the HEAVY marker into mtab (once per minimizer).
+template <int KW, int PHASE>
+__global__ void
+bforce_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ is_pal, u64 total_words, KeyGeom g, int w,
+    u32* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap)
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 word = pos >> 5;
+	if (word >= total_words || !((is_pal[word] >> (31 - (u32)(pos & 31))) & 1u))
+		return;
+	const Key<KW> x = key_palindrome_quirk(window_key_at<KW>(codes, pos, g), g);
+	const Key<KW> rx = key_revcomp(x, g);
+	if (!key_less(x, rx))
+		return; // X' is not a canonical non-palindromic k-mer: no regular query has key K'
+	u32 min_h = 0xFFFFFFFFu;
+	for (int o = 0; o < w; ++o) {
+		const u32 mf = key_mmer(x, o), mr = mmer_rc(mf);
+		const u32 h = mmer_order(mf < mr ? mf : mr);
+		min_h = h < min_h ? h : min_h;
+	}
+	for (int o = 0; o < w; ++o) {
+		const u32 mf = key_mmer(x, o), mr = mmer_rc(mf);
+		const u32 cm = mf < mr ? mf : mr;
+		if (mmer_order(cm) != min_h)
+			continue;
+		u32* cnt = ctab_slot(ckeys, ccnts, ccap, cm, true);
+		if (PHASE == 0)
+			atomicOr(cnt, kCntForced);
+		else if (!(atomicOr(cnt, kCntMarker) & kCntMarker)) {
+			u64 s = mtab_home(cm, mcap);
+			const u64 e = mtab_entry(cm, 0, kHeavyPos);
+			for (;;) {
+				u64 expect = 0;
+				if (__hip_atomic_compare_exchange_strong(
+				        mtab + s, &expect, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+					break;
+				s = (s + 1 == mcap) ? 0 : s + 1;
+			}
+		}
+	}
+}
+
+// every minimizer position -> one mtab entry, or (heavy minimizer) the heavy bit + one marker
+__global__ void
+bfill_mtab_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ is_min, u64 total_words,
+    u32* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap,
+    u32* __restrict__ heavy_min)
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 word = pos >> 5;
+	if (word >= total_words || !((is_min[word] >> (31 - (u32)(pos & 31))) & 1u))
+		return;
+	const u32 mf = mmer_fw(codes, pos);
+	const u32 mr = mmer_rc(mf);
+	const u32 cm = mf < mr ? mf : mr;
+	u32* cnt = ctab_slot(ckeys, ccnts, ccap, cm, false);
+	const u32 c = *cnt;
+	u64 e;
+	if ((c & kCntForced) || (c & kCntMask) > (u32)kHeavy) {
+		atomicOr(heavy_min + word, 1u << (31 - (u32)(pos & 31)));
+		if (atomicOr(cnt, kCntMarker) & kCntMarker)
+			return;
+		e = mtab_entry(cm, 0, kHeavyPos);
+	} else
+		e = mtab_entry(cm, mf < mr ? 1u : 0u, (u32)pos);
+	u64 s = mtab_home(cm, mcap);
+	for (;;) {
+		u64 expect = 0;
+		if (__hip_atomic_compare_exchange_strong(
+		        mtab + s, &expect, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+			break;
+		s = (s + 1 == mcap) ? 0 : s + 1;
+	}
+}
+
+// (key, value) -> table, first writer wins (every occurrence of a key carries the same value).
+template <int KW>
+__device__ inline void
+table_put(const TableView& t, const Key<KW>& c, u32 value, bool active)
+{
+	u64 s = active ? mulhi64(key_hash(c), t.cap) : 0;
+	bool done = !active;
+	// wave-uniform trip count (see insert_kernel): every lane stays in the loop until the whole
+	// wave is done, so a lane that polls a slot locked by a wave-mate cannot starve it
+	while (__ballot(!done) != 0) {
+		if (!done) {
+			u64* slot = t.slots + s * kSlotWords;
+			u32* state = reinterpret_cast<u32*>(slot + 3);
+			const u32 st = __hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+			if (st == kEmpty) {
+				u32 expect = kEmpty;
+				if (__hip_atomic_compare_exchange_strong(
+				        state, &expect, kLocked, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+				        __HIP_MEMORY_SCOPE_AGENT)) {
+#pragma unroll
+					for (int j = 0; j < KW; ++j)
+						__hip_atomic_store(slot + j, c.w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(state, value + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					done = true;
+				}
+			} else if (st != kLocked) {
+				Key<KW> sk;
+#pragma unroll
+				for (int j = 0; j < KW; ++j)
+					sk.w[j] = __hip_atomic_load(slot + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (key_eq(sk, c))
+					done = true;
+				else
+					s = (s + 1 == t.cap) ? 0 : s + 1;
+			}
+		}
+	}
+}
+
+// Windows the text path cannot (or must not) answer go to the fallback table: palindromes (their
+// key is not their sequence), quirk images (a palindromic query may ask for them), and every
+// window one of whose minimizer positions is heavy.  INSERT = false only counts them.
+template <int KW, bool INSERT>
+__global__ void
+bfallback_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ visited, const u32* __restrict__ ambig,
+    const u32* __restrict__ is_pal, const u32* __restrict__ is_img, const u32* __restrict__ heavy_min,
+    const u32* __restrict__ word_owner, u64 total_words, KeyGeom g, int w, TableView fb,
+    u64* __restrict__ counter)
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 word = pos >> 5;
+	bool take = false;
+	const u32 sh = 31 - (u32)(pos & 31);
+	if (word < total_words && ((visited[word] >> sh) & 1u)) {
+		take = ((is_pal[word] | is_img[word]) >> sh) & 1u;
+		if (!take) {
+			u32 min_h;
+			int off;
+			window_minimizer(codes, pos, w, min_h, off);
+			for (int o = off; o < w && !take; ++o) {
+				const u32 mf = mmer_fw(codes, pos + (u64)o);
+				const u32 mr = mmer_rc(mf);
+				if (mmer_order(mf < mr ? mf : mr) == min_h)
+					take = bit_at(heavy_min, pos + (u64)o);
+			}
+		}
+	}
+	if (INSERT) {
+		Key<KW> c;
+		u32 value = 0;
+#pragma unroll
+		for (int j = 0; j < KW; ++j)
+			c.w[j] = 0;
+		if (take) {
+			c = reference_key(window_key_at<KW>(codes, pos, g), g);
+			value = ((ambig[word] >> sh) & 1u) ? 0u : word_owner[word];
+		}
+		table_put<KW>(fb, c, value, take);
+	} else {
+		const u64 b = __ballot(take);
+		if ((threadIdx.x & 63) == 0 && b)
+			atomicAdd(counter, (u64)__popcll(b));
+	}
+}
+
+// export: one (key, value) record per visited window (the host removes duplicates)
+template <int KW>
+__global__ void
+bexport_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ visited, const u32* __restrict__ ambig,
+    const u32* __restrict__ word_owner, u64 total_words, KeyGeom g, u64* __restrict__ out_keys,
+    int* __restrict__ out_vals, u64* __restrict__ counter)
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 word = pos >> 5;
+	const u32 sh = 31 - (u32)(pos & 31);
+	if (word >= total_words || !((visited[word] >> sh) & 1u))
+		return;
+	const Key<KW> c = reference_key(window_key_at<KW>(codes, pos, g), g);
+	const u64 i = atomicAdd(counter, 1ull);
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		out_keys[i * KW + j] = c.w[j];
+	out_vals[i] = ((ambig[word] >> sh) & 1u) ? 0 : (int)word_owner[word];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from arks_capi.cpp through arks_kernels.hpp)
+// ------------------------------------------------------------------------------------------------
+#define ARKS_LAUNCH_CHECK()                                                                        \
+	do {                                                                                           \
+		hipError_t e_ = hipGetLastError();                                                         \
+		if (e_ != hipSuccess)                                                                      \
+			return e_;                                                                             \
+	} while (0)
+
+static inline unsigned
+blocks_for(u64 n, unsigned bs)
+{
+	u64 b = (n + bs - 1) / bs;
+	return (unsigned)(b ? b : 1);
+}
+
+hipError_t
+launch_pack(
+    const uint8_t* ascii, const u64* offsets, const u32* lens, const u64* word_off, long n_seqs,
+    u64 total_words, u64* codes, u32* nmask, u32* n_count, u32* other, hipStream_t st)
+{
+	if (n_seqs <= 0 || total_words == 0)
+		return hipSuccess;
+	pack_kernel<<<blocks_for(total_words, 256), 256, 0, st>>>(
+	    ascii, offsets, lens, word_off, n_seqs, total_words, codes, nmask, n_count, other);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_read_class(const u32* lens, const u32* n_count, const u32* other, long n, uint8_t* out, hipStream_t st)
+{
+	if (n <= 0)
+		return hipSuccess;
+	read_class_kernel<<<blocks_for((u64)n, 256), 256, 0, st>>>(lens, n_count, other, n, out);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_visit(
+    const u32* nmask, const u64* word_off, const u32* lens, long n_ends, int k, u32* visited,
+    u64* counters, hipStream_t st)
+{
+	if (n_ends <= 0)
+		return hipSuccess;
+	visit_kernel<<<blocks_for((u64)n_ends, 64), 64, 0, st>>>(nmask, word_off, lens, n_ends, k, visited, counters);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_popcount(const u32* words, u64 n, u64* out, hipStream_t st)
+{
+	if (n == 0)
+		return hipSuccess;
+	unsigned b = blocks_for(n, 256);
+	b = b > 4096 ? 4096 : b;
+	popcount_kernel<<<b, 256, 0, st>>>(words, n, out);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_insert(
+    int kw, const u64* codes, const u32* visited, const u64* word_off, long n_ends, u64 total_words,
+    const KeyGeom& g, TableView t, u64* counters, hipStream_t st)
+{
+	if (total_words == 0 || n_ends <= 0)
+		return hipSuccess;
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+	if (kw == 2)
+		insert_kernel<2><<<b, 256, 0, st>>>(codes, visited, word_off, n_ends, total_words, g, t, counters);
+	else
+		insert_kernel<3><<<b, 256, 0, st>>>(codes, visited, word_off, n_ends, total_words, g, t, counters);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_build_stats(
+    int kw, const u64* codes, const u32* visited, const u64* word_off, long n_ends, u64 total_words,
+    const KeyGeom& g, TableView t, u64* counters, hipStream_t st)
+{
+	if (total_words == 0 || n_ends <= 0)
+		return hipSuccess;
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+	if (kw == 2)
+		build_stats_kernel<2><<<b, 256, 0, st>>>(codes, visited, word_off, n_ends, total_words, g, t, counters);
+	else
+		build_stats_kernel<3><<<b, 256, 0, st>>>(codes, visited, word_off, n_ends, total_words, g, t, counters);
+	ARKS_LAUNCH_CHECK();
+	unsigned bu = blocks_for(t.cap, 256);
+	bu = bu > 4096 ? 4096 : bu;
+	count_unique_kernel<<<bu, 256, 0, st>>>(t, counters + 5);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+
+hipError_t
+launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	word_owner_kernel<<<blocks_for(total_words, 256), 256, 0, st>>>(word_off, n_ends, total_words, owner);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+#define ARKS_KW_DISPATCH(kw, CALL2, CALL3)                                                         \
+	do {                                                                                           \
+		if ((kw) == 2) { CALL2; } else { CALL3; }                                                  \
+	} while (0)
+
+hipError_t
+launch_bmark(
+    int kw, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,
+    int w, u32* ambig, u32* is_min, u32* is_pal, u32* is_img, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+	ARKS_KW_DISPATCH(kw,
+	    (bmark_kernel<2><<<b, 256, 0, st>>>(codes, visited, total_words, g, full, w, ambig, is_min, is_pal, is_img)),
+	    (bmark_kernel<3><<<b, 256, 0, st>>>(codes, visited, total_words, g, full, w, ambig, is_min, is_pal, is_img)));
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_bcount(const u64* codes, const u32* is_min, u64 total_words, u32* ckeys, u32* ccnts, u64 ccap, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	bcount_kernel<<<blocks_for(total_words * 32ull, 256), 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_bforce(
+    int kw, int phase, const u64* codes, const u32* is_pal, u64 total_words, const KeyGeom& g, int w,
+    u32* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+	if (phase == 0)
+		ARKS_KW_DISPATCH(kw,
+		    (bforce_kernel<2, 0><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)),
+		    (bforce_kernel<3, 0><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)));
+	else
+		ARKS_KW_DISPATCH(kw,
+		    (bforce_kernel<2, 1><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)),
+		    (bforce_kernel<3, 1><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)));
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_bfill_mtab(
+    const u64* codes, const u32* is_min, u64 total_words, u32* ckeys, u32* ccnts, u64 ccap, u64* mtab,
+    u64 mcap, u32* heavy_min, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	bfill_mtab_kernel<<<blocks_for(total_words * 32ull, 256), 256, 0, st>>>(
+	    codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_bfallback(
+    int kw, bool insert, const u64* codes, const u32* visited, const u32* ambig, const u32* is_pal,
+    const u32* is_img, const u32* heavy_min, const u32* word_owner, u64 total_words, const KeyGeom& g,
+    int w, TableView fb, u64* counter, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+#define ARKS_FB(KWV, INS)                                                                          \
+	bfallback_kernel<KWV, INS><<<b, 256, 0, st>>>(                                                 \
+	    codes, visited, ambig, is_pal, is_img, heavy_min, word_owner, total_words, g, w, fb, counter)
+	if (insert)
+		ARKS_KW_DISPATCH(kw, (ARKS_FB(2, true)), (ARKS_FB(3, true)));
+	else
+		ARKS_KW_DISPATCH(kw, (ARKS_FB(2, false)), (ARKS_FB(3, false)));
+#undef ARKS_FB
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_bexport(
+    int kw, const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner,
+    u64 total_words, const KeyGeom& g, u64* out_keys, int* out_vals, u64* counter, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+	ARKS_KW_DISPATCH(kw,
+	    (bexport_kernel<2><<<b, 256, 0, st>>>(codes, visited, ambig, word_owner, total_words, g, out_keys, out_vals, counter)),
+	    (bexport_kernel<3><<<b, 256, 0, st>>>(codes, visited, ambig, word_owner, total_words, g, out_keys, out_vals, counter)));
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+} // namespace arks

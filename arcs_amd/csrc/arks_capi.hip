@@ -5,6 +5,8 @@
 #include "arks_kernels.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +25,16 @@ fail_hip(hipError_t e, const char* what)
 	(void)hipGetLastError(); // clear the sticky launch error, if any
 	return e == hipErrorOutOfMemory ? ARKS_ERR_OOM : ARKS_ERR_HIP;
 }
+
+static bool g_trace = std::getenv("ARKS_TRACE") != nullptr;
+#define ARKS_TRACE_STEP(name)                                                                      \
+	do {                                                                                           \
+		if (g_trace) {                                                                             \
+			hipError_t te_ = hipDeviceSynchronize();                                               \
+			std::fprintf(stderr, "[arks] %s: %s\n", name, hipGetErrorString(te_));                 \
+			std::fflush(stderr);                                                                   \
+		}                                                                                          \
+	} while (0)
 
 #define HIP_TRY(expr)                                                                              \
 	do {                                                                                           \
@@ -95,9 +107,20 @@ struct arks_index
 	int kw = 0;
 	int device = 0;
 	int n_cu = 256;
+	int kind = 0; // 0 = plain hash table, 1 = locality index (text + minimizer table)
 	KeyGeom geom;
-	TableView table{ nullptr, 0 };
+	TableView table{ nullptr, 0 }; // kind 0: the index
+	BIndexView bx{};               // kind 1: the index (views into the buffers below)
+	u64* codes = nullptr;
+	u32* visited = nullptr;
+	u32* ambig = nullptr;
+	u32* word_owner = nullptr;
+	u64* mtab = nullptr;
+	u64 text_words = 0;  // words of text incl. front padding (excl. back padding)
+	u64 alloc_words = 0;
 	int64_t n_keys = 0;
+	int64_t n_visited = 0;
+	int64_t n_minimizers = 0, n_fallback = 0;
 	// redo queue of the map kernel (indices of reads that need the slow path)
 	mutable u32* queue = nullptr;
 	mutable u32* queue_count = nullptr;
@@ -318,6 +341,15 @@ arks_pack_reads_host(
 /* index                                                                                          */
 /* ---------------------------------------------------------------------------------------------- */
 
+static int
+want_locality(int k)
+{
+	const char* e = std::getenv("ARKS_INDEX_KIND");
+	if (e && std::strcmp(e, "hash") == 0)
+		return 0;
+	return k >= 20; // below that the minimizer window degenerates; the hash table serves
+}
+
 int
 arks_index_build(
     arks_index** out,
@@ -354,26 +386,36 @@ arks_index_build(
 	}
 
 	hipStream_t st = nullptr;
-	std::vector<uint64_t> word_off((size_t)n_ends + 1, 0);
-	// contiguous copy of the end strings (they may be scattered in the caller's buffer)
+	const int kBackPad = 16;
+	std::vector<uint64_t> word_off((size_t)n_ends + 1, 0), offs((size_t)n_ends + 1, 0);
 	uint64_t total_bases = 0;
-	for (int64_t e = 0; e < n_ends; ++e)
-		total_bases += h_lens[e];
-	std::vector<uint64_t> offs((size_t)n_ends + 1, 0);
-	DevBuf d_ascii, d_offs, d_lens, d_woff, d_codes, d_nmask, d_visited, d_counters;
-	u64 total_words = 0, counters[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	u64 visited_total = 0;
+	DevBuf d_ascii, d_offs, d_lens, d_woff, d_nmask, d_counters, d_full;
+	DevBuf d_ismin, d_ispal, d_isimg, d_heavy, d_ckeys, d_ccnts;
+	u64 text_words = 0, alloc_words = 0, counters[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	u64 visited_total = 0, n_min = 0, n_pal = 0, n_fb = 0, ccap = 0, mcap = 0;
+	TableView full{ nullptr, 0 };
+	const int w = k - kM + 1;
+	bool locality = false;
+	size_t bm_bytes = 0;
 
-	arks_word_offsets(h_lens, n_ends, word_off.data());
-	total_words = word_off[(size_t)n_ends];
 	{
-		uint64_t acc = 0;
+		uint64_t acc = kFrontPadWords, bacc = 0; // the text starts kFrontPadWords into its arrays
 		for (int64_t e = 0; e < n_ends; ++e) {
-			offs[(size_t)e] = acc;
-			acc += h_lens[e];
+			word_off[(size_t)e] = acc;
+			offs[(size_t)e] = bacc;
+			acc += ((uint64_t)h_lens[e] + 31) / 32;
+			bacc += h_lens[e];
 		}
-		offs[(size_t)n_ends] = acc;
+		word_off[(size_t)n_ends] = acc;
+		offs[(size_t)n_ends] = bacc;
+		total_bases = bacc;
+		text_words = acc;
+		alloc_words = acc + kBackPad;
 	}
+	// text positions are 32-bit in the minimizer table
+	locality = want_locality(k) && alloc_words * 32ull < 0xFFFF0000ull;
+	bm_bytes = sizeof(u32) * alloc_words;
+
 	HIP_TRY(d_ascii.alloc(total_bases + 64));
 	for (int64_t e = 0; e < n_ends; ++e) // one copy per end: the source need not be contiguous
 		if (h_lens[e])
@@ -387,44 +429,54 @@ arks_index_build(
 	if (n_ends)
 		HIP_TRY(hipMemcpy(d_lens.p, h_lens, sizeof(u32) * (size_t)n_ends, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(d_woff.p, word_off.data(), sizeof(u64) * ((size_t)n_ends + 1), hipMemcpyHostToDevice));
-	HIP_TRY(d_codes.alloc(sizeof(u64) * (total_words + ARKS_PAD_WORDS)));
-	HIP_TRY(d_nmask.alloc(sizeof(u32) * (total_words + ARKS_PAD_WORDS)));
-	HIP_TRY(d_visited.alloc(sizeof(u32) * (total_words + ARKS_PAD_WORDS)));
+	{
+		void* p = nullptr;
+		HIP_TRY(hipMalloc(&p, sizeof(u64) * alloc_words));
+		idx->codes = static_cast<u64*>(p);
+		HIP_TRY(hipMalloc(&p, bm_bytes));
+		idx->visited = static_cast<u32*>(p);
+	}
+	HIP_TRY(d_nmask.alloc(bm_bytes));
 	HIP_TRY(d_counters.alloc(sizeof(counters)));
-	HIP_TRY(hipMemsetAsync(d_codes.p, 0, sizeof(u64) * (total_words + ARKS_PAD_WORDS), st));
-	HIP_TRY(hipMemsetAsync(d_nmask.p, 0, sizeof(u32) * (total_words + ARKS_PAD_WORDS), st));
-	HIP_TRY(hipMemsetAsync(d_visited.p, 0, sizeof(u32) * (total_words + ARKS_PAD_WORDS), st));
+	HIP_TRY(hipMemsetAsync(idx->codes, 0, sizeof(u64) * alloc_words, st));
+	HIP_TRY(hipMemsetAsync(d_nmask.p, 0, bm_bytes, st));
+	HIP_TRY(hipMemsetAsync(idx->visited, 0, bm_bytes, st));
 	HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
 
 	HIP_TRY(launch_pack(
 	    d_ascii.as<uint8_t>(), d_offs.as<u64>(), d_lens.as<u32>(), d_woff.as<u64>(), (long)n_ends,
-	    total_words, d_codes.as<u64>(), d_nmask.as<u32>(), nullptr, nullptr, st));
+	    text_words, idx->codes, d_nmask.as<u32>(), nullptr, nullptr, st));
+	ARKS_TRACE_STEP("launch_pack");
 	HIP_TRY(launch_visit(
-	    d_nmask.as<u32>(), d_woff.as<u64>(), d_lens.as<u32>(), (long)n_ends, k, d_visited.as<u32>(),
+	    d_nmask.as<u32>(), d_woff.as<u64>(), d_lens.as<u32>(), (long)n_ends, k, idx->visited,
 	    d_counters.as<u64>(), st));
-	HIP_TRY(launch_popcount(d_visited.as<u32>(), total_words, d_counters.as<u64>() + 6, st));
+	ARKS_TRACE_STEP("launch_visit");
+	HIP_TRY(launch_popcount(idx->visited, text_words, d_counters.as<u64>() + 6, st));
+	ARKS_TRACE_STEP("launch_popcount");
 	HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	visited_total = counters[6];
 
-	// capacity: load factor <= 0.5 over the visited windows (an upper bound of the distinct keys)
-	idx->table.cap = std::max<u64>(1024, visited_total * 2 + 64);
-	{
-		void* p = nullptr;
-		HIP_TRY(hipMalloc(&p, idx->table.cap * kSlotWords * sizeof(u64)));
-		idx->table.slots = static_cast<u64*>(p);
-	}
-	HIP_TRY(hipMemsetAsync(idx->table.slots, 0, idx->table.cap * kSlotWords * sizeof(u64), st));
+	// the full exact table: load factor <= 0.5 over the visited windows (>= the distinct keys)
+	full.cap = std::max<u64>(1024, visited_total * 2 + 64);
+	HIP_TRY(d_full.alloc(full.cap * kSlotWords * sizeof(u64)));
+	full.slots = d_full.as<u64>();
+	HIP_TRY(hipMemsetAsync(full.slots, 0, full.cap * kSlotWords * sizeof(u64), st));
 	HIP_TRY(launch_insert(
-	    idx->kw, d_codes.as<u64>(), d_visited.as<u32>(), d_woff.as<u64>(), (long)n_ends, total_words,
-	    idx->geom, idx->table, d_counters.as<u64>(), st));
+	    idx->kw, idx->codes, idx->visited, d_woff.as<u64>(), (long)n_ends, text_words, idx->geom, full,
+	    d_counters.as<u64>(), st));
+	ARKS_TRACE_STEP("launch_insert");
 	if (stats)
 		HIP_TRY(launch_build_stats(
-		    idx->kw, d_codes.as<u64>(), d_visited.as<u32>(), d_woff.as<u64>(), (long)n_ends,
-		    total_words, idx->geom, idx->table, d_counters.as<u64>(), st));
+		    idx->kw, idx->codes, idx->visited, d_woff.as<u64>(), (long)n_ends, text_words, idx->geom,
+		    full, d_counters.as<u64>(), st));
+	ARKS_TRACE_STEP("launch_build_stats");
 	HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	idx->n_keys = (int64_t)counters[2];
+	idx->n_visited = (int64_t)visited_total;
+	idx->text_words = text_words;
+	idx->alloc_words = alloc_words;
 	if (stats) {
 		stats->total_kmers = visited_total;
 		stats->null_kmers = counters[0];
@@ -433,6 +485,111 @@ arks_index_build(
 		stats->collisions = visited_total - counters[2];
 		stats->removed_dup = visited_total - counters[4];
 		stats->unique = counters[5];
+	}
+
+	if (!locality) {
+		idx->kind = 0;
+		idx->table = full;
+		d_full.p = nullptr; // ownership moves to the index
+		(void)hipFree(idx->codes);
+		(void)hipFree(idx->visited);
+		idx->codes = nullptr;
+		idx->visited = nullptr;
+	} else {
+		idx->kind = 1;
+		{
+			void* p = nullptr;
+			HIP_TRY(hipMalloc(&p, bm_bytes));
+			idx->ambig = static_cast<u32*>(p);
+			HIP_TRY(hipMalloc(&p, bm_bytes));
+			idx->word_owner = static_cast<u32*>(p);
+		}
+		HIP_TRY(d_ismin.alloc(bm_bytes));
+		HIP_TRY(d_ispal.alloc(bm_bytes));
+		HIP_TRY(d_isimg.alloc(bm_bytes));
+		HIP_TRY(d_heavy.alloc(bm_bytes));
+		HIP_TRY(hipMemsetAsync(idx->ambig, 0, bm_bytes, st));
+		HIP_TRY(hipMemsetAsync(d_ismin.p, 0, bm_bytes, st));
+		HIP_TRY(hipMemsetAsync(d_ispal.p, 0, bm_bytes, st));
+		HIP_TRY(hipMemsetAsync(d_isimg.p, 0, bm_bytes, st));
+		HIP_TRY(hipMemsetAsync(d_heavy.p, 0, bm_bytes, st));
+		HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
+		HIP_TRY(launch_word_owner(d_woff.as<u64>(), (long)n_ends, alloc_words, idx->word_owner, st));
+	ARKS_TRACE_STEP("launch_word_owner");
+		HIP_TRY(launch_bmark(
+		    idx->kw, idx->codes, idx->visited, text_words, idx->geom, full, w, idx->ambig,
+		    d_ismin.as<u32>(), d_ispal.as<u32>(), d_isimg.as<u32>(), st));
+	ARKS_TRACE_STEP("launch_bmark");
+		HIP_TRY(launch_popcount(d_ismin.as<u32>(), text_words, d_counters.as<u64>() + 0, st));
+	ARKS_TRACE_STEP("launch_popcount");
+		HIP_TRY(launch_popcount(d_ispal.as<u32>(), text_words, d_counters.as<u64>() + 1, st));
+	ARKS_TRACE_STEP("launch_popcount");
+		HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		n_min = counters[0];
+		n_pal = counters[1];
+		// the full table is no longer needed: every position now carries its value bits
+		(void)hipFree(d_full.p);
+		d_full.p = nullptr;
+		ccap = 2 * (n_min + 4 * n_pal) + 64;
+		mcap = 2 * (n_min + 4 * n_pal) + 64;
+		HIP_TRY(d_ckeys.alloc(sizeof(u32) * ccap));
+		HIP_TRY(d_ccnts.alloc(sizeof(u32) * ccap));
+		{
+			void* p = nullptr;
+			HIP_TRY(hipMalloc(&p, sizeof(u64) * mcap));
+			idx->mtab = static_cast<u64*>(p);
+		}
+		HIP_TRY(hipMemsetAsync(d_ckeys.p, 0, sizeof(u32) * ccap, st));
+		HIP_TRY(hipMemsetAsync(d_ccnts.p, 0, sizeof(u32) * ccap, st));
+		HIP_TRY(hipMemsetAsync(idx->mtab, 0, sizeof(u64) * mcap, st));
+		HIP_TRY(launch_bcount(idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u32>(), d_ccnts.as<u32>(), ccap, st));
+	ARKS_TRACE_STEP("launch_bcount");
+		HIP_TRY(launch_bforce(
+		    idx->kw, 0, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, d_ckeys.as<u32>(),
+		    d_ccnts.as<u32>(), ccap, idx->mtab, mcap, st));
+	ARKS_TRACE_STEP("launch_bforce");
+		HIP_TRY(launch_bfill_mtab(
+		    idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u32>(), d_ccnts.as<u32>(), ccap,
+		    idx->mtab, mcap, d_heavy.as<u32>(), st));
+	ARKS_TRACE_STEP("launch_bfill_mtab");
+		HIP_TRY(launch_bforce(
+		    idx->kw, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, d_ckeys.as<u32>(),
+		    d_ccnts.as<u32>(), ccap, idx->mtab, mcap, st));
+	ARKS_TRACE_STEP("launch_bforce");
+		HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
+		HIP_TRY(launch_bfallback(
+		    idx->kw, false, idx->codes, idx->visited, idx->ambig, d_ispal.as<u32>(), d_isimg.as<u32>(),
+		    d_heavy.as<u32>(), idx->word_owner, text_words, idx->geom, w, idx->table,
+		    d_counters.as<u64>(), st));
+	ARKS_TRACE_STEP("launch_bfallback");
+		HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		n_fb = counters[0];
+		idx->table.cap = 2 * n_fb + 64;
+		{
+			void* p = nullptr;
+			HIP_TRY(hipMalloc(&p, idx->table.cap * kSlotWords * sizeof(u64)));
+			idx->table.slots = static_cast<u64*>(p);
+		}
+		HIP_TRY(hipMemsetAsync(idx->table.slots, 0, idx->table.cap * kSlotWords * sizeof(u64), st));
+		HIP_TRY(launch_bfallback(
+		    idx->kw, true, idx->codes, idx->visited, idx->ambig, d_ispal.as<u32>(), d_isimg.as<u32>(),
+		    d_heavy.as<u32>(), idx->word_owner, text_words, idx->geom, w, idx->table,
+		    d_counters.as<u64>(), st));
+	ARKS_TRACE_STEP("launch_bfallback");
+		HIP_TRY(hipStreamSynchronize(st));
+		idx->n_minimizers = (int64_t)n_min;
+		idx->n_fallback = (int64_t)n_fb;
+		idx->bx.codes = idx->codes;
+		idx->bx.visited = idx->visited;
+		idx->bx.ambig = idx->ambig;
+		idx->bx.word_owner = idx->word_owner;
+		idx->bx.mtab = idx->mtab;
+		idx->bx.mtab_cap = mcap;
+		idx->bx.fallback = idx->table;
+		idx->bx.w = w;
+		idx->bx.enabled = 1;
 	}
 	{
 		void* p = nullptr;
@@ -455,6 +612,16 @@ arks_index_free(arks_index* idx)
 	DeviceGuard guard(idx->device);
 	if (idx->table.slots)
 		(void)hipFree(idx->table.slots);
+	if (idx->codes)
+		(void)hipFree(idx->codes);
+	if (idx->visited)
+		(void)hipFree(idx->visited);
+	if (idx->ambig)
+		(void)hipFree(idx->ambig);
+	if (idx->word_owner)
+		(void)hipFree(idx->word_owner);
+	if (idx->mtab)
+		(void)hipFree(idx->mtab);
 	if (idx->queue)
 		(void)hipFree(idx->queue);
 	if (idx->queue_count)
@@ -480,7 +647,16 @@ arks_index_device_bytes(const arks_index* idx)
 {
 	if (!idx)
 		return 0;
-	return (int64_t)(idx->table.cap * kSlotWords * sizeof(u64)) + idx->queue_cap * (int64_t)sizeof(u32);
+	int64_t b = (int64_t)(idx->table.cap * kSlotWords * sizeof(u64)) + idx->queue_cap * (int64_t)sizeof(u32);
+	if (idx->kind == 1)
+		b += (int64_t)(idx->alloc_words * (sizeof(u64) + 3 * sizeof(u32))) + (int64_t)(idx->bx.mtab_cap * sizeof(u64));
+	return b;
+}
+
+int
+arks_index_kind(const arks_index* idx)
+{
+	return idx ? idx->kind : -1;
 }
 
 int
@@ -491,23 +667,67 @@ arks_index_export(const arks_index* idx, unsigned char* h_keys, int32_t* h_vals)
 	DeviceGuard guard(idx->device);
 	int rc = ARKS_OK;
 	const int kb = arks_key_bytes(idx->k);
-	std::vector<u64> host;
-	try {
-		host.resize(idx->table.cap * kSlotWords);
-	} catch (const std::bad_alloc&) {
-		return ARKS_ERR_OOM;
-	}
+	const int kw = idx->kw;
 	int64_t n = 0;
-	HIP_TRY(hipMemcpy(host.data(), idx->table.slots, host.size() * sizeof(u64), hipMemcpyDeviceToHost));
-	for (u64 s = 0; s < idx->table.cap && n < idx->n_keys; ++s) {
-		const u64* slot = host.data() + s * kSlotWords;
-		const u32 st = (u32)slot[3];
-		if (st == kEmpty)
-			continue;
+	std::vector<u64> host;
+	std::vector<int32_t> hvals;
+	std::vector<size_t> order;
+	DevBuf d_keys, d_vals, d_cnt;
+	auto emit = [&](const u64* words, int32_t val) {
 		unsigned char* kout = h_keys + (size_t)n * (size_t)kb;
 		for (int b = 0; b < kb; ++b)
-			kout[b] = (unsigned char)(slot[b >> 3] >> (56 - 8 * (b & 7)));
-		h_vals[n++] = (int32_t)(st - 1u);
+			kout[b] = (unsigned char)(words[b >> 3] >> (56 - 8 * (b & 7)));
+		h_vals[n++] = val;
+	};
+	try {
+		if (idx->kind == 0) {
+			host.resize(idx->table.cap * kSlotWords);
+			HIP_TRY(hipMemcpy(host.data(), idx->table.slots, host.size() * sizeof(u64), hipMemcpyDeviceToHost));
+			for (u64 s = 0; s < idx->table.cap && n < idx->n_keys; ++s) {
+				const u64* slot = host.data() + s * kSlotWords;
+				const u32 st = (u32)slot[3];
+				if (st != kEmpty)
+					emit(slot, (int32_t)(st - 1u));
+			}
+		} else {
+			// one record per visited window, duplicates removed on the host
+			const size_t nv = (size_t)idx->n_visited;
+			host.resize(nv * (size_t)kw + 1);
+			hvals.resize(nv + 1);
+			HIP_TRY(d_keys.alloc(sizeof(u64) * (nv * (size_t)kw + 1)));
+			HIP_TRY(d_vals.alloc(sizeof(int32_t) * (nv + 1)));
+			HIP_TRY(d_cnt.alloc(sizeof(u64)));
+			HIP_TRY(hipMemset(d_cnt.p, 0, sizeof(u64)));
+			HIP_TRY(launch_bexport(
+			    kw, idx->codes, idx->visited, idx->ambig, idx->word_owner, idx->text_words, idx->geom,
+			    d_keys.as<u64>(), d_vals.as<int>(), d_cnt.as<u64>(), nullptr));
+			HIP_TRY(hipDeviceSynchronize());
+			HIP_TRY(hipMemcpy(host.data(), d_keys.p, sizeof(u64) * nv * (size_t)kw, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(hvals.data(), d_vals.p, sizeof(int32_t) * nv, hipMemcpyDeviceToHost));
+			order.resize(nv);
+			for (size_t i = 0; i < nv; ++i)
+				order[i] = i;
+			std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+				for (int j = 0; j < kw; ++j)
+					if (host[a * kw + j] != host[b * kw + j])
+						return host[a * kw + j] < host[b * kw + j];
+				return false;
+			});
+			for (size_t i = 0; i < nv && n < idx->n_keys; ++i) {
+				const size_t a = order[i];
+				if (i > 0) {
+					const size_t b = order[i - 1];
+					bool same = true;
+					for (int j = 0; j < kw; ++j)
+						same = same && host[a * kw + j] == host[b * kw + j];
+					if (same)
+						continue;
+				}
+				emit(host.data() + a * kw, hvals[a]);
+			}
+		}
+	} catch (const std::bad_alloc&) {
+		return ARKS_ERR_OOM;
 	}
 done:
 	return rc;
@@ -564,8 +784,8 @@ arks_map_reads_device(
 		return rc;
 	HIP_TRY(launch_map_reads(
 	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads,
-	    j_index, idx->geom, idx->table, d_out_conreci, reinterpret_cast<u64*>(d_stats), idx->queue,
-	    idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream)));
+	    j_index, idx->geom, idx->table, idx->bx, d_out_conreci, reinterpret_cast<u64*>(d_stats),
+	    idx->queue, idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream)));
 done:
 	return rc;
 }

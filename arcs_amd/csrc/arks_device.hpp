@@ -123,6 +123,24 @@ window_key(const u64* __restrict__ codes, u64 wbase, int p, const KeyGeom& g)
 	return f;
 }
 
+// same, for an absolute 64-bit base position of the stream (text side)
+template <int KW>
+__device__ __forceinline__ Key<KW>
+window_key_at(const u64* __restrict__ codes, u64 pos, const KeyGeom& g)
+{
+	const u64* src = codes + (pos >> 5);
+	const int s = (int)(pos & 31) * 2;
+	u64 w[KW + 1];
+#pragma unroll
+	for (int j = 0; j <= KW; ++j)
+		w[j] = src[j];
+	Key<KW> f;
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		f.w[j] = funnel_l(w[j], w[j + 1], s) & g.mask[j];
+	return f;
+}
+
 // True iff any of the k bases of the window is flagged in the N-mask (=> NULL k-mer,
 // ReadsProcessor.cpp:397-421; the reference validates every base of the window on every branch).
 template <int KW>
@@ -312,6 +330,162 @@ table_lookup(const TableView& t, const Key<KW>& c)
 		if (key_eq(slot_key<KW>(slot), c))
 			return (int)(st - 1u);
 		s = (s + 1 == t.cap) ? 0 : s + 1;
+	}
+}
+
+
+// ================================================================================================
+// The locality index ("B"): contig-end text + minimizer table.
+//
+// The hash table above costs one random 64-B line per window (4.4x the algorithmic bytes, see
+// profiles/r01a_*).  Consecutive windows of a read overlap in k-1 bases, so the index below is
+// organised around that overlap instead: the packed contig-end TEXT itself is the key store
+// (2 bits per base, every k-mer of an end shares its bytes with its neighbours), a window is
+// located through its MINIMIZER (the smallest-hashing canonical 15-mer inside it, shared by ~w/2
+// consecutive windows, w = k - 14), and membership is decided by comparing the read against the
+// text along the implied diagonal -- exact, so the result is still "key equality" and nothing
+// else (Arcs/Arcs.h:153-156).  Per position the text carries two bits: `visited` (the window
+// starting here was inserted by mapKmers' visit rule, Arcs.cpp:887-926) and `ambig` (its key was
+// seen from two different ends => value 0, Arcs.cpp:907-914); the value of an unambiguous window is
+// the contig end that owns the position.  Keys that do not equal their own sequence (the
+// reference's palindrome quirk, ReadsProcessor.cpp:503-534), k-mers under over-full minimizers and
+// the few regular keys a palindromic query could collide with live in a small exact hash table
+// (`fallback`), reached only when the query says so.
+// ================================================================================================
+constexpr int kM = 15;            // minimizer length; odd => no 15-mer is its own reverse complement
+constexpr u32 kMmerMask = (1u << (2 * kM)) - 1u;
+constexpr int kHeavy = 8;         // a minimizer with more text occurrences than this is "heavy"
+constexpr int kFrontPadWords = 16; // the text starts 512 bases into its arrays (diagonals may underrun)
+constexpr u32 kHeavyPos = 0xFFFFFFFFu;
+
+// minimizer-table entry: [63] occupied, [62] strand (1 = the text 15-mer is the canonical one),
+// [61:32] canonical 15-mer, [31:0] text position (kHeavyPos = "heavy: ask the fallback table")
+__device__ __forceinline__ u64
+mtab_entry(u32 cm, u32 strand, u32 pos)
+{
+	return (1ull << 63) | ((u64)(strand & 1u) << 62) | ((u64)cm << 32) | pos;
+}
+
+struct BIndexView
+{
+	const u64* codes;      // packed text, front-padded by kFrontPadWords
+	const u32* visited;    // 1 bit per text position
+	const u32* ambig;      // 1 bit per text position
+	const u32* word_owner; // contig-end index (conreci) of every 32-base word, 0 in padding
+	const u64* mtab;
+	u64 mtab_cap;
+	TableView fallback;
+	int w;       // minimizer window: k - kM + 1
+	int enabled; // 0 => the plain hash table `TableView` is the index (small k)
+};
+
+// the 15-mer starting at base `pos` of a packed stream, right-aligned in 30 bits
+__device__ __forceinline__ u32
+mmer_fw(const u64* __restrict__ codes, u64 pos)
+{
+	const u64* src = codes + (pos >> 5);
+	return (u32)(funnel_l(src[0], src[1], (int)(pos & 31) * 2) >> (64 - 2 * kM));
+}
+
+__device__ __forceinline__ u32
+mmer_rc(u32 f)
+{
+	u32 t = __brev(f) >> (32 - 2 * kM);
+	t = ((t >> 1) & 0x55555555u) | ((t & 0x55555555u) << 1);
+	return ~t & kMmerMask;
+}
+
+// 23-bit ordering hash of a canonical 15-mer (decides WHICH 15-mer of a window is its minimizer;
+// equal values are ties and every tied position is registered on the text side)
+__device__ __forceinline__ u32
+mmer_order(u32 cm)
+{
+	return ((cm ^ 0x2F0B4C5Du) * 0x9E3779B1u) >> 9;
+}
+
+__device__ __forceinline__ u64
+mtab_home(u32 cm, u64 cap)
+{
+	u64 h = (u64)cm * 0x9E3779B97F4A7C15ull;
+	h ^= h >> 29;
+	return mulhi64(h * 0xD6E8FEB86659FD93ull, cap);
+}
+
+__device__ __forceinline__ u32
+bit_at(const u32* __restrict__ bits, u64 pos)
+{
+	return (bits[pos >> 5] >> (31 - (u32)(pos & 31))) & 1u;
+}
+
+// minimizer of the window that starts at base `pos` of a packed stream (window free of invalid
+// bases): smallest ordering value and the LEFTMOST offset that has it
+__device__ __forceinline__ void
+window_minimizer(const u64* __restrict__ codes, u64 pos, int w, u32& min_h, int& min_off)
+{
+	min_h = 0xFFFFFFFFu;
+	min_off = 0;
+	for (int o = 0; o < w; ++o) {
+		const u32 f = mmer_fw(codes, pos + (u64)o);
+		const u32 r = mmer_rc(f);
+		const u32 h = mmer_order(f < r ? f : r);
+		if (h < min_h) {
+			min_h = h;
+			min_off = o;
+		}
+	}
+}
+
+// exact value of the key c in the fallback table, -1 when absent
+template <int KW>
+__device__ __forceinline__ int
+fallback_lookup(const BIndexView& bx, const Key<KW>& c)
+{
+	return table_lookup<KW>(bx.fallback, c);
+}
+
+// Serial (one lane) exact lookup of one window in the locality index: value of the window whose
+// forward / reverse-complement keys are f / r (f != r) and that starts at base p of the packed
+// stream (wbase).  -1 = absent, 0 = ambiguous, > 0 = contig end.  The slow path, and the in-kernel
+// definition the cooperative fast path has to agree with.
+template <int KW>
+__device__ __forceinline__ int
+bindex_lookup_serial(
+    const BIndexView& bx, const KeyGeom& g, const u64* __restrict__ codes, u64 pos,
+    const Key<KW>& f, const Key<KW>& r)
+{
+	u32 min_h;
+	int off;
+	window_minimizer(codes, pos, bx.w, min_h, off);
+	const u32 mf = mmer_fw(codes, pos + (u64)off);
+	const u32 mr = mmer_rc(mf);
+	const u32 cm = mf < mr ? mf : mr;
+	const u32 rstrand = mf < mr ? 1u : 0u;
+	u64 s = mtab_home(cm, bx.mtab_cap);
+	for (;;) {
+		const u64 e = bx.mtab[s];
+		if (!(e >> 63))
+			return -1;
+		s = (s + 1 == bx.mtab_cap) ? 0 : s + 1;
+		if (((u32)(e >> 32) & kMmerMask) != cm)
+			continue;
+		const u32 tpos = (u32)e;
+		if (tpos == kHeavyPos) {
+			const bool lt = key_less(f, r);
+			Key<KW> c;
+#pragma unroll
+			for (int j = 0; j < KW; ++j)
+				c.w[j] = lt ? f.w[j] : r.w[j];
+			return fallback_lookup<KW>(bx, c);
+		}
+		const bool same = ((u32)(e >> 62) & 1u) == rstrand;
+		// start of the text window that would hold this k-mer
+		const u64 t = same ? (u64)tpos - (u64)off : (u64)tpos - (u64)(g.k - kM - off);
+		const Key<KW> tk = window_key_at<KW>(bx.codes, t, g);
+		if (!key_eq(tk, same ? f : r))
+			continue;
+		if (!bit_at(bx.visited, t))
+			continue;
+		return bit_at(bx.ambig, t) ? 0 : (int)bx.word_owner[t >> 5];
 	}
 }
 

@@ -22,8 +22,28 @@ hipError_t launch_build_stats(
     const KeyGeom& g, TableView t, u64* counters, hipStream_t st);
 hipError_t launch_map_reads(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens,
-    const uint8_t* eval, long n_reads, double j_index, const KeyGeom& g, TableView t, int* out,
-    u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st);
+    const uint8_t* eval, long n_reads, double j_index, const KeyGeom& g, TableView t,
+    const BIndexView& bx, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu,
+    hipStream_t st);
+hipError_t launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner, hipStream_t st);
+hipError_t launch_bmark(
+    int kw, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,
+    int w, u32* ambig, u32* is_min, u32* is_pal, u32* is_img, hipStream_t st);
+hipError_t launch_bcount(
+    const u64* codes, const u32* is_min, u64 total_words, u32* ckeys, u32* ccnts, u64 ccap, hipStream_t st);
+hipError_t launch_bforce(
+    int kw, int phase, const u64* codes, const u32* is_pal, u64 total_words, const KeyGeom& g, int w,
+    u32* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st);
+hipError_t launch_bfill_mtab(
+    const u64* codes, const u32* is_min, u64 total_words, u32* ckeys, u32* ccnts, u64 ccap, u64* mtab,
+    u64 mcap, u32* heavy_min, hipStream_t st);
+hipError_t launch_bfallback(
+    int kw, bool insert, const u64* codes, const u32* visited, const u32* ambig, const u32* is_pal,
+    const u32* is_img, const u32* heavy_min, const u32* word_owner, u64 total_words, const KeyGeom& g,
+    int w, TableView fb, u64* counter, hipStream_t st);
+hipError_t launch_bexport(
+    int kw, const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner,
+    u64 total_words, const KeyGeom& g, u64* out_keys, int* out_vals, u64* counter, hipStream_t st);
 hipError_t launch_pair_gate(
     const uint8_t* pair_ok, const uint8_t* read_class, long n_pairs, uint8_t* eval, hipStream_t st);
 hipError_t launch_pairs(

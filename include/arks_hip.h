@@ -47,11 +47,10 @@ extern "C" {
 #define ARKS_ERR_HIP 4          /* a HIP runtime call / kernel launch failed (arks_last_error_string) */
 #define ARKS_ERR_NO_DEVICE 5    /* no usable gfx950 device: the product has no CPU fallback */
 #define ARKS_ERR_BAD_ARG 6      /* NULL pointer, negative count, ... */
-#define ARKS_ERR_READ_TOO_LONG 7 /* a read has more than ARKS_MAX_WINDOWS k-mer windows */
+#define ARKS_ERR_RESERVED_7 7      /* (unused) */
 #define ARKS_ERR_FULL 8         /* accumulator table full */
 
 #define ARKS_MAX_K 96
-#define ARKS_MAX_WINDOWS 256 /* windows per read handled by the per-read vote (len - k + 1) */
 
 int arks_abi_version(void);
 const char* arks_strerror(int status);
@@ -117,6 +116,10 @@ int arks_index_k(const arks_index* idx);
 int64_t arks_index_size(const arks_index* idx);
 /* device bytes held by the index */
 int64_t arks_index_device_bytes(const arks_index* idx);
+/* layout of the index: 0 = exact open-addressed hash table of packed keys (k < 20, or when the
+ * environment says ARKS_INDEX_KIND=hash), 1 = locality index (packed contig-end text + minimizer
+ * table + exact fallback table).  Results are identical, only the traffic differs. */
+int arks_index_kind(const arks_index* idx);
 /* Copies every (key, value) to host: h_keys = size * arks_key_bytes(k) bytes in the reference's
  * byte order (what ReadsProcessor::getStr returns), h_vals = size int32.  Order unspecified. */
 int arks_index_export(const arks_index* idx, unsigned char* h_keys, int32_t* h_vals);

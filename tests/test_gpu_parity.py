@@ -154,3 +154,87 @@ def test_errors(arks, gpu):
     empty = arks.ArksIndex.build([], 30, device=gpu)
     assert len(empty) == 0 and empty.map_reads(["ACGT" * 20], 0.5).tolist() == [0]
     empty.close()
+
+
+def _unpack_key(key_bytes, k):
+    s = []
+    for i in range(k):
+        s.append("ACGT"[(key_bytes[i // 4] >> (6 - 2 * (i % 4))) & 3])
+    return "".join(s)
+
+
+def test_locality_index_exceptions(arks, gpu, oracle):
+    """the rare paths of the locality index: heavy minimizers (low-complexity repeats), palindromes
+    (quirk keys), quirk IMAGES (a regular k-mer that spells a palindrome's damaged key) and
+    duplicated segments (one minimizer, several diagonals)"""
+    rng = np.random.Generator(np.random.PCG64(321))
+    def rnd(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+    for k in (30, 60, 64):
+        # a palindrome P whose quirk image X' is a canonical, non-palindromic k-mer
+        while True:
+            h = rnd(k // 2)
+            P = h + _rc(h)
+            X = _unpack_key(oracle.key(P, 0, k), k)
+            if X < _rc(X) and oracle.key(X, 0, k) == oracle.key(P, 0, k):
+                break
+        unit = rnd(37)
+        rep = rnd(400)
+        ends = [
+            rnd(300) + P + rnd(300),                      # 1: holds the palindrome
+            rnd(200) + X + rnd(250),                      # 2: holds its quirk image -> value 0
+            rnd(150) + unit * 30 + rnd(150),              # 3: tandem repeat: heavy minimizers
+            rnd(100) + "A" * 200 + rnd(100) + "AT" * 90 + rnd(50),   # 4: poly-A, (AT)n
+            rnd(100) + rep + rnd(100),                    # 5
+            rnd(250) + rep + rnd(30),                     # 6: same segment, other diagonal/end
+            rnd(100) + _rc(rep) + rnd(60) + unit * 3,     # 7: and reverse-complemented
+        ]
+        # a second palindrome whose image is NOT in the text: regular queries for X2 must find it
+        while True:
+            h2 = rnd(k // 2)
+            P2 = h2 + _rc(h2)
+            X2 = _unpack_key(oracle.key(P2, 0, k), k)
+            if X2 < _rc(X2) and oracle.key(X2, 0, k) == oracle.key(P2, 0, k):
+                break
+        ends.append(rnd(120) + P2 + rnd(120))             # 8
+        ox = oracle.OracleIndex(k).build(ends)
+        assert ox.get(oracle.key(P, 0, k)) == 0            # P (end 1) and X (end 2) share a key
+        assert ox.get(oracle.key(X2, 0, k)) == 8
+        ix = arks.ArksIndex.build(ends, k, device=gpu)
+        assert ix.kind == 1
+        assert {f: ix.build_stats[f] for f in ox.stats.as_dict()} == ox.stats.as_dict()
+        assert index_digest(*ix.export()) == index_digest(*ox.dump())
+        genome = "".join(ends)
+        reads = [P, X, _rc(X), X2, _rc(X2), P2, rnd(20) + X2 + rnd(20), rnd(9) + _rc(X2) + rnd(31),
+                 rnd(10) + P + rnd(10), unit * 6, (unit * 6)[5:], _rc(unit * 5), "A" * 151,
+                 "AT" * 75, "TA" * 64, rep[:151], _rc(rep[100:251]), rep[300:] + rnd(40),
+                 ends[2][100:251], ends[3][60:211], ends[3][250:401]]
+        for i in range(400):
+            L = int(rng.choice([128, 151, 250]))
+            p = int(rng.integers(0, len(genome) - L))
+            r = genome[p:p + L]
+            reads.append(_rc(r) if i % 2 else r)
+        for j in (0.0, 0.3, 0.55):
+            st = oracle.MapStats()
+            want = [ox.best_contig(r, j, st) for r in reads]
+            got, gst = ix.map_reads(reads, j, want_stats=True)
+            assert got.tolist() == want, (k, j)
+            assert gst == st.as_dict(), (k, j)
+        ix.close()
+
+
+def test_hash_kind_still_exact(arks, gpu, oracle, golden_mini, monkeypatch):
+    """ARKS_INDEX_KIND=hash forces the plain hash-table index (design A): same results"""
+    monkeypatch.setenv("ARKS_INDEX_KIND", "hash")
+    cs, reads = golden_mini["contigs"], golden_mini["reads"]
+    ends = arks.contig_ends(cs, golden_mini["params"]["min_size"], golden_mini["params"]["end_length"])
+    case = golden_mini["cases"]["k60_j0.55"]
+    ix = arks.ArksIndex.build(ends, 60, device=gpu)
+    assert ix.kind == 0
+    assert index_digest(*ix.export()) == case["index_digest"]
+    ox = oracle.OracleIndex(60).build(ends)
+    st = oracle.MapStats()
+    want = [ox.best_contig(r, 0.55, st) for r in reads]
+    got, gst = ix.map_reads(reads, 0.55, want_stats=True)
+    assert got.tolist() == want and gst == st.as_dict()
+    ix.close()
