@@ -593,7 +593,7 @@ arks_index_build(
 	}
 	{
 		void* p = nullptr;
-		HIP_TRY(hipMalloc(&p, sizeof(u32)));
+		HIP_TRY(hipMalloc(&p, 2 * sizeof(u32))); // [0] redo-queue length, [1] work counter
 		idx->queue_count = static_cast<u32*>(p);
 	}
 	*out = idx;

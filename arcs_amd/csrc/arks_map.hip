@@ -308,8 +308,21 @@ map_reads_b_kernel(
 	const long n_waves = ((long)gridDim.x * blockDim.x) >> 6;
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	const int k = g.k, w = bx.w;
+	(void)wave;
+	(void)n_waves;
 
-	for (long r = wave; r < n_reads; r += n_waves) {
+	// reads are handed out in chunks through a device counter: hits, misses and rare paths cost
+	// very different amounts, a static split leaves a long tail
+	constexpr long kChunk = 16;
+	for (;;) {
+	long chunk0 = 0;
+	if (lane == 0)
+		chunk0 = (long)atomicAdd(queue_count + 1, (u32)kChunk);
+	chunk0 = __shfl(chunk0, 0);
+	if (chunk0 >= n_reads)
+		break;
+	const long chunk1 = chunk0 + kChunk < n_reads ? chunk0 + kChunk : n_reads;
+	for (long r = chunk0; r < chunk1; ++r) {
 		if (eval && !eval[r]) {
 			if (lane == 0)
 				out_conreci[r] = 0;
@@ -594,6 +607,7 @@ map_reads_b_kernel(
 			ws.win += (u64)total;
 		}
 	}
+	}
 	if (STATS && lane == 0) {
 		if (ws.valid) atomicAdd(stats + 0, ws.valid);
 		if (ws.bad) atomicAdd(stats + 1, ws.bad);
@@ -727,7 +741,7 @@ launch_map_reads(
 {
 	if (n_reads <= 0)
 		return hipSuccess;
-	hipError_t e = hipMemsetAsync(queue_count, 0, sizeof(u32), st);
+	hipError_t e = hipMemsetAsync(queue_count, 0, 2 * sizeof(u32), st);
 	if (e != hipSuccess)
 		return e;
 	// one wave per read at a time; enough resident waves to cover the memory latency
@@ -746,7 +760,13 @@ launch_map_reads(
 	} while (0)
 #define ARKS_MAP_B(KWV, ST)                                                                        \
 	do {                                                                                           \
-		map_reads_b_kernel<KWV, ST><<<b, 256, 0, st>>>(                                            \
+		int per_cu = 0;                                                                            \
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                          \
+		        &per_cu, map_reads_b_kernel<KWV, ST>, 256, 0) != hipSuccess || per_cu <= 0)        \
+			per_cu = 4;                                                                            \
+		const u64 res = (u64)(n_cu > 0 ? n_cu : 256) * (u64)per_cu;                                \
+		const unsigned bb = (unsigned)(want < res ? want : res);                                   \
+		map_reads_b_kernel<KWV, ST><<<bb, 256, 0, st>>>(                                           \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue_count);                                                                          \
 		map_reads_kernel<KWV, ST, false, true><<<bs, 256, 0, st>>>(                                \
