@@ -395,12 +395,13 @@ mmer_rc(u32 f)
 	return ~t & kMmerMask;
 }
 
-// 23-bit ordering hash of a canonical 15-mer (decides WHICH 15-mer of a window is its minimizer;
-// equal values are ties and every tied position is registered on the text side)
+// 21-bit ordering hash of a canonical 15-mer (decides WHICH 15-mer of a window is its minimizer;
+// equal values are ties and every tied position is registered on the text side).  Text side and
+// query side must use the very same function: the map kernel packs it above an 11-bit position.
 __device__ __forceinline__ u32
 mmer_order(u32 cm)
 {
-	return ((cm ^ 0x2F0B4C5Du) * 0x9E3779B1u) >> 9;
+	return ((cm ^ 0x2F0B4C5Du) * 0x9E3779B1u) >> 11;
 }
 
 __device__ __forceinline__ u64

@@ -246,33 +246,47 @@ map_reads_kernel(
 // ------------------------------------------------------------------------------------------------
 // K3b: read mapping over the locality index -- the hot kernel.
 //
-// One wave per read at a time.  Instead of one table probe per window the wave
-//   1. hashes every 15-mer of the read once (lanes = positions) and takes the sliding-window
-//      minimum by doubling through LDS  -> the minimizer position of every window;
-//   2. compacts the run heads (first window of each run of windows that share a minimizer; a
-//      151-bp read has ~5) and lets one lane per run walk the minimizer table;
-//   3. for every distinct diagonal (text position of read base 0, strand) the runs propose, XORs
-//      the read with the text once (lanes = 32-base words) and lets every window test its own
-//      2k-bit span of that mismatch stream -- exact, so the answer is still key equality
-//      (Arcs/Arcs.h:153-156); the value comes from the position's visited / ambiguous bits and owner;
-//   4. sends windows under a heavy minimizer to the exact fallback table, and reads that may hold a
-//      reverse-complement palindrome (detected through the mirrored minimizer) to the slow kernel;
-//   5. votes exactly as bestContig does (Arcs.cpp:996-1013).
-// HBM traffic per read: ~5 random 8-B minimizer entries + ~50 B of text and bit words, instead of
-// ~100 random 64-B lines.
+// One wave (= one 64-thread workgroup) processes a TILE: as many consecutive reads as fit in kTW
+// packed words, laid out as one position space in LDS.  Per tile:
+//   T1  stage the tile's code / N-mask words in LDS (every later access to the reads is LDS);
+//   T2  lanes = base positions: canonical 15-mer + 21-bit order hash of every position;
+//   T3  sliding-window minimum by doubling (ping-pong between two LDS arrays) -> the minimizer
+//       position of every window;
+//   T4  lanes = windows: validity, run heads (first window of a run sharing a minimizer) compacted
+//       by ballot + prefix popcount; reverse-complement palindromes flagged through their
+//       mirrored minimizer (-> slow kernel, which evaluates the reference's damaged key exactly);
+//   T5  one lane per run walks the minimizer table (~5 runs per 151-bp read) and publishes the
+//       matching entries (text position, strand) of its run;
+//   T6  lanes = windows again: each pending window derives its own text position from its run's
+//       entry, fetches the text k-mer and compares it with its forward / reverse-complement key --
+//       exact, so membership is still key equality (Arcs/Arcs.h:153-156); the value comes from the
+//       position's visited / ambiguous bits and owner word; windows under a heavy minimizer probe
+//       the exact fallback table;
+//   T7  per read: vote exactly as bestContig does (Arcs.cpp:996-1013).
+// HBM traffic per read: ~5 random 8-B minimizer entries + a few text / bit words, instead of ~100
+// random 64-B lines of the hash-table design.
 // ------------------------------------------------------------------------------------------------
-constexpr int kFastMaxLen = 288;               // reads up to this length take the cooperative path
-constexpr int kFastPasses = (kFastMaxLen + 63) / 64;
-constexpr int kFastWords = kFastMaxLen / 32;   // 9
+constexpr int kTW = 16;          // tile capacity in packed words
+constexpr int kTP = kTW * 32;    // ... in base positions
+constexpr int kTR = 8;           // reads per tile
+constexpr int kNH = 96;          // run heads per tile that get a published entry list
+constexpr int kChunk = 32;       // reads handed out per device-counter grab
+constexpr u32 kHnHeavy = 255, kHnOverflow = 254;
 
-struct WaveLds
+struct TileLds
 {
-	u32 ord[kFastMaxLen + 96]; // ordering values; after the sliding minimum: minimizer position per window
-	u32 mm[kFastMaxLen];       // [29:0] canonical 15-mer, [30] strand, [31] heavy
-	int vals[kFastMaxLen];     // window values
-	u64 diff[kFastWords + 3];  // read XOR text along the diagonal under test
-	u64 rc[kFastWords + 3];    // reverse complement of the read
-	unsigned short heads[kFastMaxLen];
+	u32 a[kTP + 96];
+	u32 b[kTP + 96];
+	u32 mm[kTP]; // [29:0] canonical 15-mer, [30] strand
+	u64 cw[kTW + 4];
+	u32 nm[kTW + 4];
+	u64 hc[kNH][2];
+	unsigned short heads[kNH];
+	unsigned char hn[kNH];
+	unsigned char wread[kTW + 4];
+	int rstart[kTR + 1];
+	int rlen[kTR];
+	u32 redo;
 };
 
 // lanes of one wave communicate through LDS: order the compiler's view of it
@@ -283,8 +297,25 @@ struct WaveLds
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                     \
 	} while (0)
 
+// forward key of the window at local position i of the staged tile words
+template <int KW>
+__device__ __forceinline__ Key<KW>
+tile_window_key(const u64* cw, int i, const KeyGeom& g)
+{
+	const int wi = i >> 5, sft = (i & 31) * 2;
+	u64 w[KW + 1];
+#pragma unroll
+	for (int j = 0; j <= KW; ++j)
+		w[j] = cw[wi + j];
+	Key<KW> f;
+#pragma unroll
+	for (int j = 0; j < KW; ++j)
+		f.w[j] = funnel_l(w[j], w[j + 1], sft) & g.mask[j];
+	return f;
+}
+
 template <int KW, bool STATS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 map_reads_b_kernel(
     const u64* __restrict__ codes,
     const u32* __restrict__ nmask,
@@ -300,313 +331,318 @@ map_reads_b_kernel(
     u32* __restrict__ queue,
     u32* __restrict__ queue_count)
 {
-	__shared__ WaveLds lds_all[4];
-	WaveLds& S = lds_all[threadIdx.x >> 6];
-	const int lane = threadIdx.x & 63;
-	const u64 lane_lt = (1ull << lane) - 1ull;
-	const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const long n_waves = ((long)gridDim.x * blockDim.x) >> 6;
+	__shared__ TileLds S;
+	const int lane = threadIdx.x;
+	const u64 lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	const int k = g.k, w = bx.w;
-	(void)wave;
-	(void)n_waves;
 
-	// reads are handed out in chunks through a device counter: hits, misses and rare paths cost
-	// very different amounts, a static split leaves a long tail
-	constexpr long kChunk = 16;
 	for (;;) {
-	long chunk0 = 0;
-	if (lane == 0)
-		chunk0 = (long)atomicAdd(queue_count + 1, (u32)kChunk);
-	chunk0 = __shfl(chunk0, 0);
-	if (chunk0 >= n_reads)
-		break;
-	const long chunk1 = chunk0 + kChunk < n_reads ? chunk0 + kChunk : n_reads;
-	for (long r = chunk0; r < chunk1; ++r) {
-		if (eval && !eval[r]) {
-			if (lane == 0)
-				out_conreci[r] = 0;
-			continue;
+		long c0 = 0;
+		if (lane == 0)
+			c0 = (long)atomicAdd(queue_count + 1, (u32)kChunk);
+		c0 = __shfl(c0, 0);
+		if (c0 >= n_reads)
+			break;
+		const int nchunk = (int)((c0 + kChunk < n_reads ? c0 + kChunk : n_reads) - c0);
+		// lane l holds the metadata of read c0 + l (lane nchunk: the end offset)
+		u64 wo = 0;
+		int rl = 0;
+		if (lane <= nchunk)
+			wo = word_off[c0 + lane];
+		if (lane < nchunk) {
+			rl = (int)lens[c0 + lane];
+			if (eval && !eval[c0 + lane])
+				rl = -1; // not evaluated: output 0, no counters
 		}
-		const int L = (int)lens[r];
-		const int nwin = L - k + 1;
-		if (L > kFastMaxLen) {
+		int cur = 0;
+		while (cur < nchunk) {
+			// ---- tile = reads [cur, nxt): as many as fit --------------------------------------
+			const u64 base_w = __shfl(wo, cur);
+			const u64 fit = __ballot(
+			    lane > cur && lane <= nchunk && wo - base_w <= (u64)kTW && lane - cur <= kTR);
+			if (fit == 0) { // a single read longer than a tile: slow kernel
+				if (lane == cur) {
+					if (rl >= 0)
+						queue[atomicAdd(queue_count, 1u)] = (u32)(c0 + cur);
+					else
+						out_conreci[c0 + cur] = 0;
+				}
+				cur++;
+				continue;
+			}
+			const int nxt = 63 - __clzll((long long)fit);
+			const int nr = nxt - cur;
+			const int tw = (int)(__shfl(wo, nxt) - base_w); // words of the tile
+			const int n = tw * 32;
+			// ---- T0/T1: per-read metadata and the tile's words into LDS ------------------------
+			if (lane >= cur && lane <= nxt)
+				S.rstart[lane - cur] = (int)(wo - base_w) * 32;
+			if (lane >= cur && lane < nxt)
+				S.rlen[lane - cur] = rl;
 			if (lane == 0)
-				queue[atomicAdd(queue_count, 1u)] = (u32)r;
-			continue;
-		}
-		int best = 0, best_cnt = 0;
-		WaveStats rs = { 0, 0, 0, 0, 0, 0, 0, 0 };
-		bool redo = false;
-		if (nwin > 0) {
-			const u64 wbase = word_off[r];
-			const u64 rbase = wbase * 32ull;
-			const int npos = L - kM + 1;
-			// ---- 1. ordering value of every 15-mer ------------------------------------------------
-			for (int i = lane; i < npos + 96; i += 64) {
+				S.redo = 0;
+			if (lane < tw + 4) {
+				S.cw[lane] = codes[base_w + (u64)lane];
+				S.nm[lane] = nmask[base_w + (u64)lane];
+			}
+			ARKS_WAVE_SYNC();
+			if (lane < nr) {
+				const int w0 = S.rstart[lane] >> 5, w1 = S.rstart[lane + 1] >> 5;
+				for (int x = w0; x < w1; ++x)
+					S.wread[x] = (unsigned char)lane;
+			}
+			const bool has_n = __ballot(lane < tw && S.nm[lane] != 0) != 0;
+			ARKS_WAVE_SYNC();
+			// ---- T2: order value of every 15-mer -------------------------------------------------
+			const u32* s32 = reinterpret_cast<const u32*>(S.cw); // 16 bases per u32, halves swapped
+			for (int i = lane; i < n + 96; i += 64) {
 				u32 o = 0xFFFFFFFFu;
-				if (i < npos) {
-					const u32 mf = mmer_fw(codes, rbase + (u64)i);
-					const u32* nm = nmask + wbase + (u64)(i >> 5);
-					const int t = i & 31;
-					const u32 bits = (nm[0] << t) | ((nm[1] >> 1) >> (31 - t));
+				if (i < n) {
+					const int j = S.wread[i >> 5];
+					const int rem = S.rstart[j] + S.rlen[j] - i; // bases of the read from i on
+					const int hn = i >> 4, t = (i & 15) * 2;
+					const u32 hi = s32[hn ^ 1], lo = s32[(hn + 1) ^ 1];
+					const u32 x = t ? ((hi << t) | (lo >> (32 - t))) : hi;
+					const u32 mf = x >> 2;
 					const u32 mr = mmer_rc(mf);
 					const u32 cm = mf < mr ? mf : mr;
 					S.mm[i] = cm | ((mf < mr ? 1u : 0u) << 30);
-					if ((bits >> (32 - kM)) == 0)
-						o = (mmer_order(cm) << 9) | (u32)i;
+					bool ok = rem >= kM;
+					if (has_n) {
+						const int tn = i & 31;
+						const u32 bits = (S.nm[i >> 5] << tn) | ((S.nm[(i >> 5) + 1] >> 1) >> (31 - tn));
+						ok = ok && (bits >> (32 - kM)) == 0;
+					}
+					if (ok)
+						o = (mmer_order(cm) << 11) | (u32)i;
 				}
-				S.ord[i] = o;
+				S.a[i] = o;
+				if (i >= n)
+					S.b[i] = o;
 			}
 			ARKS_WAVE_SYNC();
-			// ---- 2. sliding minimum over w positions, doubling in place ---------------------------
-			int span = 1;
-			for (;;) {
+			// ---- T3: sliding minimum over w positions by doubling, ping-pong a <-> b ---------------
+			u32* src = S.a;
+			u32* dst = S.b;
+			for (int span = 1;;) {
 				const int step = (2 * span <= w) ? span : (w - span);
 				if (step <= 0)
 					break;
-				u32 v[kFastPasses];
-#pragma unroll
-				for (int t = 0; t < kFastPasses; ++t) {
-					const int i = t * 64 + lane;
-					v[t] = 0xFFFFFFFFu;
-					if (i < npos) { // the padding beyond npos stays 0xFFFFFFFF
-						const u32 a = S.ord[i], b = S.ord[i + step];
-						v[t] = a < b ? a : b;
-					}
+				for (int i = lane; i < n; i += 64) {
+					const u32 x = src[i], y = src[i + step];
+					dst[i] = x < y ? x : y;
 				}
 				ARKS_WAVE_SYNC();
-#pragma unroll
-				for (int t = 0; t < kFastPasses; ++t)
-					if (t * 64 + lane < npos)
-						S.ord[t * 64 + lane] = v[t];
-				ARKS_WAVE_SYNC();
+				u32* tsw = src;
+				src = dst;
+				dst = tsw;
 				if (2 * span > w)
 					break;
 				span *= 2;
 			}
-			// ---- 3. windows: validity, minimizer position, run heads ------------------------------
+			// src[i] = minimizer of window i (low 11 bits: its position); dst becomes the window
+			// record: >= 0 value, -1 absent, -2 NULL window, -3 no window, <= -16 pending (q, run)
+			int* rec = reinterpret_cast<int*>(dst);
+			// ---- T4: windows, run heads --------------------------------------------------------------
 			int nheads = 0;
 			u32 carry = 0xFFFFu;
-			for (int base = 0; base < nwin; base += 64) {
-				const int p = base + lane;
-				const bool in = p < nwin;
-				bool invalid = false;
-				u32 q = 0xFFFFu;
-				if (in) {
-					invalid = window_has_invalid<KW>(nmask, wbase, p, k);
-					if (!invalid)
-						q = S.ord[p] & 511u;
+			for (int base = 0; base < n; base += 64) {
+				const int i = base + lane;
+				const int j = S.wread[i >> 5];
+				const int rem = S.rstart[j] + S.rlen[j] - i;
+				const bool is_win = rem >= k;
+				bool bad = false;
+				if (has_n && is_win) {
+					const int tn = i & 31, e = tn + k;
+					u32 any = 0;
+#pragma unroll
+					for (int x = 0; x <= KW; ++x) {
+						int lo = tn - 32 * x, hi = e - 32 * x;
+						lo = lo < 0 ? 0 : lo;
+						hi = hi > 32 ? 32 : hi;
+						if (lo < hi)
+							any |= S.nm[(i >> 5) + x] & (0xFFFFFFFFu >> lo) & ~(hi == 32 ? 0u : (0xFFFFFFFFu >> hi));
+					}
+					bad = any != 0;
 				}
+				const bool ok = is_win && !bad;
+				const u32 q = ok ? (src[i] & 2047u) : 0xFFFFu;
 				u32 qprev = __shfl_up(q, 1);
 				if (lane == 0)
 					qprev = carry;
 				carry = __shfl(q, 63);
-				const bool head = in && !invalid && q != qprev;
-				if (in) {
-					S.vals[p] = invalid ? -2 : -1;
-					if (!invalid && !(k & 1)) {
-						// a reverse-complement palindrome has its minimizer twice, mirrored about its
-						// centre: necessary condition, checked exactly by the slow kernel
-						const int qm = 2 * p + (k - kM) - (int)q;
-						if (mmer_order(S.mm[qm] & kMmerMask) == mmer_order(S.mm[q] & kMmerMask))
-							redo = true;
-					}
-				}
+				const bool head = ok && q != qprev;
 				const u64 hb = __ballot(head);
-				if (head)
-					S.heads[nheads + __popcll(hb & lane_lt)] = (unsigned short)p;
+				const int hidx = nheads + __popcll(hb & lane_le) - 1; // run of this window
+				if (head && hidx < kNH)
+					S.heads[hidx] = (unsigned short)i;
 				nheads += __popcll(hb);
+				int rv = is_win ? -2 : -3;
+				if (ok) {
+					rv = -16 - (int)(q | ((u32)hidx << 11));
+					if (!(k & 1)) {
+						// a reverse-complement palindrome carries its minimizer twice, mirrored about
+						// its centre (necessary condition; the slow kernel decides exactly)
+						const int qm = 2 * i + (k - kM) - (int)q;
+						if (((S.mm[qm] ^ S.mm[q]) & kMmerMask) == 0)
+							atomicOr(&S.redo, 1u << j);
+					}
+				}
+				rec[i] = rv;
 			}
-			redo = __ballot(redo) != 0;
 			ARKS_WAVE_SYNC();
-			// (window p's minimizer position stays in ord[p])
-			// ---- 4. run heads walk the minimizer table; distinct diagonals get verified -----------
-			bool rc_ready = false;
-			u64 last_d = ~0ull;
-			bool last_same = false;
-			for (int hb0 = 0; hb0 < nheads && !redo; hb0 += 64) {
-				const int h = hb0 + lane;
-				bool active = h < nheads;
-				u32 q = 0, cm = 0, rstrand = 0;
-				u64 slot = 0;
-				if (active) {
-					const int ph = S.heads[h];
-					q = S.ord[ph] & 511u;
-					const u32 m = S.mm[q];
-					cm = m & kMmerMask;
-					rstrand = (m >> 30) & 1u;
-					slot = mtab_home(cm, bx.mtab_cap);
-				}
-				bool have = false;
-				u64 d = 0;
-				bool same = false;
+			// ---- T5: run heads walk the minimizer table ------------------------------------------------
+			const int nh = nheads < kNH ? nheads : kNH;
+			for (int h = lane; h < nh; h += 64) {
+				const int i = S.heads[h];
+				const u32 q = (u32)(-16 - rec[i]) & 2047u;
+				const u32 cm = S.mm[q] & kMmerMask;
+				u64 slot = mtab_home(cm, bx.mtab_cap);
+				u32 cnt = 0;
 				for (;;) {
-					if (active && !have) {
-						for (;;) {
-							const u64 e = bx.mtab[slot];
-							if (!(e >> 63)) {
-								active = false;
-								break;
-							}
-							slot = (slot + 1 == bx.mtab_cap) ? 0 : slot + 1;
-							if (((u32)(e >> 32) & kMmerMask) != cm)
-								continue;
-							const u32 tpos = (u32)e;
-							if (tpos == kHeavyPos) {
-								atomicOr(&S.mm[q], 0x80000000u);
-								active = false;
-							} else {
-								same = ((u32)(e >> 62) & 1u) == rstrand;
-								// text position of base 0 of the read (same strand) / of its
-								// reverse complement (opposite strand)
-								d = same ? (u64)tpos - (u64)q : (u64)tpos + (u64)(kM + (int)q) - (u64)L;
-								have = true;
-							}
-							break;
-						}
-					}
-					const u64 hm = __ballot(have);
-					if (!hm)
+					const u64 e = bx.mtab[slot];
+					if (!(e >> 63))
 						break;
-					const int src = __ffsll((long long)hm) - 1;
-					const u64 d0 = __shfl(d, src);
-					const bool same0 = __shfl((int)same, src) != 0;
-					if (have && d == d0 && same == same0)
-						have = false; // consumed
-					if (d0 == last_d && same0 == last_same)
+					slot = (slot + 1 == bx.mtab_cap) ? 0 : slot + 1;
+					if (((u32)(e >> 32) & kMmerMask) != cm)
 						continue;
-					last_d = d0;
-					last_same = same0;
-					// ---- verify diagonal (d0, same0) -------------------------------------------
-					const int nw = (L + 31) >> 5;
-					if (!same0 && !rc_ready) {
-						// reverse complement of the read, packed like the read
-						if (lane <= nw) {
-							const int sh = 2 * (32 * nw - L); // < 64
-							const int a = nw - 1 - lane, b = nw - 2 - lane;
-							const u64 ra = a >= 0 ? ~rev_groups(codes[wbase + (u64)a]) : 0ull;
-							const u64 rb = b >= 0 ? ~rev_groups(codes[wbase + (u64)b]) : 0ull;
-							S.rc[lane] = lane < nw ? funnel_l(ra, rb, sh) : 0ull;
-						}
-						rc_ready = true;
-						ARKS_WAVE_SYNC();
+					if ((u32)e == kHeavyPos) {
+						cnt = kHnHeavy;
+						break;
 					}
-					if (lane < nw + 2) {
-						u64 x = 0;
-						if (lane < nw) {
-							const u64 rw = same0 ? codes[wbase + (u64)lane] : S.rc[lane];
-							const u64 tp = d0 + 32ull * (u64)lane;
-							const u64* tsrc = bx.codes + (tp >> 5);
-							const u64 tw = funnel_l(tsrc[0], tsrc[1], (int)(tp & 31) * 2);
-							x = rw ^ tw;
-							const int rem = L - 32 * lane; // bases of the read in this word
-							if (rem < 32)
-								x &= ~(~0ull >> (2 * rem));
-						}
-						S.diff[lane] = x;
-					}
-					ARKS_WAVE_SYNC();
-					for (int base = 0; base < nwin; base += 64) {
-						const int p = base + lane;
-						if (p < nwin && S.vals[p] == -1) {
-							const int pp = same0 ? p : (L - k - p);
-							const int wi = pp >> 5, sft = (pp & 31) * 2;
-							u64 any = 0;
+					if (cnt < 2)
+						S.hc[h][cnt] = e;
+					cnt = cnt < 2 ? cnt + 1 : kHnOverflow;
+					if (cnt == kHnOverflow)
+						break;
+				}
+				S.hn[h] = (unsigned char)cnt;
+			}
+			ARKS_WAVE_SYNC();
+			// ---- T6: every pending window checks its own text position ---------------------------------
+			for (int base = 0; base < n; base += 64) {
+				const int i = base + lane;
+				const int rv = rec[i];
+				const bool pending = rv <= -16;
+				if (__ballot(pending) == 0)
+					continue;
+				if (pending) {
+					const u32 pay = (u32)(-16 - rv);
+					const int q = (int)(pay & 2047u), hidx = (int)(pay >> 11);
+					const u32 hn = hidx < kNH ? S.hn[hidx] : kHnOverflow;
+					int val = -1;
+					if (hn != 0) {
+						const Key<KW> f = tile_window_key<KW>(S.cw, i, g);
+						const Key<KW> r = key_revcomp(f, g);
+						if (hn == kHnHeavy) {
+							Key<KW> c;
+							const bool lt = key_less(f, r);
 #pragma unroll
-							for (int j = 0; j < KW; ++j)
-								any |= funnel_l(S.diff[wi + j], S.diff[wi + j + 1], sft) & g.mask[j];
-							if (any == 0) {
-								const u64 t = d0 + (u64)pp;
-								if (bit_at(bx.visited, t))
-									S.vals[p] = bit_at(bx.ambig, t) ? 0 : (int)bx.word_owner[t >> 5];
+							for (int x = 0; x < KW; ++x)
+								c.w[x] = lt ? f.w[x] : r.w[x];
+							val = fallback_lookup<KW>(bx, c);
+						} else if (hn == kHnOverflow) {
+							val = bindex_lookup_serial<KW>(bx, g, codes, base_w * 32ull + (u64)i, f, r);
+						} else {
+							const u32 rstrand = (S.mm[q] >> 30) & 1u;
+							const int off = q - i;
+							for (u32 c = 0; c < hn && val < 0; ++c) {
+								const u64 e = S.hc[hidx][c];
+								const bool same = ((u32)(e >> 62) & 1u) == rstrand;
+								const u64 t = same ? (u64)(u32)e - (u64)off : (u64)(u32)e - (u64)(k - kM - off);
+								const Key<KW> tk = window_key_at<KW>(bx.codes, t, g);
+								if (key_eq(tk, same ? f : r) && bit_at(bx.visited, t))
+									val = bit_at(bx.ambig, t) ? 0 : (int)bx.word_owner[t >> 5];
 							}
 						}
 					}
-					ARKS_WAVE_SYNC();
+					rec[i] = val;
 				}
 			}
-			// ---- 5. windows under a heavy minimizer: exact fallback table ---------------------------
-			if (!redo) {
+			ARKS_WAVE_SYNC();
+			// ---- T7: per read: counters, vote, output ---------------------------------------------------
+			const u32 redo_mask = S.redo;
+			for (int j = 0; j < nr; ++j) {
+				const long r = c0 + cur + j;
+				const int L = S.rlen[j];
+				if (L < 0) {
+					if (lane == 0)
+						out_conreci[r] = 0;
+					continue;
+				}
+				if ((redo_mask >> j) & 1u) {
+					if (lane == 0)
+						queue[atomicAdd(queue_count, 1u)] = (u32)r;
+					continue;
+				}
+				const int nwin = L - k + 1;
+				const int p0 = S.rstart[j];
+				int best = 0, best_cnt = 0;
+				// first sweep: counters + is there more than one distinct positive value?
+				int first = 0, first_cnt = 0;
+				bool multi = false;
 				for (int base = 0; base < nwin; base += 64) {
 					const int p = base + lane;
-					if (p < nwin && S.vals[p] == -1 && (S.mm[S.ord[p] & 511u] >> 31)) {
-						const Key<KW> f = window_key<KW>(codes, wbase, p, g);
-						const Key<KW> rk = key_revcomp(f, g);
-						Key<KW> c;
-						const bool lt = key_less(f, rk);
-#pragma unroll
-						for (int j = 0; j < KW; ++j)
-							c.w[j] = lt ? f.w[j] : rk.w[j];
-						S.vals[p] = fallback_lookup<KW>(bx, c);
+					const int v = p < nwin ? rec[p0 + p] : -3;
+					if (STATS) {
+						ws.bad += __popcll(__ballot(v == -2));
+						ws.valid += __popcll(__ballot(v >= -1));
+						ws.found += __popcll(__ballot(v >= 0));
+						ws.rec += __popcll(__ballot(v > 0));
+						ws.dup += __popcll(__ballot(v == 0));
+					}
+					const u64 pos = __ballot(v > 0);
+					if (pos) {
+						if (first == 0)
+							first = __shfl(v, __ffsll((long long)pos) - 1);
+						const u64 eq = __ballot(v == first);
+						first_cnt += __popcll(eq);
+						multi = multi || (pos & ~eq) != 0;
 					}
 				}
-				ARKS_WAVE_SYNC();
-			}
-			// ---- 6. counters and vote ----------------------------------------------------------------
-			if (!redo) {
-				int vals[kFastPasses];
-#pragma unroll
-				for (int ps = 0; ps < kFastPasses; ++ps) {
-					int v = -3;
-					if (ps * 64 < nwin) {
-						const int p = ps * 64 + lane;
-						if (p < nwin)
-							v = S.vals[p];
-						if (STATS) {
-							rs.bad += __popcll(__ballot(v == -2));
-							rs.valid += __popcll(__ballot(v >= -1));
-							rs.found += __popcll(__ballot(v >= 0));
-							rs.rec += __popcll(__ballot(v > 0));
-							rs.dup += __popcll(__ballot(v == 0));
+				if (!multi) {
+					best = first;
+					best_cnt = first_cnt;
+				} else {
+					// ascending walk over the distinct values (the std::map order of Arcs.cpp:998)
+					int prev = 0;
+					for (;;) {
+						int m = 0x7FFFFFFF;
+						for (int base = 0; base < nwin; base += 64) {
+							const int p = base + lane;
+							const int v = p < nwin ? rec[p0 + p] : -3;
+							m = (v > prev && v < m) ? v : m;
 						}
+						m = wave_min_i32(m);
+						if (m == 0x7FFFFFFF)
+							break;
+						int cnt = 0;
+						for (int base = 0; base < nwin; base += 64) {
+							const int p = base + lane;
+							cnt += __popcll(__ballot(p < nwin && rec[p0 + p] == m));
+						}
+						if (cnt > best_cnt) { // strict: the smallest value keeps a tie
+							best_cnt = cnt;
+							best = m;
+						}
+						prev = m;
 					}
-					vals[ps] = v > 0 ? v : 0;
 				}
-				for (;;) {
-					int m = 0x7FFFFFFF;
-#pragma unroll
-					for (int ps = 0; ps < kFastPasses; ++ps)
-						m = (vals[ps] != 0 && vals[ps] < m) ? vals[ps] : m;
-					m = wave_min_i32(m);
-					if (m == 0x7FFFFFFF)
-						break;
-					int cnt = 0;
-#pragma unroll
-					for (int ps = 0; ps < kFastPasses; ++ps) {
-						const bool is = vals[ps] == m;
-						cnt += __popcll(__ballot(is));
-						vals[ps] = is ? 0 : vals[ps];
-					}
-					if (cnt > best_cnt) {
-						best_cnt = cnt;
-						best = m;
-					}
+				const int total = nwin > 0 ? nwin : 0;
+				const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
+				const bool pass = maxj > j_index;
+				if (lane == 0)
+					out_conreci[r] = pass ? best : 0;
+				if (STATS) {
+					ws.pass += pass;
+					ws.fail += !pass;
+					ws.win += (u64)total;
 				}
 			}
 			ARKS_WAVE_SYNC();
+			cur = nxt;
 		}
-		if (redo) {
-			if (lane == 0)
-				queue[atomicAdd(queue_count, 1u)] = (u32)r;
-			continue;
-		}
-		const int total = nwin > 0 ? nwin : 0;
-		const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
-		const bool pass = maxj > j_index;
-		if (lane == 0)
-			out_conreci[r] = pass ? best : 0;
-		if (STATS) {
-			ws.valid += rs.valid;
-			ws.bad += rs.bad;
-			ws.found += rs.found;
-			ws.rec += rs.rec;
-			ws.dup += rs.dup;
-			ws.pass += pass;
-			ws.fail += !pass;
-			ws.win += (u64)total;
-		}
-	}
 	}
 	if (STATS && lane == 0) {
 		if (ws.valid) atomicAdd(stats + 0, ws.valid);
@@ -762,11 +798,12 @@ launch_map_reads(
 	do {                                                                                           \
 		int per_cu = 0;                                                                            \
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                          \
-		        &per_cu, map_reads_b_kernel<KWV, ST>, 256, 0) != hipSuccess || per_cu <= 0)        \
-			per_cu = 4;                                                                            \
+		        &per_cu, map_reads_b_kernel<KWV, ST>, 64, 0) != hipSuccess || per_cu <= 0)         \
+			per_cu = 8;                                                                            \
 		const u64 res = (u64)(n_cu > 0 ? n_cu : 256) * (u64)per_cu;                                \
-		const unsigned bb = (unsigned)(want < res ? want : res);                                   \
-		map_reads_b_kernel<KWV, ST><<<bb, 256, 0, st>>>(                                           \
+		const u64 wantw = ((u64)n_reads + 3) / 4;                                                  \
+		const unsigned bb = (unsigned)(wantw < res ? wantw : res);                                 \
+		map_reads_b_kernel<KWV, ST><<<bb, 64, 0, st>>>(                                            \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue_count);                                                                          \
 		map_reads_kernel<KWV, ST, false, true><<<bs, 256, 0, st>>>(                                \
