@@ -1033,4 +1033,14 @@ done:
 	return rc;
 }
 
+#ifdef ARKS_PROFILE_SECTIONS
+int
+arks_debug_section_cycles(unsigned long long* out16)
+{
+	(void)hipDeviceSynchronize();
+	arks::read_section_cycles(out16);
+	return ARKS_OK;
+}
+#endif
+
 } /* extern "C" */

@@ -72,6 +72,13 @@ funnel_l(u64 a, u64 b, int s)
 	return (a << s) | ((b >> 1) >> (63 - s));
 }
 
+// (b:a) >> s, lower 64 bits (a = low word); s in [0, 63]
+__device__ __forceinline__ u64
+funnel_r(u64 a, u64 b, int s)
+{
+	return (a >> s) | ((b << 1) << (63 - s));
+}
+
 // reverse the order of the 32 two-bit groups of x
 __device__ __forceinline__ u64
 rev_groups(u64 x)

@@ -50,4 +50,8 @@ hipError_t launch_pairs(
     const int* conreci, const uint8_t* pair_ok, const u32* barcode_id, long n_pairs, int* out_pair,
     u64* imap_keys, u32* imap_counts, u64 imap_cap, u32* imap_overflow, u64* stored, hipStream_t st);
 
+#ifdef ARKS_PROFILE_SECTIONS
+void read_section_cycles(unsigned long long* out16);
+#endif
+
 } // namespace arks

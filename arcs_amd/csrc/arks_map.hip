@@ -314,6 +314,20 @@ tile_window_key(const u64* cw, int i, const KeyGeom& g)
 	return f;
 }
 
+#ifdef ARKS_PROFILE_SECTIONS
+__device__ unsigned long long g_sec_cycles[16];
+#define ARKS_SEC(nsec)                                                                             \
+	do {                                                                                           \
+		const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                               \
+		sec_acc[nsec] += t1_ - sec_t0;                                                             \
+		sec_t0 = t1_;                                                                              \
+	} while (0)
+#else
+#define ARKS_SEC(nsec)                                                                             \
+	do {                                                                                           \
+	} while (0)
+#endif
+
 template <int KW, bool STATS>
 __global__ void __launch_bounds__(64)
 map_reads_b_kernel(
@@ -336,9 +350,14 @@ map_reads_b_kernel(
 	const u64 lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	const int k = g.k, w = bx.w;
+#ifdef ARKS_PROFILE_SECTIONS
+	unsigned long long sec_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
 	for (;;) {
 		long c0 = 0;
+		ARKS_SEC(9);
 		if (lane == 0)
 			c0 = (long)atomicAdd(queue_count + 1, (u32)kChunk);
 		c0 = __shfl(c0, 0);
@@ -375,6 +394,7 @@ map_reads_b_kernel(
 			const int nr = nxt - cur;
 			const int tw = (int)(__shfl(wo, nxt) - base_w); // words of the tile
 			const int n = tw * 32;
+			ARKS_SEC(0);
 			// ---- T0/T1: per-read metadata and the tile's words into LDS ------------------------
 			if (lane >= cur && lane <= nxt)
 				S.rstart[lane - cur] = (int)(wo - base_w) * 32;
@@ -394,6 +414,7 @@ map_reads_b_kernel(
 			}
 			const bool has_n = __ballot(lane < tw && S.nm[lane] != 0) != 0;
 			ARKS_WAVE_SYNC();
+			ARKS_SEC(1);
 			// ---- T2: order value of every 15-mer -------------------------------------------------
 			const u32* s32 = reinterpret_cast<const u32*>(S.cw); // 16 bases per u32, halves swapped
 			for (int i = lane; i < n + 96; i += 64) {
@@ -422,6 +443,7 @@ map_reads_b_kernel(
 					S.b[i] = o;
 			}
 			ARKS_WAVE_SYNC();
+			ARKS_SEC(2);
 			// ---- T3: sliding minimum over w positions by doubling, ping-pong a <-> b ---------------
 			u32* src = S.a;
 			u32* dst = S.b;
@@ -444,6 +466,7 @@ map_reads_b_kernel(
 			// src[i] = minimizer of window i (low 11 bits: its position); dst becomes the window
 			// record: >= 0 value, -1 absent, -2 NULL window, -3 no window, <= -16 pending (q, run)
 			int* rec = reinterpret_cast<int*>(dst);
+			ARKS_SEC(3);
 			// ---- T4: windows, run heads --------------------------------------------------------------
 			int nheads = 0;
 			u32 carry = 0xFFFFu;
@@ -492,6 +515,7 @@ map_reads_b_kernel(
 				rec[i] = rv;
 			}
 			ARKS_WAVE_SYNC();
+			ARKS_SEC(4);
 			// ---- T5: run heads walk the minimizer table ------------------------------------------------
 			const int nh = nheads < kNH ? nheads : kNH;
 			for (int h = lane; h < nh; h += 64) {
@@ -520,6 +544,7 @@ map_reads_b_kernel(
 				S.hn[h] = (unsigned char)cnt;
 			}
 			ARKS_WAVE_SYNC();
+			ARKS_SEC(5);
 			// ---- T6: every pending window checks its own text position ---------------------------------
 			for (int base = 0; base < n; base += 64) {
 				const int i = base + lane;
@@ -561,6 +586,7 @@ map_reads_b_kernel(
 				}
 			}
 			ARKS_WAVE_SYNC();
+			ARKS_SEC(7);
 			// ---- T7: per read: counters, vote, output ---------------------------------------------------
 			const u32 redo_mask = S.redo;
 			for (int j = 0; j < nr; ++j) {
@@ -641,9 +667,15 @@ map_reads_b_kernel(
 				}
 			}
 			ARKS_WAVE_SYNC();
+			ARKS_SEC(8);
 			cur = nxt;
 		}
 	}
+#ifdef ARKS_PROFILE_SECTIONS
+	if (lane == 0)
+		for (int x = 0; x < 10; ++x)
+			atomicAdd(&g_sec_cycles[x], sec_acc[x]);
+#endif
 	if (STATS && lane == 0) {
 		if (ws.valid) atomicAdd(stats + 0, ws.valid);
 		if (ws.bad) atomicAdd(stats + 1, ws.bad);
@@ -852,5 +884,15 @@ launch_pairs(
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }
+
+#ifdef ARKS_PROFILE_SECTIONS
+void
+read_section_cycles(unsigned long long* out16)
+{
+	(void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sec_cycles), sizeof(unsigned long long) * 16);
+	unsigned long long z[16] = { 0 };
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_sec_cycles), z, sizeof z);
+}
+#endif
 
 } // namespace arks
