@@ -286,6 +286,14 @@ struct TileLds
 	unsigned char wread[kTW + 4];
 	int rstart[kTR + 1];
 	int rlen[kTR];
+	u64 pdiag[kTR]; // [39:0] D, [40] same strand, [41] valid
+	u32 tfirst[kTR];             // first text word staged for read j
+	u64 tcodes[kTW + kTR + 2];   // text words along the primary diagonals (read j: slots from
+	u32 tvis[kTW + kTR + 2];     //   (rstart[j] >> 5) + j)
+	u32 tamb[kTW + kTR + 2];
+	u32 town[kTW + kTR + 2];
+	u32 mm32[kTW + 8];           // mismatch bit per base along the primary diagonal
+	unsigned char sread[kTW + kTR + 2];
 	u32 redo;
 };
 
@@ -411,6 +419,8 @@ map_reads_b_kernel(
 				const int w0 = S.rstart[lane] >> 5, w1 = S.rstart[lane + 1] >> 5;
 				for (int x = w0; x < w1; ++x)
 					S.wread[x] = (unsigned char)lane;
+				for (int x = w0; x <= w1; ++x) // one staging slot more than the read has words
+					S.sread[x + lane] = (unsigned char)lane;
 			}
 			const bool has_n = __ballot(lane < tw && S.nm[lane] != 0) != 0;
 			ARKS_WAVE_SYNC();
@@ -545,7 +555,91 @@ map_reads_b_kernel(
 			}
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(5);
-			// ---- T6: every pending window checks its own text position ---------------------------------
+			// ---- T6a: the primary diagonal of every read = entry 0 of its first run that has entries.
+			//      Heads are in position order, so a ballot per read finds it without LDS traffic. --------
+			{
+				u32 pf = 0xFFFFFFFFu; // lane j: first head of read j with 1 or 2 entries
+				for (int hb0 = 0; hb0 < nh; hb0 += 64) {
+					const int h = hb0 + lane;
+					bool has = false;
+					int jh = -1;
+					if (h < nh) {
+						const u32 cnt = S.hn[h];
+						has = cnt >= 1 && cnt <= 2;
+						jh = S.wread[S.heads[h] >> 5];
+					}
+					for (int j = 0; j < nr; ++j) {
+						const u64 m = __ballot(has && jh == j);
+						if (lane == j && pf == 0xFFFFFFFFu && m)
+							pf = (u32)(hb0 + __ffsll((long long)m) - 1);
+					}
+				}
+				if (lane < nr) {
+					u64 pdv = 0;
+					if (pf != 0xFFFFFFFFu) {
+						const int q = (int)((u32)(-16 - rec[S.heads[pf]]) & 2047u);
+						const u64 e = S.hc[pf][0];
+						const int o = q - S.rstart[lane]; // offset of the minimizer in the read
+						const bool same = ((u32)(e >> 62) & 1u) == ((S.mm[q] >> 30) & 1u);
+						// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
+						const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(kM - 1 + o);
+						pdv = D | ((u64)same << 40) | (1ull << 41);
+					}
+					S.pdiag[lane] = pdv;
+					// first text word of the span [lo, lo + L) the read covers along its diagonal
+					const u64 Dv = pdv & 0xFFFFFFFFFFull;
+					const u64 lo = ((pdv >> 40) & 1ull) ? Dv : Dv - (u64)(S.rlen[lane] - 1);
+					S.tfirst[lane] = (u32)(lo >> 5);
+				}
+			}
+			ARKS_WAVE_SYNC();
+			// stage the text words and their visited / ambiguous / owner words (one round trip)
+			if (lane < tw + nr) {
+				const int j = S.sread[lane];
+				if (S.pdiag[j] >> 41) {
+					const u64 tw_idx = (u64)S.tfirst[j] + (u64)(lane - ((S.rstart[j] >> 5) + j));
+					S.tcodes[lane] = bx.codes[tw_idx];
+					S.tvis[lane] = bx.visited[tw_idx];
+					S.tamb[lane] = bx.ambig[tw_idx];
+					S.town[lane] = bx.word_owner[tw_idx];
+				}
+			}
+			ARKS_WAVE_SYNC();
+			// ---- T6b: lanes = read words: XOR each word of the read with the 32 text bases it faces
+			//      along the primary diagonal -> one mismatch bit per base (bit b of mm32[word]) ----------
+			if (lane < tw + 3) {
+				u32 mbits = 0;
+				if (lane < tw) {
+					const int j = S.wread[lane];
+					const u64 pdv = S.pdiag[j];
+					if (pdv >> 41) {
+						const bool same = (pdv >> 40) & 1ull;
+						const u64 D = pdv & 0xFFFFFFFFFFull;
+						const int x0 = lane * 32 - S.rstart[j]; // read offset of this word's first base
+						const int sb = (S.rstart[j] >> 5) + j;
+						// text position of the lowest-addressed base this word faces
+						const u64 tlo = same ? D + (u64)x0 : D - (u64)(x0 + 31);
+						const int slot = sb + (int)((u32)(tlo >> 5) - S.tfirst[j]);
+						const u64 t0 = slot >= sb ? S.tcodes[slot] : 0ull;
+						const u64 t32 = funnel_l(t0, S.tcodes[slot + 1], (int)(tlo & 31) * 2);
+						const u64 face = same ? t32 : ~rev_groups(t32);
+						u64 x = S.cw[lane] ^ face;
+						// one bit per base: OR the two bits of every group, gather the even bits
+						x = (x | (x >> 1)) & 0x5555555555555555ull;
+						x = (x | (x >> 1)) & 0x3333333333333333ull;
+						x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+						x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+						x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+						x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+						mbits = __brev((u32)x); // base 0 of the word -> bit 0
+					}
+				}
+				S.mm32[lane] = mbits;
+			}
+			ARKS_WAVE_SYNC();
+			ARKS_SEC(6);
+			// ---- T6c: lanes = windows: a window whose run proposes the primary diagonal only tests its
+			//      k mismatch bits; any other candidate gets the full key comparison ------------------
 			for (int base = 0; base < n; base += 64) {
 				const int i = base + lane;
 				const int rv = rec[i];
@@ -557,7 +651,41 @@ map_reads_b_kernel(
 					const int q = (int)(pay & 2047u), hidx = (int)(pay >> 11);
 					const u32 hn = hidx < kNH ? S.hn[hidx] : kHnOverflow;
 					int val = -1;
-					if (hn != 0) {
+					bool full = hn == kHnHeavy || hn == kHnOverflow;
+					if (hn == 1 || hn == 2) {
+						const int j = S.wread[i >> 5];
+						const u64 pdv = S.pdiag[j];
+						const u64 e = S.hc[hidx][0];
+						const int p = i - S.rstart[j];
+						const int o = q - S.rstart[j];
+						const bool same = ((u32)(e >> 62) & 1u) == ((S.mm[q] >> 30) & 1u);
+						const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(kM - 1 + o);
+						if (pdv == (D | ((u64)same << 40) | (1ull << 41))) {
+							const int l = i & 31;
+							const u32* mw = S.mm32 + (i >> 5);
+							const u64 m01 = (u64)mw[0] | ((u64)mw[1] << 32);
+							const u64 m23 = (u64)mw[2] | ((u64)mw[3] << 32);
+							u64 bits = funnel_r(m01, m23, l); // 64 bases from i on
+							if (k < 64)
+								bits &= (1ull << k) - 1ull;
+							if (KW > 2 && k > 64) {
+								const u64 m45 = (u64)mw[4] | ((u64)mw[5] << 32);
+								bits |= funnel_r(m23, m45, l) & ((1ull << (k - 64)) - 1ull);
+							}
+							if (bits == 0) {
+								const u64 t = same ? D + (u64)p : D - (u64)(p + k - 1);
+								const int slot = (S.rstart[j] >> 5) + j + (int)((u32)(t >> 5) - S.tfirst[j]);
+								const u32 sh = 31 - (u32)(t & 31);
+								if ((S.tvis[slot] >> sh) & 1u)
+									val = ((S.tamb[slot] >> sh) & 1u) ? 0 : (int)S.town[slot];
+								else
+									full = hn == 2;
+							} else
+								full = hn == 2;
+						} else
+							full = true;
+					}
+					if (full) {
 						const Key<KW> f = tile_window_key<KW>(S.cw, i, g);
 						const Key<KW> r = key_revcomp(f, g);
 						if (hn == kHnHeavy) {
