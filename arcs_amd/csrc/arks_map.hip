@@ -284,6 +284,7 @@ struct TileLds
 	unsigned short heads[kNH];
 	unsigned char hn[kNH];
 	unsigned char wread[kTW + 4];
+	u32 wmeta[kTW + 4]; // per word: read index << 16 | local end position of that read (0 = none)
 	int rstart[kTR + 1];
 	int rlen[kTR];
 	u64 pdiag[kTR]; // [39:0] D, [40] same strand, [41] valid
@@ -417,8 +418,11 @@ map_reads_b_kernel(
 			ARKS_WAVE_SYNC();
 			if (lane < nr) {
 				const int w0 = S.rstart[lane] >> 5, w1 = S.rstart[lane + 1] >> 5;
-				for (int x = w0; x < w1; ++x)
+				const int rend = S.rlen[lane] > 0 ? S.rstart[lane] + S.rlen[lane] : 0;
+				for (int x = w0; x < w1; ++x) {
 					S.wread[x] = (unsigned char)lane;
+					S.wmeta[x] = ((u32)lane << 16) | (u32)rend;
+				}
 				for (int x = w0; x <= w1; ++x) // one staging slot more than the read has words
 					S.sread[x + lane] = (unsigned char)lane;
 			}
@@ -430,8 +434,7 @@ map_reads_b_kernel(
 			for (int i = lane; i < n + 96; i += 64) {
 				u32 o = 0xFFFFFFFFu;
 				if (i < n) {
-					const int j = S.wread[i >> 5];
-					const int rem = S.rstart[j] + S.rlen[j] - i; // bases of the read from i on
+					const int rem = (int)(S.wmeta[i >> 5] & 0xFFFFu) - i; // bases of the read from i on
 					const int hn = i >> 4, t = (i & 15) * 2;
 					const u32 hi = s32[hn ^ 1], lo = s32[(hn + 1) ^ 1];
 					const u32 x = t ? ((hi << t) | (lo >> (32 - t))) : hi;
@@ -457,21 +460,45 @@ map_reads_b_kernel(
 			// ---- T3: sliding minimum over w positions by doubling, ping-pong a <-> b ---------------
 			u32* src = S.a;
 			u32* dst = S.b;
-			for (int span = 1;;) {
-				const int step = (2 * span <= w) ? span : (w - span);
-				if (step <= 0)
-					break;
-				for (int i = lane; i < n; i += 64) {
-					const u32 x = src[i], y = src[i + step];
-					dst[i] = x < y ? x : y;
+			if (w >= 16) {
+				// two dependent LDS round trips instead of log2(w): (1) minimum of every aligned-free
+				// block of 8, (2) minimum of the <= 11 blocks that tile [i, i + w)
+				for (int i = lane; i < n + 96 - 8; i += 64) {
+					u32 m = src[i];
+#pragma unroll
+					for (int o = 1; o < 8; ++o) {
+						const u32 y = src[i + o];
+						m = y < m ? y : m;
+					}
+					dst[i] = m;
 				}
 				ARKS_WAVE_SYNC();
-				u32* tsw = src;
-				src = dst;
-				dst = tsw;
-				if (2 * span > w)
-					break;
-				span *= 2;
+				for (int i = lane; i < n; i += 64) {
+					u32 m = dst[i + w - 8];
+					for (int o = 0; o + 8 < w; o += 8) {
+						const u32 y = dst[i + o];
+						m = y < m ? y : m;
+					}
+					src[i] = m;
+				}
+				ARKS_WAVE_SYNC();
+			} else {
+				for (int span = 1;;) {
+					const int step = (2 * span <= w) ? span : (w - span);
+					if (step <= 0)
+						break;
+					for (int i = lane; i < n; i += 64) {
+						const u32 x = src[i], y = src[i + step];
+						dst[i] = x < y ? x : y;
+					}
+					ARKS_WAVE_SYNC();
+					u32* tsw = src;
+					src = dst;
+					dst = tsw;
+					if (2 * span > w)
+						break;
+					span *= 2;
+				}
 			}
 			// src[i] = minimizer of window i (low 11 bits: its position); dst becomes the window
 			// record: >= 0 value, -1 absent, -2 NULL window, -3 no window, <= -16 pending (q, run)
@@ -482,8 +509,9 @@ map_reads_b_kernel(
 			u32 carry = 0xFFFFu;
 			for (int base = 0; base < n; base += 64) {
 				const int i = base + lane;
-				const int j = S.wread[i >> 5];
-				const int rem = S.rstart[j] + S.rlen[j] - i;
+				const u32 wm = S.wmeta[i >> 5];
+				const int j = (int)(wm >> 16);
+				const int rem = (int)(wm & 0xFFFFu) - i;
 				const bool is_win = rem >= k;
 				bool bad = false;
 				if (has_n && is_win) {
