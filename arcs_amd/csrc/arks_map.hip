@@ -431,6 +431,7 @@ map_reads_b_kernel(
 			ARKS_SEC(1);
 			// ---- T2: order value of every 15-mer -------------------------------------------------
 			const u32* s32 = reinterpret_cast<const u32*>(S.cw); // 16 bases per u32, halves swapped
+#pragma unroll 2
 			for (int i = lane; i < n + 96; i += 64) {
 				u32 o = 0xFFFFFFFFu;
 				if (i < n) {
@@ -463,6 +464,7 @@ map_reads_b_kernel(
 			if (w >= 16) {
 				// two dependent LDS round trips instead of log2(w): (1) minimum of every aligned-free
 				// block of 8, (2) minimum of the <= 11 blocks that tile [i, i + w)
+#pragma unroll 2
 				for (int i = lane; i < n + 96 - 8; i += 64) {
 					u32 m = src[i];
 #pragma unroll
@@ -473,6 +475,7 @@ map_reads_b_kernel(
 					dst[i] = m;
 				}
 				ARKS_WAVE_SYNC();
+#pragma unroll 2
 				for (int i = lane; i < n; i += 64) {
 					u32 m = dst[i + w - 8];
 					for (int o = 0; o + 8 < w; o += 8) {
