@@ -1,0 +1,56 @@
+"""Multi-GPU driver logic (one process per GPU, torch.distributed; backend "nccl" = RCCL on ROCm,
+"gloo" in the CPU tests).  The path shards over reads: every rank holds a replica of the contig
+k-mer index and maps its own slice of the read pairs; the only exchange is the final merge of the
+per-rank IndexMap triples (a sum), which mirrors `imap[barcode][end]++` being commutative
+(Arcs/Arcs.cpp:1282-1285).  No data-path collective."""
+import numpy as np
+
+
+def shard_pairs(n_pairs, rank, world):
+    """contiguous slice [lo, hi) of the pairs that rank maps (mates stay together)"""
+    base, rem = divmod(n_pairs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def merge_triples(local, group=None):
+    """all ranks contribute uint32[n, 3] (barcode id, conreci, count); every rank gets the merged,
+    sorted sum.  Sizes differ per rank, so sizes are gathered first and the payload is padded."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    loc = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint32).astype(np.int64)).to(dev)
+    n = torch.tensor([loc.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    m = int(max(int(x.item()) for x in sizes))
+    pad = torch.zeros((m, 3), dtype=torch.int64, device=dev)
+    pad[: loc.shape[0]] = loc.reshape(-1, 3)
+    parts = [torch.zeros((m, 3), dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    rows = torch.cat([p[: int(s.item())] for p, s in zip(parts, sizes)]).cpu().numpy()
+    return sum_triples(rows)
+
+
+def sum_triples(rows):
+    """uint32[n, 3] with duplicate (barcode, conreci) keys summed, sorted by key"""
+    rows = np.asarray(rows, dtype=np.int64).reshape(-1, 3)
+    if len(rows) == 0:
+        return np.zeros((0, 3), dtype=np.uint32)
+    key = rows[:, 0] * (1 << 32) + rows[:, 1]
+    uk, inv = np.unique(key, return_inverse=True)
+    cnt = np.bincount(inv, weights=rows[:, 2]).astype(np.int64)
+    return np.stack([uk >> 32, uk & 0xFFFFFFFF, cnt], axis=1).astype(np.uint32)
+
+
+def sum_stats(stats, group=None):
+    """element-wise sum of the 8 arks_map_stats counters over ranks"""
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.as_tensor(np.asarray(stats, dtype=np.int64)).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
