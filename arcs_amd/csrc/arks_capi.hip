@@ -523,11 +523,13 @@ arks_index_build(
 		HIP_TRY(launch_popcount(d_ismin.as<u32>(), text_words, d_counters.as<u64>() + 0, st));
 	ARKS_TRACE_STEP("launch_popcount");
 		HIP_TRY(launch_popcount(d_ispal.as<u32>(), text_words, d_counters.as<u64>() + 1, st));
+		HIP_TRY(launch_popcount(d_isimg.as<u32>(), text_words, d_counters.as<u64>() + 2, st));
 	ARKS_TRACE_STEP("launch_popcount");
 		HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 		n_min = counters[0];
 		n_pal = counters[1];
+		idx->bx.has_img = counters[2] != 0;
 		// the full table is no longer needed: every position now carries its value bits
 		(void)hipFree(d_full.p);
 		d_full.p = nullptr;

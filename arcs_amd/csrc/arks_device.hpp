@@ -384,6 +384,7 @@ struct BIndexView
 	TableView fallback;
 	int w;       // minimizer window: k - kM + 1
 	int enabled; // 0 => the plain hash table `TableView` is the index (small k)
+	int has_img; // the index holds regular keys that are quirk images (a palindromic query could hit them)
 };
 
 // the 15-mer starting at base `pos` of a packed stream, right-aligned in 30 bits
@@ -402,13 +403,14 @@ mmer_rc(u32 f)
 	return ~t & kMmerMask;
 }
 
-// 21-bit ordering hash of a canonical 15-mer (decides WHICH 15-mer of a window is its minimizer;
+// 20-bit ordering hash of a canonical 15-mer (decides WHICH 15-mer of a window is its minimizer;
 // equal values are ties and every tied position is registered on the text side).  Text side and
-// query side must use the very same function: the map kernel packs it above an 11-bit position.
+// query side must use the very same function: the map kernel packs it above an 11-bit position
+// and a strand bit.
 __device__ __forceinline__ u32
 mmer_order(u32 cm)
 {
-	return ((cm ^ 0x2F0B4C5Du) * 0x9E3779B1u) >> 11;
+	return ((cm ^ 0x2F0B4C5Du) * 0x9E3779B1u) >> 12;
 }
 
 __device__ __forceinline__ u64
@@ -452,7 +454,7 @@ fallback_lookup(const BIndexView& bx, const Key<KW>& c)
 }
 
 // Serial (one lane) exact lookup of one window in the locality index: value of the window whose
-// forward / reverse-complement keys are f / r (f != r) and that starts at base p of the packed
+// forward / reverse-complement keys are f / r (equal for a palindrome) and that starts at base p of the packed
 // stream (wbase).  -1 = absent, 0 = ambiguous, > 0 = contig end.  The slow path, and the in-kernel
 // definition the cooperative fast path has to agree with.
 template <int KW>
@@ -483,6 +485,8 @@ bindex_lookup_serial(
 #pragma unroll
 			for (int j = 0; j < KW; ++j)
 				c.w[j] = lt ? f.w[j] : r.w[j];
+			if (key_eq(f, r)) // a palindrome lives in the fallback table under its damaged key
+				c = key_palindrome_quirk(f, g);
 			return fallback_lookup<KW>(bx, c);
 		}
 		const bool same = ((u32)(e >> 62) & 1u) == rstrand;

@@ -277,7 +277,6 @@ struct TileLds
 {
 	u32 a[kTP + 96];
 	u32 b[kTP + 96];
-	u32 mm[kTP]; // [29:0] canonical 15-mer, [30] strand
 	u64 cw[kTW + 4];
 	u32 nm[kTW + 4];
 	u64 hc[kNH][2];
@@ -336,6 +335,18 @@ __device__ unsigned long long g_sec_cycles[16];
 	do {                                                                                           \
 	} while (0)
 #endif
+
+// canonical 15-mer at local position i of the staged tile words
+__device__ __forceinline__ u32
+tile_canonical_mmer(const u64* cw, int i)
+{
+	const u32* s32 = reinterpret_cast<const u32*>(cw); // 16 bases per u32, halves swapped
+	const int hn = i >> 4, t = (i & 15) * 2;
+	const u32 hi = s32[hn ^ 1], lo = s32[(hn + 1) ^ 1];
+	const u32 mf = (t ? ((hi << t) | (lo >> (32 - t))) : hi) >> 2;
+	const u32 mr = mmer_rc(mf);
+	return mf < mr ? mf : mr;
+}
 
 template <int KW, bool STATS>
 __global__ void __launch_bounds__(64)
@@ -431,7 +442,7 @@ map_reads_b_kernel(
 			ARKS_SEC(1);
 			// ---- T2: order value of every 15-mer -------------------------------------------------
 			const u32* s32 = reinterpret_cast<const u32*>(S.cw); // 16 bases per u32, halves swapped
-#pragma unroll 2
+// (no unroll: registers)
 			for (int i = lane; i < n + 96; i += 64) {
 				u32 o = 0xFFFFFFFFu;
 				if (i < n) {
@@ -442,7 +453,6 @@ map_reads_b_kernel(
 					const u32 mf = x >> 2;
 					const u32 mr = mmer_rc(mf);
 					const u32 cm = mf < mr ? mf : mr;
-					S.mm[i] = cm | ((mf < mr ? 1u : 0u) << 30);
 					bool ok = rem >= kM;
 					if (has_n) {
 						const int tn = i & 31;
@@ -450,7 +460,7 @@ map_reads_b_kernel(
 						ok = ok && (bits >> (32 - kM)) == 0;
 					}
 					if (ok)
-						o = (mmer_order(cm) << 11) | (u32)i;
+						o = (mmer_order(cm) << 12) | ((u32)i << 1) | (mf < mr ? 1u : 0u);
 				}
 				S.a[i] = o;
 				if (i >= n)
@@ -464,7 +474,7 @@ map_reads_b_kernel(
 			if (w >= 16) {
 				// two dependent LDS round trips instead of log2(w): (1) minimum of every aligned-free
 				// block of 8, (2) minimum of the <= 11 blocks that tile [i, i + w)
-#pragma unroll 2
+// (no unroll: registers)
 				for (int i = lane; i < n + 96 - 8; i += 64) {
 					u32 m = src[i];
 #pragma unroll
@@ -475,7 +485,7 @@ map_reads_b_kernel(
 					dst[i] = m;
 				}
 				ARKS_WAVE_SYNC();
-#pragma unroll 2
+// (no unroll: registers)
 				for (int i = lane; i < n; i += 64) {
 					u32 m = dst[i + w - 8];
 					for (int o = 0; o + 8 < w; o += 8) {
@@ -531,7 +541,8 @@ map_reads_b_kernel(
 					bad = any != 0;
 				}
 				const bool ok = is_win && !bad;
-				const u32 q = ok ? (src[i] & 2047u) : 0xFFFFu;
+				const u32 sv = src[i];
+				const u32 q = ok ? ((sv >> 1) & 2047u) : 0xFFFFu;
 				u32 qprev = __shfl_up(q, 1);
 				if (lane == 0)
 					qprev = carry;
@@ -544,12 +555,15 @@ map_reads_b_kernel(
 				nheads += __popcll(hb);
 				int rv = is_win ? -2 : -3;
 				if (ok) {
-					rv = -16 - (int)(q | ((u32)hidx << 11));
-					if (!(k & 1)) {
-						// a reverse-complement palindrome carries its minimizer twice, mirrored about
-						// its centre (necessary condition; the slow kernel decides exactly)
+					rv = -16 - (int)(q | ((sv & 1u) << 11) | ((u32)hidx << 12)); // position, strand, run
+					if (bx.has_img && !(k & 1)) {
+						// Only when the index holds quirk images can a palindromic window have a key
+						// that the text path would miss (otherwise it is either in the text, where its
+						// position carries the value of its damaged key, or absent).  A reverse-
+						// complement palindrome carries its minimizer twice, mirrored about its centre:
+						// necessary condition; the slow kernel decides exactly.
 						const int qm = 2 * i + (k - kM) - (int)q;
-						if (((S.mm[qm] ^ S.mm[q]) & kMmerMask) == 0)
+						if (tile_canonical_mmer(S.cw, qm) == tile_canonical_mmer(S.cw, (int)q))
 							atomicOr(&S.redo, 1u << j);
 					}
 				}
@@ -562,7 +576,7 @@ map_reads_b_kernel(
 			for (int h = lane; h < nh; h += 64) {
 				const int i = S.heads[h];
 				const u32 q = (u32)(-16 - rec[i]) & 2047u;
-				const u32 cm = S.mm[q] & kMmerMask;
+				const u32 cm = tile_canonical_mmer(S.cw, (int)q);
 				u64 slot = mtab_home(cm, bx.mtab_cap);
 				u32 cnt = 0;
 				for (;;) {
@@ -608,10 +622,11 @@ map_reads_b_kernel(
 				if (lane < nr) {
 					u64 pdv = 0;
 					if (pf != 0xFFFFFFFFu) {
-						const int q = (int)((u32)(-16 - rec[S.heads[pf]]) & 2047u);
+						const u32 payh = (u32)(-16 - rec[S.heads[pf]]);
+						const int q = (int)(payh & 2047u);
 						const u64 e = S.hc[pf][0];
 						const int o = q - S.rstart[lane]; // offset of the minimizer in the read
-						const bool same = ((u32)(e >> 62) & 1u) == ((S.mm[q] >> 30) & 1u);
+						const bool same = ((u32)(e >> 62) & 1u) == ((payh >> 11) & 1u);
 						// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
 						const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(kM - 1 + o);
 						pdv = D | ((u64)same << 40) | (1ull << 41);
@@ -679,7 +694,8 @@ map_reads_b_kernel(
 					continue;
 				if (pending) {
 					const u32 pay = (u32)(-16 - rv);
-					const int q = (int)(pay & 2047u), hidx = (int)(pay >> 11);
+					const int q = (int)(pay & 2047u), hidx = (int)(pay >> 12);
+					const u32 rstrand = (pay >> 11) & 1u;
 					const u32 hn = hidx < kNH ? S.hn[hidx] : kHnOverflow;
 					int val = -1;
 					bool full = hn == kHnHeavy || hn == kHnOverflow;
@@ -689,7 +705,7 @@ map_reads_b_kernel(
 						const u64 e = S.hc[hidx][0];
 						const int p = i - S.rstart[j];
 						const int o = q - S.rstart[j];
-						const bool same = ((u32)(e >> 62) & 1u) == ((S.mm[q] >> 30) & 1u);
+						const bool same = ((u32)(e >> 62) & 1u) == rstrand;
 						const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(kM - 1 + o);
 						if (pdv == (D | ((u64)same << 40) | (1ull << 41))) {
 							const int l = i & 31;
@@ -725,11 +741,12 @@ map_reads_b_kernel(
 #pragma unroll
 							for (int x = 0; x < KW; ++x)
 								c.w[x] = lt ? f.w[x] : r.w[x];
+							if (key_eq(f, r)) // a palindrome lives in the fallback table under its damaged key
+								c = key_palindrome_quirk(f, g);
 							val = fallback_lookup<KW>(bx, c);
 						} else if (hn == kHnOverflow) {
 							val = bindex_lookup_serial<KW>(bx, g, codes, base_w * 32ull + (u64)i, f, r);
 						} else {
-							const u32 rstrand = (S.mm[q] >> 30) & 1u;
 							const int off = q - i;
 							for (u32 c = 0; c < hn && val < 0; ++c) {
 								const u64 e = S.hc[hidx][c];
