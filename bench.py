@@ -38,6 +38,23 @@ def alg_bytes_per_window(k, bases, windows):
     return 2.0 * bases / (8.0 * windows) + (2 * k + 7) // 8 + 4
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this
+    very workload (profiles/traffic_r*.json, written from separate --pmc passes by profiles/prof.sh);
+    None when no summary matches the workload being run."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        wl = d.get("workload", {})
+        if wl.get("pairs_per_gpu") == args.pairs and wl.get("draft_mbp") == args.draft_mbp and wl.get("k") == args.k:
+            best = d
+    return best
+
+
 def cpu_baseline(cs, batch, k, j, n_pairs_total, log):
     """the CPU oracle (a literal port of the reference path: per-window O(k) re-encode, exact
     hash map, ordered histogram; OpenMP over pairs) timed on the host cores, on a bounded sample
@@ -158,6 +175,7 @@ def main():
                        "windows"), stats.cpu().tolist()))
         assert st["windows"] <= windows
         achieved = windows * b_alg / (map_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(args)
         out = {
             "metric": METRIC, "value": value, "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps,
@@ -166,11 +184,17 @@ def main():
             "config": {"workload": f"synthetic {args.draft_mbp:g} Mbp draft + {args.pairs} linked-read "
                                    f"pairs per GPU (R1 128 / R2 151 bp), k={k} j={j}",
                        "k": k, "j": j, "pairs_per_gpu": args.pairs, "windows_per_gpu": windows,
-                       "index_keys": len(index), "parallelism": f"index replica x{world}, reads sharded"},
+                       "index_keys": len(index),
+                       "index_kind": "locality (text + minimizer table)" if index.kind == 1 else "hash table",
+                       "index_bytes": index.device_bytes, "parallelism": f"index replica x{world}, reads sharded"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "map_reads_kernel", "kernel_ms": map_ms,
-                         "alg_bytes_per_window": b_alg},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (traffic["hbm_bytes_per_launch"] / 1e9) if traffic else None,
+                         "traffic_unit": "GB per launch (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE)",
+                         "traffic_source": traffic["source"] if traffic else None,
+                         "alg_bytes_per_launch_GB": windows * b_alg / 1e9,
+                         "kernel": "map_reads_b_kernel" if index.kind == 1 else "map_reads_kernel",
+                         "kernel_ms": map_ms, "alg_bytes_per_window": b_alg},
             "counters": st, "stored_pairs": int(stored.item()),
         }
         if not args.no_cpu_baseline and world == 1:
