@@ -32,5 +32,28 @@ def build(force=False, verbose=False):
     return OUT
 
 
+HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("arcs.cpp", "graph.hpp", "seqio.hpp")]
+HOST_OUT = os.path.join(HERE, "bin", "arcs")
+
+
+def build_host(force=False, verbose=False):
+    """the `arcs --arks` front end (C++17 host program over the C ABI; needs zlib)"""
+    build(force=False, verbose=verbose)
+    if not force and os.path.exists(HOST_OUT) and \
+            all(os.path.getmtime(p) <= os.path.getmtime(HOST_OUT) for p in HOST_SOURCES + [OUT]):
+        return HOST_OUT
+    os.makedirs(os.path.dirname(HOST_OUT), exist_ok=True)
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "host"), HOST_SOURCES[0],
+           "-L" + os.path.dirname(OUT), "-larks_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz",
+           "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-o", HOST_OUT]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return HOST_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

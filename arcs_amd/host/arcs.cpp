@@ -1,0 +1,868 @@
+// arcs.cpp -- host front end `arcs --arks ...` over libarks_hip.so (MI355X).
+//
+// Keeps the command line of the reference's `arcs` (Arcs/Arcs.cpp:105-157, main :1961-2184) and the
+// files it writes (<base>_original.gv, <base>.dist.gv, <base>_main.tsv, optional barcode counts
+// and pair TSV), so that bin/arcs-make (`arcs --arks -v -f draft.fa -c -m -r -e -z -j -k -t -d --gap
+// -b base reads.fq.gz --barcode-counts x.tsv`, arcs-make:290) -> makeTSVfile.py -> LINKS runs
+// unchanged.  The ARKS stages of runArcs (Arcs.cpp:1871-1903) run as:
+//   barcode multiplicities   host  (createIndexMultMap :392-448 / readBarcodes :481-547)
+//   contig ends -> index     GPU   (arks_index_build; replaces getContigKmers/mapKmers)
+//   read pairs -> IndexMap   host parse (chromiumRead :1185-1262) + GPU (gate, bestContig x2,
+//                            pair rule, imap accumulation)
+//   graph stage and writers  host  (graph.hpp)
+// Not offered: the alignment (SAM/BAM) mode and -D distance estimation (outside the ARKS k-mer
+// path); both are reported as errors instead of being silently ignored.
+#include "arks_hip.h"
+#include "graph.hpp"
+#include "seqio.hpp"
+
+#include <getopt.h>
+#include <hip/hip_runtime_api.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <ctime>
+
+using namespace arks_host;
+
+#define PROGRAM "arcs"
+#define PACKAGE_VERSION "1.2.8-mi355x"
+
+namespace {
+
+struct Params
+{
+	std::string file, fofName, base_name, dist_graph_name, tsv_name, barcode_counts_name, multfile;
+	int seq_id = 98;
+	int min_size = 500;
+	int end_length = 30000;
+	int verbose = 0;
+	int k_value = 30;
+	double j_index = 0.55;
+	unsigned threads = 1;
+	bool arks = false, output_pair = false, dist_est = false;
+	unsigned dist_bin_size = 20;
+	std::string dist_samples_tsv, dist_tsv;
+	GraphParams g;
+	long batch_pairs = 2000000; // --batch-pairs (this build only): read pairs per GPU batch
+	int device = 0;             // --device (this build only)
+};
+
+Params params;
+
+enum
+{
+	OPT_HELP = 1,
+	OPT_VERSION,
+	OPT_BX,
+	OPT_GAP,
+	OPT_TSV,
+	OPT_BARCODE_COUNTS,
+	OPT_SAMPLES_TSV,
+	OPT_DIST_TSV,
+	OPT_NO_DIST_EST,
+	OPT_DIST_MEDIAN,
+	OPT_DIST_UPPER,
+	OPT_ARKS_METHOD,
+	OPT_BATCH_PAIRS,
+	OPT_DEVICE
+};
+
+const char shortopts[] = "f:a:B:s:c:Dl:z:b:g:m:d:e:r:vt:u:j:k:P";
+
+const struct option longopts[] = {
+	{ "file", required_argument, NULL, 'f' },
+	{ "fofName", required_argument, NULL, 'a' },
+	{ "bin_size", required_argument, NULL, 'B' },
+	{ "bx", no_argument, NULL, OPT_BX },
+	{ "samples_tsv", required_argument, NULL, OPT_SAMPLES_TSV },
+	{ "dist_tsv", required_argument, NULL, OPT_DIST_TSV },
+	{ "seq_id", required_argument, NULL, 's' },
+	{ "min_reads", required_argument, NULL, 'c' },
+	{ "dist_est", no_argument, NULL, 'D' },
+	{ "no_dist_est", no_argument, NULL, OPT_NO_DIST_EST },
+	{ "dist_median", no_argument, NULL, OPT_DIST_MEDIAN },
+	{ "dist_upper", no_argument, NULL, OPT_DIST_UPPER },
+	{ "min_links", required_argument, NULL, 'l' },
+	{ "min_size", required_argument, NULL, 'z' },
+	{ "base_name", required_argument, NULL, 'b' },
+	{ "graph", required_argument, NULL, 'g' },
+	{ "tsv", required_argument, NULL, OPT_TSV },
+	{ "barcode-counts", required_argument, NULL, OPT_BARCODE_COUNTS },
+	{ "gap", required_argument, NULL, OPT_GAP },
+	{ "index_multiplicity", required_argument, NULL, 'm' },
+	{ "max_degree", required_argument, NULL, 'd' },
+	{ "end_length", required_argument, NULL, 'e' },
+	{ "error_percent", required_argument, NULL, 'r' },
+	{ "run_verbose", required_argument, NULL, 'v' },
+	{ "version", no_argument, NULL, OPT_VERSION },
+	{ "help", no_argument, NULL, OPT_HELP },
+	{ "threads", required_argument, NULL, 't' },
+	{ "multfile", required_argument, NULL, 'u' },
+	{ "k_value", required_argument, NULL, 'k' },
+	{ "j_index", required_argument, NULL, 'j' },
+	{ "arks", no_argument, NULL, OPT_ARKS_METHOD },
+	{ "pair", no_argument, NULL, 'P' },
+	{ "batch-pairs", required_argument, NULL, OPT_BATCH_PAIRS },
+	{ "device", required_argument, NULL, OPT_DEVICE },
+	{ NULL, 0, NULL, 0 }
+};
+
+const char USAGE[] =
+    PROGRAM " " PACKAGE_VERSION "\n\n"
+            "Usage: arcs [Options] --arks -f <contig sequence file> <list of linked read files>\n\n"
+            "MI355X build of the ARKS method of bcgsc/arcs: same options and output files as the\n"
+            "reference for --arks; the alignment (SAM/BAM) method and -D are not part of this build.\n\n"
+            "   -a, --fofName=FILE    text file listing input filenames\n"
+            "   -u, --multfile        tsv or csv file listing barcode multiplicities [optional]\n"
+            "   -f, --file=FILE       FASTA file of contig sequences to scaffold\n"
+            "   -c, --min_reads=N     min aligned read pairs per barcode mapping [5]\n"
+            "   -l, --min_links=N     min shared barcodes between contigs [0]\n"
+            "   -z, --min_size=N      min contig length [500]\n"
+            "   -b, --base_name=STR   output file prefix\n"
+            "   -g, --graph=FILE      write the ABySS dist.gv to FILE\n"
+            "       --gap=N           fixed gap size for ABySS dist.gv file [100]\n"
+            "       --tsv=FILE        write graph in TSV format to FILE\n"
+            "       --barcode-counts=FILE       write number of reads per barcode to FILE\n"
+            "   -m, --index_multiplicity=RANGE  barcode multiplicity range [50-10000]\n"
+            "   -d, --max_degree=N    max node degree in scaffold graph [0]\n"
+            "   -e, --end_length=N    contig head/tail length for masking alignments [30000]\n"
+            "   -r, --error_percent=N p-value for head/tail assignment and link orientation [0.05]\n"
+            "   -v, --run_verbose     verbose logging\n"
+            "   -k  --k_value         size of a k-mer [30]\n"
+            "   -j  --j_index         minimum fraction of read kmers matching a contigId [0.55]\n"
+            "   -t  --threads         number of threads [1] (accepted; the mapping runs on the GPU)\n"
+            "   -P, --pair            output scaffolds pairing TSV\n"
+            "       --batch-pairs=N   read pairs per GPU batch [2000000]\n"
+            "       --device=N        GPU ordinal [0]\n";
+
+void
+die_arks(int rc, const char* what)
+{
+	std::cerr << PROGRAM ": " << what << ": " << arks_strerror(rc) << " " << arks_last_error_string() << "\n";
+	exit(EXIT_FAILURE);
+}
+
+void
+assert_readable(const std::string& path)
+{
+	if (access(path.c_str(), R_OK) == -1) {
+		std::cerr << "error: `" << path << "': " << strerror(errno) << std::endl;
+		exit(EXIT_FAILURE);
+	}
+}
+
+std::vector<std::string>
+read_fof(const std::string& fof)
+{
+	std::vector<std::string> v;
+	if (fof.empty())
+		return v;
+	std::ifstream in(fof.c_str());
+	std::string s;
+	while (in >> s)
+		v.push_back(s);
+	return v;
+}
+
+// Arcs.cpp:243-254
+void
+strip_read_num(std::string& name)
+{
+	const size_t pos = name.rfind('/');
+	if (pos == std::string::npos || pos == 0 || pos == name.length() - 1)
+		return;
+	if (!std::isdigit((unsigned char)name.at(pos + 1)))
+		return;
+	name.resize(pos);
+}
+
+// text after "BX:Z:" up to the next space (Arcs.cpp:1227-1237); empty when the tag is absent
+std::string
+bx_barcode(const std::string& comment)
+{
+	const size_t tag = comment.find("BX:Z:");
+	if (tag == std::string::npos)
+		return std::string();
+	const size_t end = comment.find(' ', tag);
+	return end != std::string::npos ? comment.substr(tag + 5, end - tag - 5) : comment.substr(tag + 5);
+}
+
+// Arcs.cpp:336-361
+bool
+check_same_format(const std::vector<std::string>& names, bool& all_alignment)
+{
+	int prev = 0, cur = 0;
+	for (const auto& f : names) {
+		cur = 0;
+		if (f.find(".sam") != std::string::npos || f.find(".bam") != std::string::npos)
+			cur = 1;
+		if (f.find(".fastq") != std::string::npos || f.find(".fq") != std::string::npos)
+			cur = 2;
+		if (!cur) {
+			std::cout << "Unknown type file is observed!" << std::endl;
+			return false;
+		}
+		if (!(!prev || prev == cur))
+			return false;
+		prev = cur;
+	}
+	all_alignment = cur == 1;
+	return true;
+}
+
+// Arcs.cpp:392-448
+void
+create_index_mult_map(const std::string& multfile, std::unordered_map<std::string, int>& mult)
+{
+	size_t numbarcodes = 0;
+	const bool tsv = multfile.find(".tsv") != std::string::npos;
+	std::ifstream in(multfile.c_str());
+	if (!in) {
+		std::cerr << "Could not open " << multfile << ". --fatal.\n";
+		exit(EXIT_FAILURE);
+	}
+	std::string line;
+	while (getline(in, line)) {
+		std::string barcode, ms;
+		if (tsv) {
+			std::stringstream sst(line);
+			sst >> barcode >> ms;
+		} else {
+			std::istringstream iss(line);
+			getline(iss, barcode, ',');
+			iss >> ms;
+		}
+		numbarcodes++;
+		const size_t m = (size_t)std::stoi(ms);
+		if (!barcode.empty())
+			mult[barcode] = (int)m;
+		else
+			std::cout << "Please check your multiplicity file." << std::endl;
+	}
+	if (params.verbose)
+		std::cout << "Saw " << numbarcodes << "  distinct barcodes." << std::endl;
+}
+
+// Arcs.cpp:481-547: counts READS per barcode; a record of length <= 0 ends the file
+void
+read_barcodes(const std::vector<std::string>& files, std::unordered_map<std::string, int>& mult)
+{
+	size_t added = 0;
+	for (const auto& f : files) {
+		if (params.verbose)
+			std::cout << "Reading chrom " << f << std::endl;
+		SeqReader rd(f.c_str());
+		if (!rd.ok()) {
+			std::cerr << "File " << f << " cannot be opened." << std::endl;
+			exit(1);
+		}
+		std::cerr << "File " << f << " opened." << std::endl;
+		for (;;) {
+			const int l = rd.next();
+			if (l <= 0)
+				break;
+			if (rd.comment.empty())
+				continue;
+			const size_t tag = rd.comment.find("BX:Z:");
+			if (tag != std::string::npos) {
+				mult[bx_barcode(rd.comment)]++;
+				added++;
+			}
+			if (params.verbose && added % 100000000 == 0)
+				std::cout << added << " read with valid barcode" << std::endl;
+		}
+	}
+	if (params.verbose)
+		std::cout << "Saw " << mult.size() << " distinct barcode." << std::endl;
+}
+
+// Arcs.cpp:317-331
+bool
+check_contig_sequence(const std::string& seq)
+{
+	for (char ch : seq) {
+		const char c = (char)toupper((unsigned char)ch);
+		if (!strchr("ATGCNMRWSYKVHDB", c) || c == '\0') {
+			std::cout << c << std::endl;
+			return false;
+		}
+	}
+	return true;
+}
+
+const char*
+maybe_na(const std::string& s)
+{
+	return s.empty() ? "NA" : s.c_str();
+}
+
+const char*
+now()
+{
+	static char buf[64];
+	std::time_t t;
+	time(&t);
+	std::strncpy(buf, ctime(&t), sizeof buf - 1);
+	return buf;
+}
+
+int
+memory_usage()
+{
+	std::ifstream proc("/proc/self/status");
+	std::string s;
+	while (getline(proc, s))
+		if (s.compare(0, 5, "VmRSS") == 0) {
+			int mem = 0;
+			std::stringstream ss(s.substr(s.find_last_of('\t')));
+			ss >> mem;
+			return mem;
+		}
+	return 0;
+}
+
+template <typename T>
+struct DevArray
+{
+	T* p = nullptr;
+	size_t cap = 0;
+	~DevArray()
+	{
+		if (p)
+			(void)hipFree(p);
+	}
+	void reserve(size_t n)
+	{
+		if (n <= cap)
+			return;
+		if (p)
+			(void)hipFree(p);
+		cap = n + n / 4 + 64;
+		if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) {
+			std::cerr << PROGRAM ": out of device memory\n";
+			exit(EXIT_FAILURE);
+		}
+	}
+};
+
+// ---- the contig index (replaces initContigArray + getContigKmers, Arcs.cpp:451-479, 1021-1129) ----
+arks_index*
+build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength)
+{
+	// pass 1 of the reference only sizes contigRecord; it also filters on the IUPAC alphabet, which
+	// the second pass does not (Q10 of SURVEY.md): a contig with a foreign character would leave
+	// contigRecord too short in the reference.  Here the record simply grows.
+	{
+		SeqReader rd(params.file.c_str());
+		size_t count = 0;
+		while (rd.next() >= 0)
+			if (check_contig_sequence(rd.seq) && (int)rd.seq.length() >= params.min_size)
+				count++;
+		if (params.verbose)
+			std::cerr << "Number of contigs:" << count << "\nSize of Contig Array:" << count * 2 + 1 << std::endl;
+	}
+	std::string bases;
+	std::vector<uint64_t> off;
+	std::vector<uint32_t> len;
+	int total = 0, skipped = 0, valid = 0;
+	contigRecord.clear();
+	contigRecord.push_back(CI("null contig", false));
+	SeqReader rd(params.file.c_str());
+	while (rd.next() >= 0) {
+		total++;
+		int cut = 0;
+		if (arks_end_cutoff((int)rd.seq.length(), params.min_size, params.end_length, &cut)) {
+			contigToLength[rd.name] = (int)rd.seq.length();
+			contigRecord.push_back(CI(rd.name, true));
+			off.push_back(bases.size());
+			len.push_back((uint32_t)cut);
+			bases.append(rd.seq, 0, (size_t)cut);
+			contigRecord.push_back(CI(rd.name, false));
+			off.push_back(bases.size());
+			len.push_back((uint32_t)cut);
+			bases.append(rd.seq, rd.seq.length() - (size_t)cut, (size_t)cut);
+			valid++;
+		} else
+			skipped++;
+		if (params.verbose && total % 1000 == 0)
+			printf("Finished %d Contigs...\n", total);
+	}
+	bases.push_back('\0');
+	arks_index* idx = nullptr;
+	arks_build_stats st;
+	std::memset(&st, 0, sizeof st);
+	const int rc = arks_index_build(&idx, params.k_value, bases.data(), off.data(), len.data(), (int64_t)len.size(),
+	                                params.device, params.verbose ? &st : nullptr);
+	if (rc != ARKS_OK)
+		die_arks(rc, "building the contig k-mer index");
+	if (params.verbose) {
+		for (uint64_t i = 0; i < st.short_ends; ++i) // Arcs.cpp:877-882 prints one line per short end
+			std::cout << "Warning: ends of contig is shorter than k-value (no k-mers added)" << std::endl;
+		printf("%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n",
+		       "Total number of contigs in draft genome: ", (unsigned)total, "Total valid contigs: ", (unsigned)valid,
+		       "Total skipped contigs: ", (unsigned)skipped, "Total number of Kmers: ", (unsigned)st.total_kmers,
+		       "Number Null Kmers: ", (unsigned)st.null_kmers, "Number Kmers Recorded: ", (unsigned)st.recorded,
+		       "Number Kmer Collisions: ", (unsigned)st.collisions,
+		       "Number Times Kmers Removed (since duplicate in different contig): ", (unsigned)st.removed_dup,
+		       "Number of unique kmers (only one contig): ", (unsigned)st.unique);
+	}
+	return idx;
+}
+
+// ---- read mapping (replaces readChroms / chromiumRead, Arcs.cpp:1132-1370) -------------------------
+struct MapCounters
+{
+	uint64_t stored = 0, skipped_invalid = 0, skipped_unpaired = 0, gated = 0, invalidbarcode = 0, emptybarcode = 0;
+};
+
+struct Batch
+{
+	std::string bases;
+	std::vector<uint64_t> off;
+	std::vector<uint32_t> len;
+	std::vector<uint8_t> pair_ok;
+	std::vector<uint32_t> barcode_id;
+	void clear()
+	{
+		bases.clear();
+		off.clear();
+		len.clear();
+		pair_ok.clear();
+		barcode_id.clear();
+	}
+	size_t pairs() const { return pair_ok.size(); }
+};
+
+struct Mapper
+{
+	arks_index* idx;
+	arks_imap* imap = nullptr;
+	hipStream_t stream = nullptr;
+	DevArray<uint64_t> d_codes, d_woff;
+	DevArray<uint32_t> d_nmask, d_len, d_bid;
+	DevArray<uint8_t> d_class, d_ok, d_eval;
+	DevArray<int32_t> d_conreci;
+	uint64_t* d_stored = nullptr;
+	arks_map_stats* d_stats = nullptr;
+	std::vector<uint64_t> h_codes, h_woff;
+	std::vector<uint32_t> h_nmask;
+	std::vector<uint8_t> h_class;
+
+	explicit Mapper(arks_index* i, int64_t imap_capacity)
+	  : idx(i)
+	{
+		int rc = arks_imap_create(&imap, imap_capacity, params.device);
+		if (rc != ARKS_OK)
+			die_arks(rc, "creating the IndexMap accumulator");
+		if (hipMalloc((void**)&d_stored, sizeof(uint64_t)) != hipSuccess ||
+		    hipMalloc((void**)&d_stats, sizeof(arks_map_stats)) != hipSuccess) {
+			std::cerr << PROGRAM ": out of device memory\n";
+			exit(EXIT_FAILURE);
+		}
+		(void)hipMemset(d_stored, 0, sizeof(uint64_t));
+		(void)hipMemset(d_stats, 0, sizeof(arks_map_stats));
+	}
+
+	void run(Batch& b, MapCounters& mc)
+	{
+		const int64_t n = (int64_t)b.len.size(), np = (int64_t)b.pairs();
+		if (n == 0)
+			return;
+		h_woff.resize((size_t)n + 1);
+		arks_word_offsets(b.len.data(), n, h_woff.data());
+		const size_t words = (size_t)h_woff[(size_t)n] + ARKS_PAD_WORDS;
+		h_codes.assign(words, 0);
+		h_nmask.assign(words, 0);
+		h_class.resize((size_t)n);
+		b.bases.push_back('\0');
+		arks_pack_reads_host(b.bases.data(), b.off.data(), b.len.data(), h_woff.data(), n, h_codes.data(),
+		                     h_nmask.data(), h_class.data());
+		for (int64_t p = 0; p < np; ++p)
+			if (b.pair_ok[(size_t)p]) {
+				mc.gated++;
+				if (!(h_class[(size_t)(2 * p)] && h_class[(size_t)(2 * p + 1)]))
+					mc.skipped_invalid++;
+			}
+		d_codes.reserve(words);
+		d_nmask.reserve(words);
+		d_woff.reserve((size_t)n + 1);
+		d_len.reserve((size_t)n);
+		d_class.reserve((size_t)n);
+		d_eval.reserve((size_t)n);
+		d_conreci.reserve((size_t)n);
+		d_ok.reserve((size_t)np);
+		d_bid.reserve((size_t)np);
+		auto up = [&](void* d, const void* h, size_t bytes) {
+			if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) {
+				std::cerr << PROGRAM ": host to device copy failed\n";
+				exit(EXIT_FAILURE);
+			}
+		};
+		up(d_codes.p, h_codes.data(), words * sizeof(uint64_t));
+		up(d_nmask.p, h_nmask.data(), words * sizeof(uint32_t));
+		up(d_woff.p, h_woff.data(), ((size_t)n + 1) * sizeof(uint64_t));
+		up(d_len.p, b.len.data(), (size_t)n * sizeof(uint32_t));
+		up(d_class.p, h_class.data(), (size_t)n);
+		up(d_ok.p, b.pair_ok.data(), (size_t)np);
+		up(d_bid.p, b.barcode_id.data(), (size_t)np * sizeof(uint32_t));
+		int rc = arks_pair_gate_device(d_ok.p, d_class.p, np, d_eval.p, params.device, stream);
+		if (rc == ARKS_OK)
+			rc = arks_map_reads_device(idx, d_codes.p, d_nmask.p, d_woff.p, d_len.p, d_eval.p, 2 * np,
+			                           params.j_index, d_conreci.p, params.verbose ? d_stats : nullptr, stream);
+		if (rc == ARKS_OK)
+			rc = arks_pairs_device(d_conreci.p, d_ok.p, d_bid.p, np, nullptr, imap, d_stored, params.device, stream);
+		if (rc != ARKS_OK)
+			die_arks(rc, "mapping a read batch");
+		if (hipStreamSynchronize(stream) != hipSuccess) {
+			std::cerr << PROGRAM ": device error while mapping\n";
+			exit(EXIT_FAILURE);
+		}
+		b.clear();
+	}
+};
+
+void
+read_chroms(
+    const std::vector<std::string>& files, arks_index* idx, IndexMap& imap,
+    const std::unordered_map<std::string, int>& mult, const std::vector<CI>& contigRecord)
+{
+	std::unordered_map<std::string, uint32_t> barcode_id;
+	std::vector<const std::string*> barcode_name;
+	barcode_id.reserve(mult.size());
+	Mapper mapper(idx, std::max<int64_t>(1 << 16, (int64_t)mult.size() * 8));
+	for (const auto& file : files) {
+		if (params.verbose)
+			std::cout << "Reading chrom " << file << std::endl;
+		SeqReader rd(file.c_str());
+		if (!rd.ok()) {
+			std::cerr << "File " << file << " cannot be opened." << std::endl;
+			exit(1);
+		}
+		std::cerr << "File " << file << " opened." << std::endl;
+		MapCounters mc;
+		Batch b;
+		size_t count = 0;
+		bool stop = false;
+		std::string n1, n2, c1, c2, s1, s2;
+		uint64_t stored_before = 0;
+		(void)hipMemcpy(&stored_before, mapper.d_stored, sizeof(uint64_t), hipMemcpyDeviceToHost);
+		arks_map_stats st_before;
+		(void)hipMemcpy(&st_before, mapper.d_stats, sizeof st_before, hipMemcpyDeviceToHost);
+		while (!stop) {
+			n1.clear(), n2.clear(), c1.clear(), c2.clear(), s1.clear(), s2.clear();
+			int l = rd.next(); // Arcs.cpp:1187-1206
+			if (l >= 0) {
+				n1 = rd.name, c1 = rd.comment, s1 = rd.seq;
+				l = rd.next();
+				if (l >= 0)
+					n2 = rd.name, c2 = rd.comment, s2 = rd.seq;
+				else
+					stop = true;
+			} else
+				stop = true;
+			strip_read_num(n1);
+			strip_read_num(n2);
+			const bool paired = n1 == n2;
+			if (!paired) {
+				std::cout << "File contains unpaired reads: " << n1 << " " << n2 << std::endl;
+				mc.skipped_unpaired++;
+			}
+			count += 2;
+			if (params.verbose && count % 10000000 == 0)
+				std::cout << "Processed " << count << " read pairs." << std::endl;
+			if (stop)
+				break;
+			const std::string b1 = bx_barcode(c1), b2 = bx_barcode(c2);
+			bool valid = false;
+			if (b1.empty() || b2.empty())
+				mc.emptybarcode++;
+			else {
+				valid = mult.find(b1) != mult.end();
+				if (!valid)
+					mc.invalidbarcode++;
+			}
+			const bool ok = paired && valid && b1 == b2; // Arcs.cpp:1264-1265 (goodmult is always true)
+			uint32_t bid = 0;
+			if (ok) {
+				auto it = barcode_id.find(b1);
+				if (it == barcode_id.end()) {
+					it = barcode_id.emplace(b1, (uint32_t)barcode_name.size()).first;
+					barcode_name.push_back(&it->first);
+				}
+				bid = it->second;
+			}
+			b.off.push_back(b.bases.size());
+			b.len.push_back((uint32_t)s1.size());
+			b.bases += s1;
+			b.off.push_back(b.bases.size());
+			b.len.push_back((uint32_t)s2.size());
+			b.bases += s2;
+			b.pair_ok.push_back(ok ? 1 : 0);
+			b.barcode_id.push_back(bid);
+			if ((long)b.pairs() >= params.batch_pairs)
+				mapper.run(b, mc);
+		}
+		mapper.run(b, mc);
+		if (params.verbose) {
+			uint64_t stored_after = 0;
+			arks_map_stats st;
+			(void)hipMemcpy(&stored_after, mapper.d_stored, sizeof(uint64_t), hipMemcpyDeviceToHost);
+			(void)hipMemcpy(&st, mapper.d_stats, sizeof st, hipMemcpyDeviceToHost);
+			const uint64_t stored = stored_after - stored_before;
+			printf("Stored read pairs: %u\nSkipped invalid read pairs: %u\nSkipped unpaired reads: "
+			       "%u\nSkipped reads pairs without a good contig: %u\n",
+			       (unsigned)stored, (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
+			       (unsigned)(mc.gated - stored));
+			// the reference's s_* counters are process-wide: cumulative over the files
+			printf("Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
+			       "%u\nNumber of kmers recorded in Ktrack: %u\nNumber of kmers found in ContigKmap but "
+			       "duplicate: %u\nNumber of reads passing jaccard threshold: %u\nNumber of reads failing "
+			       "jaccard threshold: %u\n",
+			       (unsigned)st.total_valid, (unsigned)st.bad, (unsigned)st.found, (unsigned)st.recorded,
+			       (unsigned)st.dups, (unsigned)st.reads_pass, (unsigned)st.reads_fail);
+			if (mc.emptybarcode > 0)
+				printf("WARNING:: Your chromium read file has %d readpairs that have an empty barcode.",
+				       (int)mc.emptybarcode);
+			if (mc.invalidbarcode > 0)
+				printf("WARNING:: Your chromium read file has %d read pairs that have barcodes not in the "
+				       "barcode multiplicity file.",
+				       (int)mc.invalidbarcode);
+		}
+		// the reference completes the IndexMap after every file (Arcs.cpp:1304-1319); the
+		// accumulator is additive, so the rebuild below after the last file gives the same map
+	}
+	const int64_t n = arks_imap_size(mapper.imap);
+	if (n < 0)
+		die_arks((int)-n, "reading the IndexMap accumulator");
+	std::vector<uint32_t> triples((size_t)n * 3 + 3);
+	const int rc = arks_imap_export(mapper.imap, triples.data());
+	if (rc != ARKS_OK)
+		die_arks(rc, "exporting the IndexMap");
+	for (int64_t i = 0; i < n; ++i)
+		imap[*barcode_name[triples[3 * i]]][contigRecord[triples[3 * i + 1]]] += (int)triples[3 * i + 2];
+	add_opposite_ends(imap);
+	arks_imap_free(mapper.imap);
+}
+
+void
+run_arks(const std::vector<std::string>& filenames)
+{
+	std::cout << "Running: " << PROGRAM << " " << PACKAGE_VERSION << "\nARKS method\n pid " << ::getpid()
+	          << "\n -c " << params.g.min_reads << "\n -d " << params.g.max_degree << "\n -e " << params.end_length
+	          << "\n -l " << params.g.min_links << "\n -m " << params.g.min_mult << '-' << params.g.max_mult
+	          << "\n -r " << params.g.error_percent << "\n -v " << params.verbose << "\n -z " << params.min_size
+	          << "\n --gap=" << params.g.gap << "\n -k " << params.k_value << "\n -j " << params.j_index << "\n -t "
+	          << params.threads << "\n -b " << maybe_na(params.base_name) << "\n -g "
+	          << maybe_na(params.dist_graph_name) << "\n --barcode-counts=" << maybe_na(params.barcode_counts_name)
+	          << "\n --tsv=" << maybe_na(params.tsv_name) << "\n -a " << maybe_na(params.fofName) << "\n -f "
+	          << maybe_na(params.file) << "\n -u " << maybe_na(params.multfile) << '\n';
+	for (const auto& f : filenames)
+		std::cout << ' ' << f << '\n';
+	std::cout.flush();
+
+	IndexMap imap;
+	PairMap pmap;
+	ScaffoldGraph g;
+	std::unordered_map<std::string, int> mult;
+	ContigToLength contigToLength;
+	std::vector<CI> contigRecord;
+
+	std::cout << "\n=>Preprocessing: Gathering barcode multiplicity information..." << now();
+	if (!params.multfile.empty())
+		create_index_mult_map(params.multfile, mult);
+	else {
+		std::cout << "Multiplicity information is being formed from reads as no barcode multiplicity file provided."
+		          << std::endl;
+		read_barcodes(filenames, mult);
+	}
+	std::cout << "\n=>Preprocessing: Gathering draft information..." << now() << "\n";
+	std::cout << "\n=>Storing Kmers from Contig ends... " << now() << std::endl;
+	arks_index* idx = build_contig_index(contigRecord, contigToLength);
+	std::cout << "\n=>Reading Chromium FASTQ file(s)... " << now() << std::endl;
+	read_chroms(filenames, idx, imap, mult, contigRecord);
+	arks_index_free(idx);
+	std::cout << "Cumulative memory usage: " << memory_usage() << std::endl;
+
+	std::cout << "\n=> Pairing scaffolds... " << now();
+	pair_contigs(imap, pmap, mult, params.g);
+	if (params.output_pair) {
+		std::cout << "\n=> Outputting Pairing information... " << now();
+		std::ofstream out((params.base_name + "_pair.tsv").c_str());
+		write_pair_map(out, pmap);
+	}
+	std::cout << "\n=> Creating the graph... " << now();
+	create_graph(pmap, g, params.g);
+	std::cout << "\n=> Writing graph file... " << now() << "\n";
+	const std::string graph_file = params.base_name + "_original.gv";
+	if (params.g.max_degree != 0) {
+		std::cout << "      Deleting nodes with degree > " << params.g.max_degree << "... \n";
+		remove_degree_nodes(g, params.g.max_degree);
+	} else
+		std::cout << "      Max Degree (-d) set to: " << params.g.max_degree
+		          << ". Will not delete any vertices from graph.\n";
+	std::cout << "      Writing graph file to " << graph_file << "...\n";
+	{
+		std::ofstream out(graph_file.c_str());
+		write_graph(out, g);
+	}
+	std::cout << "\n=> Creating the ABySS graph... " << now();
+	std::cout << "\n=> Writing the ABySS graph file... " << now() << "\n";
+	{
+		std::ofstream out(params.dist_graph_name.c_str());
+		if (!out.good()) {
+			std::cerr << "error: `" << params.dist_graph_name << "': " << strerror(errno) << std::endl;
+			exit(EXIT_FAILURE);
+		}
+		std::string err;
+		if (!write_dist_graph(out, contigToLength, g, params.g.gap, &err)) {
+			std::cerr << err << std::endl;
+			exit(EXIT_FAILURE);
+		}
+	}
+	if (!params.tsv_name.empty()) {
+		const size_t barcode_count = count_barcodes(imap, mult, params.g);
+		std::cout << "\n=> Writing TSV file... " << now();
+		std::ofstream f(params.tsv_name.c_str());
+		write_tsv(f, imap, pmap, barcode_count, params.g);
+	}
+	if (!params.barcode_counts_name.empty()) {
+		std::cout << "\n=> Writing reads per barcode TSV file... " << now();
+		if (params.barcode_counts_name.find(".tsv") == std::string::npos)
+			params.barcode_counts_name += ".tsv";
+		std::ofstream f(params.barcode_counts_name.c_str());
+		write_barcode_counts(f, mult);
+	}
+	std::cout << "\n=> Done.\n" << now();
+}
+
+} // namespace
+
+int
+main(int argc, char** argv)
+{
+	printf("Reading user inputs...\n");
+	bool arcsOnly = false, arksOnly = false, die = false;
+	for (int c; (c = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1;) {
+		std::istringstream arg(optarg != NULL ? optarg : "");
+		switch (c) {
+		case 'u': arg >> params.multfile; break;
+		case 'k': arg >> params.k_value; arksOnly = true; break;
+		case 'j': arg >> params.j_index; arksOnly = true; break;
+		case 't': arg >> params.threads; arksOnly = true; break;
+		case '?': die = true; break;
+		case 'f': arg >> params.file; break;
+		case 'a': arg >> params.fofName; break;
+		case 'B': arg >> params.dist_bin_size; break;
+		case 's': arg >> params.seq_id; arcsOnly = true; break;
+		case 'c': arg >> params.g.min_reads; break;
+		case 'P': params.output_pair = true; break;
+		case 'D': params.dist_est = true; break;
+		case 'l': arg >> params.g.min_links; break;
+		case 'z': arg >> params.min_size; break;
+		case 'b': arg >> params.base_name; break;
+		case 'g': arg >> params.dist_graph_name; break;
+		case OPT_TSV: arg >> params.tsv_name; break;
+		case OPT_GAP: arg >> params.g.gap; break;
+		case OPT_BARCODE_COUNTS: arg >> params.barcode_counts_name; break;
+		case OPT_SAMPLES_TSV: arg >> params.dist_samples_tsv; break;
+		case OPT_DIST_TSV: arg >> params.dist_tsv; break;
+		case OPT_NO_DIST_EST: params.dist_est = false; break;
+		case OPT_DIST_MEDIAN:
+		case OPT_DIST_UPPER: break;
+		case OPT_ARKS_METHOD: params.arks = true; break;
+		case OPT_BATCH_PAIRS: arg >> params.batch_pairs; break;
+		case OPT_DEVICE: arg >> params.device; break;
+		case 'm': {
+			std::string first, second;
+			std::getline(arg, first, '-');
+			std::getline(arg, second);
+			std::stringstream ss;
+			ss << first << "\t" << second;
+			ss >> params.g.min_mult >> params.g.max_mult;
+		} break;
+		case 'd': arg >> params.g.max_degree; break;
+		case 'e': arg >> params.end_length; break;
+		case 'r': arg >> params.g.error_percent; break;
+		case 'v': ++params.verbose; break;
+		case OPT_HELP: std::cout << USAGE; exit(EXIT_SUCCESS);
+		case OPT_VERSION: std::cout << PROGRAM " " PACKAGE_VERSION "\n"; exit(EXIT_SUCCESS);
+		}
+		if (optarg != NULL && (!arg.eof() || arg.fail())) {
+			std::cerr << PROGRAM ": invalid option: `-" << (char)c << optarg << "'\n";
+			exit(EXIT_FAILURE);
+		}
+	}
+	if ((params.arks && arcsOnly) || (!params.arks && arksOnly)) {
+		std::cerr << PROGRAM ": error: You specified an option that does not match with method "
+		                     "choosen.\nCheck --help for method specific options.\n";
+		die = true;
+	}
+	if (!params.arks) {
+		std::cerr << PROGRAM ": error: this build provides the ARKS method only (--arks); the alignment "
+		                     "(SAM/BAM) method is not part of it.\n";
+		die = true;
+	}
+	if (params.dist_est) {
+		std::cerr << PROGRAM ": error: -D/--dist_est (distance estimation) is not part of this build.\n";
+		die = true;
+	}
+	std::vector<std::string> filenames(argv + optind, argv + argc);
+	if (params.fofName.empty() && filenames.empty()) {
+		std::cerr << PROGRAM ": error: specify input (chromium reads) or a list of files with -a option\n";
+		die = true;
+	}
+	bool stdIn = false;
+	if (!filenames.empty())
+		stdIn = filenames[0] == "/dev/stdin";
+	if (!params.file.empty())
+		assert_readable(params.file);
+	if (!params.fofName.empty())
+		assert_readable(params.fofName);
+	for (const auto& f : filenames)
+		assert_readable(f);
+	const std::vector<std::string> fof = read_fof(params.fofName);
+	filenames.insert(filenames.end(), fof.begin(), fof.end());
+	bool alignment = false;
+	if (!stdIn && !check_same_format(filenames, alignment)) {
+		std::cerr << "Input files must be all alignment or all read files." << params.file << ". Exiting... \n";
+		die = true;
+	}
+	if (!stdIn && !(alignment ^ params.arks)) {
+		std::cerr << "File type must be compatible with the method. (BAM/SAM for ARCS) or (Read file for ARKS "
+		             "(--arks)). Exiting... \n";
+		die = true;
+	}
+	{
+		std::ifstream g(params.file.c_str());
+		if (!g.good() && params.arks) {
+			std::cerr << "Cannot find [-f] scaffold file which is required for --arks" << params.file
+			          << ". Exiting... \n";
+			die = true;
+		}
+	}
+	if (params.base_name.empty()) { // Arcs.cpp:2144-2152
+		std::ostringstream fn;
+		fn << params.file << ".scaff"
+		   << "_arks"
+		   << "_c" << params.g.min_reads << "_k" << params.k_value << "_j" << params.j_index << "_l"
+		   << params.g.min_links << "_d" << params.g.max_degree << "_e" << params.end_length << "_r"
+		   << params.g.error_percent;
+		params.base_name = fn.str();
+	}
+	if (params.dist_graph_name.empty())
+		params.dist_graph_name = params.base_name + ".dist.gv";
+	if (params.tsv_name.empty())
+		params.tsv_name = params.base_name + "_main.tsv";
+	if (die) {
+		std::cerr << "Try " << PROGRAM << " --help for more information.\n";
+		exit(EXIT_FAILURE);
+	}
+	if (arks_device_count() < 1) {
+		std::cerr << PROGRAM ": error: no gfx950 (MI355X) device is visible; this build has no CPU path.\n";
+		exit(EXIT_FAILURE);
+	}
+	printf("%s\n", "Finished reading user inputs...entering runArcs()...");
+	run_arks(filenames);
+	return 0;
+}

@@ -1,0 +1,114 @@
+// graph_check.cpp -- test driver for graph.hpp (no GPU): runs the graph stage on an IndexMap given as
+// text and writes the reference's output files.  Built and used by tests/test_host_graph.py only.
+//   graph_check imap  <imap.tsv> <mult.tsv> <lengths.tsv> <out_base> c l m_lo m_hi d r gap
+//       imap.tsv: barcode \t contig \t H|T \t count   (the post-pass for missing ends is applied)
+//   graph_check gv    <original.gv> <lengths.tsv> <out.dist.gv> gap
+//       rebuilds the scaffold graph from an _original.gv and writes the ABySS dist.gv for it
+#include "graph.hpp"
+
+#include <cstring>
+
+using namespace arks_host;
+
+static void
+read_lengths(const char* path, ContigToLength& len)
+{
+	std::ifstream in(path);
+	std::string id;
+	int l;
+	while (in >> id >> l)
+		len[id] = l; // insertion order = FASTA order, as in getContigKmers
+}
+
+int
+main(int argc, char** argv)
+{
+	if (argc >= 6 && std::strcmp(argv[1], "gv") == 0) {
+		ScaffoldGraph g;
+		std::ifstream in(argv[2]);
+		std::string line;
+		while (std::getline(in, line)) {
+			int a, b, lab, w;
+			char idbuf[256];
+			if (std::sscanf(line.c_str(), "%d--%d [label=%d, weight=%d];", &a, &b, &lab, &w) == 4)
+				g.edges.push_back(Edge{ a, b, lab, w });
+			else if (std::sscanf(line.c_str(), "%d [id=%255[^]]];", &a, idbuf) == 2) {
+				g.id.push_back(idbuf);
+				g.alive.push_back(true);
+			}
+		}
+		ContigToLength len;
+		read_lengths(argv[3], len);
+		std::ofstream out(argv[4]);
+		std::string err;
+		if (!write_dist_graph(out, len, g, (unsigned)std::atoi(argv[5]), &err)) {
+			std::cerr << err << "\n";
+			return 1;
+		}
+		return 0;
+	}
+	if (argc >= 14 && std::strcmp(argv[1], "imap") == 0) {
+		IndexMap imap;
+		std::unordered_map<std::string, int> mult;
+		ContigToLength len;
+		{
+			std::ifstream in(argv[2]);
+			std::string bc, ctg, ht;
+			int cnt;
+			while (in >> bc >> ctg >> ht >> cnt)
+				imap[bc][CI(ctg, ht == "H")] += cnt;
+		}
+		{
+			std::ifstream in(argv[3]);
+			std::string bc;
+			int m;
+			while (in >> bc >> m)
+				mult[bc] = m;
+		}
+		read_lengths(argv[4], len);
+		const std::string base = argv[5];
+		GraphParams P;
+		P.min_reads = std::atoi(argv[6]);
+		P.min_links = std::atoi(argv[7]);
+		P.min_mult = std::atoi(argv[8]);
+		P.max_mult = std::atoi(argv[9]);
+		P.max_degree = std::atoi(argv[10]);
+		P.error_percent = (float)std::atof(argv[11]);
+		P.gap = (unsigned)std::atoi(argv[12]);
+		add_opposite_ends(imap);
+		PairMap pmap;
+		pair_contigs(imap, pmap, mult, P);
+		{
+			std::ofstream out(base + "_pair.tsv");
+			write_pair_map(out, pmap);
+		}
+		ScaffoldGraph g;
+		create_graph(pmap, g, P);
+		if (P.max_degree != 0)
+			remove_degree_nodes(g, P.max_degree);
+		{
+			std::ofstream out(base + "_original.gv");
+			write_graph(out, g);
+		}
+		{
+			std::ofstream out(base + ".dist.gv");
+			std::string err;
+			if (!write_dist_graph(out, len, g, P.gap, &err)) {
+				std::cerr << err << "\n";
+				return 1;
+			}
+		}
+		{
+			const size_t n = count_barcodes(imap, mult, P);
+			std::ofstream f(base + "_main.tsv");
+			write_tsv(f, imap, pmap, n, P);
+		}
+		{
+			std::ofstream f(base + "_counts.tsv");
+			write_barcode_counts(f, mult);
+		}
+		return 0;
+	}
+	std::cerr << "usage: graph_check imap ... | gv ...\n";
+	return 2;
+}

@@ -1,0 +1,131 @@
+// seqio.hpp -- gz/plain FASTA/FASTQ record reader with the record semantics of Heng Li's kseq as
+// the reference uses it (Arcs/kseq.h:146-186, instantiated over gzread, Arcs.cpp:187):
+//   * a record starts at the next '>' or '@'; name = header up to the first white space, comment =
+//     rest of the header line; sequence lines are concatenated until a line starting with '>', '+'
+//     or '@'; FASTQ quality lines are read until they cover the sequence;
+//   * next() returns the sequence length, -1 at end of file, -2 when the quality string is missing
+//     or its length differs from the sequence's (the callers stop at any negative value).
+// Written from that behaviour; no code of kseq.h is used.
+#pragma once
+
+#include <zlib.h>
+
+#include <string>
+
+namespace arks_host {
+
+class SeqReader
+{
+  public:
+	std::string name, comment, seq, qual;
+
+	explicit SeqReader(const char* path)
+	  : fp_(gzopen(path, "r"))
+	{}
+	~SeqReader()
+	{
+		if (fp_)
+			gzclose(fp_);
+	}
+	SeqReader(const SeqReader&) = delete;
+	SeqReader& operator=(const SeqReader&) = delete;
+	bool ok() const { return fp_ != nullptr; }
+
+	int next()
+	{
+		int c;
+		if (last_ == 0) { // find the next header
+			while ((c = getc()) != -1 && c != '>' && c != '@') {
+			}
+			if (c == -1)
+				return -1;
+			last_ = c;
+		}
+		comment.clear();
+		seq.clear();
+		qual.clear();
+		name.clear();
+		// name: up to white space
+		bool got = false;
+		int term = -1;
+		while ((c = getc()) != -1) {
+			got = true;
+			if (c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r') {
+				term = c;
+				break;
+			}
+			name.push_back((char)c);
+		}
+		if (!got)
+			return -1;
+		if (term != '\n' && term != -1)
+			read_line(comment, false);
+		// sequence
+		while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
+			if (c == '\n')
+				continue;
+			seq.push_back((char)c);
+			read_line(seq, true);
+		}
+		if (c == '>' || c == '@')
+			last_ = c;
+		if (c != '+')
+			return (int)seq.size();
+		while ((c = getc()) != -1 && c != '\n') {
+		}
+		if (c == -1)
+			return -2;
+		while (read_line(qual, true) >= 0 && qual.size() < seq.size()) {
+		}
+		last_ = 0;
+		if (seq.size() != qual.size())
+			return -2;
+		return (int)seq.size();
+	}
+
+  private:
+	gzFile fp_;
+	unsigned char buf_[1 << 16];
+	int begin_ = 0, end_ = 0;
+	bool eof_ = false;
+	int last_ = 0;
+
+	int getc()
+	{
+		if (begin_ >= end_) {
+			if (eof_ || !fp_)
+				return -1;
+			begin_ = 0;
+			end_ = gzread(fp_, buf_, sizeof buf_);
+			if (end_ <= 0) {
+				end_ = 0;
+				eof_ = true;
+				return -1;
+			}
+		}
+		return buf_[begin_++];
+	}
+
+	// appends (or assigns) the rest of the current line; returns the string length, or -1 when
+	// nothing could be read because the stream is at its end
+	int read_line(std::string& s, bool append)
+	{
+		if (!append)
+			s.clear();
+		bool got = false;
+		int c;
+		while ((c = getc()) != -1) {
+			got = true;
+			if (c == '\n')
+				break;
+			s.push_back((char)c);
+		}
+		if (!got)
+			return -1;
+		if (s.size() > 1 && s.back() == '\r')
+			s.pop_back();
+		return (int)s.size();
+	}
+};
+
+} // namespace arks_host

@@ -1,0 +1,149 @@
+"""End-to-end check of the host front end `arcs --arks` (arcs_amd/host/arcs.cpp over libarks_hip.so):
+FASTA draft + interleaved FASTQ.gz with BX:Z: barcodes in, <base>_original.gv / _main.tsv /
+_pair.tsv / barcode counts / .dist.gv out, compared with the Python restatement of the same flow
+(CPU oracle for the k-mer mapping, tests/graph_ref.py for the graph stage)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import graph_ref as G
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _strip_read_num(name):
+    pos = name.rfind("/")
+    if pos in (-1, 0, len(name) - 1) or not name[pos + 1].isdigit():
+        return name
+    return name[:pos]
+
+
+@pytest.mark.parametrize("use_mult_file,k,extra", [(False, 60, []), (True, 40, ["-d", "2", "-l", "1"])])
+def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extra):
+    from arcs_amd import build as b, synth
+    exe = b.build_host()
+    rng = np.random.Generator(np.random.PCG64(5 + k))
+    contigs = synth.make_draft(400_000, seed=40 + k, lengths=(60000, 20000, 90000, 45000), small_frac=0.5)
+    cs = synth.contigs_to_strings(contigs)
+    names = [str(i + 1) for i in range(len(cs))]
+    names[2] = "scaf_three"
+    fa = tmp_path / "draft.fa"
+    with open(fa, "w") as f:
+        for n, s in zip(names, cs):
+            f.write(f">{n} some description\n")
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + "\n")
+    n_pairs = 6000
+    batch = synth.make_read_pairs(contigs, n_pairs, seed=41 + k, mol_len=30000, pairs_per_mol=30,
+                                  one_n_rate=0.03, many_n_rate=0.01)
+    reads = synth.reads_to_strings(batch)
+    bid = batch["barcode_id"].numpy()
+    recs = []   # (name1, comment1, seq1, name2, comment2, seq2)
+    for p in range(n_pairs):
+        bc = "".join("ACGT"[(int(bid[p]) >> (2 * t)) & 3] for t in range(12)) + "-1"
+        n1, n2 = f"read{p}/1", f"read{p}/2"
+        c1 = c2 = f"BX:Z:{bc}"
+        u = rng.random()
+        if u < 0.01:
+            n2 = f"other{p}/2"                       # unpaired names
+        elif u < 0.02:
+            c1 = "RG:Z:x"                            # no barcode on mate 1
+        elif u < 0.03:
+            c2 = f"BX:Z:{bc[:-1]}2"                  # barcodes differ
+        elif u < 0.04:
+            c1 = c2 = f"XY:i:1 BX:Z:{bc} QT:Z:FFF"   # tag in the middle of the comment
+        elif u < 0.05:
+            n1, n2 = f"read{p}", f"read{p}"           # no /1 /2
+        recs.append((n1, c1, reads[2 * p], n2, c2, reads[2 * p + 1]))
+    fq = tmp_path / "reads.fq.gz"
+    with gzip.open(fq, "wt") as f:
+        for (n1, c1, s1, n2, c2, s2) in recs:
+            f.write(f"@{n1} {c1}\n{s1}\n+\n{'F' * len(s1)}\n@{n2} {c2}\n{s2}\n+\n{'F' * len(s2)}\n")
+    # ---- barcode multiplicities as the reference derives them (reads per barcode, Arcs.cpp:481-547)
+    def bx(c):
+        t = c.find("BX:Z:")
+        if t < 0:
+            return ""
+        e = c.find(" ", t)
+        return c[t + 5:e] if e >= 0 else c[t + 5:]
+    mult = {}
+    for (n1, c1, s1, n2, c2, s2) in recs:
+        for c in (c1, c2):
+            if "BX:Z:" in c:
+                mult[bx(c)] = mult.get(bx(c), 0) + 1
+    args = [exe, "--arks", "-v", "-f", str(fa), "-c", "3", "-m", "8-10000", "-r", "0.05", "-e", "30000",
+            "-z", "500", "-j", "0.55", "-k", str(k), "-t", "8", "--gap", "100", "-b", str(tmp_path / "out"),
+            "-P", "--barcode-counts", str(tmp_path / "counts"), "--batch-pairs", "1700"] + extra
+    if use_mult_file:
+        # a multiplicity file that lacks some barcodes: those pairs are "invalid barcode"
+        keep = {b: m for i, (b, m) in enumerate(sorted(mult.items())) if i % 7}
+        mf = tmp_path / "mult.csv"
+        mf.write_text("".join(f"{b},{m}\n" for b, m in keep.items()))
+        mult = keep
+        args += ["-u", str(mf)]
+    args.append(str(fq))
+    res = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    # ---- the same flow in Python ------------------------------------------------------------
+    ends = oracle.contig_ends(cs)
+    kept = [n for n, s in zip(names, cs) if len(s) >= 500]
+    record = [None] + [(n, h) for n in kept for h in (True, False)]
+    lengths = {n: len(s) for n, s in zip(names, cs) if len(s) >= 500}
+    ox = oracle.OracleIndex(k).build(ends)
+    pair_ok, barcode = [], []
+    for (n1, c1, s1, n2, c2, s2) in recs:
+        b1, b2 = bx(c1), bx(c2)
+        ok = _strip_read_num(n1) == _strip_read_num(n2) and b1 != "" and b2 != "" and b1 in mult and b1 == b2
+        pair_ok.append(1 if ok else 0)
+        barcode.append(b1)
+    data = "".join(reads).encode() + b"\0"
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    offs = np.zeros(len(reads), dtype=np.uint64)
+    offs[1:] = np.cumsum(lens[:-1])
+    conreci, pair, st = ox.map_pairs(data, offs, lens, 0.55, pair_ok=np.array(pair_ok, dtype=np.uint8))
+    imap = {}
+    for p, c in enumerate(pair):
+        if c:
+            sm = imap.setdefault(barcode[p], {})
+            sm[record[int(c)]] = sm.get(record[int(c)], 0) + 1
+    G.add_opposite_ends(imap)
+    P = {"min_reads": 3, "min_links": 0, "min_mult": 8, "max_mult": 10000, "max_degree": 0,
+         "error_percent": 0.05, "gap": 100}
+    for i in range(0, len(extra), 2):
+        P[{"-d": "max_degree", "-l": "min_links"}[extra[i]]] = int(extra[i + 1])
+    pmap = G.pair_contigs(imap, mult, P)
+    ids, edges = G.create_graph(pmap, P)
+    dead = set()
+    if P["max_degree"]:
+        dead, edges = G.remove_degree_nodes(ids, edges, P["max_degree"])
+    assert len(edges) >= 2, "the synthetic data should link some contigs"
+    base = str(tmp_path / "out")
+    assert open(base + "_original.gv").read() == G.graph_text(ids, edges, dead)
+    assert open(base + "_pair.tsv").read() == G.pair_text(pmap)
+    assert open(base + "_main.tsv").read() == G.tsv_text(imap, pmap, mult, P)
+    assert open(str(tmp_path / "counts.tsv")).read() == G.counts_text(mult)
+    lines = open(base + ".dist.gv").read().split("\n")
+    vl, el = G.dist_graph_lines(lengths, ids, edges, 100)
+    assert set(lines[1:1 + 2 * len(lengths)]) == vl and set(lines[1 + 2 * len(lengths):-2]) == el
+    # ---- the -v counters (Arcs.cpp:1107-1128, 1321-1340) -----------------------------------------
+    out = res.stdout
+    bs = ox.stats.as_dict()
+    for label, key in (("Total number of Kmers: ", "total_kmers"), ("Number Null Kmers: ", "null_kmers"),
+                       ("Number Kmers Recorded: ", "recorded"), ("Number Kmer Collisions: ", "collisions"),
+                       ("Number Times Kmers Removed (since duplicate in different contig): ", "removed_dup"),
+                       ("Number of unique kmers (only one contig): ", "unique")):
+        assert f"{label} {bs[key]}\n" in out, label
+    stored = int((pair != 0).sum())
+    gated = int(sum(pair_ok))
+    assert f"Stored read pairs: {stored}\n" in out
+    assert f"Skipped reads pairs without a good contig: {gated - stored}\n" in out
+    assert f"Total valid kmers: {st['total_valid']}\n" in out
+    assert f"Number of kmers found in ContigKmap: {st['found']}\n" in out
+    assert f"Number of reads passing jaccard threshold: {st['reads_pass']}\n" in out
+    n_unpaired = sum(1 for r in recs if _strip_read_num(r[0]) != _strip_read_num(r[3]))
+    assert out.count("File contains unpaired reads:") == n_unpaired
+    assert f"Skipped unpaired reads: {n_unpaired}\n" in out

@@ -1,0 +1,117 @@
+"""The host graph stage (arcs_amd/host/graph.hpp: IndexMap -> PairMap -> graph -> .gv / .dist.gv /
+TSV writers) on CPU: (1) pinned byte-for-byte to the reference's own arks-long demo outputs
+(_original.gv + contig lengths -> .dist.gv), (2) compared with the Python restatement on random
+IndexMaps."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import graph_ref as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def graph_check(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("bin") / "graph_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "arcs_amd", "host"),
+                           os.path.join(ROOT, "arcs_amd", "host", "graph_check.cpp"), "-o", out])
+    return out
+
+
+def test_demo_dist_gv(graph_check, tmp_path):
+    """Examples/arks-long_test-demo/output: the committed _original.gv and .dist.gv come from one
+    reference run; contig lengths 1:61348 2:38068 3:23450 (its dist.gv), --gap 100.  The ORDER of the
+    vertex (and hence edge) lines is the iteration order of a std::unordered_map<std::string,int>
+    (Arcs.cpp:1622), which depends on the libstdc++ version the reference was built with (the bucket
+    growth sequence changed between GCC releases), so lines are compared as a set, the per-contig
+    "+"/"-" adjacency and the file frame exactly."""
+    lengths = tmp_path / "len.tsv"
+    lengths.write_text("1\t61348\n2\t38068\n3\t23450\n")
+    out = tmp_path / "out.dist.gv"
+    subprocess.check_call([graph_check, "gv", os.path.join(GOLDEN, "arks-long_demo_original.gv"),
+                           str(lengths), str(out), "100"])
+    got = out.read_text().split("\n")
+    want = open(os.path.join(GOLDEN, "arks-long_demo.dist.gv")).read().split("\n")
+    assert got[0] == want[0] == "digraph arcs {" and got[-2:] == want[-2:] == ["}", ""]
+    assert sorted(got) == sorted(want) and len(got) == len(want)
+    assert sorted(got[1:7]) == sorted(want[1:7])          # vertex block, then edge block
+    for i in range(1, 7, 2):
+        assert got[i].split('"')[1][:-1] == got[i + 1].split('"')[1][:-1]
+        assert got[i].split('"')[1][-1] == "+" and got[i + 1].split('"')[1][-1] == "-"
+
+
+def test_gv_format_matches_reference_demo():
+    """write_graph reproduces the boost::write_graphviz layout of the arks demo output"""
+    want = open(os.path.join(GOLDEN, "arks_demo_original.gv")).read()
+    ids, edges = ["1", "2", "3"], [(0, 1, 2, 15), (1, 2, 2, 28)]
+    assert G.graph_text(ids, edges) == want
+
+
+@pytest.mark.parametrize("seed,c,l,d,r", [(1, 5, 0, 0, 0.05), (2, 3, 2, 0, 0.05), (3, 5, 0, 3, 0.05),
+                                          (4, 1, 0, 0, 0.5), (5, 4, 1, 2, 0.01)])
+def test_graph_stage_vs_python(graph_check, tmp_path, seed, c, l, d, r):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    contigs = [str(x) for x in rng.permutation(40)[:25] + 1] + ["ctgA", "scaf_10", "9"]
+    lengths = {x: int(rng.integers(500, 200000)) for x in contigs}
+    imap, mult = {}, {}
+    for b in range(400):
+        bc = "".join(rng.choice(list("ACGT"), size=16)) + "-1"
+        mult[bc] = int(rng.integers(1, 300))
+        if rng.random() < 0.2:
+            continue
+        sm = {}
+        base = int(rng.integers(len(contigs)))
+        for t in range(int(rng.integers(1, 5))):
+            ctg = contigs[(base + t) % len(contigs)]
+            if rng.random() < 0.8:
+                sm[(ctg, bool(rng.random() < 0.5))] = int(rng.integers(1, 30))
+            if rng.random() < 0.3:
+                sm[(ctg, bool(rng.random() < 0.5))] = int(rng.integers(1, 12))
+        if sm:
+            imap[bc] = sm
+    P = {"min_reads": c, "min_links": l, "min_mult": 20, "max_mult": 250, "max_degree": d,
+         "error_percent": r, "gap": 77}
+    (tmp_path / "imap.tsv").write_text("".join(
+        f"{bc}\t{ctg}\t{'H' if h else 'T'}\t{n}\n" for bc, sm in imap.items() for (ctg, h), n in sm.items()))
+    (tmp_path / "mult.tsv").write_text("".join(f"{b}\t{m}\n" for b, m in mult.items()))
+    (tmp_path / "len.tsv").write_text("".join(f"{k}\t{v}\n" for k, v in lengths.items()))
+    base = str(tmp_path / "out")
+    subprocess.check_call([graph_check, "imap", str(tmp_path / "imap.tsv"), str(tmp_path / "mult.tsv"),
+                           str(tmp_path / "len.tsv"), base, str(c), str(l), "20", "250", str(d), str(r),
+                           "77", "x"], stdout=subprocess.DEVNULL)
+    G.add_opposite_ends(imap)
+    pmap = G.pair_contigs(imap, mult, P)
+    assert len(pmap) > 5
+    ids, edges = G.create_graph(pmap, P)
+    dead = set()
+    if d:
+        dead, edges = G.remove_degree_nodes(ids, edges, d)
+    assert open(base + "_pair.tsv").read() == G.pair_text(pmap)
+    assert open(base + "_original.gv").read() == G.graph_text(ids, edges, dead)
+    assert open(base + "_main.tsv").read() == G.tsv_text(imap, pmap, mult, P)
+    assert open(base + "_counts.tsv").read() == G.counts_text(mult)
+    lines = open(base + ".dist.gv").read().split("\n")
+    assert lines[0] == "digraph arcs {" and lines[-2] == "}" and lines[-1] == ""
+    vl, el = G.dist_graph_lines(lengths, ids, edges, 77)
+    body = lines[1:-2]
+    assert set(body[: 2 * len(lengths)]) == vl and len(body[: 2 * len(lengths)]) == len(vl)
+    assert set(body[2 * len(lengths):]) == el and len(body[2 * len(lengths):]) == len(el)
+    # '+' and '-' of a contig are adjacent, '+' first (ContigGraph::add_vertex)
+    for i in range(0, 2 * len(lengths), 2):
+        assert body[i].split('"')[1][:-1] == body[i + 1].split('"')[1][:-1]
+        assert body[i].split('"')[1][-1] == "+" and body[i + 1].split('"')[1][-1] == "-"
+
+
+def test_normal_estimation_cases():
+    """headOrTail / checkSignificance edge cases: sum below -c, all on one end, even split"""
+    P = {"min_reads": 5, "error_percent": 0.05}
+    assert G.head_or_tail(2, 2, P) == (False, False)
+    assert G.head_or_tail(10, 0, P) == (True, True)
+    assert G.head_or_tail(0, 10, P) == (True, False)
+    assert G.head_or_tail(5, 5, P) == (False, False)
+    assert G.head_or_tail(4, 1, P) == (False, False)   # 1 - Phi(1.34) = 0.09 > 0.05
+    assert G.head_or_tail(5, 0, P) == (True, True)
