@@ -115,3 +115,53 @@ def test_normal_estimation_cases():
     assert G.head_or_tail(5, 5, P) == (False, False)
     assert G.head_or_tail(4, 1, P) == (False, False)   # 1 - Phi(1.34) = 0.09 > 0.05
     assert G.head_or_tail(5, 0, P) == (True, True)
+
+
+def _make_tsv(gv_path, fasta_path):
+    """what bin/makeTSVfile.py does with an _original.gv (label -> LINKS orientation pairs,
+    bin/makeTSVfile.py:38-113), restated for the test; the committed checkpoint files were produced
+    by the reference script itself (tests/golden/make_tigpair_golden.py)"""
+    import re
+    num, n = {}, 0
+    for line in open(fasta_path):
+        if line[0] == ">":
+            n += 1
+            num[line.rstrip().split()[0][1:]] = str(n)
+    name = {}
+    for line in open(gv_path):
+        m = re.match(r"(\d+)\s+\[id=\"?([^\]\"]+)\"?\]", line.rstrip())
+        if m:
+            name[m.group(1)] = m.group(2)
+    out = []
+    table = {0: ("r", "f", "r", "f"), 1: ("r", "r", "f", "f"), 2: ("f", "f", "r", "r"), 3: ("f", "r", "f", "r")}
+    for line in open(gv_path):
+        m = re.search(r"(\d+)--(\d+)\s+\[label=(\d+), weight=(\d+)", line.rstrip())
+        if not m:
+            continue
+        a, b = name[m.group(1)], name[m.group(2)]
+        if a > b:
+            a, b = b, a
+        oa, ob, rb, ra = table[int(m.group(3))]
+        links = int(m.group(4))
+        out.append(f"10\t{oa}{num[a]}\t{ob}{num[b]}\t{links}\t{links * 100}\n")
+        out.append(f"10\t{rb}{num[b]}\t{ra}{num[a]}\t{links}\t{links * 100}\n")
+    return "".join(out)
+
+
+def test_gv_to_tigpair_chain(graph_check, tmp_path):
+    """fixed IndexMap -> host graph stage -> _original.gv identical to the committed one, whose
+    tigpair_checkpoint.tsv was written by the reference's bin/makeTSVfile.py; and the reference demo's
+    own (_original.gv, tigpair_checkpoint.tsv) pair"""
+    base = str(tmp_path / "out")
+    subprocess.check_call([graph_check, "imap", os.path.join(GOLDEN, "tigpair_imap.tsv"),
+                           os.path.join(GOLDEN, "tigpair_mult.tsv"), os.path.join(GOLDEN, "tigpair_lengths.tsv"),
+                           base, "5", "0", "50", "10000", "0", "0.05", "100", "x"], stdout=subprocess.DEVNULL)
+    gv = open(base + "_original.gv").read()
+    assert gv == open(os.path.join(GOLDEN, "tigpair_original.gv")).read()
+    assert gv.count("--") >= 5
+    assert _make_tsv(base + "_original.gv", os.path.join(GOLDEN, "tigpair_draft_headers.fa")) == \
+        open(os.path.join(GOLDEN, "tigpair_checkpoint.tsv")).read()
+    demo_fa = tmp_path / "demo.fa"
+    demo_fa.write_text(">1\nA\n>2\nA\n>3\nA\n")
+    assert _make_tsv(os.path.join(GOLDEN, "arks_demo_original.gv"), str(demo_fa)) == \
+        open(os.path.join(GOLDEN, "arks_demo.tigpair_checkpoint.tsv")).read()
