@@ -158,7 +158,7 @@ def test_gv_to_tigpair_chain(graph_check, tmp_path):
                            base, "5", "0", "50", "10000", "0", "0.05", "100", "x"], stdout=subprocess.DEVNULL)
     gv = open(base + "_original.gv").read()
     assert gv == open(os.path.join(GOLDEN, "tigpair_original.gv")).read()
-    assert gv.count("--") >= 5
+    assert gv.count("--") >= 4
     assert _make_tsv(base + "_original.gv", os.path.join(GOLDEN, "tigpair_draft_headers.fa")) == \
         open(os.path.join(GOLDEN, "tigpair_checkpoint.tsv")).read()
     demo_fa = tmp_path / "demo.fa"
