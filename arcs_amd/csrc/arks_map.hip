@@ -579,22 +579,40 @@ map_reads_b_kernel(
 				const u32 cm = tile_canonical_mmer(S.cw, (int)q);
 				u64 slot = mtab_home(cm, bx.mtab_cap);
 				u32 cnt = 0;
-				for (;;) {
-					const u64 e = bx.mtab[slot];
-					if (!(e >> 63))
-						break;
-					slot = (slot + 1 == bx.mtab_cap) ? 0 : slot + 1;
-					if (((u32)(e >> 32) & kMmerMask) != cm)
-						continue;
-					if ((u32)e == kHeavyPos) {
-						cnt = kHnHeavy;
-						break;
+				bool end = false;
+				while (!end) {
+					// four consecutive entries per round trip (single steps next to the wrap-around)
+					const bool wide = slot + 4 <= bx.mtab_cap;
+					u64 ev[4];
+					ev[0] = bx.mtab[slot];
+#pragma unroll
+					for (int x = 1; x < 4; ++x)
+						ev[x] = wide ? bx.mtab[slot + x] : 0ull;
+#pragma unroll
+					for (int x = 0; x < 4; ++x) {
+						const u64 e = ev[x];
+						if (end || (x > 0 && !wide))
+							continue;
+						if (!(e >> 63)) {
+							end = true;
+							continue;
+						}
+						if (((u32)(e >> 32) & kMmerMask) != cm)
+							continue;
+						if ((u32)e == kHeavyPos) {
+							cnt = kHnHeavy;
+							end = true;
+							continue;
+						}
+						if (cnt < 2)
+							S.hc[h][cnt] = e;
+						cnt = cnt < 2 ? cnt + 1 : kHnOverflow;
+						if (cnt == kHnOverflow)
+							end = true;
 					}
-					if (cnt < 2)
-						S.hc[h][cnt] = e;
-					cnt = cnt < 2 ? cnt + 1 : kHnOverflow;
-					if (cnt == kHnOverflow)
-						break;
+					slot += wide ? 4 : 1;
+					if (slot >= bx.mtab_cap)
+						slot -= bx.mtab_cap;
 				}
 				S.hn[h] = (unsigned char)cnt;
 			}
