@@ -595,7 +595,7 @@ arks_index_build(
 	}
 	{
 		void* p = nullptr;
-		HIP_TRY(hipMalloc(&p, 2 * sizeof(u32))); // [0] redo-queue length, [1] work counter
+		HIP_TRY(hipMalloc(&p, 4 * sizeof(u32))); // slow-queue length, work counter, medium-queue length, its work counter
 		idx->queue_count = static_cast<u32*>(p);
 	}
 	*out = idx;
@@ -752,9 +752,9 @@ ensure_queue(const arks_index* idx, int64_t n_reads)
 	}
 	void* p = nullptr;
 	const int64_t cap = n_reads + n_reads / 4 + 1024;
-	hipError_t e = hipMalloc(&p, sizeof(u32) * (size_t)cap);
+	hipError_t e = hipMalloc(&p, 2 * sizeof(u32) * (size_t)cap); // slow queue + medium queue
 	if (e != hipSuccess)
-		return fail_hip(e, "hipMalloc(redo queue)");
+		return fail_hip(e, "hipMalloc(redo queues)");
 	idx->queue = static_cast<u32*>(p);
 	idx->queue_cap = cap;
 	return ARKS_OK;
@@ -1033,6 +1033,17 @@ arks_pairs_device(
 	    (u64*)d_stored, static_cast<hipStream_t>(stream)));
 done:
 	return rc;
+}
+
+/* debugging aid (not part of the ABI): lengths of the slow / medium queues after the last map call */
+int
+arks_debug_queue_counts(const arks_index* idx, unsigned* out4)
+{
+	if (!idx || !out4)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(idx->device);
+	(void)hipDeviceSynchronize();
+	return hipMemcpy(out4, idx->queue_count, 4 * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess ? ARKS_OK : ARKS_ERR_HIP;
 }
 
 #ifdef ARKS_PROFILE_SECTIONS

@@ -269,7 +269,7 @@ map_reads_kernel(
 constexpr int kTW = 16;          // tile capacity in packed words
 constexpr int kTP = kTW * 32;    // ... in base positions
 constexpr int kTR = 8;           // reads per tile
-constexpr int kNH = 96;          // run heads per tile that get a published entry list
+constexpr int kNH = 64;          // run heads per tile that get a published entry list
 constexpr int kChunk = 32;       // reads handed out per device-counter grab
 constexpr u32 kHnHeavy = 255, kHnOverflow = 254;
 
@@ -286,15 +286,16 @@ struct TileLds
 	u32 wmeta[kTW + 4]; // per word: read index << 16 | local end position of that read (0 = none)
 	int rstart[kTR + 1];
 	int rlen[kTR];
-	u64 pdiag[kTR]; // [39:0] D, [40] same strand, [41] valid
-	u32 tfirst[kTR];             // first text word staged for read j
-	u64 tcodes[kTW + kTR + 2];   // text words along the primary diagonals (read j: slots from
-	u32 tvis[kTW + kTR + 2];     //   (rstart[j] >> 5) + j)
-	u32 tamb[kTW + kTR + 2];
-	u32 town[kTW + kTR + 2];
-	u32 mm32[kTW + 8];           // mismatch bit per base along the primary diagonal
+	u64 pdiag[kTR][2]; // the read's two staged diagonals: [39:0] D, [40] same strand, [41] valid
+	u32 tfirst[kTR][2];             // first text word staged for read j on diagonal d
+	u64 tcodes[2][kTW + kTR + 2];   // text words along the diagonals (read j: slots from
+	u32 tvis[2][kTW + kTR + 2];     //   (rstart[j] >> 5) + j)
+	u32 tamb[2][kTW + kTR + 2];
+	u32 town[2][kTW + kTR + 2];
+	u32 mm32[2][kTW + 8];           // mismatch bit per base along the diagonals
 	unsigned char sread[kTW + kTR + 2];
 	u32 redo;
+	u32 redo2; // reads that need the general verification (hot instantiation only)
 };
 
 // lanes of one wave communicate through LDS: order the compiler's view of it
@@ -348,7 +349,12 @@ tile_canonical_mmer(const u64* cw, int i)
 	return mf < mr ? mf : mr;
 }
 
-template <int KW, bool STATS>
+// FULL = false: the hot instantiation.  A window that needs the general verification (an entry off
+//                both staged diagonals of its read, a heavy minimizer, a run with more than two
+//                entries) sends its read to the "medium" queue instead, which keeps that code's
+//                registers out of the hot kernel.
+// FULL = true : the same kernel over the medium queue, one queued read per tile, every path.
+template <int KW, bool STATS, bool FULL>
 __global__ void __launch_bounds__(64)
 map_reads_b_kernel(
     const u64* __restrict__ codes,
@@ -362,8 +368,9 @@ map_reads_b_kernel(
     BIndexView bx,
     int* __restrict__ out_conreci,
     u64* __restrict__ stats,
-    u32* __restrict__ queue,
-    u32* __restrict__ queue_count)
+    u32* __restrict__ queue,       // slow queue (palindromes next to quirk images, reads longer than a tile)
+    u32* __restrict__ mqueue,      // medium queue
+    u32* __restrict__ queue_count) // [0] slow length, [1] work counter, [2] medium length, [3] medium work counter
 {
 	__shared__ TileLds S;
 	const int lane = threadIdx.x;
@@ -375,15 +382,28 @@ map_reads_b_kernel(
 	unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
+	const u32 n_medium = FULL ? __hip_atomic_load(queue_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 	for (;;) {
 		long c0 = 0;
 		ARKS_SEC(9);
-		if (lane == 0)
-			c0 = (long)atomicAdd(queue_count + 1, (u32)kChunk);
-		c0 = __shfl(c0, 0);
-		if (c0 >= n_reads)
-			break;
-		const int nchunk = (int)((c0 + kChunk < n_reads ? c0 + kChunk : n_reads) - c0);
+		int nchunk;
+		if (FULL) { // one queued read per grab
+			u32 qi = 0;
+			if (lane == 0)
+				qi = atomicAdd(queue_count + 3, 1u);
+			qi = __shfl(qi, 0);
+			if (qi >= n_medium)
+				break;
+			c0 = (long)mqueue[qi];
+			nchunk = 1;
+		} else {
+			if (lane == 0)
+				c0 = (long)atomicAdd(queue_count + 1, (u32)kChunk);
+			c0 = __shfl(c0, 0);
+			if (c0 >= n_reads)
+				break;
+			nchunk = (int)((c0 + kChunk < n_reads ? c0 + kChunk : n_reads) - c0);
+		}
 		// lane l holds the metadata of read c0 + l (lane nchunk: the end offset)
 		u64 wo = 0;
 		int rl = 0;
@@ -391,7 +411,7 @@ map_reads_b_kernel(
 			wo = word_off[c0 + lane];
 		if (lane < nchunk) {
 			rl = (int)lens[c0 + lane];
-			if (eval && !eval[c0 + lane])
+			if (!FULL && eval && !eval[c0 + lane])
 				rl = -1; // not evaluated: output 0, no counters
 		}
 		int cur = 0;
@@ -420,8 +440,10 @@ map_reads_b_kernel(
 				S.rstart[lane - cur] = (int)(wo - base_w) * 32;
 			if (lane >= cur && lane < nxt)
 				S.rlen[lane - cur] = rl;
-			if (lane == 0)
+			if (lane == 0) {
 				S.redo = 0;
+				S.redo2 = 0;
+			}
 			if (lane < tw + 4) {
 				S.cw[lane] = codes[base_w + (u64)lane];
 				S.nm[lane] = nmask[base_w + (u64)lane];
@@ -618,92 +640,125 @@ map_reads_b_kernel(
 			}
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(5);
-			// ---- T6a: the primary diagonal of every read = entry 0 of its first run that has entries.
-			//      Heads are in position order, so a ballot per read finds it without LDS traffic. --------
+			// ---- T6a: up to two diagonals per read: A = entry 0 of its first run that has entries, B = the
+			//      first entry (in run order) on another diagonal (a duplicated segment, a chance 15-mer
+			//      match).  Heads are in position order: ballots find both without LDS traffic. -----------
 			{
-				u32 pf = 0xFFFFFFFFu; // lane j: first head of read j with 1 or 2 entries
+				u64 dA = 0, dB = 0; // lane j: diagonals of read j ([39:0] D, [40] same strand, [41] valid)
 				for (int hb0 = 0; hb0 < nh; hb0 += 64) {
 					const int h = hb0 + lane;
-					bool has = false;
 					int jh = -1;
+					u64 dk0 = 0, dk1 = 0;
 					if (h < nh) {
 						const u32 cnt = S.hn[h];
-						has = cnt >= 1 && cnt <= 2;
-						jh = S.wread[S.heads[h] >> 5];
+						if (cnt >= 1 && cnt <= 2) {
+							const int ih = S.heads[h];
+							jh = S.wread[ih >> 5];
+							const u32 payh = (u32)(-16 - rec[ih]);
+							const int o = (int)(payh & 2047u) - S.rstart[jh]; // offset of the minimizer in the read
+							const u32 rstrand = (payh >> 11) & 1u;
+							// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
+							const u64 e0 = S.hc[h][0];
+							const bool s0 = ((u32)(e0 >> 62) & 1u) == rstrand;
+							dk0 = (s0 ? (u64)(u32)e0 - (u64)o : (u64)(u32)e0 + (u64)(kM - 1 + o)) |
+							      ((u64)s0 << 40) | (1ull << 41);
+							if (cnt == 2) {
+								const u64 e1 = S.hc[h][1];
+								const bool s1 = ((u32)(e1 >> 62) & 1u) == rstrand;
+								dk1 = (s1 ? (u64)(u32)e1 - (u64)o : (u64)(u32)e1 + (u64)(kM - 1 + o)) |
+								      ((u64)s1 << 40) | (1ull << 41);
+							}
+						}
 					}
 					for (int j = 0; j < nr; ++j) {
-						const u64 m = __ballot(has && jh == j);
-						if (lane == j && pf == 0xFFFFFFFFu && m)
-							pf = (u32)(hb0 + __ffsll((long long)m) - 1);
+						const u64 mA = __ballot(jh == j);
+						if (mA == 0)
+							continue;
+						const u64 a0 = __shfl(dk0, __ffsll((long long)mA) - 1);
+						u64 aj = __shfl(dA, j);
+						if (aj == 0) {
+							aj = a0;
+							if (lane == j)
+								dA = a0;
+						}
+						const bool diff0 = jh == j && dk0 != aj;
+						const bool diff1 = jh == j && dk1 != 0 && dk1 != aj;
+						const u64 mB = __ballot(diff0 || diff1);
+						if (mB) {
+							const u64 b0 = __shfl(diff0 ? dk0 : dk1, __ffsll((long long)mB) - 1);
+							if (lane == j && dB == 0)
+								dB = b0;
+						}
 					}
 				}
 				if (lane < nr) {
-					u64 pdv = 0;
-					if (pf != 0xFFFFFFFFu) {
-						const u32 payh = (u32)(-16 - rec[S.heads[pf]]);
-						const int q = (int)(payh & 2047u);
-						const u64 e = S.hc[pf][0];
-						const int o = q - S.rstart[lane]; // offset of the minimizer in the read
-						const bool same = ((u32)(e >> 62) & 1u) == ((payh >> 11) & 1u);
-						// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
-						const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(kM - 1 + o);
-						pdv = D | ((u64)same << 40) | (1ull << 41);
+					S.pdiag[lane][0] = dA;
+					S.pdiag[lane][1] = dB;
+					// first text word of the span [lo, lo + L) the read covers along each diagonal
+#pragma unroll
+					for (int d = 0; d < 2; ++d) {
+						const u64 pdv = d ? dB : dA;
+						const u64 Dv = pdv & 0xFFFFFFFFFFull;
+						const u64 lo = ((pdv >> 40) & 1ull) ? Dv : Dv - (u64)(S.rlen[lane] - 1);
+						S.tfirst[lane][d] = (u32)(lo >> 5);
 					}
-					S.pdiag[lane] = pdv;
-					// first text word of the span [lo, lo + L) the read covers along its diagonal
-					const u64 Dv = pdv & 0xFFFFFFFFFFull;
-					const u64 lo = ((pdv >> 40) & 1ull) ? Dv : Dv - (u64)(S.rlen[lane] - 1);
-					S.tfirst[lane] = (u32)(lo >> 5);
 				}
 			}
 			ARKS_WAVE_SYNC();
 			// stage the text words and their visited / ambiguous / owner words (one round trip)
-			if (lane < tw + nr) {
-				const int j = S.sread[lane];
-				if (S.pdiag[j] >> 41) {
-					const u64 tw_idx = (u64)S.tfirst[j] + (u64)(lane - ((S.rstart[j] >> 5) + j));
-					S.tcodes[lane] = bx.codes[tw_idx];
-					S.tvis[lane] = bx.visited[tw_idx];
-					S.tamb[lane] = bx.ambig[tw_idx];
-					S.town[lane] = bx.word_owner[tw_idx];
+			{
+				const int ns = tw + nr;
+				const int d = lane >= ns ? 1 : 0, sl = lane - d * ns;
+				if (lane < 2 * ns) {
+					const int j = S.sread[sl];
+					if (S.pdiag[j][d] >> 41) {
+						const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
+						S.tcodes[d][sl] = bx.codes[tw_idx];
+						S.tvis[d][sl] = bx.visited[tw_idx];
+						S.tamb[d][sl] = bx.ambig[tw_idx];
+						S.town[d][sl] = bx.word_owner[tw_idx];
+					}
 				}
 			}
 			ARKS_WAVE_SYNC();
-			// ---- T6b: lanes = read words: XOR each word of the read with the 32 text bases it faces
-			//      along the primary diagonal -> one mismatch bit per base (bit b of mm32[word]) ----------
-			if (lane < tw + 3) {
-				u32 mbits = 0;
-				if (lane < tw) {
-					const int j = S.wread[lane];
-					const u64 pdv = S.pdiag[j];
-					if (pdv >> 41) {
-						const bool same = (pdv >> 40) & 1ull;
-						const u64 D = pdv & 0xFFFFFFFFFFull;
-						const int x0 = lane * 32 - S.rstart[j]; // read offset of this word's first base
-						const int sb = (S.rstart[j] >> 5) + j;
-						// text position of the lowest-addressed base this word faces
-						const u64 tlo = same ? D + (u64)x0 : D - (u64)(x0 + 31);
-						const int slot = sb + (int)((u32)(tlo >> 5) - S.tfirst[j]);
-						const u64 t0 = slot >= sb ? S.tcodes[slot] : 0ull;
-						const u64 t32 = funnel_l(t0, S.tcodes[slot + 1], (int)(tlo & 31) * 2);
-						const u64 face = same ? t32 : ~rev_groups(t32);
-						u64 x = S.cw[lane] ^ face;
-						// one bit per base: OR the two bits of every group, gather the even bits
-						x = (x | (x >> 1)) & 0x5555555555555555ull;
-						x = (x | (x >> 1)) & 0x3333333333333333ull;
-						x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-						x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-						x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-						x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-						mbits = __brev((u32)x); // base 0 of the word -> bit 0
+			// ---- T6b: lanes = read words (x2 diagonals): XOR each word of the read with the 32 text bases
+			//      it faces -> one mismatch bit per base (bit b of mm32[d][word]) -------------------------
+			{
+				const int d = lane >= 32 ? 1 : 0, wl = lane & 31;
+				if (wl < tw + 6) {
+					u32 mbits = 0;
+					if (wl < tw) {
+						const int j = S.wread[wl];
+						const u64 pdv = S.pdiag[j][d];
+						if (pdv >> 41) {
+							const bool same = (pdv >> 40) & 1ull;
+							const u64 D = pdv & 0xFFFFFFFFFFull;
+							const int x0 = wl * 32 - S.rstart[j]; // read offset of this word's first base
+							const int sb = (S.rstart[j] >> 5) + j;
+							// text position of the lowest-addressed base this word faces
+							const u64 tlo = same ? D + (u64)x0 : D - (u64)(x0 + 31);
+							const int slot = sb + (int)((u32)(tlo >> 5) - S.tfirst[j][d]);
+							const u64 t0 = slot >= sb ? S.tcodes[d][slot] : 0ull;
+							const u64 t32 = funnel_l(t0, S.tcodes[d][slot + 1], (int)(tlo & 31) * 2);
+							const u64 face = same ? t32 : ~rev_groups(t32);
+							u64 x = S.cw[wl] ^ face;
+							// one bit per base: OR the two bits of every group, gather the even bits
+							x = (x | (x >> 1)) & 0x5555555555555555ull;
+							x = (x | (x >> 1)) & 0x3333333333333333ull;
+							x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+							x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+							x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+							x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+							mbits = __brev((u32)x); // base 0 of the word -> bit 0
+						}
 					}
+					S.mm32[d][wl] = mbits;
 				}
-				S.mm32[lane] = mbits;
 			}
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(6);
-			// ---- T6c: lanes = windows: a window whose run proposes the primary diagonal only tests its
-			//      k mismatch bits; any other candidate gets the full key comparison ------------------
+			// ---- T6c: lanes = windows: an entry on one of the read's two staged diagonals only tests the
+			//      window's k mismatch bits; anything else needs the general verification ----------------
 			for (int base = 0; base < n; base += 64) {
 				const int i = base + lane;
 				const int rv = rec[i];
@@ -719,15 +774,22 @@ map_reads_b_kernel(
 					bool full = hn == kHnHeavy || hn == kHnOverflow;
 					if (hn == 1 || hn == 2) {
 						const int j = S.wread[i >> 5];
-						const u64 pdv = S.pdiag[j];
-						const u64 e = S.hc[hidx][0];
 						const int p = i - S.rstart[j];
 						const int o = q - S.rstart[j];
-						const bool same = ((u32)(e >> 62) & 1u) == rstrand;
-						const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(kM - 1 + o);
-						if (pdv == (D | ((u64)same << 40) | (1ull << 41))) {
-							const int l = i & 31;
-							const u32* mw = S.mm32 + (i >> 5);
+						const int l = i & 31;
+						for (u32 c = 0; c < hn && val < 0; ++c) {
+							const u64 e = S.hc[hidx][c];
+							const bool same = ((u32)(e >> 62) & 1u) == rstrand;
+							const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(kM - 1 + o);
+							const u64 dk = D | ((u64)same << 40) | (1ull << 41);
+							int d = -1;
+							d = dk == S.pdiag[j][1] ? 1 : d;
+							d = dk == S.pdiag[j][0] ? 0 : d;
+							if (d < 0) {
+								full = true;
+								continue;
+							}
+							const u32* mw = S.mm32[d] + (i >> 5);
 							const u64 m01 = (u64)mw[0] | ((u64)mw[1] << 32);
 							const u64 m23 = (u64)mw[2] | ((u64)mw[3] << 32);
 							u64 bits = funnel_r(m01, m23, l); // 64 bases from i on
@@ -739,18 +801,18 @@ map_reads_b_kernel(
 							}
 							if (bits == 0) {
 								const u64 t = same ? D + (u64)p : D - (u64)(p + k - 1);
-								const int slot = (S.rstart[j] >> 5) + j + (int)((u32)(t >> 5) - S.tfirst[j]);
+								const int slot = (S.rstart[j] >> 5) + j + (int)((u32)(t >> 5) - S.tfirst[j][d]);
 								const u32 sh = 31 - (u32)(t & 31);
-								if ((S.tvis[slot] >> sh) & 1u)
-									val = ((S.tamb[slot] >> sh) & 1u) ? 0 : (int)S.town[slot];
-								else
-									full = hn == 2;
-							} else
-								full = hn == 2;
-						} else
-							full = true;
+								if ((S.tvis[d][slot] >> sh) & 1u)
+									val = ((S.tamb[d][slot] >> sh) & 1u) ? 0 : (int)S.town[d][slot];
+							}
+						}
+						if (val >= 0)
+							full = false;
 					}
-					if (full) {
+					if (full && !FULL)
+						atomicOr(&S.redo2, 1u << S.wread[i >> 5]);
+					if (full && FULL) {
 						const Key<KW> f = tile_window_key<KW>(S.cw, i, g);
 						const Key<KW> r = key_revcomp(f, g);
 						if (hn == kHnHeavy) {
@@ -783,6 +845,7 @@ map_reads_b_kernel(
 			ARKS_SEC(7);
 			// ---- T7: per read: counters, vote, output ---------------------------------------------------
 			const u32 redo_mask = S.redo;
+			const u32 redo2_mask = FULL ? 0u : S.redo2;
 			for (int j = 0; j < nr; ++j) {
 				const long r = c0 + cur + j;
 				const int L = S.rlen[j];
@@ -794,6 +857,11 @@ map_reads_b_kernel(
 				if ((redo_mask >> j) & 1u) {
 					if (lane == 0)
 						queue[atomicAdd(queue_count, 1u)] = (u32)r;
+					continue;
+				}
+				if ((redo2_mask >> j) & 1u) {
+					if (lane == 0)
+						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)r;
 					continue;
 				}
 				const int nwin = L - k + 1;
@@ -1003,7 +1071,7 @@ launch_map_reads(
 {
 	if (n_reads <= 0)
 		return hipSuccess;
-	hipError_t e = hipMemsetAsync(queue_count, 0, 2 * sizeof(u32), st);
+	hipError_t e = hipMemsetAsync(queue_count, 0, 4 * sizeof(u32), st);
 	if (e != hipSuccess)
 		return e;
 	// one wave per read at a time; enough resident waves to cover the memory latency
@@ -1024,14 +1092,18 @@ launch_map_reads(
 	do {                                                                                           \
 		int per_cu = 0;                                                                            \
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                          \
-		        &per_cu, map_reads_b_kernel<KWV, ST>, 64, 0) != hipSuccess || per_cu <= 0)         \
+		        &per_cu, map_reads_b_kernel<KWV, ST, false>, 64, 0) != hipSuccess || per_cu <= 0)  \
 			per_cu = 8;                                                                            \
 		const u64 res = (u64)(n_cu > 0 ? n_cu : 256) * (u64)per_cu;                                \
 		const u64 wantw = ((u64)n_reads + 3) / 4;                                                  \
 		const unsigned bb = (unsigned)(wantw < res ? wantw : res);                                 \
-		map_reads_b_kernel<KWV, ST><<<bb, 64, 0, st>>>(                                            \
+		const unsigned bm = (unsigned)(wantw < 2048 ? wantw : 2048);                               \
+		map_reads_b_kernel<KWV, ST, false><<<bb, 64, 0, st>>>(                                     \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
-		    queue_count);                                                                          \
+		    queue + n_reads, queue_count);                                                         \
+		map_reads_b_kernel<KWV, ST, true><<<bm, 64, 0, st>>>(                                      \
+		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
+		    queue + n_reads, queue_count);                                                         \
 		map_reads_kernel<KWV, ST, false, true><<<bs, 256, 0, st>>>(                                \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, t, bx, out, stats, queue,     \
 		    queue_count);                                                                          \
