@@ -414,7 +414,7 @@ is_quirk_image(const Key<KW>& c, const KeyGeom& g)
 
 // per visited window: ambiguity bit (value 0 in the full table), palindrome / quirk-image bits,
 // and the positions of its minimizer (all ties)
-template <int KW>
+template <int KW, int MM>
 __global__ void
 bmark_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ visited, u64 total_words, KeyGeom g,
@@ -444,35 +444,37 @@ bmark_kernel(
 		atomicOr(is_pal + word, bit);
 	else if (is_quirk_image(c, g))
 		atomicOr(is_img + word, bit);
+	typedef typename Mmer<MM>::type mm_t;
 	u32 min_h;
 	int off;
-	window_minimizer(codes, pos, w, min_h, off);
+	window_minimizer<MM>(codes, pos, w, min_h, off);
 	for (int o = off; o < w; ++o) {
-		const u32 mf = mmer_fw(codes, pos + (u64)o);
-		const u32 mr = mmer_rc(mf);
-		if (mmer_order(mf < mr ? mf : mr) == min_h) {
+		const mm_t mf = mmer_fw<MM>(codes, pos + (u64)o);
+		const mm_t mr = mmer_rc<MM>(mf);
+		if (mmer_order<MM>(mf < mr ? mf : mr) == min_h) {
 			const u64 q = pos + (u64)o;
 			atomicOr(is_min + (q >> 5), 1u << (31 - (u32)(q & 31)));
 		}
 	}
 }
 
-// ---- minimizer occurrence counts: open-addressed u32 key (cm | 0x80000000) -> u32 counter -------
+// ---- minimizer occurrence counts: open-addressed u64 key (canonical m-mer | 1 << 63) -> u32 counter
 constexpr u32 kCntForced = 0x80000000u; // heavy by decree (quirk-image minimizers)
 constexpr u32 kCntMarker = 0x40000000u; // the HEAVY marker entry has been written to mtab
 constexpr u32 kCntMask = 0x3FFFFFFFu;
 
+template <int MM>
 __device__ inline u32*
-ctab_slot(u32* __restrict__ keys, u32* __restrict__ cnts, u64 cap, u32 cm, bool insert)
+ctab_slot(u64* __restrict__ keys, u32* __restrict__ cnts, u64 cap, typename Mmer<MM>::type cm, bool insert)
 {
-	const u32 key = cm | 0x80000000u;
-	u64 s = mtab_home(cm, cap);
+	const u64 key = (u64)cm | (1ull << 63);
+	u64 s = mtab_home<MM>(cm, cap);
 	for (;;) {
-		u32 cur = __hip_atomic_load(keys + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		u64 cur = __hip_atomic_load(keys + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (cur == 0) {
 			if (!insert)
 				return nullptr;
-			u32 expect = 0;
+			u64 expect = 0;
 			if (__hip_atomic_compare_exchange_strong(
 			        keys + s, &expect, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 				cur = key;
@@ -485,27 +487,29 @@ ctab_slot(u32* __restrict__ keys, u32* __restrict__ cnts, u64 cap, u32 cm, bool 
 	}
 }
 
+template <int MM>
 __global__ void
 bcount_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ is_min, u64 total_words,
-    u32* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap)
+    u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap)
 {
+	typedef typename Mmer<MM>::type mm_t;
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	const u64 word = pos >> 5;
 	if (word >= total_words || !((is_min[word] >> (31 - (u32)(pos & 31))) & 1u))
 		return;
-	const u32 mf = mmer_fw(codes, pos);
-	const u32 mr = mmer_rc(mf);
-	atomicAdd(ctab_slot(ckeys, ccnts, ccap, mf < mr ? mf : mr, true), 1u);
+	const mm_t mf = mmer_fw<MM>(codes, pos);
+	const mm_t mr = mmer_rc<MM>(mf);
+	atomicAdd(ctab_slot<MM>(ckeys, ccnts, ccap, mf < mr ? mf : mr, true), 1u);
 }
 
-// 15-mer at offset o of a key (rare paths only)
-template <int KW>
-__device__ inline u32
+// m-mer at offset o of a key (rare paths only)
+template <int KW, int MM>
+__device__ inline typename Mmer<MM>::type
 key_mmer(const Key<KW>& x, int o)
 {
-	u32 m = 0;
-	for (int i = 0; i < kM; ++i)
+	typename Mmer<MM>::type m = 0;
+	for (int i = 0; i < MM; ++i)
 		m = (m << 2) | key_base(x, o + i);
 	return m;
 }
@@ -514,12 +518,13 @@ key_mmer(const Key<KW>& x, int o)
 // whose canonical k-mer is X' must find K' -- which is not in the text -- so the minimizer of X' is
 // decreed heavy: such queries then consult the fallback table, where K' lives.
 // PHASE 0: decree (count table); PHASE 1: write the HEAVY marker into mtab (once per minimizer).
-template <int KW, int PHASE>
+template <int KW, int MM, int PHASE>
 __global__ void
 bforce_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ is_pal, u64 total_words, KeyGeom g, int w,
-    u32* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap)
+    u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap)
 {
+	typedef typename Mmer<MM>::type mm_t;
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	const u64 word = pos >> 5;
 	if (word >= total_words || !((is_pal[word] >> (31 - (u32)(pos & 31))) & 1u))
@@ -530,21 +535,21 @@ bforce_kernel(
 		return; // X' is not a canonical non-palindromic k-mer: no regular query has key K'
 	u32 min_h = 0xFFFFFFFFu;
 	for (int o = 0; o < w; ++o) {
-		const u32 mf = key_mmer(x, o), mr = mmer_rc(mf);
-		const u32 h = mmer_order(mf < mr ? mf : mr);
+		const mm_t mf = key_mmer<KW, MM>(x, o), mr = mmer_rc<MM>(mf);
+		const u32 h = mmer_order<MM>(mf < mr ? mf : mr);
 		min_h = h < min_h ? h : min_h;
 	}
 	for (int o = 0; o < w; ++o) {
-		const u32 mf = key_mmer(x, o), mr = mmer_rc(mf);
-		const u32 cm = mf < mr ? mf : mr;
-		if (mmer_order(cm) != min_h)
+		const mm_t mf = key_mmer<KW, MM>(x, o), mr = mmer_rc<MM>(mf);
+		const mm_t cm = mf < mr ? mf : mr;
+		if (mmer_order<MM>(cm) != min_h)
 			continue;
-		u32* cnt = ctab_slot(ckeys, ccnts, ccap, cm, true);
+		u32* cnt = ctab_slot<MM>(ckeys, ccnts, ccap, cm, true);
 		if (PHASE == 0)
 			atomicOr(cnt, kCntForced);
 		else if (!(atomicOr(cnt, kCntMarker) & kCntMarker)) {
-			u64 s = mtab_home(cm, mcap);
-			const u64 e = mtab_entry(cm, 0, kHeavyPos);
+			u64 s = mtab_home<MM>(cm, mcap);
+			const u64 e = mtab_entry(mmer_fp<MM>(cm), 0, kHeavyPos);
 			for (;;) {
 				u64 expect = 0;
 				if (__hip_atomic_compare_exchange_strong(
@@ -557,30 +562,32 @@ bforce_kernel(
 }
 
 // every minimizer position -> one mtab entry, or (heavy minimizer) the heavy bit + one marker
+template <int MM>
 __global__ void
 bfill_mtab_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ is_min, u64 total_words,
-    u32* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap,
+    u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap,
     u32* __restrict__ heavy_min)
 {
+	typedef typename Mmer<MM>::type mm_t;
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	const u64 word = pos >> 5;
 	if (word >= total_words || !((is_min[word] >> (31 - (u32)(pos & 31))) & 1u))
 		return;
-	const u32 mf = mmer_fw(codes, pos);
-	const u32 mr = mmer_rc(mf);
-	const u32 cm = mf < mr ? mf : mr;
-	u32* cnt = ctab_slot(ckeys, ccnts, ccap, cm, false);
+	const mm_t mf = mmer_fw<MM>(codes, pos);
+	const mm_t mr = mmer_rc<MM>(mf);
+	const mm_t cm = mf < mr ? mf : mr;
+	u32* cnt = ctab_slot<MM>(ckeys, ccnts, ccap, cm, false);
 	const u32 c = *cnt;
 	u64 e;
 	if ((c & kCntForced) || (c & kCntMask) > (u32)kHeavy) {
 		atomicOr(heavy_min + word, 1u << (31 - (u32)(pos & 31)));
 		if (atomicOr(cnt, kCntMarker) & kCntMarker)
 			return;
-		e = mtab_entry(cm, 0, kHeavyPos);
+		e = mtab_entry(mmer_fp<MM>(cm), 0, kHeavyPos);
 	} else
-		e = mtab_entry(cm, mf < mr ? 1u : 0u, (u32)pos);
-	u64 s = mtab_home(cm, mcap);
+		e = mtab_entry(mmer_fp<MM>(cm), mf < mr ? 1u : 0u, (u32)pos);
+	u64 s = mtab_home<MM>(cm, mcap);
 	for (;;) {
 		u64 expect = 0;
 		if (__hip_atomic_compare_exchange_strong(
@@ -632,7 +639,7 @@ table_put(const TableView& t, const Key<KW>& c, u32 value, bool active)
 // Windows the text path cannot (or must not) answer go to the fallback table: palindromes (their
 // key is not their sequence), quirk images (a palindromic query may ask for them), and every
 // window one of whose minimizer positions is heavy.  INSERT = false only counts them.
-template <int KW, bool INSERT>
+template <int KW, int MM, bool INSERT>
 __global__ void
 bfallback_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ visited, const u32* __restrict__ ambig,
@@ -647,13 +654,14 @@ bfallback_kernel(
 	if (word < total_words && ((visited[word] >> sh) & 1u)) {
 		take = ((is_pal[word] | is_img[word]) >> sh) & 1u;
 		if (!take) {
+			typedef typename Mmer<MM>::type mm_t;
 			u32 min_h;
 			int off;
-			window_minimizer(codes, pos, w, min_h, off);
+			window_minimizer<MM>(codes, pos, w, min_h, off);
 			for (int o = off; o < w && !take; ++o) {
-				const u32 mf = mmer_fw(codes, pos + (u64)o);
-				const u32 mr = mmer_rc(mf);
-				if (mmer_order(mf < mr ? mf : mr) == min_h)
+				const mm_t mf = mmer_fw<MM>(codes, pos + (u64)o);
+				const mm_t mr = mmer_rc<MM>(mf);
+				if (mmer_order<MM>(mf < mr ? mf : mr) == min_h)
 					take = bit_at(heavy_min, pos + (u64)o);
 			}
 		}
@@ -813,81 +821,103 @@ launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner,
 		if ((kw) == 2) { CALL2; } else { CALL3; }                                                  \
 	} while (0)
 
+#define ARKS_KM_DISPATCH(kw, mm, CALL)                                                             \
+	do {                                                                                           \
+		if ((kw) == 2 && (mm) == kMShort) { CALL(2, kMShort); }                                    \
+		else if ((kw) == 2) { CALL(2, kMLong); }                                                   \
+		else if ((mm) == kMShort) { CALL(3, kMShort); }                                            \
+		else { CALL(3, kMLong); }                                                                  \
+	} while (0)
+
 hipError_t
 launch_bmark(
-    int kw, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,
+    int kw, int mm, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,
     int w, u32* ambig, u32* is_min, u32* is_pal, u32* is_img, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
-	ARKS_KW_DISPATCH(kw,
-	    (bmark_kernel<2><<<b, 256, 0, st>>>(codes, visited, total_words, g, full, w, ambig, is_min, is_pal, is_img)),
-	    (bmark_kernel<3><<<b, 256, 0, st>>>(codes, visited, total_words, g, full, w, ambig, is_min, is_pal, is_img)));
+#define ARKS_CALL(KWV, MMV)                                                                        \
+	bmark_kernel<KWV, MMV><<<b, 256, 0, st>>>(codes, visited, total_words, g, full, w, ambig, is_min, is_pal, is_img)
+	ARKS_KM_DISPATCH(kw, mm, ARKS_CALL);
+#undef ARKS_CALL
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }
 
 hipError_t
-launch_bcount(const u64* codes, const u32* is_min, u64 total_words, u32* ckeys, u32* ccnts, u64 ccap, hipStream_t st)
+launch_bcount(int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
-	bcount_kernel<<<blocks_for(total_words * 32ull, 256), 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap);
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+	if (mm == kMShort)
+		bcount_kernel<kMShort><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap);
+	else
+		bcount_kernel<kMLong><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }
 
 hipError_t
 launch_bforce(
-    int kw, int phase, const u64* codes, const u32* is_pal, u64 total_words, const KeyGeom& g, int w,
-    u32* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st)
+    int kw, int mm, int phase, const u64* codes, const u32* is_pal, u64 total_words, const KeyGeom& g, int w,
+    u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
+#define ARKS_CALL0(KWV, MMV)                                                                       \
+	bforce_kernel<KWV, MMV, 0><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)
+#define ARKS_CALL1(KWV, MMV)                                                                       \
+	bforce_kernel<KWV, MMV, 1><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)
 	if (phase == 0)
-		ARKS_KW_DISPATCH(kw,
-		    (bforce_kernel<2, 0><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)),
-		    (bforce_kernel<3, 0><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)));
+		ARKS_KM_DISPATCH(kw, mm, ARKS_CALL0);
 	else
-		ARKS_KW_DISPATCH(kw,
-		    (bforce_kernel<2, 1><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)),
-		    (bforce_kernel<3, 1><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)));
+		ARKS_KM_DISPATCH(kw, mm, ARKS_CALL1);
+#undef ARKS_CALL0
+#undef ARKS_CALL1
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }
 
 hipError_t
 launch_bfill_mtab(
-    const u64* codes, const u32* is_min, u64 total_words, u32* ckeys, u32* ccnts, u64 ccap, u64* mtab,
+    int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab,
     u64 mcap, u32* heavy_min, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
-	bfill_mtab_kernel<<<blocks_for(total_words * 32ull, 256), 256, 0, st>>>(
-	    codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min);
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+	if (mm == kMShort)
+		bfill_mtab_kernel<kMShort><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min);
+	else
+		bfill_mtab_kernel<kMLong><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }
 
 hipError_t
 launch_bfallback(
-    int kw, bool insert, const u64* codes, const u32* visited, const u32* ambig, const u32* is_pal,
+    int kw, int mm, bool insert, const u64* codes, const u32* visited, const u32* ambig, const u32* is_pal,
     const u32* is_img, const u32* heavy_min, const u32* word_owner, u64 total_words, const KeyGeom& g,
     int w, TableView fb, u64* counter, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
-#define ARKS_FB(KWV, INS)                                                                          \
-	bfallback_kernel<KWV, INS><<<b, 256, 0, st>>>(                                                 \
+#define ARKS_FB_T(KWV, MMV)                                                                        \
+	bfallback_kernel<KWV, MMV, true><<<b, 256, 0, st>>>(                                           \
+	    codes, visited, ambig, is_pal, is_img, heavy_min, word_owner, total_words, g, w, fb, counter)
+#define ARKS_FB_F(KWV, MMV)                                                                        \
+	bfallback_kernel<KWV, MMV, false><<<b, 256, 0, st>>>(                                          \
 	    codes, visited, ambig, is_pal, is_img, heavy_min, word_owner, total_words, g, w, fb, counter)
 	if (insert)
-		ARKS_KW_DISPATCH(kw, (ARKS_FB(2, true)), (ARKS_FB(3, true)));
+		ARKS_KM_DISPATCH(kw, mm, ARKS_FB_T);
 	else
-		ARKS_KW_DISPATCH(kw, (ARKS_FB(2, false)), (ARKS_FB(3, false)));
-#undef ARKS_FB
+		ARKS_KM_DISPATCH(kw, mm, ARKS_FB_F);
+#undef ARKS_FB_T
+#undef ARKS_FB_F
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

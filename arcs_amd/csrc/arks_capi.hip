@@ -394,7 +394,7 @@ arks_index_build(
 	u64 text_words = 0, alloc_words = 0, counters[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	u64 visited_total = 0, n_min = 0, n_pal = 0, n_fb = 0, ccap = 0, mcap = 0;
 	TableView full{ nullptr, 0 };
-	const int w = k - kM + 1;
+	int mm = kMShort, w = 0;
 	bool locality = false;
 	size_t bm_bytes = 0;
 
@@ -414,6 +414,14 @@ arks_index_build(
 	}
 	// text positions are 32-bit in the minimizer table
 	locality = want_locality(k) && alloc_words * 32ull < 0xFFFF0000ull;
+	// minimizer length: a 15-mer is specific enough only while the text is small (the expected
+	// number of chance occurrences of a minimizer is ~ text / 5.4e8); ARKS_MINIMIZER_LEN overrides
+	mm = total_bases > 64000000ull ? kMLong : kMShort;
+	if (const char* e = std::getenv("ARKS_MINIMIZER_LEN"))
+		mm = std::atoi(e) >= 19 ? kMLong : kMShort;
+	if (k < mm + 5)
+		mm = kMShort;
+	w = k - mm + 1;
 	bm_bytes = sizeof(u32) * alloc_words;
 
 	HIP_TRY(d_ascii.alloc(total_bases + 64));
@@ -517,7 +525,7 @@ arks_index_build(
 		HIP_TRY(launch_word_owner(d_woff.as<u64>(), (long)n_ends, alloc_words, idx->word_owner, st));
 	ARKS_TRACE_STEP("launch_word_owner");
 		HIP_TRY(launch_bmark(
-		    idx->kw, idx->codes, idx->visited, text_words, idx->geom, full, w, idx->ambig,
+		    idx->kw, mm, idx->codes, idx->visited, text_words, idx->geom, full, w, idx->ambig,
 		    d_ismin.as<u32>(), d_ispal.as<u32>(), d_isimg.as<u32>(), st));
 	ARKS_TRACE_STEP("launch_bmark");
 		HIP_TRY(launch_popcount(d_ismin.as<u32>(), text_words, d_counters.as<u64>() + 0, st));
@@ -535,33 +543,33 @@ arks_index_build(
 		d_full.p = nullptr;
 		ccap = 2 * (n_min + 4 * n_pal) + 64;
 		mcap = 2 * (n_min + 4 * n_pal) + 64;
-		HIP_TRY(d_ckeys.alloc(sizeof(u32) * ccap));
+		HIP_TRY(d_ckeys.alloc(sizeof(u64) * ccap));
 		HIP_TRY(d_ccnts.alloc(sizeof(u32) * ccap));
 		{
 			void* p = nullptr;
 			HIP_TRY(hipMalloc(&p, sizeof(u64) * mcap));
 			idx->mtab = static_cast<u64*>(p);
 		}
-		HIP_TRY(hipMemsetAsync(d_ckeys.p, 0, sizeof(u32) * ccap, st));
+		HIP_TRY(hipMemsetAsync(d_ckeys.p, 0, sizeof(u64) * ccap, st));
 		HIP_TRY(hipMemsetAsync(d_ccnts.p, 0, sizeof(u32) * ccap, st));
 		HIP_TRY(hipMemsetAsync(idx->mtab, 0, sizeof(u64) * mcap, st));
-		HIP_TRY(launch_bcount(idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u32>(), d_ccnts.as<u32>(), ccap, st));
+		HIP_TRY(launch_bcount(mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap, st));
 	ARKS_TRACE_STEP("launch_bcount");
 		HIP_TRY(launch_bforce(
-		    idx->kw, 0, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, d_ckeys.as<u32>(),
+		    idx->kw, mm, 0, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, d_ckeys.as<u64>(),
 		    d_ccnts.as<u32>(), ccap, idx->mtab, mcap, st));
 	ARKS_TRACE_STEP("launch_bforce");
 		HIP_TRY(launch_bfill_mtab(
-		    idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u32>(), d_ccnts.as<u32>(), ccap,
+		    mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap,
 		    idx->mtab, mcap, d_heavy.as<u32>(), st));
 	ARKS_TRACE_STEP("launch_bfill_mtab");
 		HIP_TRY(launch_bforce(
-		    idx->kw, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, d_ckeys.as<u32>(),
+		    idx->kw, mm, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, d_ckeys.as<u64>(),
 		    d_ccnts.as<u32>(), ccap, idx->mtab, mcap, st));
 	ARKS_TRACE_STEP("launch_bforce");
 		HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
 		HIP_TRY(launch_bfallback(
-		    idx->kw, false, idx->codes, idx->visited, idx->ambig, d_ispal.as<u32>(), d_isimg.as<u32>(),
+		    idx->kw, mm, false, idx->codes, idx->visited, idx->ambig, d_ispal.as<u32>(), d_isimg.as<u32>(),
 		    d_heavy.as<u32>(), idx->word_owner, text_words, idx->geom, w, idx->table,
 		    d_counters.as<u64>(), st));
 	ARKS_TRACE_STEP("launch_bfallback");
@@ -576,7 +584,7 @@ arks_index_build(
 		}
 		HIP_TRY(hipMemsetAsync(idx->table.slots, 0, idx->table.cap * kSlotWords * sizeof(u64), st));
 		HIP_TRY(launch_bfallback(
-		    idx->kw, true, idx->codes, idx->visited, idx->ambig, d_ispal.as<u32>(), d_isimg.as<u32>(),
+		    idx->kw, mm, true, idx->codes, idx->visited, idx->ambig, d_ispal.as<u32>(), d_isimg.as<u32>(),
 		    d_heavy.as<u32>(), idx->word_owner, text_words, idx->geom, w, idx->table,
 		    d_counters.as<u64>(), st));
 	ARKS_TRACE_STEP("launch_bfallback");
@@ -590,6 +598,7 @@ arks_index_build(
 		idx->bx.mtab = idx->mtab;
 		idx->bx.mtab_cap = mcap;
 		idx->bx.fallback = idx->table;
+		idx->bx.m = mm;
 		idx->bx.w = w;
 		idx->bx.enabled = 1;
 	}

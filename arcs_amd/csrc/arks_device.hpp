@@ -348,8 +348,8 @@ table_lookup(const TableView& t, const Key<KW>& c)
 // profiles/r01a_*).  Consecutive windows of a read overlap in k-1 bases, so the index below is
 // organised around that overlap instead: the packed contig-end TEXT itself is the key store
 // (2 bits per base, every k-mer of an end shares its bytes with its neighbours), a window is
-// located through its MINIMIZER (the smallest-hashing canonical 15-mer inside it, shared by ~w/2
-// consecutive windows, w = k - 14), and membership is decided by comparing the read against the
+// located through its MINIMIZER (the smallest-hashing canonical m-mer inside it, m = 15 or 21,
+// shared by ~w/2 consecutive windows, w = k - m + 1), and membership is decided by comparing the read against the
 // text along the implied diagonal -- exact, so the result is still "key equality" and nothing
 // else (Arcs/Arcs.h:153-156).  Per position the text carries two bits: `visited` (the window
 // starting here was inserted by mapKmers' visit rule, Arcs.cpp:887-926) and `ambig` (its key was
@@ -359,18 +359,33 @@ table_lookup(const TableView& t, const Key<KW>& c)
 // the few regular keys a palindromic query could collide with live in a small exact hash table
 // (`fallback`), reached only when the query says so.
 // ================================================================================================
-constexpr int kM = 15;            // minimizer length; odd => no 15-mer is its own reverse complement
-constexpr u32 kMmerMask = (1u << (2 * kM)) - 1u;
+constexpr int kMShort = 15; // minimizer length for small indexes: fits 30 bits, all 32-bit arithmetic
+constexpr int kMLong = 21;  // ... for large ones (a 15-mer stops being specific near 10^8 text bases)
+constexpr u32 kFpMask = (1u << 30) - 1u;
 constexpr int kHeavy = 8;         // a minimizer with more text occurrences than this is "heavy"
 constexpr int kFrontPadWords = 16; // the text starts 512 bases into its arrays (diagonals may underrun)
 constexpr u32 kHeavyPos = 0xFFFFFFFFu;
 
-// minimizer-table entry: [63] occupied, [62] strand (1 = the text 15-mer is the canonical one),
-// [61:32] canonical 15-mer, [31:0] text position (kHeavyPos = "heavy: ask the fallback table")
-__device__ __forceinline__ u64
-mtab_entry(u32 cm, u32 strand, u32 pos)
+// Both lengths are odd: no minimizer is its own reverse complement, so its strand is defined.
+template <int MM>
+struct Mmer
 {
-	return (1ull << 63) | ((u64)(strand & 1u) << 62) | ((u64)cm << 32) | pos;
+	typedef u64 type;
+};
+template <>
+struct Mmer<kMShort>
+{
+	typedef u32 type;
+};
+
+// minimizer-table entry: [63] occupied, [62] strand (1 = the text m-mer is the canonical one),
+// [61:32] 30-bit fingerprint of the canonical m-mer (the 15-mer itself, a hash of the 21-mer),
+// [31:0] text position (kHeavyPos = "heavy: ask the fallback table").  A fingerprint collision only
+// proposes a diagonal that the exact verification then rejects.
+__device__ __forceinline__ u64
+mtab_entry(u32 fp, u32 strand, u32 pos)
+{
+	return (1ull << 63) | ((u64)(strand & 1u) << 62) | ((u64)(fp & kFpMask) << 32) | pos;
 }
 
 struct BIndexView
@@ -382,39 +397,80 @@ struct BIndexView
 	const u64* mtab;
 	u64 mtab_cap;
 	TableView fallback;
-	int w;       // minimizer window: k - kM + 1
+	int m;       // minimizer length (kMShort or kMLong)
+	int w;       // minimizer window: k - m + 1
 	int enabled; // 0 => the plain hash table `TableView` is the index (small k)
 	int has_img; // the index holds regular keys that are quirk images (a palindromic query could hit them)
 };
 
-// the 15-mer starting at base `pos` of a packed stream, right-aligned in 30 bits
-__device__ __forceinline__ u32
+// the m-mer starting at base `pos` of a packed stream, right-aligned in 2*MM bits
+template <int MM>
+__device__ __forceinline__ typename Mmer<MM>::type
 mmer_fw(const u64* __restrict__ codes, u64 pos)
 {
 	const u64* src = codes + (pos >> 5);
-	return (u32)(funnel_l(src[0], src[1], (int)(pos & 31) * 2) >> (64 - 2 * kM));
+	return (typename Mmer<MM>::type)(funnel_l(src[0], src[1], (int)(pos & 31) * 2) >> (64 - 2 * MM));
 }
 
 __device__ __forceinline__ u32
-mmer_rc(u32 f)
+mmer_rc_bits(u32 f, int mm)
 {
-	u32 t = __brev(f) >> (32 - 2 * kM);
+	u32 t = __brev(f) >> (32 - 2 * mm);
 	t = ((t >> 1) & 0x55555555u) | ((t & 0x55555555u) << 1);
-	return ~t & kMmerMask;
-}
-
-// 20-bit ordering hash of a canonical 15-mer (decides WHICH 15-mer of a window is its minimizer;
-// equal values are ties and every tied position is registered on the text side).  Text side and
-// query side must use the very same function: the map kernel packs it above an 11-bit position
-// and a strand bit.
-__device__ __forceinline__ u32
-mmer_order(u32 cm)
-{
-	return ((cm ^ 0x2F0B4C5Du) * 0x9E3779B1u) >> 12;
+	return ~t & ((1u << (2 * mm)) - 1u);
 }
 
 __device__ __forceinline__ u64
-mtab_home(u32 cm, u64 cap)
+mmer_rc_bits(u64 f, int mm)
+{
+	u64 t = __brevll(f) >> (64 - 2 * mm);
+	t = ((t >> 1) & 0x5555555555555555ull) | ((t & 0x5555555555555555ull) << 1);
+	return ~t & ((1ull << (2 * mm)) - 1ull);
+}
+
+template <int MM>
+__device__ __forceinline__ typename Mmer<MM>::type
+mmer_rc(typename Mmer<MM>::type f)
+{
+	return mmer_rc_bits(f, MM);
+}
+
+__device__ __forceinline__ u32
+mmer_fold(u32 cm)
+{
+	return cm;
+}
+
+__device__ __forceinline__ u32
+mmer_fold(u64 cm)
+{
+	return (u32)cm ^ ((u32)(cm >> 32) * 0x85EBCA6Bu);
+}
+
+// 20-bit ordering hash of a canonical m-mer (decides WHICH m-mer of a window is its minimizer; equal
+// values are ties and every tied position is registered on the text side).  Text side and query
+// side must use the very same function: the map kernel packs it above an 11-bit position and a
+// strand bit.
+template <int MM>
+__device__ __forceinline__ u32
+mmer_order(typename Mmer<MM>::type cm)
+{
+	return ((mmer_fold(cm) ^ 0x2F0B4C5Du) * 0x9E3779B1u) >> 12;
+}
+
+// the 30 bits of a canonical m-mer that a table entry keeps
+template <int MM>
+__device__ __forceinline__ u32
+mmer_fp(typename Mmer<MM>::type cm)
+{
+	if (MM == kMShort)
+		return (u32)cm;
+	return ((mmer_fold(cm) ^ 0x68E31DA4u) * 0xB5297A4Du) >> 2;
+}
+
+template <int MM>
+__device__ __forceinline__ u64
+mtab_home(typename Mmer<MM>::type cm, u64 cap)
 {
 	u64 h = (u64)cm * 0x9E3779B97F4A7C15ull;
 	h ^= h >> 29;
@@ -429,15 +485,16 @@ bit_at(const u32* __restrict__ bits, u64 pos)
 
 // minimizer of the window that starts at base `pos` of a packed stream (window free of invalid
 // bases): smallest ordering value and the LEFTMOST offset that has it
+template <int MM>
 __device__ __forceinline__ void
 window_minimizer(const u64* __restrict__ codes, u64 pos, int w, u32& min_h, int& min_off)
 {
 	min_h = 0xFFFFFFFFu;
 	min_off = 0;
 	for (int o = 0; o < w; ++o) {
-		const u32 f = mmer_fw(codes, pos + (u64)o);
-		const u32 r = mmer_rc(f);
-		const u32 h = mmer_order(f < r ? f : r);
+		const typename Mmer<MM>::type f = mmer_fw<MM>(codes, pos + (u64)o);
+		const typename Mmer<MM>::type r = mmer_rc<MM>(f);
+		const u32 h = mmer_order<MM>(f < r ? f : r);
 		if (h < min_h) {
 			min_h = h;
 			min_off = o;
@@ -457,26 +514,28 @@ fallback_lookup(const BIndexView& bx, const Key<KW>& c)
 // forward / reverse-complement keys are f / r (equal for a palindrome) and that starts at base p of the packed
 // stream (wbase).  -1 = absent, 0 = ambiguous, > 0 = contig end.  The slow path, and the in-kernel
 // definition the cooperative fast path has to agree with.
-template <int KW>
+template <int KW, int MM>
 __device__ __forceinline__ int
 bindex_lookup_serial(
     const BIndexView& bx, const KeyGeom& g, const u64* __restrict__ codes, u64 pos,
     const Key<KW>& f, const Key<KW>& r)
 {
+	typedef typename Mmer<MM>::type mm_t;
 	u32 min_h;
 	int off;
-	window_minimizer(codes, pos, bx.w, min_h, off);
-	const u32 mf = mmer_fw(codes, pos + (u64)off);
-	const u32 mr = mmer_rc(mf);
-	const u32 cm = mf < mr ? mf : mr;
+	window_minimizer<MM>(codes, pos, bx.w, min_h, off);
+	const mm_t mf = mmer_fw<MM>(codes, pos + (u64)off);
+	const mm_t mr = mmer_rc<MM>(mf);
+	const mm_t cm = mf < mr ? mf : mr;
+	const u32 fp = mmer_fp<MM>(cm);
 	const u32 rstrand = mf < mr ? 1u : 0u;
-	u64 s = mtab_home(cm, bx.mtab_cap);
+	u64 s = mtab_home<MM>(cm, bx.mtab_cap);
 	for (;;) {
 		const u64 e = bx.mtab[s];
 		if (!(e >> 63))
 			return -1;
 		s = (s + 1 == bx.mtab_cap) ? 0 : s + 1;
-		if (((u32)(e >> 32) & kMmerMask) != cm)
+		if (((u32)(e >> 32) & kFpMask) != fp)
 			continue;
 		const u32 tpos = (u32)e;
 		if (tpos == kHeavyPos) {
@@ -491,7 +550,7 @@ bindex_lookup_serial(
 		}
 		const bool same = ((u32)(e >> 62) & 1u) == rstrand;
 		// start of the text window that would hold this k-mer
-		const u64 t = same ? (u64)tpos - (u64)off : (u64)tpos - (u64)(g.k - kM - off);
+		const u64 t = same ? (u64)tpos - (u64)off : (u64)tpos - (u64)(g.k - MM - off);
 		const Key<KW> tk = window_key_at<KW>(bx.codes, t, g);
 		if (!key_eq(tk, same ? f : r))
 			continue;

@@ -44,7 +44,7 @@ struct WaveStats
 // value of window p of a read: -2 = NULL k-mer, -1 = absent, 0 = ambiguous, > 0 = contig end;
 // with QUIRK = false a palindromic window is not resolved but reported as -4.
 // BMODE = true: the locality index (serial lookup) instead of the plain hash table.
-template <int KW, bool QUIRK, bool BMODE>
+template <int KW, bool QUIRK, bool BMODE, int MM>
 __device__ __forceinline__ int
 window_value(
     const u64* __restrict__ codes, const u32* __restrict__ nmask, u64 wbase, int p,
@@ -61,7 +61,7 @@ window_value(
 		return BMODE ? fallback_lookup<KW>(bx, c) : table_lookup<KW>(t, c);
 	}
 	if (BMODE)
-		return bindex_lookup_serial<KW>(bx, g, codes, wbase * 32ull + (u64)p, f, r);
+		return bindex_lookup_serial<KW, MM>(bx, g, codes, wbase * 32ull + (u64)p, f, r);
 	Key<KW> c;
 	const bool lt = key_less(f, r);
 #pragma unroll
@@ -73,7 +73,7 @@ window_value(
 // Slow path only.  Reads with more than 64 * kMaxPass windows (not produced by the linked-read
 // pipelines, but bestContig accepts any length): instead of holding the window values, re-scan the
 // read once per distinct value in ascending order.
-template <int KW, bool STATS, bool BMODE>
+template <int KW, bool STATS, bool BMODE, int MM>
 __device__ __forceinline__ void
 vote_long_read(
     const u64* __restrict__ codes, const u32* __restrict__ nmask, u64 wbase, int nwin,
@@ -88,7 +88,7 @@ vote_long_read(
 		int m = 0x7FFFFFFF, cnt = 0;
 		for (int base = 0; base < nwin; base += 64) {
 			const int p = base + lane;
-			const int v = p < nwin ? window_value<KW, true, BMODE>(codes, nmask, wbase, p, g, t, bx) : -3;
+			const int v = p < nwin ? window_value<KW, true, BMODE, MM>(codes, nmask, wbase, p, g, t, bx) : -3;
 			if (STATS && first) {
 				ws.bad += __popcll(__ballot(v == -2));
 				ws.valid += __popcll(__ballot(v >= -1));
@@ -122,7 +122,7 @@ vote_long_read(
 //               damaged branch; or more than 64 * kMaxPass windows) is appended to `queue`
 //               untouched, which keeps those paths' registers out of this kernel.
 // FAST = false: the same algorithm with every path, over the reads listed in `queue`.
-template <int KW, bool STATS, bool FAST, bool BMODE>
+template <int KW, bool STATS, bool FAST, bool BMODE, int MM>
 __global__ void __launch_bounds__(256)
 map_reads_kernel(
     const u64* __restrict__ codes,
@@ -162,7 +162,7 @@ map_reads_kernel(
 			if (FAST)
 				redo = true;
 			else
-				vote_long_read<KW, STATS, BMODE>(codes, nmask, wbase, nwin, g, t, bx, lane, rs, best, best_cnt);
+				vote_long_read<KW, STATS, BMODE, MM>(codes, nmask, wbase, nwin, g, t, bx, lane, rs, best, best_cnt);
 		} else {
 			int vals[kMaxPass];
 #pragma unroll
@@ -171,7 +171,7 @@ map_reads_kernel(
 				if (ps * 64 < nwin) { // wave-uniform
 					const int p = ps * 64 + lane;
 					if (p < nwin)
-						v = window_value<KW, !FAST, BMODE>(codes, nmask, wbase, p, g, t, bx);
+						v = window_value<KW, !FAST, BMODE, MM>(codes, nmask, wbase, p, g, t, bx);
 					if (FAST)
 						redo = redo || __ballot(v == -4) != 0;
 					if (STATS) {
@@ -337,15 +337,26 @@ __device__ unsigned long long g_sec_cycles[16];
 	} while (0)
 #endif
 
-// canonical 15-mer at local position i of the staged tile words
-__device__ __forceinline__ u32
+// forward m-mer at local position i of the staged tile words, right-aligned in 2*MM bits
+template <int MM>
+__device__ __forceinline__ typename Mmer<MM>::type
+tile_mmer(const u64* cw, int i)
+{
+	if (MM == kMShort) {
+		const u32* s32 = reinterpret_cast<const u32*>(cw); // 16 bases per u32, halves swapped
+		const int hn = i >> 4, t = (i & 15) * 2;
+		const u32 hi = s32[hn ^ 1], lo = s32[(hn + 1) ^ 1];
+		return (typename Mmer<MM>::type)((t ? ((hi << t) | (lo >> (32 - t))) : hi) >> (32 - 2 * kMShort));
+	}
+	return (typename Mmer<MM>::type)(funnel_l(cw[i >> 5], cw[(i >> 5) + 1], (i & 31) * 2) >> (64 - 2 * MM));
+}
+
+template <int MM>
+__device__ __forceinline__ typename Mmer<MM>::type
 tile_canonical_mmer(const u64* cw, int i)
 {
-	const u32* s32 = reinterpret_cast<const u32*>(cw); // 16 bases per u32, halves swapped
-	const int hn = i >> 4, t = (i & 15) * 2;
-	const u32 hi = s32[hn ^ 1], lo = s32[(hn + 1) ^ 1];
-	const u32 mf = (t ? ((hi << t) | (lo >> (32 - t))) : hi) >> 2;
-	const u32 mr = mmer_rc(mf);
+	const typename Mmer<MM>::type mf = tile_mmer<MM>(cw, i);
+	const typename Mmer<MM>::type mr = mmer_rc<MM>(mf);
 	return mf < mr ? mf : mr;
 }
 
@@ -354,8 +365,8 @@ tile_canonical_mmer(const u64* cw, int i)
 //                entries) sends its read to the "medium" queue instead, which keeps that code's
 //                registers out of the hot kernel.
 // FULL = true : the same kernel over the medium queue, one queued read per tile, every path.
-template <int KW, bool STATS, bool FULL>
-__global__ void __launch_bounds__(64)
+template <int KW, bool STATS, bool FULL, int MM>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5)))
 map_reads_b_kernel(
     const u64* __restrict__ codes,
     const u32* __restrict__ nmask,
@@ -463,26 +474,21 @@ map_reads_b_kernel(
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(1);
 			// ---- T2: order value of every 15-mer -------------------------------------------------
-			const u32* s32 = reinterpret_cast<const u32*>(S.cw); // 16 bases per u32, halves swapped
-// (no unroll: registers)
 			for (int i = lane; i < n + 96; i += 64) {
 				u32 o = 0xFFFFFFFFu;
 				if (i < n) {
 					const int rem = (int)(S.wmeta[i >> 5] & 0xFFFFu) - i; // bases of the read from i on
-					const int hn = i >> 4, t = (i & 15) * 2;
-					const u32 hi = s32[hn ^ 1], lo = s32[(hn + 1) ^ 1];
-					const u32 x = t ? ((hi << t) | (lo >> (32 - t))) : hi;
-					const u32 mf = x >> 2;
-					const u32 mr = mmer_rc(mf);
-					const u32 cm = mf < mr ? mf : mr;
-					bool ok = rem >= kM;
+					const typename Mmer<MM>::type mf = tile_mmer<MM>(S.cw, i);
+					const typename Mmer<MM>::type mr = mmer_rc<MM>(mf);
+					const typename Mmer<MM>::type cm = mf < mr ? mf : mr;
+					bool ok = rem >= MM;
 					if (has_n) {
 						const int tn = i & 31;
 						const u32 bits = (S.nm[i >> 5] << tn) | ((S.nm[(i >> 5) + 1] >> 1) >> (31 - tn));
-						ok = ok && (bits >> (32 - kM)) == 0;
+						ok = ok && (bits >> (32 - MM)) == 0;
 					}
 					if (ok)
-						o = (mmer_order(cm) << 12) | ((u32)i << 1) | (mf < mr ? 1u : 0u);
+						o = (mmer_order<MM>(cm) << 12) | ((u32)i << 1) | (mf < mr ? 1u : 0u);
 				}
 				S.a[i] = o;
 				if (i >= n)
@@ -584,8 +590,8 @@ map_reads_b_kernel(
 						// position carries the value of its damaged key, or absent).  A reverse-
 						// complement palindrome carries its minimizer twice, mirrored about its centre:
 						// necessary condition; the slow kernel decides exactly.
-						const int qm = 2 * i + (k - kM) - (int)q;
-						if (tile_canonical_mmer(S.cw, qm) == tile_canonical_mmer(S.cw, (int)q))
+						const int qm = 2 * i + (k - MM) - (int)q;
+						if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q))
 							atomicOr(&S.redo, 1u << j);
 					}
 				}
@@ -598,8 +604,9 @@ map_reads_b_kernel(
 			for (int h = lane; h < nh; h += 64) {
 				const int i = S.heads[h];
 				const u32 q = (u32)(-16 - rec[i]) & 2047u;
-				const u32 cm = tile_canonical_mmer(S.cw, (int)q);
-				u64 slot = mtab_home(cm, bx.mtab_cap);
+				const typename Mmer<MM>::type cm = tile_canonical_mmer<MM>(S.cw, (int)q);
+				const u32 fp = mmer_fp<MM>(cm);
+				u64 slot = mtab_home<MM>(cm, bx.mtab_cap);
 				u32 cnt = 0;
 				bool end = false;
 				while (!end) {
@@ -619,7 +626,7 @@ map_reads_b_kernel(
 							end = true;
 							continue;
 						}
-						if (((u32)(e >> 32) & kMmerMask) != cm)
+						if (((u32)(e >> 32) & kFpMask) != fp)
 							continue;
 						if ((u32)e == kHeavyPos) {
 							cnt = kHnHeavy;
@@ -660,12 +667,12 @@ map_reads_b_kernel(
 							// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
 							const u64 e0 = S.hc[h][0];
 							const bool s0 = ((u32)(e0 >> 62) & 1u) == rstrand;
-							dk0 = (s0 ? (u64)(u32)e0 - (u64)o : (u64)(u32)e0 + (u64)(kM - 1 + o)) |
+							dk0 = (s0 ? (u64)(u32)e0 - (u64)o : (u64)(u32)e0 + (u64)(MM - 1 + o)) |
 							      ((u64)s0 << 40) | (1ull << 41);
 							if (cnt == 2) {
 								const u64 e1 = S.hc[h][1];
 								const bool s1 = ((u32)(e1 >> 62) & 1u) == rstrand;
-								dk1 = (s1 ? (u64)(u32)e1 - (u64)o : (u64)(u32)e1 + (u64)(kM - 1 + o)) |
+								dk1 = (s1 ? (u64)(u32)e1 - (u64)o : (u64)(u32)e1 + (u64)(MM - 1 + o)) |
 								      ((u64)s1 << 40) | (1ull << 41);
 							}
 						}
@@ -780,7 +787,7 @@ map_reads_b_kernel(
 						for (u32 c = 0; c < hn && val < 0; ++c) {
 							const u64 e = S.hc[hidx][c];
 							const bool same = ((u32)(e >> 62) & 1u) == rstrand;
-							const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(kM - 1 + o);
+							const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(MM - 1 + o);
 							const u64 dk = D | ((u64)same << 40) | (1ull << 41);
 							int d = -1;
 							d = dk == S.pdiag[j][1] ? 1 : d;
@@ -825,13 +832,13 @@ map_reads_b_kernel(
 								c = key_palindrome_quirk(f, g);
 							val = fallback_lookup<KW>(bx, c);
 						} else if (hn == kHnOverflow) {
-							val = bindex_lookup_serial<KW>(bx, g, codes, base_w * 32ull + (u64)i, f, r);
+							val = bindex_lookup_serial<KW, MM>(bx, g, codes, base_w * 32ull + (u64)i, f, r);
 						} else {
 							const int off = q - i;
 							for (u32 c = 0; c < hn && val < 0; ++c) {
 								const u64 e = S.hc[hidx][c];
 								const bool same = ((u32)(e >> 62) & 1u) == rstrand;
-								const u64 t = same ? (u64)(u32)e - (u64)off : (u64)(u32)e - (u64)(k - kM - off);
+								const u64 t = same ? (u64)(u32)e - (u64)off : (u64)(u32)e - (u64)(k - MM - off);
 								const Key<KW> tk = window_key_at<KW>(bx.codes, t, g);
 								if (key_eq(tk, same ? f : r) && bit_at(bx.visited, t))
 									val = bit_at(bx.ambig, t) ? 0 : (int)bx.word_owner[t >> 5];
@@ -1081,39 +1088,42 @@ launch_map_reads(
 	const unsigned bs = (unsigned)(want < 256 ? want : 256); // slow path: the queue is short
 #define ARKS_MAP_HASH(KWV, ST)                                                                     \
 	do {                                                                                           \
-		map_reads_kernel<KWV, ST, true, false><<<b, 256, 0, st>>>(                                 \
+		map_reads_kernel<KWV, ST, true, false, kMShort><<<b, 256, 0, st>>>(                        \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, t, bx, out, stats, queue,     \
 		    queue_count);                                                                          \
-		map_reads_kernel<KWV, ST, false, false><<<bs, 256, 0, st>>>(                               \
+		map_reads_kernel<KWV, ST, false, false, kMShort><<<bs, 256, 0, st>>>(                      \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, t, bx, out, stats, queue,     \
 		    queue_count);                                                                          \
 	} while (0)
-#define ARKS_MAP_B(KWV, ST)                                                                        \
+#define ARKS_MAP_B(KWV, ST, MMV)                                                                   \
 	do {                                                                                           \
 		int per_cu = 0;                                                                            \
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                          \
-		        &per_cu, map_reads_b_kernel<KWV, ST, false>, 64, 0) != hipSuccess || per_cu <= 0)  \
+		        &per_cu, map_reads_b_kernel<KWV, ST, false, MMV>, 64, 0) != hipSuccess ||          \
+		    per_cu <= 0)                                                                           \
 			per_cu = 8;                                                                            \
 		const u64 res = (u64)(n_cu > 0 ? n_cu : 256) * (u64)per_cu;                                \
 		const u64 wantw = ((u64)n_reads + 3) / 4;                                                  \
 		const unsigned bb = (unsigned)(wantw < res ? wantw : res);                                 \
-		const unsigned bm = (unsigned)(wantw < 2048 ? wantw : 2048);                               \
-		map_reads_b_kernel<KWV, ST, false><<<bb, 64, 0, st>>>(                                     \
+		map_reads_b_kernel<KWV, ST, false, MMV><<<bb, 64, 0, st>>>(                                \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue + n_reads, queue_count);                                                         \
-		map_reads_b_kernel<KWV, ST, true><<<bm, 64, 0, st>>>(                                      \
+		map_reads_b_kernel<KWV, ST, true, MMV><<<bb, 64, 0, st>>>(                                 \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue + n_reads, queue_count);                                                         \
-		map_reads_kernel<KWV, ST, false, true><<<bs, 256, 0, st>>>(                                \
+		map_reads_kernel<KWV, ST, false, true, MMV><<<bs, 256, 0, st>>>(                           \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, t, bx, out, stats, queue,     \
 		    queue_count);                                                                          \
 	} while (0)
+#define ARKS_MAP_B_ST(KWV, MMV)                                                                    \
+	do {                                                                                           \
+		if (stats) ARKS_MAP_B(KWV, true, MMV); else ARKS_MAP_B(KWV, false, MMV);                   \
+	} while (0)
 	if (bx.enabled) {
-		if (kw == 2) {
-			if (stats) ARKS_MAP_B(2, true); else ARKS_MAP_B(2, false);
-		} else {
-			if (stats) ARKS_MAP_B(3, true); else ARKS_MAP_B(3, false);
-		}
+		if (kw == 2 && bx.m == kMShort) ARKS_MAP_B_ST(2, kMShort);
+		else if (kw == 2) ARKS_MAP_B_ST(2, kMLong);
+		else if (bx.m == kMShort) ARKS_MAP_B_ST(3, kMShort);
+		else ARKS_MAP_B_ST(3, kMLong);
 	} else {
 		if (kw == 2) {
 			if (stats) ARKS_MAP_HASH(2, true); else ARKS_MAP_HASH(2, false);
@@ -1123,6 +1133,7 @@ launch_map_reads(
 	}
 #undef ARKS_MAP_HASH
 #undef ARKS_MAP_B
+#undef ARKS_MAP_B_ST
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

@@ -238,3 +238,33 @@ def test_hash_kind_still_exact(arks, gpu, oracle, golden_mini, monkeypatch):
     got, gst = ix.map_reads(reads, 0.55, want_stats=True)
     assert got.tolist() == want and gst == st.as_dict()
     ix.close()
+
+
+@pytest.mark.parametrize("k", [30, 60, 64, 96])
+def test_long_minimizer_variant(arks, gpu, oracle, golden_mini, monkeypatch, k):
+    """ARKS_MINIMIZER_LEN=21 selects the 21-mer minimizer build that large indexes use (a 15-mer
+    stops being specific near 10^8 text bases): identical results, incl. the exception paths"""
+    monkeypatch.setenv("ARKS_MINIMIZER_LEN", "21")
+    cs, reads = golden_mini["contigs"], golden_mini["reads"]
+    ends = arks.contig_ends(cs, golden_mini["params"]["min_size"], golden_mini["params"]["end_length"])
+    ix = arks.ArksIndex.build(ends, k, device=gpu)
+    ox = oracle.OracleIndex(k).build(ends)
+    assert {f: ix.build_stats[f] for f in ox.stats.as_dict()} == ox.stats.as_dict()
+    assert index_digest(*ix.export()) == index_digest(*ox.dump())
+    rng = np.random.Generator(np.random.PCG64(k))
+    genome = "".join(cs)
+    more = []
+    for i in range(600):
+        L = int(rng.choice([128, 151, 250, 700]))
+        p = int(rng.integers(0, len(genome) - L))
+        r = genome[p:p + L]
+        more.append(_rc(r) if i % 2 else r)
+    more += ["AT" * 75, "A" * 151, ("ACGT" * 40)[:151]]
+    allreads = reads + more
+    for j in (0.05, 0.55):
+        st = oracle.MapStats()
+        want = [ox.best_contig(r, j, st) for r in allreads]
+        got, gst = ix.map_reads(allreads, j, want_stats=True)
+        assert got.tolist() == want, (k, j)
+        assert gst == st.as_dict(), (k, j)
+    ix.close()
