@@ -414,13 +414,12 @@ arks_index_build(
 	}
 	// text positions are 32-bit in the minimizer table
 	locality = want_locality(k) && alloc_words * 32ull < 0xFFFF0000ull;
-	// minimizer length: a 15-mer is specific enough only while the text is small (the expected
-	// number of chance occurrences of a minimizer is ~ text / 5.4e8); ARKS_MINIMIZER_LEN overrides
-	mm = total_bases > 64000000ull ? kMLong : kMShort;
+	// minimizer length: 21-mers stay specific at any text size (a 15-mer sees ~ text / 5.4e8 chance
+	// occurrences) and leave a shorter sliding window; 15-mers only where k leaves no room.
+	// ARKS_MINIMIZER_LEN overrides (tests).
+	mm = k >= kMLong + 9 ? kMLong : kMShort;
 	if (const char* e = std::getenv("ARKS_MINIMIZER_LEN"))
-		mm = std::atoi(e) >= 19 ? kMLong : kMShort;
-	if (k < mm + 5)
-		mm = kMShort;
+		mm = (std::atoi(e) >= 19 && k >= kMLong + 2) ? kMLong : kMShort;
 	w = k - mm + 1;
 	bm_bytes = sizeof(u32) * alloc_words;
 

@@ -240,11 +240,11 @@ def test_hash_kind_still_exact(arks, gpu, oracle, golden_mini, monkeypatch):
     ix.close()
 
 
-@pytest.mark.parametrize("k", [30, 60, 64, 96])
-def test_long_minimizer_variant(arks, gpu, oracle, golden_mini, monkeypatch, k):
-    """ARKS_MINIMIZER_LEN=21 selects the 21-mer minimizer build that large indexes use (a 15-mer
-    stops being specific near 10^8 text bases): identical results, incl. the exception paths"""
-    monkeypatch.setenv("ARKS_MINIMIZER_LEN", "21")
+@pytest.mark.parametrize("k,mlen", [(24, 21), (30, 15), (60, 15), (64, 15), (96, 15), (40, 21)])
+def test_minimizer_length_variants(arks, gpu, oracle, golden_mini, monkeypatch, k, mlen):
+    """ARKS_MINIMIZER_LEN forces the other minimizer length (default: 21-mers from k = 30 on,
+    15-mers below): identical results, incl. the exception paths"""
+    monkeypatch.setenv("ARKS_MINIMIZER_LEN", str(mlen))
     cs, reads = golden_mini["contigs"], golden_mini["reads"]
     ends = arks.contig_ends(cs, golden_mini["params"]["min_size"], golden_mini["params"]["end_length"])
     ix = arks.ArksIndex.build(ends, k, device=gpu)
