@@ -51,6 +51,13 @@ def build_host(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    # the arks-long feeder (no GPU code)
+    cmd2 = [cxx, "-O2", "-std=c++17", "-I" + os.path.join(HERE, "host"),
+            os.path.join(HERE, "host", "long_to_linked_pe.cpp"), "-lz",
+            "-o", os.path.join(HERE, "bin", "long-to-linked-pe")]
+    if verbose:
+        print(" ".join(cmd2), file=sys.stderr)
+    subprocess.check_call(cmd2)
     return HOST_OUT
 
 
