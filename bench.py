@@ -102,12 +102,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU; ARKS_BENCH_BACKEND=gloo lets several ranks share one GPU (smoke tests of
+    # the multi-rank control flow on a single-GPU box; the driver's runs use nccl = RCCL)
+    backend = os.environ.get("ARKS_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     def log(msg):
         if rank == 0:
@@ -162,8 +170,8 @@ def main():
     elapsed = time.perf_counter() - t0
     map_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    win = torch.tensor([float(windows)], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    win = torch.tensor([float(windows)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(win, op=dist.ReduceOp.SUM)

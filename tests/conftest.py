@@ -62,6 +62,9 @@ def golden_mini():
 def arks():
     """the product library; GPU tests fail (not skip) when it is missing"""
     import arcs_amd
+    from arcs_amd import build as b
+    if b.needs_build():          # hipcc cross-compiles gfx950 without a GPU; built in-tree
+        b.build()
     arcs_amd.lib()
     return arcs_amd
 
