@@ -35,6 +35,15 @@ wave_sum_i32(int v)
 	return v;
 }
 
+__device__ __forceinline__ u64
+wave_sum_u64(u64 v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v += __shfl_xor(v, off);
+	return v;
+}
+
 // per-wave counters of arks_map_stats (uniform across the lanes of a wave)
 struct WaveStats
 {
@@ -280,7 +289,7 @@ struct TileLds
 	u64 cw[kTW + 4];
 	u32 nm[kTW + 4];
 	u64 hc[kNH][2];
-	unsigned short heads[kNH];
+	u32 heads[kNH]; // run heads: [10:0] minimizer position, [11] its strand, [31:12] window position
 	unsigned char hn[kNH];
 	unsigned char wread[kTW + 4];
 	u32 wmeta[kTW + 4]; // per word: read index << 16 | local end position of that read (0 = none)
@@ -360,6 +369,53 @@ tile_canonical_mmer(const u64* cw, int i)
 	return mf < mr ? mf : mr;
 }
 
+// 128-bit helpers for the bit-parallel window tests (bit b of the pair = position b)
+struct U128
+{
+	u64 lo, hi;
+};
+
+__device__ __forceinline__ U128
+shr128(U128 v, int s) // s in [0, 127]
+{
+	U128 r;
+	if (s >= 64) {
+		r.lo = v.hi >> (s - 64);
+		r.hi = 0;
+	} else {
+		r.lo = funnel_r(v.lo, v.hi, s);
+		r.hi = v.hi >> s;
+	}
+	return r;
+}
+
+// bit b of the result = AND of bits [b, b + k) of v   (k >= 1; bits beyond 127 count as 1)
+__device__ __forceinline__ U128
+and_window128(U128 v, int k)
+{
+	// p = AND over `have` consecutive bits, doubled while it fits; the remainder is combined from
+	// the powers of two in k
+	U128 res = { ~0ull, ~0ull };
+	U128 p = v;
+	int have = 1, off = 0;
+	for (int bit = 0; bit < 7; ++bit) {
+		if (k & have) {
+			const U128 sh = shr128(p, off);
+			// bits shifted in from beyond 127 are zeros: make them ones
+			res.lo &= sh.lo | (off >= 64 ? (off - 64 >= 64 ? ~0ull : ~(~0ull >> (off - 64))) : 0ull);
+			res.hi &= sh.hi | (off == 0 ? 0ull : (off >= 64 ? ~0ull : ~(~0ull >> off)));
+			off += have;
+		}
+		if (2 * have > k)
+			break;
+		const U128 sh = shr128(p, have);
+		p.lo &= sh.lo;
+		p.hi &= sh.hi | ~(~0ull >> have);
+		have *= 2;
+	}
+	return res;
+}
+
 // FULL = false: the hot instantiation.  A window that needs the general verification (an entry off
 //                both staged diagonals of its read, a heavy minimizer, a run with more than two
 //                entries) sends its read to the "medium" queue instead, which keeps that code's
@@ -387,6 +443,7 @@ map_reads_b_kernel(
 	const int lane = threadIdx.x;
 	const u64 lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	WaveStats ls = { 0, 0, 0, 0, 0, 0, 0, 0 }; // per-lane counters of the hot instantiation
 	const int k = g.k, w = bx.w;
 #ifdef ARKS_PROFILE_SECTIONS
 	unsigned long long sec_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -544,66 +601,100 @@ map_reads_b_kernel(
 			// src[i] = minimizer of window i (low 11 bits: its position); dst becomes the window
 			// record: >= 0 value, -1 absent, -2 NULL window, -3 no window, <= -16 pending (q, run)
 			int* rec = reinterpret_cast<int*>(dst);
+			// hot instantiation: no window records; the same storage holds one bit per window instead
+			// (per 32 window starts and diagonal d): wok = matched on d and indexed there, wamb = ... with
+			// value 0, wown = contig end of the others (~0 = more than one), wvalid = exists, no invalid base
+			u32* const wok = dst;            // [2][32]
+			u32* const wamb = dst + 64;      // [2][32]
+			u32* const wown = dst + 128;     // [2][32]
+			u32* const wvalid = dst + 192;   // [32]
 			ARKS_SEC(3);
 			// ---- T4: windows, run heads --------------------------------------------------------------
 			int nheads = 0;
 			u32 carry = 0xFFFFu;
-			for (int base = 0; base < n; base += 64) {
-				const int i = base + lane;
-				const u32 wm = S.wmeta[i >> 5];
-				const int j = (int)(wm >> 16);
-				const int rem = (int)(wm & 0xFFFFu) - i;
-				const bool is_win = rem >= k;
-				bool bad = false;
-				if (has_n && is_win) {
-					const int tn = i & 31, e = tn + k;
-					u32 any = 0;
-#pragma unroll
-					for (int x = 0; x <= KW; ++x) {
-						int lo = tn - 32 * x, hi = e - 32 * x;
-						lo = lo < 0 ? 0 : lo;
-						hi = hi > 32 ? 32 : hi;
-						if (lo < hi)
-							any |= S.nm[(i >> 5) + x] & (0xFFFFFFFFu >> lo) & ~(hi == 32 ? 0u : (0xFFFFFFFFu >> hi));
-					}
-					bad = any != 0;
-				}
-				const bool ok = is_win && !bad;
-				const u32 sv = src[i];
-				const u32 q = ok ? ((sv >> 1) & 2047u) : 0xFFFFu;
-				u32 qprev = __shfl_up(q, 1);
-				if (lane == 0)
-					qprev = carry;
-				carry = __shfl(q, 63);
-				const bool head = ok && q != qprev;
-				const u64 hb = __ballot(head);
-				const int hidx = nheads + __popcll(hb & lane_le) - 1; // run of this window
-				if (head && hidx < kNH)
-					S.heads[hidx] = (unsigned short)i;
-				nheads += __popcll(hb);
-				int rv = is_win ? -2 : -3;
-				if (ok) {
-					rv = -16 - (int)(q | ((sv & 1u) << 11) | ((u32)hidx << 12)); // position, strand, run
-					if (bx.has_img && !(k & 1)) {
-						// Only when the index holds quirk images can a palindromic window have a key
-						// that the text path would miss (otherwise it is either in the text, where its
-						// position carries the value of its damaged key, or absent).  A reverse-
-						// complement palindrome carries its minimizer twice, mirrored about its centre:
-						// necessary condition; the slow kernel decides exactly.
+			if (!FULL) {
+				// hot path: only the run heads; window validity and values are worked out per 32-window
+				// word further down
+				for (int base = 0; base < n; base += 64) {
+					const int i = base + lane;
+					const u32 wm = S.wmeta[i >> 5];
+					const int rem = (int)(wm & 0xFFFFu) - i;
+					const u32 sv = src[i];
+					const bool cand = rem >= k && sv != 0xFFFFFFFFu;
+					const u32 q = cand ? ((sv >> 1) & 2047u) : 0xFFFFu;
+					u32 qprev = __shfl_up(q, 1);
+					if (lane == 0)
+						qprev = carry;
+					carry = __shfl(q, 63);
+					const bool head = cand && q != qprev;
+					const u64 hb = __ballot(head);
+					const int hidx = nheads + __popcll(hb & lane_le) - 1;
+					if (head && hidx < kNH)
+						S.heads[hidx] = q | ((sv & 1u) << 11) | ((u32)i << 12);
+					nheads += __popcll(hb);
+					if (cand && bx.has_img && !(k & 1)) { // see the comment in the FULL path below
 						const int qm = 2 * i + (k - MM) - (int)q;
 						if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q))
-							atomicOr(&S.redo, 1u << j);
+							atomicOr(&S.redo, 1u << (wm >> 16));
 					}
 				}
-				rec[i] = rv;
+			} else {
+				for (int base = 0; base < n; base += 64) {
+					const int i = base + lane;
+					const u32 wm = S.wmeta[i >> 5];
+					const int j = (int)(wm >> 16);
+					const int rem = (int)(wm & 0xFFFFu) - i;
+					const bool is_win = rem >= k;
+					bool bad = false;
+					if (has_n && is_win) {
+						const int tn = i & 31, e = tn + k;
+						u32 any = 0;
+	#pragma unroll
+						for (int x = 0; x <= KW; ++x) {
+							int lo = tn - 32 * x, hi = e - 32 * x;
+							lo = lo < 0 ? 0 : lo;
+							hi = hi > 32 ? 32 : hi;
+							if (lo < hi)
+								any |= S.nm[(i >> 5) + x] & (0xFFFFFFFFu >> lo) & ~(hi == 32 ? 0u : (0xFFFFFFFFu >> hi));
+						}
+						bad = any != 0;
+					}
+					const bool ok = is_win && !bad;
+					const u32 sv = src[i];
+					const u32 q = ok ? ((sv >> 1) & 2047u) : 0xFFFFu;
+					u32 qprev = __shfl_up(q, 1);
+					if (lane == 0)
+						qprev = carry;
+					carry = __shfl(q, 63);
+					const bool head = ok && q != qprev;
+					const u64 hb = __ballot(head);
+					const int hidx = nheads + __popcll(hb & lane_le) - 1; // run of this window
+					if (head && hidx < kNH)
+						S.heads[hidx] = q | ((sv & 1u) << 11) | ((u32)i << 12);
+					nheads += __popcll(hb);
+					int rv = is_win ? -2 : -3;
+					if (ok) {
+						rv = -16 - (int)(q | ((sv & 1u) << 11) | ((u32)hidx << 12)); // position, strand, run
+						if (bx.has_img && !(k & 1)) {
+							// Only when the index holds quirk images can a palindromic window have a key
+							// that the text path would miss (otherwise it is either in the text, where its
+							// position carries the value of its damaged key, or absent).  A reverse-
+							// complement palindrome carries its minimizer twice, mirrored about its centre:
+							// necessary condition; the slow kernel decides exactly.
+							const int qm = 2 * i + (k - MM) - (int)q;
+							if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q))
+								atomicOr(&S.redo, 1u << j);
+						}
+					}
+					rec[i] = rv;
+				}
 			}
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(4);
 			// ---- T5: run heads walk the minimizer table ------------------------------------------------
 			const int nh = nheads < kNH ? nheads : kNH;
 			for (int h = lane; h < nh; h += 64) {
-				const int i = S.heads[h];
-				const u32 q = (u32)(-16 - rec[i]) & 2047u;
+				const u32 q = S.heads[h] & 2047u;
 				const typename Mmer<MM>::type cm = tile_canonical_mmer<MM>(S.cw, (int)q);
 				const u32 fp = mmer_fp<MM>(cm);
 				u64 slot = mtab_home<MM>(cm, bx.mtab_cap);
@@ -659,11 +750,10 @@ map_reads_b_kernel(
 					if (h < nh) {
 						const u32 cnt = S.hn[h];
 						if (cnt >= 1 && cnt <= 2) {
-							const int ih = S.heads[h];
-							jh = S.wread[ih >> 5];
-							const u32 payh = (u32)(-16 - rec[ih]);
-							const int o = (int)(payh & 2047u) - S.rstart[jh]; // offset of the minimizer in the read
-							const u32 rstrand = (payh >> 11) & 1u;
+							const u32 hv = S.heads[h];
+							jh = S.wread[hv >> 17]; // window position >> 5
+							const int o = (int)(hv & 2047u) - S.rstart[jh]; // offset of the minimizer in the read
+							const u32 rstrand = (hv >> 11) & 1u;
 							// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
 							const u64 e0 = S.hc[h][0];
 							const bool s0 = ((u32)(e0 >> 62) & 1u) == rstrand;
@@ -712,6 +802,37 @@ map_reads_b_kernel(
 				}
 			}
 			ARKS_WAVE_SYNC();
+			if (!FULL) {
+				// hot path: a read with a run that proposes a third diagonal, sits under a heavy
+				// minimizer or had more than two entries goes to the medium queue as a whole
+				for (int h = lane; h < nheads; h += 64) {
+					const u32 cnt = h < kNH ? S.hn[h] : kHnOverflow;
+					bool off = cnt == kHnHeavy || cnt == kHnOverflow;
+					int jh = 0;
+					if (h < kNH) {
+						const u32 hv = S.heads[h];
+						jh = S.wread[hv >> 17];
+						if (cnt == 1 || cnt == 2) {
+							const int o = (int)(hv & 2047u) - S.rstart[jh];
+							const u32 rstrand = (hv >> 11) & 1u;
+							for (u32 c = 0; c < cnt; ++c) {
+								const u64 e = S.hc[h][c];
+								const bool sm = ((u32)(e >> 62) & 1u) == rstrand;
+								const u64 dk = (sm ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(MM - 1 + o)) |
+								               ((u64)sm << 40) | (1ull << 41);
+								off = off || (dk != S.pdiag[jh][0] && dk != S.pdiag[jh][1]);
+							}
+						}
+					} else
+						off = true; // more runs than the tile publishes: let the medium kernel take every read
+					if (off) {
+						if (h < kNH)
+							atomicOr(&S.redo2, 1u << jh);
+						else
+							atomicOr(&S.redo2, 0xFFFFFFFFu);
+					}
+				}
+			}
 			// stage the text words and their visited / ambiguous / owner words (one round trip)
 			{
 				const int ns = tw + nr;
@@ -764,6 +885,75 @@ map_reads_b_kernel(
 			}
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(6);
+			if (!FULL) {
+				// ---- T6c': lanes = 32-window words (x2 diagonals).  Window p of the tile matches the text on
+				//      diagonal d iff its k mismatch bits are all clear (AND over a sliding span, done on the
+				//      bit stream); it is in the index iff the text position it maps to is `visited`; its
+				//      value is 0 iff that position is `ambig`.  Everything stays a bit per window.
+				const int d = lane >= 32 ? 1 : 0, wl = lane & 31;
+				if (wl < tw) {
+					const int j = S.wread[wl];
+					const int nwin = S.rlen[j] - k + 1;
+					const int p0 = wl * 32 - S.rstart[j]; // first window of this word, relative to the read
+					// windows that exist: p0 + b < nwin
+					int cexist = nwin - p0;
+					cexist = cexist < 0 ? 0 : (cexist > 32 ? 32 : cexist);
+					u32 valid = cexist == 32 ? 0xFFFFFFFFu : ((1u << cexist) - 1u);
+					if (has_n && valid) { // ... and hold no invalid base: AND-window over the N-free bits
+						U128 nf;
+						nf.lo = ~((u64)__brev(S.nm[wl]) | ((u64)__brev(S.nm[wl + 1]) << 32));
+						nf.hi = ~((u64)__brev(S.nm[wl + 2]) | ((u64)__brev(S.nm[wl + 3]) << 32));
+						valid &= (u32)and_window128(nf, k).lo;
+					}
+					u32 ok = 0, amb = 0, own = 0;
+					const u64 pdv = S.pdiag[j][d];
+					if ((pdv >> 41) && valid) {
+						U128 z; // match bit per base from this word on
+						z.lo = ~((u64)S.mm32[d][wl] | ((u64)S.mm32[d][wl + 1] << 32));
+						z.hi = ~((u64)S.mm32[d][wl + 2] | ((u64)S.mm32[d][wl + 3] << 32));
+						ok = (u32)and_window128(z, k).lo & valid;
+						if (ok) {
+							const bool same = (pdv >> 40) & 1ull;
+							const u64 D = pdv & 0xFFFFFFFFFFull;
+							const int sb = (S.rstart[j] >> 5) + j, nst = (S.rlen[j] + 31) / 32; // staged: sb .. sb + nst
+							// text positions of the 32 window starts: same strand D + p0 + b, opposite
+							// strand (D - k + 1 - p0) - b; `lo` = the lowest of them
+							const u64 lo = same ? D + (u64)p0 : D - (u64)(k - 1 + p0 + 31);
+							const int slot = sb + (int)((u32)(lo >> 5) - S.tfirst[j][d]);
+							const int sh = (int)(lo & 31);
+							const u32 v0 = (slot >= sb && slot <= sb + nst) ? S.tvis[d][slot] : 0u;
+							const u32 v1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? S.tvis[d][slot + 1] : 0u;
+							const u32 a0 = (slot >= sb && slot <= sb + nst) ? S.tamb[d][slot] : 0u;
+							const u32 a1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? S.tamb[d][slot + 1] : 0u;
+							// 32 bits from text position lo on, most significant = lo
+							u32 vis = sh ? ((v0 << sh) | (v1 >> (32 - sh))) : v0;
+							u32 am = sh ? ((a0 << sh) | (a1 >> (32 - sh))) : a0;
+							if (same) { // bit b must be position lo + b
+								vis = __brev(vis);
+								am = __brev(am);
+							} // opposite strand: bit b is position lo + 31 - b already
+							ok &= vis;
+							amb = ok & am;
+							// contig end of the matched, unambiguous windows: the word(s) their text
+							// positions fall in.  `inlo` = window bits whose position lies in `slot`.
+							const u32 recm = ok & ~amb;
+							const u32 inlo = same ? (sh ? (1u << (32 - sh)) - 1u : 0xFFFFFFFFu) : (0xFFFFFFFFu << sh);
+							const u32 o0 = (recm & inlo) ? S.town[d][slot] : 0u;
+							const u32 o1 = (recm & ~inlo) ? S.town[d][slot + 1] : 0u;
+							own = o0 ? o0 : o1;
+							if (o0 && o1 && o0 != o1)
+								own = 0xFFFFFFFFu;
+						}
+					}
+					wok[d * 32 + wl] = ok;
+					wamb[d * 32 + wl] = amb;
+					wown[d * 32 + wl] = own;
+					if (d == 0)
+						wvalid[wl] = valid;
+				}
+				ARKS_WAVE_SYNC();
+			}
+			if (FULL) {
 			// ---- T6c: lanes = windows: an entry on one of the read's two staged diagonals only tests the
 			//      window's k mismatch bits; anything else needs the general verification ----------------
 			for (int base = 0; base < n; base += 64) {
@@ -849,11 +1039,83 @@ map_reads_b_kernel(
 				}
 			}
 			ARKS_WAVE_SYNC();
+			}
 			ARKS_SEC(7);
 			// ---- T7: per read: counters, vote, output ---------------------------------------------------
 			const u32 redo_mask = S.redo;
 			const u32 redo2_mask = FULL ? 0u : S.redo2;
-			for (int j = 0; j < nr; ++j) {
+			if (!FULL) {
+				// hot path: lane j = read j; popcounts over its window words.  At most two distinct
+				// positive values can occur (one per diagonal): the vote of Arcs.cpp:998-1004 is a compare.
+				if (lane < nr) {
+					const int j = lane;
+					const long r = c0 + cur + j;
+					const int L = S.rlen[j];
+					if (L < 0) {
+						out_conreci[r] = 0;
+					} else if ((redo_mask >> j) & 1u) {
+						queue[atomicAdd(queue_count, 1u)] = (u32)r;
+					} else {
+						bool medium = (redo2_mask >> j) & 1u;
+						int rec_a = 0, amb_a = 0, rec_b = 0, amb_b = 0, nvalid = 0;
+						u32 own_a = 0, own_b = 0;
+						if (!medium) {
+							const int w0 = S.rstart[j] >> 5, w1 = S.rstart[j + 1] >> 5;
+							for (int wl = w0; wl < w1; ++wl) {
+								const u32 oka = wok[wl], aa = wamb[wl];
+								const u32 okb = wok[32 + wl] & ~oka, ab = wamb[32 + wl] & okb;
+								const u32 ra = oka & ~aa, rb = okb & ~ab;
+								rec_a += __popc(ra);
+								amb_a += __popc(aa);
+								rec_b += __popc(rb);
+								amb_b += __popc(ab);
+								nvalid += __popc(wvalid[wl]);
+								if (ra) {
+									const u32 o = wown[wl];
+									medium = medium || o == 0xFFFFFFFFu || (own_a != 0 && own_a != o);
+									own_a = o;
+								}
+								if (rb) {
+									const u32 o = wown[32 + wl];
+									medium = medium || o == 0xFFFFFFFFu || (own_b != 0 && own_b != o);
+									own_b = o;
+								}
+							}
+						}
+						if (medium) {
+							mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)r;
+						} else {
+							int best = 0, best_cnt = 0;
+							if (rec_a > 0 && rec_b > 0 && own_a == own_b) {
+								best = (int)own_a;
+								best_cnt = rec_a + rec_b;
+							} else if (rec_a > rec_b || (rec_a == rec_b && own_a < own_b)) {
+								best = (int)own_a; // strict `>` of the reference walk: the smaller value keeps a tie
+								best_cnt = rec_a;
+							} else {
+								best = (int)own_b;
+								best_cnt = rec_b;
+							}
+							const int nwin = L - k + 1;
+							const int total = nwin > 0 ? nwin : 0;
+							const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
+							const bool pass = maxj > j_index;
+							out_conreci[r] = pass ? best : 0;
+							if (STATS) {
+								ls.valid += (u64)nvalid;
+								ls.bad += (u64)(total - nvalid);
+								ls.found += (u64)(rec_a + amb_a + rec_b + amb_b);
+								ls.rec += (u64)(rec_a + rec_b);
+								ls.dup += (u64)(amb_a + amb_b);
+								ls.pass += pass;
+								ls.fail += !pass;
+								ls.win += (u64)total;
+							}
+						}
+					}
+				}
+			}
+			for (int j = 0; FULL && j < nr; ++j) {
 				const long r = c0 + cur + j;
 				const int L = S.rlen[j];
 				if (L < 0) {
@@ -945,6 +1207,16 @@ map_reads_b_kernel(
 		for (int x = 0; x < 10; ++x)
 			atomicAdd(&g_sec_cycles[x], sec_acc[x]);
 #endif
+	if (STATS && !FULL) {
+		ws.valid += wave_sum_u64(ls.valid);
+		ws.bad += wave_sum_u64(ls.bad);
+		ws.found += wave_sum_u64(ls.found);
+		ws.rec += wave_sum_u64(ls.rec);
+		ws.dup += wave_sum_u64(ls.dup);
+		ws.pass += wave_sum_u64(ls.pass);
+		ws.fail += wave_sum_u64(ls.fail);
+		ws.win += wave_sum_u64(ls.win);
+	}
 	if (STATS && lane == 0) {
 		if (ws.valid) atomicAdd(stats + 0, ws.valid);
 		if (ws.bad) atomicAdd(stats + 1, ws.bad);
