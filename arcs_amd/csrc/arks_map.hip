@@ -445,6 +445,9 @@ map_reads_b_kernel(
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	WaveStats ls = { 0, 0, 0, 0, 0, 0, 0, 0 }; // per-lane counters of the hot instantiation
 	const int k = g.k, w = bx.w;
+	// the sliding minimum reads up to w - 1 + 7 positions past the tile: a constant pad
+	for (int x = lane; x < 96; x += 64)
+		S.a[kTP + x] = 0xFFFFFFFFu;
 #ifdef ARKS_PROFILE_SECTIONS
 	unsigned long long sec_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();
@@ -530,75 +533,89 @@ map_reads_b_kernel(
 			const bool has_n = __ballot(lane < tw && S.nm[lane] != 0) != 0;
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(1);
-			// ---- T2: order value of every 15-mer -------------------------------------------------
-			for (int i = lane; i < n + 96; i += 64) {
-				u32 o = 0xFFFFFFFFu;
-				if (i < n) {
-					const int rem = (int)(S.wmeta[i >> 5] & 0xFFFFu) - i; // bases of the read from i on
-					const typename Mmer<MM>::type mf = tile_mmer<MM>(S.cw, i);
-					const typename Mmer<MM>::type mr = mmer_rc<MM>(mf);
-					const typename Mmer<MM>::type cm = mf < mr ? mf : mr;
-					bool ok = rem >= MM;
-					if (has_n) {
-						const int tn = i & 31;
-						const u32 bits = (S.nm[i >> 5] << tn) | ((S.nm[(i >> 5) + 1] >> 1) >> (31 - tn));
-						ok = ok && (bits >> (32 - MM)) == 0;
+			// ---- T2: lane l owns the 8 positions 8l .. 8l+7 of the tile (16 words = 512 positions = one
+			//      pass).  The 8 + MM - 1 <= 32 bases its m-mers span are one funnel shift of two words;
+			//      every m-mer and its reverse complement is a shift + mask of that or of its complement. --
+			typedef typename Mmer<MM>::type mm_t;
+			const int i0 = lane * 8;
+			const bool in_tile = i0 < n;
+			const int rem0 = in_tile ? (int)(S.wmeta[lane >> 2] & 0xFFFFu) - i0 : 0; // bases of the read from i0 on
+			u32 wmin[8]; // minimizer (order value) of the window starting at each of the 8 positions
+			{
+				u32 v[8];
+				{
+					const int wq = lane >> 2, sft = (lane & 3) * 16;
+					const u64 x = funnel_l(S.cw[wq], S.cw[wq + 1], sft);
+					const u64 xr = ~rev_groups(x);
+					u32 nb = 0;
+					if (has_n)
+						nb = (S.nm[wq] << (sft >> 1)) | ((S.nm[wq + 1] >> 1) >> (31 - (sft >> 1)));
+					const mm_t mmask = (mm_t)((1ull << (2 * MM)) - 1ull);
+#pragma unroll
+					for (int t = 0; t < 8; ++t) {
+						const mm_t mf = (mm_t)(x >> (64 - 2 * MM - 2 * t)) & mmask;
+						const mm_t mr = (mm_t)(xr >> (2 * t)) & mmask;
+						const mm_t cm = mf < mr ? mf : mr;
+						const bool ok = rem0 - t >= MM && ((nb << t) >> (32 - MM)) == 0;
+						v[t] = ok ? ((mmer_order<MM>(cm) << 12) | ((u32)(i0 + t) << 1) | (mf < mr ? 1u : 0u))
+						          : 0xFFFFFFFFu;
 					}
-					if (ok)
-						o = (mmer_order<MM>(cm) << 12) | ((u32)i << 1) | (mf < mr ? 1u : 0u);
 				}
-				S.a[i] = o;
-				if (i >= n)
-					S.b[i] = o;
+				ARKS_SEC(2);
+				// ---- T3: sliding minimum over w positions.  [i, i + w) = a suffix of the lane's own 8
+				//      values, whole lanes in between, a prefix of a later lane's 8: prefix minima go
+				//      through LDS (S.a), the lanes' block minima too (S.b); everything else is registers.
+				if (w >= 9) {
+					u32 pre[8], suf[8];
+					pre[0] = v[0];
+#pragma unroll
+					for (int t = 1; t < 8; ++t)
+						pre[t] = v[t] < pre[t - 1] ? v[t] : pre[t - 1];
+					suf[7] = v[7];
+#pragma unroll
+					for (int t = 6; t >= 0; --t)
+						suf[t] = v[t] < suf[t + 1] ? v[t] : suf[t + 1];
+					uint4* pa = reinterpret_cast<uint4*>(S.a + i0);
+					pa[0] = make_uint4(pre[0], pre[1], pre[2], pre[3]);
+					pa[1] = make_uint4(pre[4], pre[5], pre[6], pre[7]);
+					S.b[lane] = pre[7];
+					if (lane < 16)
+						S.b[64 + lane] = 0xFFFFFFFFu;
+					ARKS_WAVE_SYNC();
+					const int e0 = (w - 1) >> 3, tb = 8 - ((w - 1) & 7);
+					u32 fa = 0xFFFFFFFFu;
+					for (int x = 1; x < e0; ++x) {
+						const u32 y = S.b[lane + x];
+						fa = y < fa ? y : fa;
+					}
+					u32 fb = S.b[lane + e0];
+					fb = fb < fa ? fb : fa;
+#pragma unroll
+					for (int t = 0; t < 8; ++t) {
+						const u32 y = S.a[i0 + t + w - 1];
+						const u32 f = t < tb ? fa : fb;
+						u32 m = suf[t] < y ? suf[t] : y;
+						wmin[t] = f < m ? f : m;
+					}
+				} else {
+					uint4* pa = reinterpret_cast<uint4*>(S.a + i0);
+					pa[0] = make_uint4(v[0], v[1], v[2], v[3]);
+					pa[1] = make_uint4(v[4], v[5], v[6], v[7]);
+					ARKS_WAVE_SYNC();
+#pragma unroll
+					for (int t = 0; t < 8; ++t) {
+						u32 m = v[t];
+						for (int o = 1; o < w; ++o) {
+							const u32 y = S.a[i0 + t + o];
+							m = y < m ? y : m;
+						}
+						wmin[t] = m;
+					}
+				}
 			}
-			ARKS_WAVE_SYNC();
-			ARKS_SEC(2);
-			// ---- T3: sliding minimum over w positions by doubling, ping-pong a <-> b ---------------
 			u32* src = S.a;
 			u32* dst = S.b;
-			if (w >= 16) {
-				// two dependent LDS round trips instead of log2(w): (1) minimum of every aligned-free
-				// block of 8, (2) minimum of the <= 11 blocks that tile [i, i + w)
-// (no unroll: registers)
-				for (int i = lane; i < n + 96 - 8; i += 64) {
-					u32 m = src[i];
-#pragma unroll
-					for (int o = 1; o < 8; ++o) {
-						const u32 y = src[i + o];
-						m = y < m ? y : m;
-					}
-					dst[i] = m;
-				}
-				ARKS_WAVE_SYNC();
-// (no unroll: registers)
-				for (int i = lane; i < n; i += 64) {
-					u32 m = dst[i + w - 8];
-					for (int o = 0; o + 8 < w; o += 8) {
-						const u32 y = dst[i + o];
-						m = y < m ? y : m;
-					}
-					src[i] = m;
-				}
-				ARKS_WAVE_SYNC();
-			} else {
-				for (int span = 1;;) {
-					const int step = (2 * span <= w) ? span : (w - span);
-					if (step <= 0)
-						break;
-					for (int i = lane; i < n; i += 64) {
-						const u32 x = src[i], y = src[i + step];
-						dst[i] = x < y ? x : y;
-					}
-					ARKS_WAVE_SYNC();
-					u32* tsw = src;
-					src = dst;
-					dst = tsw;
-					if (2 * span > w)
-						break;
-					span *= 2;
-				}
-			}
-			// src[i] = minimizer of window i (low 11 bits: its position); dst becomes the window
+			// wmin[t] = minimizer of window i0 + t (bits [11:1]: its position); dst becomes the window
 			// record: >= 0 value, -1 absent, -2 NULL window, -3 no window, <= -16 pending (q, run)
 			int* rec = reinterpret_cast<int*>(dst);
 			// hot instantiation: no window records; the same storage holds one bit per window instead
@@ -611,34 +628,61 @@ map_reads_b_kernel(
 			ARKS_SEC(3);
 			// ---- T4: windows, run heads --------------------------------------------------------------
 			int nheads = 0;
-			u32 carry = 0xFFFFu;
 			if (!FULL) {
 				// hot path: only the run heads; window validity and values are worked out per 32-window
 				// word further down
-				for (int base = 0; base < n; base += 64) {
-					const int i = base + lane;
-					const u32 wm = S.wmeta[i >> 5];
-					const int rem = (int)(wm & 0xFFFFu) - i;
-					const u32 sv = src[i];
-					const bool cand = rem >= k && sv != 0xFFFFFFFFu;
-					const u32 q = cand ? ((sv >> 1) & 2047u) : 0xFFFFu;
-					u32 qprev = __shfl_up(q, 1);
-					if (lane == 0)
-						qprev = carry;
-					carry = __shfl(q, 63);
-					const bool head = cand && q != qprev;
-					const u64 hb = __ballot(head);
-					const int hidx = nheads + __popcll(hb & lane_le) - 1;
-					if (head && hidx < kNH)
-						S.heads[hidx] = q | ((sv & 1u) << 11) | ((u32)i << 12);
-					nheads += __popcll(hb);
-					if (cand && bx.has_img && !(k & 1)) { // see the comment in the FULL path below
-						const int qm = 2 * i + (k - MM) - (int)q;
-						if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q))
-							atomicOr(&S.redo, 1u << (wm >> 16));
+				u32 q[8];
+				u32 hm = 0;
+#pragma unroll
+				for (int t = 0; t < 8; ++t) {
+					const bool cand = rem0 - t >= k && wmin[t] != 0xFFFFFFFFu;
+					q[t] = cand ? ((wmin[t] >> 1) & 2047u) : 0xFFFFu;
+				}
+				u32 qprev = __shfl_up(q[7], 1);
+				if (lane == 0)
+					qprev = 0xFFFFu;
+#pragma unroll
+				for (int t = 0; t < 8; ++t) {
+					const bool head = q[t] != 0xFFFFu && q[t] != (t ? q[t - 1] : qprev);
+					hm |= head ? (1u << t) : 0u;
+				}
+				// exclusive prefix of the per-lane head counts (<= 8: four bit planes)
+				const u32 cnt = __popc(hm);
+				const u64 lane_lt = lane_le >> 1;
+				int hidx = 0;
+#pragma unroll
+				for (int bp = 0; bp < 4; ++bp) {
+					const u64 m = __ballot((cnt >> bp) & 1u);
+					hidx += __popcll(m & lane_lt) << bp;
+					nheads += __popcll(m) << bp;
+				}
+#pragma unroll
+				for (int t = 0; t < 8; ++t) {
+					if ((hm >> t) & 1u) {
+						if (hidx < kNH)
+							S.heads[hidx] = q[t] | ((wmin[t] & 1u) << 11) | ((u32)(i0 + t) << 12);
+						++hidx;
+					}
+				}
+				if (bx.has_img && !(k & 1)) { // see the comment in the FULL path below
+#pragma unroll
+					for (int t = 0; t < 8; ++t) {
+						if (q[t] != 0xFFFFu) {
+							const int qm = 2 * (i0 + t) + (k - MM) - (int)q[t];
+							if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q[t]))
+								atomicOr(&S.redo, 1u << (S.wmeta[lane >> 2] >> 16));
+						}
 					}
 				}
 			} else {
+				u32 carry = 0xFFFFu;
+				ARKS_WAVE_SYNC();
+				{
+					uint4* pa = reinterpret_cast<uint4*>(S.a + i0);
+					pa[0] = make_uint4(wmin[0], wmin[1], wmin[2], wmin[3]);
+					pa[1] = make_uint4(wmin[4], wmin[5], wmin[6], wmin[7]);
+				}
+				ARKS_WAVE_SYNC();
 				for (int base = 0; base < n; base += 64) {
 					const int i = base + lane;
 					const u32 wm = S.wmeta[i >> 5];
