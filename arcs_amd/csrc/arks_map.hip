@@ -783,62 +783,72 @@ map_reads_b_kernel(
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(5);
 			// ---- T6a: up to two diagonals per read: A = entry 0 of its first run that has entries, B = the
-			//      first entry (in run order) on another diagonal (a duplicated segment, a chance 15-mer
-			//      match).  Heads are in position order: ballots find both without LDS traffic. -----------
+			//      first entry (in run order) on another diagonal (a duplicated segment, a chance m-mer
+			//      match).  Lanes = run heads; the "first" is an LDS atomic minimum keyed by the run index. --
 			{
-				u64 dA = 0, dB = 0; // lane j: diagonals of read j ([39:0] D, [40] same strand, [41] valid)
-				for (int hb0 = 0; hb0 < nh; hb0 += 64) {
-					const int h = hb0 + lane;
-					int jh = -1;
-					u64 dk0 = 0, dk1 = 0;
-					if (h < nh) {
-						const u32 cnt = S.hn[h];
-						if (cnt >= 1 && cnt <= 2) {
-							const u32 hv = S.heads[h];
-							jh = S.wread[hv >> 17]; // window position >> 5
-							const int o = (int)(hv & 2047u) - S.rstart[jh]; // offset of the minimizer in the read
-							const u32 rstrand = (hv >> 11) & 1u;
-							// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
-							const u64 e0 = S.hc[h][0];
-							const bool s0 = ((u32)(e0 >> 62) & 1u) == rstrand;
-							dk0 = (s0 ? (u64)(u32)e0 - (u64)o : (u64)(u32)e0 + (u64)(MM - 1 + o)) |
-							      ((u64)s0 << 40) | (1ull << 41);
-							if (cnt == 2) {
-								const u64 e1 = S.hc[h][1];
-								const bool s1 = ((u32)(e1 >> 62) & 1u) == rstrand;
-								dk1 = (s1 ? (u64)(u32)e1 - (u64)o : (u64)(u32)e1 + (u64)(MM - 1 + o)) |
-								      ((u64)s1 << 40) | (1ull << 41);
-							}
+				constexpr u64 kDiagMask = (1ull << 42) - 1ull; // [39:0] D, [40] same strand, [41] valid
+				if (lane < 2 * nr)
+					(&S.pdiag[0][0])[lane] = ~0ull;
+				ARKS_WAVE_SYNC();
+				int jh = -1;
+				u64 dk0 = 0, dk1 = 0;
+				bool off = false;
+				if (lane < nh) {
+					const u32 cnt = S.hn[lane];
+					const u32 hv = S.heads[lane];
+					jh = S.wread[hv >> 17]; // window position >> 5
+					off = cnt == kHnHeavy || cnt == kHnOverflow;
+					if (cnt >= 1 && cnt <= 2) {
+						const int o = (int)(hv & 2047u) - S.rstart[jh]; // offset of the minimizer in the read
+						const u32 rstrand = (hv >> 11) & 1u;
+						// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
+						const u64 e0 = S.hc[lane][0];
+						const bool s0 = ((u32)(e0 >> 62) & 1u) == rstrand;
+						dk0 = (s0 ? (u64)(u32)e0 - (u64)o : (u64)(u32)e0 + (u64)(MM - 1 + o)) |
+						      ((u64)s0 << 40) | (1ull << 41);
+						if (cnt == 2) {
+							const u64 e1 = S.hc[lane][1];
+							const bool s1 = ((u32)(e1 >> 62) & 1u) == rstrand;
+							dk1 = (s1 ? (u64)(u32)e1 - (u64)o : (u64)(u32)e1 + (u64)(MM - 1 + o)) |
+							      ((u64)s1 << 40) | (1ull << 41);
 						}
-					}
-					for (int j = 0; j < nr; ++j) {
-						const u64 mA = __ballot(jh == j);
-						if (mA == 0)
-							continue;
-						const u64 a0 = __shfl(dk0, __ffsll((long long)mA) - 1);
-						u64 aj = __shfl(dA, j);
-						if (aj == 0) {
-							aj = a0;
-							if (lane == j)
-								dA = a0;
-						}
-						const bool diff0 = jh == j && dk0 != aj;
-						const bool diff1 = jh == j && dk1 != 0 && dk1 != aj;
-						const u64 mB = __ballot(diff0 || diff1);
-						if (mB) {
-							const u64 b0 = __shfl(diff0 ? dk0 : dk1, __ffsll((long long)mB) - 1);
-							if (lane == j && dB == 0)
-								dB = b0;
-						}
+						atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][0]),
+						          (unsigned long long)(((u64)lane << 42) | dk0));
 					}
 				}
+				ARKS_WAVE_SYNC();
+				u64 dA = 0;
+				if (dk0) {
+					dA = S.pdiag[jh][0] & kDiagMask;
+					if (dk0 != dA)
+						atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][1]),
+						          (unsigned long long)(((u64)lane << 43) | dk0));
+					else if (dk1 && dk1 != dA)
+						atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][1]),
+						          (unsigned long long)(((u64)lane << 43) | (1ull << 42) | dk1));
+				}
+				ARKS_WAVE_SYNC();
+				if (!FULL) {
+					// hot path: a read with a run that proposes a third diagonal, sits under a heavy
+					// minimizer or had more than two entries goes to the medium queue as a whole
+					if (dk0) {
+						const u64 rb = S.pdiag[jh][1];
+						const u64 dB = rb == ~0ull ? 0ull : (rb & kDiagMask);
+						off = off || (dk0 != dA && dk0 != dB) || (dk1 && dk1 != dA && dk1 != dB);
+					}
+					if (off)
+						atomicOr(&S.redo2, 1u << jh);
+					if (nheads > kNH && lane == 0) // more runs than the tile publishes: every read
+						atomicOr(&S.redo2, 0xFFFFFFFFu);
+					ARKS_WAVE_SYNC();
+				}
 				if (lane < nr) {
-					S.pdiag[lane][0] = dA;
-					S.pdiag[lane][1] = dB;
-					// first text word of the span [lo, lo + L) the read covers along each diagonal
+					// strip the run index; first text word of the span [lo, lo + L) the read covers
 #pragma unroll
 					for (int d = 0; d < 2; ++d) {
-						const u64 pdv = d ? dB : dA;
+						const u64 raw = S.pdiag[lane][d];
+						const u64 pdv = raw == ~0ull ? 0ull : (raw & kDiagMask);
+						S.pdiag[lane][d] = pdv;
 						const u64 Dv = pdv & 0xFFFFFFFFFFull;
 						const u64 lo = ((pdv >> 40) & 1ull) ? Dv : Dv - (u64)(S.rlen[lane] - 1);
 						S.tfirst[lane][d] = (u32)(lo >> 5);
@@ -846,37 +856,6 @@ map_reads_b_kernel(
 				}
 			}
 			ARKS_WAVE_SYNC();
-			if (!FULL) {
-				// hot path: a read with a run that proposes a third diagonal, sits under a heavy
-				// minimizer or had more than two entries goes to the medium queue as a whole
-				for (int h = lane; h < nheads; h += 64) {
-					const u32 cnt = h < kNH ? S.hn[h] : kHnOverflow;
-					bool off = cnt == kHnHeavy || cnt == kHnOverflow;
-					int jh = 0;
-					if (h < kNH) {
-						const u32 hv = S.heads[h];
-						jh = S.wread[hv >> 17];
-						if (cnt == 1 || cnt == 2) {
-							const int o = (int)(hv & 2047u) - S.rstart[jh];
-							const u32 rstrand = (hv >> 11) & 1u;
-							for (u32 c = 0; c < cnt; ++c) {
-								const u64 e = S.hc[h][c];
-								const bool sm = ((u32)(e >> 62) & 1u) == rstrand;
-								const u64 dk = (sm ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(MM - 1 + o)) |
-								               ((u64)sm << 40) | (1ull << 41);
-								off = off || (dk != S.pdiag[jh][0] && dk != S.pdiag[jh][1]);
-							}
-						}
-					} else
-						off = true; // more runs than the tile publishes: let the medium kernel take every read
-					if (off) {
-						if (h < kNH)
-							atomicOr(&S.redo2, 1u << jh);
-						else
-							atomicOr(&S.redo2, 0xFFFFFFFFu);
-					}
-				}
-			}
 			// stage the text words and their visited / ambiguous / owner words (one round trip)
 			{
 				const int ns = tw + nr;
