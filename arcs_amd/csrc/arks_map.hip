@@ -282,6 +282,23 @@ constexpr int kNH = 64;          // run heads per tile that get a published entr
 constexpr int kChunk = 32;       // reads handed out per device-counter grab
 constexpr u32 kHnHeavy = 255, kHnOverflow = 254;
 
+// Bit b of the result: none of the positions [b, b + k) of the 128-bit vector m3:m2:m1:m0 (m0 = positions
+// 0..31) is set, for b in [0, 32) and k in [32, 96].  Such a span always reaches the end of m0, so: b lies
+// above the highest set bit of m0, and b + k does not pass the first set bit of the later words.
+__device__ __forceinline__ u32
+clear_spans32(u32 m0, u32 m1, u32 m2, u32 m3, int k)
+{
+	const int hi = 32 - __clz((int)m0); // clz(0) = 32
+	const u32 r0 = hi == 32 ? 0u : (0xFFFFFFFFu << hi);
+	int f = 128;
+	f = m3 ? 95 + __ffs((int)m3) : f;
+	f = m2 ? 63 + __ffs((int)m2) : f;
+	f = m1 ? 31 + __ffs((int)m1) : f;
+	const int top = f - k; // the highest admissible b
+	const u32 r1 = top >= 31 ? 0xFFFFFFFFu : (top < 0 ? 0u : ((2u << top) - 1u));
+	return r0 & r1;
+}
+
 struct TileLds
 {
 	u32 a[kTP + 96];
@@ -923,18 +940,28 @@ map_reads_b_kernel(
 					cexist = cexist < 0 ? 0 : (cexist > 32 ? 32 : cexist);
 					u32 valid = cexist == 32 ? 0xFFFFFFFFu : ((1u << cexist) - 1u);
 					if (has_n && valid) { // ... and hold no invalid base: AND-window over the N-free bits
-						U128 nf;
-						nf.lo = ~((u64)__brev(S.nm[wl]) | ((u64)__brev(S.nm[wl + 1]) << 32));
-						nf.hi = ~((u64)__brev(S.nm[wl + 2]) | ((u64)__brev(S.nm[wl + 3]) << 32));
-						valid &= (u32)and_window128(nf, k).lo;
+						if (k >= 32) {
+							valid &= clear_spans32(__brev(S.nm[wl]), __brev(S.nm[wl + 1]), __brev(S.nm[wl + 2]),
+							                       __brev(S.nm[wl + 3]), k);
+						} else {
+							U128 nf;
+							nf.lo = ~((u64)__brev(S.nm[wl]) | ((u64)__brev(S.nm[wl + 1]) << 32));
+							nf.hi = ~((u64)__brev(S.nm[wl + 2]) | ((u64)__brev(S.nm[wl + 3]) << 32));
+							valid &= (u32)and_window128(nf, k).lo;
+						}
 					}
 					u32 ok = 0, amb = 0, own = 0;
 					const u64 pdv = S.pdiag[j][d];
 					if ((pdv >> 41) && valid) {
-						U128 z; // match bit per base from this word on
-						z.lo = ~((u64)S.mm32[d][wl] | ((u64)S.mm32[d][wl + 1] << 32));
-						z.hi = ~((u64)S.mm32[d][wl + 2] | ((u64)S.mm32[d][wl + 3] << 32));
-						ok = (u32)and_window128(z, k).lo & valid;
+						if (k >= 32) {
+							ok = clear_spans32(S.mm32[d][wl], S.mm32[d][wl + 1], S.mm32[d][wl + 2],
+							                   S.mm32[d][wl + 3], k) & valid;
+						} else {
+							U128 z; // match bit per base from this word on
+							z.lo = ~((u64)S.mm32[d][wl] | ((u64)S.mm32[d][wl + 1] << 32));
+							z.hi = ~((u64)S.mm32[d][wl + 2] | ((u64)S.mm32[d][wl + 3] << 32));
+							ok = (u32)and_window128(z, k).lo & valid;
+						}
 						if (ok) {
 							const bool same = (pdv >> 40) & 1ull;
 							const u64 D = pdv & 0xFFFFFFFFFFull;
