@@ -299,13 +299,18 @@ clear_spans32(u32 m0, u32 m1, u32 m2, u32 m3, int k)
 	return r0 & r1;
 }
 
+#ifndef ARKS_TILE_WAVES
+#define ARKS_TILE_WAVES 5
+#endif
+
+template <bool FULL>
 struct TileLds
 {
 	u32 a[kTP + 96];
-	u32 b[kTP + 96];
+	// hot instantiation: the block minima of T3, then the per-word result bits (no window records)
+	u32 b[FULL ? kTP + 96 : 256];
 	u64 cw[kTW + 4];
 	u32 nm[kTW + 4];
-	u64 hc[kNH][2];
 	u32 heads[kNH]; // run heads: [10:0] minimizer position, [11] its strand, [31:12] window position
 	unsigned char hn[kNH];
 	unsigned char wread[kTW + 4];
@@ -439,7 +444,7 @@ and_window128(U128 v, int k)
 //                registers out of the hot kernel.
 // FULL = true : the same kernel over the medium queue, one queued read per tile, every path.
 template <int KW, bool STATS, bool FULL, int MM>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ARKS_TILE_WAVES)))
 map_reads_b_kernel(
     const u64* __restrict__ codes,
     const u32* __restrict__ nmask,
@@ -456,14 +461,16 @@ map_reads_b_kernel(
     u32* __restrict__ mqueue,      // medium queue
     u32* __restrict__ queue_count) // [0] slow length, [1] work counter, [2] medium length, [3] medium work counter
 {
-	__shared__ TileLds S;
-	const int lane = threadIdx.x;
-	const u64 lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+	__shared__ TileLds<FULL> S;
+	// entry lists of the run heads (T5 on): S.a is free once the window minimizers are taken
+	u64 (*const hc)[2] = reinterpret_cast<u64(*)[2]>(S.a);
+	static_assert(sizeof(u64) * 2 * kNH <= sizeof(u32) * kTP, "hc must not reach the pad of S.a");
+	const int lane_id = threadIdx.x;
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	WaveStats ls = { 0, 0, 0, 0, 0, 0, 0, 0 }; // per-lane counters of the hot instantiation
+	WaveStats ls = { 0, 0, 0, 0, 0, 0, 0, 0 }; // per-lane_id counters of the hot instantiation
 	const int k = g.k, w = bx.w;
 	// the sliding minimum reads up to w - 1 + 7 positions past the tile: a constant pad
-	for (int x = lane; x < 96; x += 64)
+	for (int x = lane_id; x < 96; x += 64)
 		S.a[kTP + x] = 0xFFFFFFFFu;
 #ifdef ARKS_PROFILE_SECTIONS
 	unsigned long long sec_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -477,7 +484,7 @@ map_reads_b_kernel(
 		int nchunk;
 		if (FULL) { // one queued read per grab
 			u32 qi = 0;
-			if (lane == 0)
+			if (lane_id == 0)
 				qi = atomicAdd(queue_count + 3, 1u);
 			qi = __shfl(qi, 0);
 			if (qi >= n_medium)
@@ -485,25 +492,30 @@ map_reads_b_kernel(
 			c0 = (long)mqueue[qi];
 			nchunk = 1;
 		} else {
-			if (lane == 0)
+			if (lane_id == 0)
 				c0 = (long)atomicAdd(queue_count + 1, (u32)kChunk);
 			c0 = __shfl(c0, 0);
 			if (c0 >= n_reads)
 				break;
 			nchunk = (int)((c0 + kChunk < n_reads ? c0 + kChunk : n_reads) - c0);
 		}
-		// lane l holds the metadata of read c0 + l (lane nchunk: the end offset)
+		// lane_id l holds the metadata of read c0 + l (lane_id nchunk: the end offset)
 		u64 wo = 0;
 		int rl = 0;
-		if (lane <= nchunk)
-			wo = word_off[c0 + lane];
-		if (lane < nchunk) {
-			rl = (int)lens[c0 + lane];
-			if (!FULL && eval && !eval[c0 + lane])
+		if (lane_id <= nchunk)
+			wo = word_off[c0 + lane_id];
+		if (lane_id < nchunk) {
+			rl = (int)lens[c0 + lane_id];
+			if (!FULL && eval && !eval[c0 + lane_id])
 				rl = -1; // not evaluated: output 0, no counters
 		}
 		int cur = 0;
 		while (cur < nchunk) {
+			// re-derive the lane index inside the tile loop: everything computed from it is a couple of
+			// VALU ops, cheaper to redo per tile than to keep (or spill) as loop invariants
+			int lane = lane_id;
+			asm volatile("" : "+v"(lane));
+			const u64 lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
 			// ---- tile = reads [cur, nxt): as many as fit --------------------------------------
 			const u64 base_w = __shfl(wo, cur);
 			const u64 fit = __ballot(
@@ -568,14 +580,23 @@ map_reads_b_kernel(
 					if (has_n)
 						nb = (S.nm[wq] << (sft >> 1)) | ((S.nm[wq + 1] >> 1) >> (31 - (sft >> 1)));
 					const mm_t mmask = (mm_t)((1ull << (2 * MM)) - 1ull);
+					// positions whose m-mer lies inside the read (t <= rem0 - MM) and holds no invalid base
+					const int tmax = rem0 - MM;
+					u32 okmask = tmax >= 7 ? 0xFFu : (tmax < 0 ? 0u : ((2u << tmax) - 1u));
+					if (nb) {
+#pragma unroll
+						for (int t = 0; t < 8; ++t)
+							okmask &= ((nb << t) >> (32 - MM)) ? ~(1u << t) : 0xFFFFFFFFu;
+					}
 #pragma unroll
 					for (int t = 0; t < 8; ++t) {
-						const mm_t mf = (mm_t)(x >> (64 - 2 * MM - 2 * t)) & mmask;
-						const mm_t mr = (mm_t)(xr >> (2 * t)) & mmask;
-						const mm_t cm = mf < mr ? mf : mr;
-						const bool ok = rem0 - t >= MM && ((nb << t) >> (32 - MM)) == 0;
-						v[t] = ok ? ((mmer_order<MM>(cm) << 12) | ((u32)(i0 + t) << 1) | (mf < mr ? 1u : 0u))
-						          : 0xFFFFFFFFu;
+						v[t] = 0xFFFFFFFFu;
+						if ((okmask >> t) & 1u) {
+							const mm_t mf = (mm_t)(x >> (64 - 2 * MM - 2 * t)) & mmask;
+							const mm_t mr = (mm_t)(xr >> (2 * t)) & mmask;
+							const mm_t cm = mf < mr ? mf : mr;
+							v[t] = (mmer_order<MM>(cm) << 12) | ((u32)(i0 + t) << 1) | (mf < mr ? 1u : 0u);
+						}
 					}
 				}
 				ARKS_SEC(2);
@@ -786,7 +807,7 @@ map_reads_b_kernel(
 							continue;
 						}
 						if (cnt < 2)
-							S.hc[h][cnt] = e;
+							hc[h][cnt] = e;
 						cnt = cnt < 2 ? cnt + 1 : kHnOverflow;
 						if (cnt == kHnOverflow)
 							end = true;
@@ -819,12 +840,12 @@ map_reads_b_kernel(
 						const int o = (int)(hv & 2047u) - S.rstart[jh]; // offset of the minimizer in the read
 						const u32 rstrand = (hv >> 11) & 1u;
 						// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
-						const u64 e0 = S.hc[lane][0];
+						const u64 e0 = hc[lane][0];
 						const bool s0 = ((u32)(e0 >> 62) & 1u) == rstrand;
 						dk0 = (s0 ? (u64)(u32)e0 - (u64)o : (u64)(u32)e0 + (u64)(MM - 1 + o)) |
 						      ((u64)s0 << 40) | (1ull << 41);
 						if (cnt == 2) {
-							const u64 e1 = S.hc[lane][1];
+							const u64 e1 = hc[lane][1];
 							const bool s1 = ((u32)(e1 >> 62) & 1u) == rstrand;
 							dk1 = (s1 ? (u64)(u32)e1 - (u64)o : (u64)(u32)e1 + (u64)(MM - 1 + o)) |
 							      ((u64)s1 << 40) | (1ull << 41);
@@ -1025,7 +1046,7 @@ map_reads_b_kernel(
 						const int o = q - S.rstart[j];
 						const int l = i & 31;
 						for (u32 c = 0; c < hn && val < 0; ++c) {
-							const u64 e = S.hc[hidx][c];
+							const u64 e = hc[hidx][c];
 							const bool same = ((u32)(e >> 62) & 1u) == rstrand;
 							const u64 D = same ? (u64)(u32)e - (u64)o : (u64)(u32)e + (u64)(MM - 1 + o);
 							const u64 dk = D | ((u64)same << 40) | (1ull << 41);
@@ -1076,7 +1097,7 @@ map_reads_b_kernel(
 						} else {
 							const int off = q - i;
 							for (u32 c = 0; c < hn && val < 0; ++c) {
-								const u64 e = S.hc[hidx][c];
+								const u64 e = hc[hidx][c];
 								const bool same = ((u32)(e >> 62) & 1u) == rstrand;
 								const u64 t = same ? (u64)(u32)e - (u64)off : (u64)(u32)e - (u64)(k - MM - off);
 								const Key<KW> tk = window_key_at<KW>(bx.codes, t, g);
@@ -1253,7 +1274,7 @@ map_reads_b_kernel(
 		}
 	}
 #ifdef ARKS_PROFILE_SECTIONS
-	if (lane == 0)
+	if (lane_id == 0)
 		for (int x = 0; x < 10; ++x)
 			atomicAdd(&g_sec_cycles[x], sec_acc[x]);
 #endif
@@ -1267,7 +1288,7 @@ map_reads_b_kernel(
 		ws.fail += wave_sum_u64(ls.fail);
 		ws.win += wave_sum_u64(ls.win);
 	}
-	if (STATS && lane == 0) {
+	if (STATS && lane_id == 0) {
 		if (ws.valid) atomicAdd(stats + 0, ws.valid);
 		if (ws.bad) atomicAdd(stats + 1, ws.bad);
 		if (ws.found) atomicAdd(stats + 2, ws.found);
