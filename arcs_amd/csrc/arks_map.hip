@@ -300,7 +300,7 @@ clear_spans32(u32 m0, u32 m1, u32 m2, u32 m3, int k)
 }
 
 #ifndef ARKS_TILE_WAVES
-#define ARKS_TILE_WAVES 5
+#define ARKS_TILE_WAVES 8
 #endif
 
 template <bool FULL>
@@ -319,8 +319,8 @@ struct TileLds
 	int rlen[kTR];
 	u64 pdiag[kTR][2]; // the read's two staged diagonals: [39:0] D, [40] same strand, [41] valid
 	u32 tfirst[kTR][2];             // first text word staged for read j on diagonal d
-	u64 tcodes[2][kTW + kTR + 2];   // text words along the diagonals (read j: slots from
-	u32 tvis[2][kTW + kTR + 2];     //   (rstart[j] >> 5) + j)
+	// text words along the diagonals (read j: slots from (rstart[j] >> 5) + j): codes and visited bits
+	// live in S.a (see the kernel), ambiguous bits and owners here
 	u32 tamb[2][kTW + kTR + 2];
 	u32 town[2][kTW + kTR + 2];
 	u32 mm32[2][kTW + 8];           // mismatch bit per base along the diagonals
@@ -464,7 +464,11 @@ map_reads_b_kernel(
 	__shared__ TileLds<FULL> S;
 	// entry lists of the run heads (T5 on): S.a is free once the window minimizers are taken
 	u64 (*const hc)[2] = reinterpret_cast<u64(*)[2]>(S.a);
-	static_assert(sizeof(u64) * 2 * kNH <= sizeof(u32) * kTP, "hc must not reach the pad of S.a");
+	// ... and behind them the staged text words / visited words of T6 (written after T6a)
+	constexpr int kSlots = kTW + kTR + 2;
+	u64 (*const tcodes)[kSlots] = reinterpret_cast<u64(*)[kSlots]>(S.a + 4 * kNH + 64);
+	u32 (*const tvis)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(S.a + 4 * kNH + 64 + 4 * kSlots);
+	static_assert(4 * kNH + 64 + 6 * kSlots <= kTP, "aliases must not reach the pad of S.a");
 	const int lane_id = threadIdx.x;
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	WaveStats ls = { 0, 0, 0, 0, 0, 0, 0, 0 }; // per-lane_id counters of the hot instantiation
@@ -902,8 +906,8 @@ map_reads_b_kernel(
 					const int j = S.sread[sl];
 					if (S.pdiag[j][d] >> 41) {
 						const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
-						S.tcodes[d][sl] = bx.codes[tw_idx];
-						S.tvis[d][sl] = bx.visited[tw_idx];
+						tcodes[d][sl] = bx.codes[tw_idx];
+						tvis[d][sl] = bx.visited[tw_idx];
 						S.tamb[d][sl] = bx.ambig[tw_idx];
 						S.town[d][sl] = bx.word_owner[tw_idx];
 					}
@@ -927,8 +931,8 @@ map_reads_b_kernel(
 							// text position of the lowest-addressed base this word faces
 							const u64 tlo = same ? D + (u64)x0 : D - (u64)(x0 + 31);
 							const int slot = sb + (int)((u32)(tlo >> 5) - S.tfirst[j][d]);
-							const u64 t0 = slot >= sb ? S.tcodes[d][slot] : 0ull;
-							const u64 t32 = funnel_l(t0, S.tcodes[d][slot + 1], (int)(tlo & 31) * 2);
+							const u64 t0 = slot >= sb ? tcodes[d][slot] : 0ull;
+							const u64 t32 = funnel_l(t0, tcodes[d][slot + 1], (int)(tlo & 31) * 2);
 							const u64 face = same ? t32 : ~rev_groups(t32);
 							u64 x = S.cw[wl] ^ face;
 							// one bit per base: OR the two bits of every group, gather the even bits
@@ -992,8 +996,8 @@ map_reads_b_kernel(
 							const u64 lo = same ? D + (u64)p0 : D - (u64)(k - 1 + p0 + 31);
 							const int slot = sb + (int)((u32)(lo >> 5) - S.tfirst[j][d]);
 							const int sh = (int)(lo & 31);
-							const u32 v0 = (slot >= sb && slot <= sb + nst) ? S.tvis[d][slot] : 0u;
-							const u32 v1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? S.tvis[d][slot + 1] : 0u;
+							const u32 v0 = (slot >= sb && slot <= sb + nst) ? tvis[d][slot] : 0u;
+							const u32 v1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? tvis[d][slot + 1] : 0u;
 							const u32 a0 = (slot >= sb && slot <= sb + nst) ? S.tamb[d][slot] : 0u;
 							const u32 a1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? S.tamb[d][slot + 1] : 0u;
 							// 32 bits from text position lo on, most significant = lo
@@ -1071,7 +1075,7 @@ map_reads_b_kernel(
 								const u64 t = same ? D + (u64)p : D - (u64)(p + k - 1);
 								const int slot = (S.rstart[j] >> 5) + j + (int)((u32)(t >> 5) - S.tfirst[j][d]);
 								const u32 sh = 31 - (u32)(t & 31);
-								if ((S.tvis[d][slot] >> sh) & 1u)
+								if ((tvis[d][slot] >> sh) & 1u)
 									val = ((S.tamb[d][slot] >> sh) & 1u) ? 0 : (int)S.town[d][slot];
 							}
 						}
