@@ -548,6 +548,8 @@ map_reads_b_kernel(
 				S.redo = 0;
 				S.redo2 = 0;
 			}
+			if (!FULL && lane < 48) // per-read counters of T6c' (S.b + 128 ..: clear of the T3 block minima)
+				S.b[128 + lane] = lane < 16 ? 0u : (lane < 32 ? 0xFFFFFFFFu : 0u);
 			if (lane < tw + 4) {
 				S.cw[lane] = codes[base_w + (u64)lane];
 				S.nm[lane] = nmask[base_w + (u64)lane];
@@ -660,13 +662,14 @@ map_reads_b_kernel(
 			// wmin[t] = minimizer of window i0 + t (bits [11:1]: its position); dst becomes the window
 			// record: >= 0 value, -1 absent, -2 NULL window, -3 no window, <= -16 pending (q, run)
 			int* rec = reinterpret_cast<int*>(dst);
-			// hot instantiation: no window records; the same storage holds one bit per window instead
-			// (per 32 window starts and diagonal d): wok = matched on d and indexed there, wamb = ... with
-			// value 0, wown = contig end of the others (~0 = more than one), wvalid = exists, no invalid base
-			u32* const wok = dst;            // [2][32]
-			u32* const wamb = dst + 64;      // [2][32]
-			u32* const wown = dst + 128;     // [2][32]
-			u32* const wvalid = dst + 192;   // [32]
+			// hot instantiation: no window records; the same storage holds per-read counters instead, summed
+			// by the word lanes of T6c': rcnt[j][d] = matched unambiguous windows on diagonal d | ambiguous
+			// ones << 10 | (d = 0: windows that exist and hold no invalid base) << 20; rmin/rmax[j][d] =
+			// smallest / largest contig end among the former (they differ iff more than one)
+			u32* const rcnt = dst + 128; // [kTR][2]
+			u32* const rmin = dst + 144; // [kTR][2]
+			u32* const rmax = dst + 160; // [kTR][2]
+			static_assert(kTR * 2 <= 16, "per-read counters");
 			ARKS_SEC(3);
 			// ---- T4: windows, run heads --------------------------------------------------------------
 			int nheads = 0;
@@ -956,14 +959,16 @@ map_reads_b_kernel(
 				//      bit stream); it is in the index iff the text position it maps to is `visited`; its
 				//      value is 0 iff that position is `ambig`.  Everything stays a bit per window.
 				const int d = lane >= 32 ? 1 : 0, wl = lane & 31;
+				u32 ok = 0, amb = 0, own = 0, valid = 0;
+				int j = 0;
 				if (wl < tw) {
-					const int j = S.wread[wl];
+					j = S.wread[wl];
 					const int nwin = S.rlen[j] - k + 1;
 					const int p0 = wl * 32 - S.rstart[j]; // first window of this word, relative to the read
 					// windows that exist: p0 + b < nwin
 					int cexist = nwin - p0;
 					cexist = cexist < 0 ? 0 : (cexist > 32 ? 32 : cexist);
-					u32 valid = cexist == 32 ? 0xFFFFFFFFu : ((1u << cexist) - 1u);
+					valid = cexist == 32 ? 0xFFFFFFFFu : ((1u << cexist) - 1u);
 					if (has_n && valid) { // ... and hold no invalid base: AND-window over the N-free bits
 						if (k >= 32) {
 							valid &= clear_spans32(__brev(S.nm[wl]), __brev(S.nm[wl + 1]), __brev(S.nm[wl + 2]),
@@ -975,7 +980,6 @@ map_reads_b_kernel(
 							valid &= (u32)and_window128(nf, k).lo;
 						}
 					}
-					u32 ok = 0, amb = 0, own = 0;
 					const u64 pdv = S.pdiag[j][d];
 					if ((pdv >> 41) && valid) {
 						if (k >= 32) {
@@ -1020,11 +1024,22 @@ map_reads_b_kernel(
 								own = 0xFFFFFFFFu;
 						}
 					}
-					wok[d * 32 + wl] = ok;
-					wamb[d * 32 + wl] = amb;
-					wown[d * 32 + wl] = own;
-					if (d == 0)
-						wvalid[wl] = valid;
+				}
+				{
+					// a window matched on both diagonals counts once (on A; the value is the same)
+					const u32 other = __shfl_xor(ok, 32);
+					if (d) {
+						ok &= ~other;
+						amb &= ok;
+					}
+					const u32 recm = ok & ~amb;
+					const u32 pack = (u32)__popc(recm) | ((u32)__popc(amb) << 10) | (d ? 0u : ((u32)__popc(valid) << 20));
+					if (pack)
+						atomicAdd(&rcnt[j * 2 + d], pack);
+					if (recm) {
+						atomicMin(&rmin[j * 2 + d], own == 0xFFFFFFFFu ? 1u : own); // mixed word: min != max
+						atomicMax(&rmax[j * 2 + d], own);
+					}
 				}
 				ARKS_WAVE_SYNC();
 			}
@@ -1132,31 +1147,13 @@ map_reads_b_kernel(
 						queue[atomicAdd(queue_count, 1u)] = (u32)r;
 					} else {
 						bool medium = (redo2_mask >> j) & 1u;
-						int rec_a = 0, amb_a = 0, rec_b = 0, amb_b = 0, nvalid = 0;
-						u32 own_a = 0, own_b = 0;
-						if (!medium) {
-							const int w0 = S.rstart[j] >> 5, w1 = S.rstart[j + 1] >> 5;
-							for (int wl = w0; wl < w1; ++wl) {
-								const u32 oka = wok[wl], aa = wamb[wl];
-								const u32 okb = wok[32 + wl] & ~oka, ab = wamb[32 + wl] & okb;
-								const u32 ra = oka & ~aa, rb = okb & ~ab;
-								rec_a += __popc(ra);
-								amb_a += __popc(aa);
-								rec_b += __popc(rb);
-								amb_b += __popc(ab);
-								nvalid += __popc(wvalid[wl]);
-								if (ra) {
-									const u32 o = wown[wl];
-									medium = medium || o == 0xFFFFFFFFu || (own_a != 0 && own_a != o);
-									own_a = o;
-								}
-								if (rb) {
-									const u32 o = wown[32 + wl];
-									medium = medium || o == 0xFFFFFFFFu || (own_b != 0 && own_b != o);
-									own_b = o;
-								}
-							}
-						}
+						const u32 ca = rcnt[j * 2], cb = rcnt[j * 2 + 1];
+						const int rec_a = (int)(ca & 1023u), amb_a = (int)((ca >> 10) & 1023u);
+						const int rec_b = (int)(cb & 1023u), amb_b = (int)((cb >> 10) & 1023u);
+						const int nvalid = (int)(ca >> 20);
+						const u32 own_a = rec_a ? rmin[j * 2] : 0u, own_b = rec_b ? rmin[j * 2 + 1] : 0u;
+						// matches on one diagonal that belong to different contig ends: general path
+						medium = medium || (rec_a && rmax[j * 2] != own_a) || (rec_b && rmax[j * 2 + 1] != own_b);
 						if (medium) {
 							mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)r;
 						} else {
