@@ -223,6 +223,41 @@ def test_locality_index_exceptions(arks, gpu, oracle):
         ix.close()
 
 
+def test_reads_across_adjacent_text_sequences(arks, gpu, oracle):
+    """contig ends whose lengths are multiples of 32 sit back to back in the packed text: a chimeric
+    read that continues from one end into the next stays on ONE diagonal but collects two different
+    contig ends there (per-diagonal owner bookkeeping of the tile kernel); also reads whose windows
+    match on both of their diagonals (a segment duplicated inside one end)"""
+    rng = np.random.Generator(np.random.PCG64(99))
+    def rnd(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+    for k in (32, 60, 64):
+        seg = rnd(200)
+        ends = [rnd(320), rnd(640), rnd(96) + seg + rnd(24), rnd(32) + seg + rnd(8) + seg + rnd(200),
+                rnd(1024)]
+        assert all(len(e) % 32 == 0 for e in ends)
+        ox = oracle.OracleIndex(k).build(ends)
+        ix = arks.ArksIndex.build(ends, k, device=gpu)
+        assert index_digest(*ix.export()) == index_digest(*ox.dump())
+        genome = "".join(ends)
+        reads = []
+        for b in np.cumsum([len(e) for e in ends])[:-1]:
+            for left in (k - 1, k, k + 10, 75, 100, 128, 151 - k, 151 - k + 1):
+                for L in (128, 151, 250):
+                    if 0 < left < L and b - left >= 0 and b - left + L <= len(genome):
+                        r = genome[b - left:b - left + L]
+                        reads += [r, _rc(r)]
+        reads += [seg[:151], _rc(seg[20:171]), seg[60:] + rnd(11), ends[3][10:161], _rc(ends[3][200:351]),
+                  ends[3][232 - 75:232 + 76]]
+        for j in (0.0, 0.2, 0.55):
+            st = oracle.MapStats()
+            want = [ox.best_contig(r, j, st) for r in reads]
+            got, gst = ix.map_reads(reads, j, want_stats=True)
+            assert got.tolist() == want, (k, j)
+            assert gst == st.as_dict(), (k, j)
+        ix.close()
+
+
 def test_hash_kind_still_exact(arks, gpu, oracle, golden_mini, monkeypatch):
     """ARKS_INDEX_KIND=hash forces the plain hash-table index (design A): same results"""
     monkeypatch.setenv("ARKS_INDEX_KIND", "hash")
