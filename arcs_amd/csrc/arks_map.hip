@@ -275,11 +275,12 @@ map_reads_kernel(
 // HBM traffic per read: ~5 random 8-B minimizer entries + a few text / bit words, instead of ~100
 // random 64-B lines of the hash-table design.
 // ------------------------------------------------------------------------------------------------
-constexpr int kTW = 16;          // tile capacity in packed words
-constexpr int kTP = kTW * 32;    // ... in base positions
-constexpr int kTR = 8;           // reads per tile
+constexpr int kSW = 16;          // words per minimizer pass (64 lanes x 8 positions = 512 bases)
+constexpr int kTP = kSW * 32;    // ... in base positions
+constexpr int kTW = 32;          // tile capacity in packed words: two passes, one joint back half
+constexpr int kTR = 16;          // reads per tile
 constexpr int kNH = 64;          // run heads per tile that get a published entry list
-constexpr int kChunk = 32;       // reads handed out per device-counter grab
+constexpr int kChunk = 63;       // reads handed out per device-counter grab (lane l holds read l's metadata)
 constexpr u32 kHnHeavy = 255, kHnOverflow = 254;
 
 // Bit b of the result: none of the positions [b, b + k) of the 128-bit vector m3:m2:m1:m0 (m0 = positions
@@ -300,7 +301,7 @@ clear_spans32(u32 m0, u32 m1, u32 m2, u32 m3, int k)
 }
 
 #ifndef ARKS_TILE_WAVES
-#define ARKS_TILE_WAVES 8
+#define ARKS_TILE_WAVES 7
 #endif
 
 template <bool FULL>
@@ -319,10 +320,12 @@ struct TileLds
 	int rlen[kTR];
 	u64 pdiag[kTR][2]; // the read's two staged diagonals: [39:0] D, [40] same strand, [41] valid
 	u32 tfirst[kTR][2];             // first text word staged for read j on diagonal d
-	// text words along the diagonals (read j: slots from (rstart[j] >> 5) + j): codes and visited bits
-	// live in S.a (see the kernel), ambiguous bits and owners here
-	u32 tamb[2][kTW + kTR + 2];
-	u32 town[2][kTW + kTR + 2];
+	// text words along the diagonals (read j: slots from (rstart[j] >> 5) + j): the hot instantiation
+	// keeps them in storage that is free by then (S.a, S.b; see the kernel), the medium one here
+	u64 tcodes_f[FULL ? 2 * (kTW + kTR + 2) : 1];
+	u32 tvis_f[FULL ? 2 * (kTW + kTR + 2) : 1];
+	u32 tamb_f[FULL ? 2 * (kTW + kTR + 2) : 1];
+	u32 town_f[FULL ? 2 * (kTW + kTR + 2) : 1];
 	u32 mm32[2][kTW + 8];           // mismatch bit per base along the diagonals
 	unsigned char sread[kTW + kTR + 2];
 	u32 redo;
@@ -462,13 +465,18 @@ map_reads_b_kernel(
     u32* __restrict__ queue_count) // [0] slow length, [1] work counter, [2] medium length, [3] medium work counter
 {
 	__shared__ TileLds<FULL> S;
-	// entry lists of the run heads (T5 on): S.a is free once the window minimizers are taken
+	// entry lists of the run heads (T5 .. T6a; the medium kernel reads them again in T6c): S.a is free
+	// once the window minimizers are taken
 	u64 (*const hc)[2] = reinterpret_cast<u64(*)[2]>(S.a);
-	// ... and behind them the staged text words / visited words of T6 (written after T6a)
+	// staged text words of T6 (written after T6a).  Hot: visited / ambiguous words over the entry lists,
+	// codes behind them, owners over the block minima of S.b.
 	constexpr int kSlots = kTW + kTR + 2;
-	u64 (*const tcodes)[kSlots] = reinterpret_cast<u64(*)[kSlots]>(S.a + 4 * kNH + 64);
-	u32 (*const tvis)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(S.a + 4 * kNH + 64 + 4 * kSlots);
-	static_assert(4 * kNH + 64 + 6 * kSlots <= kTP, "aliases must not reach the pad of S.a");
+	u64 (*const tcodes)[kSlots] = reinterpret_cast<u64(*)[kSlots]>(FULL ? (void*)S.tcodes_f : (void*)(S.a + 4 * kNH));
+	u32 (*const tvis)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(FULL ? S.tvis_f : S.a);
+	u32 (*const tamb)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(FULL ? S.tamb_f : S.a + 2 * kSlots);
+	u32 (*const town)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(FULL ? S.town_f : S.b);
+	static_assert(4 * kSlots <= 4 * kNH && 4 * kNH + 4 * kSlots <= kTP, "aliases must stay clear of the pad of S.a");
+	static_assert(2 * kSlots <= 128, "owners must stay clear of the per-read counters in S.b");
 	const int lane_id = threadIdx.x;
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	WaveStats ls = { 0, 0, 0, 0, 0, 0, 0, 0 }; // per-lane_id counters of the hot instantiation
@@ -522,9 +530,10 @@ map_reads_b_kernel(
 			const u64 lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
 			// ---- tile = reads [cur, nxt): as many as fit --------------------------------------
 			const u64 base_w = __shfl(wo, cur);
+			// first pass: reads [cur, mid) within kSW words; second pass: [mid, nxt) likewise
 			const u64 fit = __ballot(
-			    lane > cur && lane <= nchunk && wo - base_w <= (u64)kTW && lane - cur <= kTR);
-			if (fit == 0) { // a single read longer than a tile: slow kernel
+			    lane > cur && lane <= nchunk && wo - base_w <= (u64)kSW && lane - cur <= kTR);
+			if (fit == 0) { // a single read longer than a pass: slow kernel
 				if (lane == cur) {
 					if (rl >= 0)
 						queue[atomicAdd(queue_count, 1u)] = (u32)(c0 + cur);
@@ -534,8 +543,17 @@ map_reads_b_kernel(
 				cur++;
 				continue;
 			}
-			const int nxt = 63 - __clzll((long long)fit);
+			const int mid = 63 - __clzll((long long)fit);
+			const u64 mid_w = __shfl(wo, mid);
+			int nxt = mid;
+			if (!FULL) {
+				const u64 fit2 = __ballot(
+				    lane > mid && lane <= nchunk && wo - mid_w <= (u64)kSW && lane - cur <= kTR);
+				if (fit2)
+					nxt = 63 - __clzll((long long)fit2);
+			}
 			const int nr = nxt - cur;
+			const int tw0 = (int)(mid_w - base_w);          // words of the first pass
 			const int tw = (int)(__shfl(wo, nxt) - base_w); // words of the tile
 			const int n = tw * 32;
 			ARKS_SEC(0);
@@ -548,8 +566,11 @@ map_reads_b_kernel(
 				S.redo = 0;
 				S.redo2 = 0;
 			}
-			if (!FULL && lane < 48) // per-read counters of T6c' (S.b + 128 ..: clear of the T3 block minima)
-				S.b[128 + lane] = lane < 16 ? 0u : (lane < 32 ? 0xFFFFFFFFu : 0u);
+			if (!FULL) { // per-read counters of T6c' (S.b + 128 ..: clear of the T3 block minima and the owners)
+				S.b[128 + lane] = lane < 32 ? 0u : 0xFFFFFFFFu; // rcnt, rmin
+				if (lane < 32)
+					S.b[192 + lane] = 0u; // rmax
+			}
 			if (lane < tw + 4) {
 				S.cw[lane] = codes[base_w + (u64)lane];
 				S.nm[lane] = nmask[base_w + (u64)lane];
@@ -568,95 +589,6 @@ map_reads_b_kernel(
 			const bool has_n = __ballot(lane < tw && S.nm[lane] != 0) != 0;
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(1);
-			// ---- T2: lane l owns the 8 positions 8l .. 8l+7 of the tile (16 words = 512 positions = one
-			//      pass).  The 8 + MM - 1 <= 32 bases its m-mers span are one funnel shift of two words;
-			//      every m-mer and its reverse complement is a shift + mask of that or of its complement. --
-			typedef typename Mmer<MM>::type mm_t;
-			const int i0 = lane * 8;
-			const bool in_tile = i0 < n;
-			const int rem0 = in_tile ? (int)(S.wmeta[lane >> 2] & 0xFFFFu) - i0 : 0; // bases of the read from i0 on
-			u32 wmin[8]; // minimizer (order value) of the window starting at each of the 8 positions
-			{
-				u32 v[8];
-				{
-					const int wq = lane >> 2, sft = (lane & 3) * 16;
-					const u64 x = funnel_l(S.cw[wq], S.cw[wq + 1], sft);
-					const u64 xr = ~rev_groups(x);
-					u32 nb = 0;
-					if (has_n)
-						nb = (S.nm[wq] << (sft >> 1)) | ((S.nm[wq + 1] >> 1) >> (31 - (sft >> 1)));
-					const mm_t mmask = (mm_t)((1ull << (2 * MM)) - 1ull);
-					// positions whose m-mer lies inside the read (t <= rem0 - MM) and holds no invalid base
-					const int tmax = rem0 - MM;
-					u32 okmask = tmax >= 7 ? 0xFFu : (tmax < 0 ? 0u : ((2u << tmax) - 1u));
-					if (nb) {
-#pragma unroll
-						for (int t = 0; t < 8; ++t)
-							okmask &= ((nb << t) >> (32 - MM)) ? ~(1u << t) : 0xFFFFFFFFu;
-					}
-#pragma unroll
-					for (int t = 0; t < 8; ++t) {
-						v[t] = 0xFFFFFFFFu;
-						if ((okmask >> t) & 1u) {
-							const mm_t mf = (mm_t)(x >> (64 - 2 * MM - 2 * t)) & mmask;
-							const mm_t mr = (mm_t)(xr >> (2 * t)) & mmask;
-							const mm_t cm = mf < mr ? mf : mr;
-							v[t] = (mmer_order<MM>(cm) << 12) | ((u32)(i0 + t) << 1) | (mf < mr ? 1u : 0u);
-						}
-					}
-				}
-				ARKS_SEC(2);
-				// ---- T3: sliding minimum over w positions.  [i, i + w) = a suffix of the lane's own 8
-				//      values, whole lanes in between, a prefix of a later lane's 8: prefix minima go
-				//      through LDS (S.a), the lanes' block minima too (S.b); everything else is registers.
-				if (w >= 9) {
-					u32 pre[8], suf[8];
-					pre[0] = v[0];
-#pragma unroll
-					for (int t = 1; t < 8; ++t)
-						pre[t] = v[t] < pre[t - 1] ? v[t] : pre[t - 1];
-					suf[7] = v[7];
-#pragma unroll
-					for (int t = 6; t >= 0; --t)
-						suf[t] = v[t] < suf[t + 1] ? v[t] : suf[t + 1];
-					uint4* pa = reinterpret_cast<uint4*>(S.a + i0);
-					pa[0] = make_uint4(pre[0], pre[1], pre[2], pre[3]);
-					pa[1] = make_uint4(pre[4], pre[5], pre[6], pre[7]);
-					S.b[lane] = pre[7];
-					if (lane < 16)
-						S.b[64 + lane] = 0xFFFFFFFFu;
-					ARKS_WAVE_SYNC();
-					const int e0 = (w - 1) >> 3, tb = 8 - ((w - 1) & 7);
-					u32 fa = 0xFFFFFFFFu;
-					for (int x = 1; x < e0; ++x) {
-						const u32 y = S.b[lane + x];
-						fa = y < fa ? y : fa;
-					}
-					u32 fb = S.b[lane + e0];
-					fb = fb < fa ? fb : fa;
-#pragma unroll
-					for (int t = 0; t < 8; ++t) {
-						const u32 y = S.a[i0 + t + w - 1];
-						const u32 f = t < tb ? fa : fb;
-						u32 m = suf[t] < y ? suf[t] : y;
-						wmin[t] = f < m ? f : m;
-					}
-				} else {
-					uint4* pa = reinterpret_cast<uint4*>(S.a + i0);
-					pa[0] = make_uint4(v[0], v[1], v[2], v[3]);
-					pa[1] = make_uint4(v[4], v[5], v[6], v[7]);
-					ARKS_WAVE_SYNC();
-#pragma unroll
-					for (int t = 0; t < 8; ++t) {
-						u32 m = v[t];
-						for (int o = 1; o < w; ++o) {
-							const u32 y = S.a[i0 + t + o];
-							m = y < m ? y : m;
-						}
-						wmin[t] = m;
-					}
-				}
-			}
 			u32* src = S.a;
 			u32* dst = S.b;
 			// wmin[t] = minimizer of window i0 + t (bits [11:1]: its position); dst becomes the window
@@ -667,116 +599,212 @@ map_reads_b_kernel(
 			// ones << 10 | (d = 0: windows that exist and hold no invalid base) << 20; rmin/rmax[j][d] =
 			// smallest / largest contig end among the former (they differ iff more than one)
 			u32* const rcnt = dst + 128; // [kTR][2]
-			u32* const rmin = dst + 144; // [kTR][2]
-			u32* const rmax = dst + 160; // [kTR][2]
-			static_assert(kTR * 2 <= 16, "per-read counters");
-			ARKS_SEC(3);
-			// ---- T4: windows, run heads --------------------------------------------------------------
+			u32* const rmin = dst + 160; // [kTR][2]
+			u32* const rmax = dst + 192; // [kTR][2]
+			static_assert(kTR * 2 <= 32, "per-read counters");
 			int nheads = 0;
-			if (!FULL) {
-				// hot path: only the run heads; window validity and values are worked out per 32-window
-				// word further down
-				u32 q[8];
-				u32 hm = 0;
-#pragma unroll
-				for (int t = 0; t < 8; ++t) {
-					const bool cand = rem0 - t >= k && wmin[t] != 0xFFFFFFFFu;
-					q[t] = cand ? ((wmin[t] >> 1) & 2047u) : 0xFFFFu;
-				}
-				u32 qprev = __shfl_up(q[7], 1);
-				if (lane == 0)
-					qprev = 0xFFFFu;
-#pragma unroll
-				for (int t = 0; t < 8; ++t) {
-					const bool head = q[t] != 0xFFFFu && q[t] != (t ? q[t - 1] : qprev);
-					hm |= head ? (1u << t) : 0u;
-				}
-				// exclusive prefix of the per-lane head counts (<= 8: four bit planes)
-				const u32 cnt = __popc(hm);
-				const u64 lane_lt = lane_le >> 1;
-				int hidx = 0;
-#pragma unroll
-				for (int bp = 0; bp < 4; ++bp) {
-					const u64 m = __ballot((cnt >> bp) & 1u);
-					hidx += __popcll(m & lane_lt) << bp;
-					nheads += __popcll(m) << bp;
-				}
-#pragma unroll
-				for (int t = 0; t < 8; ++t) {
-					if ((hm >> t) & 1u) {
-						if (hidx < kNH)
-							S.heads[hidx] = q[t] | ((wmin[t] & 1u) << 11) | ((u32)(i0 + t) << 12);
-						++hidx;
-					}
-				}
-				if (bx.has_img && !(k & 1)) { // see the comment in the FULL path below
-#pragma unroll
-					for (int t = 0; t < 8; ++t) {
-						if (q[t] != 0xFFFFu) {
-							const int qm = 2 * (i0 + t) + (k - MM) - (int)q[t];
-							if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q[t]))
-								atomicOr(&S.redo, 1u << (S.wmeta[lane >> 2] >> 16));
-						}
-					}
-				}
-			} else {
-				u32 carry = 0xFFFFu;
-				ARKS_WAVE_SYNC();
+			// ---- T2 .. T4 once per pass of <= kSW words; the medium kernel's single read is one pass ---------
+			const int npass = (FULL || tw0 == tw) ? 1 : 2;
+			for (int ps = 0; ps < npass; ++ps) {
+				// ---- T2: lane l owns the 8 positions 8l .. 8l+7 of the tile (16 words = 512 positions = one
+				//      pass).  The 8 + MM - 1 <= 32 bases its m-mers span are one funnel shift of two words;
+				//      every m-mer and its reverse complement is a shift + mask of that or of its complement. --
+				typedef typename Mmer<MM>::type mm_t;
+				const int l0 = lane * 8;                      // index into the pass-local minimum arrays
+				const int i0 = (ps ? tw0 * 32 : 0) + l0;      // tile position
+				const bool in_tile = i0 < (ps ? n : tw0 * 32);
+				const int rem0 = in_tile ? (int)(S.wmeta[i0 >> 5] & 0xFFFFu) - i0 : 0; // bases of the read from i0 on
+				u32 wmin[8]; // minimizer (order value) of the window starting at each of the 8 positions
 				{
-					uint4* pa = reinterpret_cast<uint4*>(S.a + i0);
-					pa[0] = make_uint4(wmin[0], wmin[1], wmin[2], wmin[3]);
-					pa[1] = make_uint4(wmin[4], wmin[5], wmin[6], wmin[7]);
-				}
-				ARKS_WAVE_SYNC();
-				for (int base = 0; base < n; base += 64) {
-					const int i = base + lane;
-					const u32 wm = S.wmeta[i >> 5];
-					const int j = (int)(wm >> 16);
-					const int rem = (int)(wm & 0xFFFFu) - i;
-					const bool is_win = rem >= k;
-					bool bad = false;
-					if (has_n && is_win) {
-						const int tn = i & 31, e = tn + k;
-						u32 any = 0;
+					u32 v[8];
+					{
+						const int wq = i0 >> 5, sft = (lane & 3) * 16;
+						const u64 x = funnel_l(S.cw[wq], S.cw[wq + 1], sft);
+						const u64 xr = ~rev_groups(x);
+						u32 nb = 0;
+						if (has_n)
+							nb = (S.nm[wq] << (sft >> 1)) | ((S.nm[wq + 1] >> 1) >> (31 - (sft >> 1)));
+						const mm_t mmask = (mm_t)((1ull << (2 * MM)) - 1ull);
+						// positions whose m-mer lies inside the read (t <= rem0 - MM) and holds no invalid base
+						const int tmax = rem0 - MM;
+						u32 okmask = tmax >= 7 ? 0xFFu : (tmax < 0 ? 0u : ((2u << tmax) - 1u));
+						if (nb) {
 	#pragma unroll
-						for (int x = 0; x <= KW; ++x) {
-							int lo = tn - 32 * x, hi = e - 32 * x;
-							lo = lo < 0 ? 0 : lo;
-							hi = hi > 32 ? 32 : hi;
-							if (lo < hi)
-								any |= S.nm[(i >> 5) + x] & (0xFFFFFFFFu >> lo) & ~(hi == 32 ? 0u : (0xFFFFFFFFu >> hi));
+							for (int t = 0; t < 8; ++t)
+								okmask &= ((nb << t) >> (32 - MM)) ? ~(1u << t) : 0xFFFFFFFFu;
 						}
-						bad = any != 0;
-					}
-					const bool ok = is_win && !bad;
-					const u32 sv = src[i];
-					const u32 q = ok ? ((sv >> 1) & 2047u) : 0xFFFFu;
-					u32 qprev = __shfl_up(q, 1);
-					if (lane == 0)
-						qprev = carry;
-					carry = __shfl(q, 63);
-					const bool head = ok && q != qprev;
-					const u64 hb = __ballot(head);
-					const int hidx = nheads + __popcll(hb & lane_le) - 1; // run of this window
-					if (head && hidx < kNH)
-						S.heads[hidx] = q | ((sv & 1u) << 11) | ((u32)i << 12);
-					nheads += __popcll(hb);
-					int rv = is_win ? -2 : -3;
-					if (ok) {
-						rv = -16 - (int)(q | ((sv & 1u) << 11) | ((u32)hidx << 12)); // position, strand, run
-						if (bx.has_img && !(k & 1)) {
-							// Only when the index holds quirk images can a palindromic window have a key
-							// that the text path would miss (otherwise it is either in the text, where its
-							// position carries the value of its damaged key, or absent).  A reverse-
-							// complement palindrome carries its minimizer twice, mirrored about its centre:
-							// necessary condition; the slow kernel decides exactly.
-							const int qm = 2 * i + (k - MM) - (int)q;
-							if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q))
-								atomicOr(&S.redo, 1u << j);
+	#pragma unroll
+						for (int t = 0; t < 8; ++t) {
+							v[t] = 0xFFFFFFFFu;
+							if ((okmask >> t) & 1u) {
+								const mm_t mf = (mm_t)(x >> (64 - 2 * MM - 2 * t)) & mmask;
+								const mm_t mr = (mm_t)(xr >> (2 * t)) & mmask;
+								const mm_t cm = mf < mr ? mf : mr;
+								v[t] = (mmer_order<MM>(cm) << 12) | ((u32)(i0 + t) << 1) | (mf < mr ? 1u : 0u);
+							}
 						}
 					}
-					rec[i] = rv;
+					ARKS_SEC(2);
+					// ---- T3: sliding minimum over w positions.  [i, i + w) = a suffix of the lane's own 8
+					//      values, whole lanes in between, a prefix of a later lane's 8: prefix minima go
+					//      through LDS (S.a), the lanes' block minima too (S.b); everything else is registers.
+					if (w >= 9) {
+						u32 pre[8], suf[8];
+						pre[0] = v[0];
+	#pragma unroll
+						for (int t = 1; t < 8; ++t)
+							pre[t] = v[t] < pre[t - 1] ? v[t] : pre[t - 1];
+						suf[7] = v[7];
+	#pragma unroll
+						for (int t = 6; t >= 0; --t)
+							suf[t] = v[t] < suf[t + 1] ? v[t] : suf[t + 1];
+						uint4* pa = reinterpret_cast<uint4*>(S.a + l0);
+						pa[0] = make_uint4(pre[0], pre[1], pre[2], pre[3]);
+						pa[1] = make_uint4(pre[4], pre[5], pre[6], pre[7]);
+						S.b[lane] = pre[7];
+						if (lane < 16)
+							S.b[64 + lane] = 0xFFFFFFFFu;
+						ARKS_WAVE_SYNC();
+						const int e0 = (w - 1) >> 3, tb = 8 - ((w - 1) & 7);
+						u32 fa = 0xFFFFFFFFu;
+						for (int x = 1; x < e0; ++x) {
+							const u32 y = S.b[lane + x];
+							fa = y < fa ? y : fa;
+						}
+						u32 fb = S.b[lane + e0];
+						fb = fb < fa ? fb : fa;
+	#pragma unroll
+						for (int t = 0; t < 8; ++t) {
+							const u32 y = S.a[l0 + t + w - 1];
+							const u32 f = t < tb ? fa : fb;
+							u32 m = suf[t] < y ? suf[t] : y;
+							wmin[t] = f < m ? f : m;
+						}
+					} else {
+						uint4* pa = reinterpret_cast<uint4*>(S.a + l0);
+						pa[0] = make_uint4(v[0], v[1], v[2], v[3]);
+						pa[1] = make_uint4(v[4], v[5], v[6], v[7]);
+						ARKS_WAVE_SYNC();
+	#pragma unroll
+						for (int t = 0; t < 8; ++t) {
+							u32 m = v[t];
+							for (int o = 1; o < w; ++o) {
+								const u32 y = S.a[l0 + t + o];
+								m = y < m ? y : m;
+							}
+							wmin[t] = m;
+						}
+					}
 				}
+				ARKS_SEC(3);
+				// ---- T4: windows, run heads --------------------------------------------------------------
+				if (!FULL) {
+					// hot path: only the run heads; window validity and values are worked out per 32-window
+					// word further down
+					u32 q[8];
+					u32 hm = 0;
+	#pragma unroll
+					for (int t = 0; t < 8; ++t) {
+						const bool cand = rem0 - t >= k && wmin[t] != 0xFFFFFFFFu;
+						q[t] = cand ? ((wmin[t] >> 1) & 2047u) : 0xFFFFu;
+					}
+					u32 qprev = __shfl_up(q[7], 1);
+					if (lane == 0)
+						qprev = 0xFFFFu;
+	#pragma unroll
+					for (int t = 0; t < 8; ++t) {
+						const bool head = q[t] != 0xFFFFu && q[t] != (t ? q[t - 1] : qprev);
+						hm |= head ? (1u << t) : 0u;
+					}
+					// exclusive prefix of the per-lane head counts (<= 8: four bit planes)
+					const u32 cnt = __popc(hm);
+					const u64 lane_lt = lane_le >> 1;
+					int hidx = nheads;
+	#pragma unroll
+					for (int bp = 0; bp < 4; ++bp) {
+						const u64 m = __ballot((cnt >> bp) & 1u);
+						hidx += __popcll(m & lane_lt) << bp;
+						nheads += __popcll(m) << bp;
+					}
+	#pragma unroll
+					for (int t = 0; t < 8; ++t) {
+						if ((hm >> t) & 1u) {
+							if (hidx < kNH)
+								S.heads[hidx] = q[t] | ((wmin[t] & 1u) << 11) | ((u32)(i0 + t) << 12);
+							++hidx;
+						}
+					}
+					if (bx.has_img && !(k & 1)) { // see the comment in the FULL path below
+	#pragma unroll
+						for (int t = 0; t < 8; ++t) {
+							if (q[t] != 0xFFFFu) {
+								const int qm = 2 * (i0 + t) + (k - MM) - (int)q[t];
+								if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q[t]))
+									atomicOr(&S.redo, 1u << (S.wmeta[i0 >> 5] >> 16));
+							}
+						}
+					}
+				} else {
+					u32 carry = 0xFFFFu;
+					ARKS_WAVE_SYNC();
+					{
+						uint4* pa = reinterpret_cast<uint4*>(S.a + l0);
+						pa[0] = make_uint4(wmin[0], wmin[1], wmin[2], wmin[3]);
+						pa[1] = make_uint4(wmin[4], wmin[5], wmin[6], wmin[7]);
+					}
+					ARKS_WAVE_SYNC();
+					for (int base = 0; base < n; base += 64) {
+						const int i = base + lane;
+						const u32 wm = S.wmeta[i >> 5];
+						const int j = (int)(wm >> 16);
+						const int rem = (int)(wm & 0xFFFFu) - i;
+						const bool is_win = rem >= k;
+						bool bad = false;
+						if (has_n && is_win) {
+							const int tn = i & 31, e = tn + k;
+							u32 any = 0;
+		#pragma unroll
+							for (int x = 0; x <= KW; ++x) {
+								int lo = tn - 32 * x, hi = e - 32 * x;
+								lo = lo < 0 ? 0 : lo;
+								hi = hi > 32 ? 32 : hi;
+								if (lo < hi)
+									any |= S.nm[(i >> 5) + x] & (0xFFFFFFFFu >> lo) & ~(hi == 32 ? 0u : (0xFFFFFFFFu >> hi));
+							}
+							bad = any != 0;
+						}
+						const bool ok = is_win && !bad;
+						const u32 sv = src[i];
+						const u32 q = ok ? ((sv >> 1) & 2047u) : 0xFFFFu;
+						u32 qprev = __shfl_up(q, 1);
+						if (lane == 0)
+							qprev = carry;
+						carry = __shfl(q, 63);
+						const bool head = ok && q != qprev;
+						const u64 hb = __ballot(head);
+						const int hidx = nheads + __popcll(hb & lane_le) - 1; // run of this window
+						if (head && hidx < kNH)
+							S.heads[hidx] = q | ((sv & 1u) << 11) | ((u32)i << 12);
+						nheads += __popcll(hb);
+						int rv = is_win ? -2 : -3;
+						if (ok) {
+							rv = -16 - (int)(q | ((sv & 1u) << 11) | ((u32)hidx << 12)); // position, strand, run
+							if (bx.has_img && !(k & 1)) {
+								// Only when the index holds quirk images can a palindromic window have a key
+								// that the text path would miss (otherwise it is either in the text, where its
+								// position carries the value of its damaged key, or absent).  A reverse-
+								// complement palindrome carries its minimizer twice, mirrored about its centre:
+								// necessary condition; the slow kernel decides exactly.
+								const int qm = 2 * i + (k - MM) - (int)q;
+								if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q))
+									atomicOr(&S.redo, 1u << j);
+							}
+						}
+						rec[i] = rv;
+					}
+				}
+				if (!FULL)
+					ARKS_WAVE_SYNC(); // S.a / S.b are rewritten by the next pass
 			}
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(4);
@@ -904,15 +932,15 @@ map_reads_b_kernel(
 			// stage the text words and their visited / ambiguous / owner words (one round trip)
 			{
 				const int ns = tw + nr;
-				const int d = lane >= ns ? 1 : 0, sl = lane - d * ns;
-				if (lane < 2 * ns) {
+				for (int x = lane; x < 2 * ns; x += 64) {
+					const int d = x >= ns ? 1 : 0, sl = x - d * ns;
 					const int j = S.sread[sl];
 					if (S.pdiag[j][d] >> 41) {
 						const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
 						tcodes[d][sl] = bx.codes[tw_idx];
 						tvis[d][sl] = bx.visited[tw_idx];
-						S.tamb[d][sl] = bx.ambig[tw_idx];
-						S.town[d][sl] = bx.word_owner[tw_idx];
+						tamb[d][sl] = bx.ambig[tw_idx];
+						town[d][sl] = bx.word_owner[tw_idx];
 					}
 				}
 			}
@@ -921,9 +949,11 @@ map_reads_b_kernel(
 			//      it faces -> one mismatch bit per base (bit b of mm32[d][word]) -------------------------
 			{
 				const int d = lane >= 32 ? 1 : 0, wl = lane & 31;
-				if (wl < tw + 6) {
+				if (lane < 16) // the spans of the last words read past the tile: no mismatch there
+					S.mm32[lane >> 3][tw + (lane & 7)] = 0u;
+				if (wl < tw) {
 					u32 mbits = 0;
-					if (wl < tw) {
+					{
 						const int j = S.wread[wl];
 						const u64 pdv = S.pdiag[j][d];
 						if (pdv >> 41) {
@@ -1002,8 +1032,8 @@ map_reads_b_kernel(
 							const int sh = (int)(lo & 31);
 							const u32 v0 = (slot >= sb && slot <= sb + nst) ? tvis[d][slot] : 0u;
 							const u32 v1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? tvis[d][slot + 1] : 0u;
-							const u32 a0 = (slot >= sb && slot <= sb + nst) ? S.tamb[d][slot] : 0u;
-							const u32 a1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? S.tamb[d][slot + 1] : 0u;
+							const u32 a0 = (slot >= sb && slot <= sb + nst) ? tamb[d][slot] : 0u;
+							const u32 a1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? tamb[d][slot + 1] : 0u;
 							// 32 bits from text position lo on, most significant = lo
 							u32 vis = sh ? ((v0 << sh) | (v1 >> (32 - sh))) : v0;
 							u32 am = sh ? ((a0 << sh) | (a1 >> (32 - sh))) : a0;
@@ -1017,8 +1047,8 @@ map_reads_b_kernel(
 							// positions fall in.  `inlo` = window bits whose position lies in `slot`.
 							const u32 recm = ok & ~amb;
 							const u32 inlo = same ? (sh ? (1u << (32 - sh)) - 1u : 0xFFFFFFFFu) : (0xFFFFFFFFu << sh);
-							const u32 o0 = (recm & inlo) ? S.town[d][slot] : 0u;
-							const u32 o1 = (recm & ~inlo) ? S.town[d][slot + 1] : 0u;
+							const u32 o0 = (recm & inlo) ? town[d][slot] : 0u;
+							const u32 o1 = (recm & ~inlo) ? town[d][slot + 1] : 0u;
 							own = o0 ? o0 : o1;
 							if (o0 && o1 && o0 != o1)
 								own = 0xFFFFFFFFu;
@@ -1091,7 +1121,7 @@ map_reads_b_kernel(
 								const int slot = (S.rstart[j] >> 5) + j + (int)((u32)(t >> 5) - S.tfirst[j][d]);
 								const u32 sh = 31 - (u32)(t & 31);
 								if ((tvis[d][slot] >> sh) & 1u)
-									val = ((S.tamb[d][slot] >> sh) & 1u) ? 0 : (int)S.town[d][slot];
+									val = ((tamb[d][slot] >> sh) & 1u) ? 0 : (int)town[d][slot];
 							}
 						}
 						if (val >= 0)
