@@ -326,7 +326,7 @@ struct TileLds
 	u32 tvis_f[FULL ? 2 * (kTW + kTR + 2) : 1];
 	u32 tamb_f[FULL ? 2 * (kTW + kTR + 2) : 1];
 	u32 town_f[FULL ? 2 * (kTW + kTR + 2) : 1];
-	u32 mm32[2][kTW + 8];           // mismatch bit per base along the diagonals
+	u32 mm32_f[FULL ? 2 * (kTW + 8) : 1]; // mismatch bit per base along the diagonals
 	unsigned char sread[kTW + kTR + 2];
 	u32 redo;
 	u32 redo2; // reads that need the general verification (hot instantiation only)
@@ -447,7 +447,7 @@ and_window128(U128 v, int k)
 //                registers out of the hot kernel.
 // FULL = true : the same kernel over the medium queue, one queued read per tile, every path.
 template <int KW, bool STATS, bool FULL, int MM>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ARKS_TILE_WAVES)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FULL ? 4 : ARKS_TILE_WAVES)))
 map_reads_b_kernel(
     const u64* __restrict__ codes,
     const u32* __restrict__ nmask,
@@ -468,14 +468,15 @@ map_reads_b_kernel(
 	// entry lists of the run heads (T5 .. T6a; the medium kernel reads them again in T6c): S.a is free
 	// once the window minimizers are taken
 	u64 (*const hc)[2] = reinterpret_cast<u64(*)[2]>(S.a);
-	// staged text words of T6 (written after T6a).  Hot: visited / ambiguous words over the entry lists,
-	// codes behind them, owners over the block minima of S.b.
+	// staged text words of T6 (written after T6a, when the entry lists are done with).  Hot: codes, visited /
+	// ambiguous words and the mismatch bits of T6b all over S.a, owners over the block minima of S.b.
 	constexpr int kSlots = kTW + kTR + 2;
-	u64 (*const tcodes)[kSlots] = reinterpret_cast<u64(*)[kSlots]>(FULL ? (void*)S.tcodes_f : (void*)(S.a + 4 * kNH));
-	u32 (*const tvis)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(FULL ? S.tvis_f : S.a);
-	u32 (*const tamb)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(FULL ? S.tamb_f : S.a + 2 * kSlots);
+	u64 (*const tcodes)[kSlots] = reinterpret_cast<u64(*)[kSlots]>(FULL ? (void*)S.tcodes_f : (void*)S.a);
+	u32 (*const tvis)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(FULL ? S.tvis_f : S.a + 4 * kSlots);
+	u32 (*const tamb)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(FULL ? S.tamb_f : S.a + 6 * kSlots);
+	u32 (*const mm32)[kTW + 8] = reinterpret_cast<u32(*)[kTW + 8]>(FULL ? S.mm32_f : S.a + 8 * kSlots);
 	u32 (*const town)[kSlots] = reinterpret_cast<u32(*)[kSlots]>(FULL ? S.town_f : S.b);
-	static_assert(4 * kSlots <= 4 * kNH && 4 * kNH + 4 * kSlots <= kTP, "aliases must stay clear of the pad of S.a");
+	static_assert(8 * kSlots + 2 * (kTW + 8) <= kTP, "aliases must stay clear of the pad of S.a");
 	static_assert(2 * kSlots <= 128, "owners must stay clear of the per-read counters in S.b");
 	const int lane_id = threadIdx.x;
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -950,7 +951,7 @@ map_reads_b_kernel(
 			{
 				const int d = lane >= 32 ? 1 : 0, wl = lane & 31;
 				if (lane < 16) // the spans of the last words read past the tile: no mismatch there
-					S.mm32[lane >> 3][tw + (lane & 7)] = 0u;
+					mm32[lane >> 3][tw + (lane & 7)] = 0u;
 				if (wl < tw) {
 					u32 mbits = 0;
 					{
@@ -978,7 +979,7 @@ map_reads_b_kernel(
 							mbits = __brev((u32)x); // base 0 of the word -> bit 0
 						}
 					}
-					S.mm32[d][wl] = mbits;
+					mm32[d][wl] = mbits;
 				}
 			}
 			ARKS_WAVE_SYNC();
@@ -1013,12 +1014,12 @@ map_reads_b_kernel(
 					const u64 pdv = S.pdiag[j][d];
 					if ((pdv >> 41) && valid) {
 						if (k >= 32) {
-							ok = clear_spans32(S.mm32[d][wl], S.mm32[d][wl + 1], S.mm32[d][wl + 2],
-							                   S.mm32[d][wl + 3], k) & valid;
+							ok = clear_spans32(mm32[d][wl], mm32[d][wl + 1], mm32[d][wl + 2],
+							                   mm32[d][wl + 3], k) & valid;
 						} else {
 							U128 z; // match bit per base from this word on
-							z.lo = ~((u64)S.mm32[d][wl] | ((u64)S.mm32[d][wl + 1] << 32));
-							z.hi = ~((u64)S.mm32[d][wl + 2] | ((u64)S.mm32[d][wl + 3] << 32));
+							z.lo = ~((u64)mm32[d][wl] | ((u64)mm32[d][wl + 1] << 32));
+							z.hi = ~((u64)mm32[d][wl + 2] | ((u64)mm32[d][wl + 3] << 32));
 							ok = (u32)and_window128(z, k).lo & valid;
 						}
 						if (ok) {
@@ -1106,7 +1107,7 @@ map_reads_b_kernel(
 								full = true;
 								continue;
 							}
-							const u32* mw = S.mm32[d] + (i >> 5);
+							const u32* mw = mm32[d] + (i >> 5);
 							const u64 m01 = (u64)mw[0] | ((u64)mw[1] << 32);
 							const u64 m23 = (u64)mw[2] | ((u64)mw[3] << 32);
 							u64 bits = funnel_r(m01, m23, l); // 64 bases from i on
