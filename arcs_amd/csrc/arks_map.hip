@@ -35,6 +35,22 @@ wave_sum_i32(int v)
 	return v;
 }
 
+// number of set bits of m below this lane's own bit
+__device__ __forceinline__ u32
+mask_below(u64 m)
+{
+	return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
+// value of lane l (wave-uniform l) as a scalar: stays in SGPRs, unlike the result of __shfl
+__device__ __forceinline__ u64
+lane_value_u64(u64 v, int l)
+{
+	const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+	const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+	return ((u64)hi << 32) | lo;
+}
+
 __device__ __forceinline__ u64
 wave_sum_u64(u64 v)
 {
@@ -301,7 +317,7 @@ clear_spans32(u32 m0, u32 m1, u32 m2, u32 m3, int k)
 }
 
 #ifndef ARKS_TILE_WAVES
-#define ARKS_TILE_WAVES 7
+#define ARKS_TILE_WAVES 8
 #endif
 
 template <bool FULL>
@@ -499,15 +515,16 @@ map_reads_b_kernel(
 			u32 qi = 0;
 			if (lane_id == 0)
 				qi = atomicAdd(queue_count + 3, 1u);
-			qi = __shfl(qi, 0);
+			qi = (u32)__builtin_amdgcn_readfirstlane((int)qi);
 			if (qi >= n_medium)
 				break;
 			c0 = (long)mqueue[qi];
 			nchunk = 1;
 		} else {
+			u32 g0 = 0;
 			if (lane_id == 0)
-				c0 = (long)atomicAdd(queue_count + 1, (u32)kChunk);
-			c0 = __shfl(c0, 0);
+				g0 = atomicAdd(queue_count + 1, (u32)kChunk);
+			c0 = (long)(u32)__builtin_amdgcn_readfirstlane((int)g0);
 			if (c0 >= n_reads)
 				break;
 			nchunk = (int)((c0 + kChunk < n_reads ? c0 + kChunk : n_reads) - c0);
@@ -528,9 +545,8 @@ map_reads_b_kernel(
 			// VALU ops, cheaper to redo per tile than to keep (or spill) as loop invariants
 			int lane = lane_id;
 			asm volatile("" : "+v"(lane));
-			const u64 lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
 			// ---- tile = reads [cur, nxt): as many as fit --------------------------------------
-			const u64 base_w = __shfl(wo, cur);
+			const u64 base_w = lane_value_u64(wo, cur);
 			// first pass: reads [cur, mid) within kSW words; second pass: [mid, nxt) likewise
 			const u64 fit = __ballot(
 			    lane > cur && lane <= nchunk && wo - base_w <= (u64)kSW && lane - cur <= kTR);
@@ -545,7 +561,7 @@ map_reads_b_kernel(
 				continue;
 			}
 			const int mid = 63 - __clzll((long long)fit);
-			const u64 mid_w = __shfl(wo, mid);
+			const u64 mid_w = lane_value_u64(wo, mid);
 			int nxt = mid;
 			if (!FULL) {
 				const u64 fit2 = __ballot(
@@ -555,7 +571,7 @@ map_reads_b_kernel(
 			}
 			const int nr = nxt - cur;
 			const int tw0 = (int)(mid_w - base_w);          // words of the first pass
-			const int tw = (int)(__shfl(wo, nxt) - base_w); // words of the tile
+			const int tw = (int)(lane_value_u64(wo, nxt) - base_w); // words of the tile
 			const int n = tw * 32;
 			ARKS_SEC(0);
 			// ---- T0/T1: per-read metadata and the tile's words into LDS ------------------------
@@ -719,12 +735,11 @@ map_reads_b_kernel(
 					}
 					// exclusive prefix of the per-lane head counts (<= 8: four bit planes)
 					const u32 cnt = __popc(hm);
-					const u64 lane_lt = lane_le >> 1;
 					int hidx = nheads;
 	#pragma unroll
 					for (int bp = 0; bp < 4; ++bp) {
 						const u64 m = __ballot((cnt >> bp) & 1u);
-						hidx += __popcll(m & lane_lt) << bp;
+						hidx += (int)mask_below(m) << bp;
 						nheads += __popcll(m) << bp;
 					}
 	#pragma unroll
@@ -783,7 +798,7 @@ map_reads_b_kernel(
 						carry = __shfl(q, 63);
 						const bool head = ok && q != qprev;
 						const u64 hb = __ballot(head);
-						const int hidx = nheads + __popcll(hb & lane_le) - 1; // run of this window
+						const int hidx = nheads + (int)mask_below(hb) + (head ? 1 : 0) - 1; // run of this window
 						if (head && hidx < kNH)
 							S.heads[hidx] = q | ((sv & 1u) << 11) | ((u32)i << 12);
 						nheads += __popcll(hb);
