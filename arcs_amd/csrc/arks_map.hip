@@ -328,7 +328,7 @@ struct TileLds
 	u32 b[FULL ? kTP + 96 : 256];
 	u64 cw[kTW + 4];
 	u32 nm[kTW + 4];
-	u32 heads[kNH]; // run heads: [10:0] minimizer position, [11] its strand, [31:12] window position
+	u32 heads[kNH]; // run heads: [0] minimizer strand, [11:1] its position, [31:12] window position
 	unsigned char hn[kNH];
 	unsigned char wread[kTW + 4];
 	u32 wmeta[kTW + 4]; // per word: read index << 16 | local end position of that read (0 = none)
@@ -718,44 +718,36 @@ map_reads_b_kernel(
 				if (!FULL) {
 					// hot path: only the run heads; window validity and values are worked out per 32-window
 					// word further down
-					u32 q[8];
-					u32 hm = 0;
+					// wc[t] = minimizer of window t when that window exists (and has any valid m-mer), else ~0
+					const int tc = rem0 - k; // windows t <= tc exist
+					u32 wc[8];
 	#pragma unroll
-					for (int t = 0; t < 8; ++t) {
-						const bool cand = rem0 - t >= k && wmin[t] != 0xFFFFFFFFu;
-						q[t] = cand ? ((wmin[t] >> 1) & 2047u) : 0xFFFFu;
-					}
-					u32 qprev = __shfl_up(q[7], 1);
+					for (int t = 0; t < 8; ++t)
+						wc[t] = t <= tc ? wmin[t] : 0xFFFFFFFFu;
+					u32 wprev = __shfl_up(wc[7], 1);
 					if (lane == 0)
-						qprev = 0xFFFFu;
+						wprev = 0xFFFFFFFFu;
+					// a run head = a window whose minimizer (value includes its position) differs from its
+					// predecessor's.  Heads are numbered position-class-major (all t = 0 heads of the pass,
+					// then t = 1, ...): a ballot + mbcnt per class, no per-lane serial numbering.  Which run
+					// comes first only decides which two diagonals get staged -- any choice is exact.
 	#pragma unroll
 					for (int t = 0; t < 8; ++t) {
-						const bool head = q[t] != 0xFFFFu && q[t] != (t ? q[t - 1] : qprev);
-						hm |= head ? (1u << t) : 0u;
-					}
-					// exclusive prefix of the per-lane head counts (<= 8: four bit planes)
-					const u32 cnt = __popc(hm);
-					int hidx = nheads;
-	#pragma unroll
-					for (int bp = 0; bp < 4; ++bp) {
-						const u64 m = __ballot((cnt >> bp) & 1u);
-						hidx += (int)mask_below(m) << bp;
-						nheads += __popcll(m) << bp;
-					}
-	#pragma unroll
-					for (int t = 0; t < 8; ++t) {
-						if ((hm >> t) & 1u) {
-							if (hidx < kNH)
-								S.heads[hidx] = q[t] | ((wmin[t] & 1u) << 11) | ((u32)(i0 + t) << 12);
-							++hidx;
-						}
+						const bool head = wc[t] != 0xFFFFFFFFu && wc[t] != (t ? wc[t - 1] : wprev);
+						const u64 hb = __ballot(head);
+						const u32 rank = (u32)nheads + mask_below(hb);
+						const u32 hv = (wc[t] & 0xFFFu) | ((u32)(i0 + t) << 12);
+						if (head && rank < (u32)kNH)
+							S.heads[rank] = hv;
+						nheads += __popcll(hb);
 					}
 					if (bx.has_img && !(k & 1)) { // see the comment in the FULL path below
 	#pragma unroll
 						for (int t = 0; t < 8; ++t) {
-							if (q[t] != 0xFFFFu) {
-								const int qm = 2 * (i0 + t) + (k - MM) - (int)q[t];
-								if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, (int)q[t]))
+							if (wc[t] != 0xFFFFFFFFu) {
+								const int q = (int)((wc[t] >> 1) & 2047u);
+								const int qm = 2 * (i0 + t) + (k - MM) - q;
+								if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, q))
 									atomicOr(&S.redo, 1u << (S.wmeta[i0 >> 5] >> 16));
 							}
 						}
@@ -800,7 +792,7 @@ map_reads_b_kernel(
 						const u64 hb = __ballot(head);
 						const int hidx = nheads + (int)mask_below(hb) + (head ? 1 : 0) - 1; // run of this window
 						if (head && hidx < kNH)
-							S.heads[hidx] = q | ((sv & 1u) << 11) | ((u32)i << 12);
+							S.heads[hidx] = (sv & 0xFFFu) | ((u32)i << 12);
 						nheads += __popcll(hb);
 						int rv = is_win ? -2 : -3;
 						if (ok) {
@@ -827,7 +819,7 @@ map_reads_b_kernel(
 			// ---- T5: run heads walk the minimizer table ------------------------------------------------
 			const int nh = nheads < kNH ? nheads : kNH;
 			for (int h = lane; h < nh; h += 64) {
-				const u32 q = S.heads[h] & 2047u;
+				const u32 q = (S.heads[h] >> 1) & 2047u;
 				const typename Mmer<MM>::type cm = tile_canonical_mmer<MM>(S.cw, (int)q);
 				const u32 fp = mmer_fp<MM>(cm);
 				u64 slot = mtab_home<MM>(cm, bx.mtab_cap);
@@ -888,8 +880,8 @@ map_reads_b_kernel(
 					jh = S.wread[hv >> 17]; // window position >> 5
 					off = cnt == kHnHeavy || cnt == kHnOverflow;
 					if (cnt >= 1 && cnt <= 2) {
-						const int o = (int)(hv & 2047u) - S.rstart[jh]; // offset of the minimizer in the read
-						const u32 rstrand = (hv >> 11) & 1u;
+						const int o = (int)((hv >> 1) & 2047u) - S.rstart[jh]; // offset of the minimizer in the read
+						const u32 rstrand = hv & 1u;
 						// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
 						const u64 e0 = hc[lane][0];
 						const bool s0 = ((u32)(e0 >> 62) & 1u) == rstrand;
