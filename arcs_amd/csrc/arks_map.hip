@@ -271,23 +271,32 @@ map_reads_kernel(
 // ------------------------------------------------------------------------------------------------
 // K3b: read mapping over the locality index -- the hot kernel.
 //
-// One wave (= one 64-thread workgroup) processes a TILE: as many consecutive reads as fit in kTW
-// packed words, laid out as one position space in LDS.  Per tile:
+// One wave (= one 64-thread workgroup) processes a TILE: consecutive reads in up to kTW packed words,
+// laid out as one position space in LDS.  The minimizer front half (T2-T4) runs once per PASS of
+// kSW words (64 lanes x 8 positions), the back half (T5-T7) once per tile so that its lanes
+// (run heads, 32-base words x 2 diagonals) are full.  FULL = false is the hot instantiation, FULL =
+// true the medium one (one queued read per tile, per-window records, general verification).
 //   T1  stage the tile's code / N-mask words in LDS (every later access to the reads is LDS);
-//   T2  lanes = base positions: canonical 15-mer + 21-bit order hash of every position;
-//   T3  sliding-window minimum by doubling (ping-pong between two LDS arrays) -> the minimizer
-//       position of every window;
-//   T4  lanes = windows: validity, run heads (first window of a run sharing a minimizer) compacted
-//       by ballot + prefix popcount; reverse-complement palindromes flagged through their
-//       mirrored minimizer (-> slow kernel, which evaluates the reference's damaged key exactly);
-//   T5  one lane per run walks the minimizer table (~5 runs per 151-bp read) and publishes the
-//       matching entries (text position, strand) of its run;
-//   T6  lanes = windows again: each pending window derives its own text position from its run's
-//       entry, fetches the text k-mer and compares it with its forward / reverse-complement key --
-//       exact, so membership is still key equality (Arcs/Arcs.h:153-156); the value comes from the
-//       position's visited / ambiguous bits and owner word; windows under a heavy minimizer probe
-//       the exact fallback table;
-//   T7  per read: vote exactly as bestContig does (Arcs.cpp:996-1013).
+//   T2  lane l owns positions 8l..8l+7: one funnel shift gives the <= 32 bases its m-mers span,
+//       every forward / reverse-complement m-mer is a shift + mask of that register pair; order
+//       value = 20-bit hash (two 24-bit multiply-adds) above position and strand bit;
+//   T3  sliding-window minimum: suffix minima of the lane's own 8 values (registers) + block minima
+//       of the whole lanes in between + prefix minima of a later lane (one LDS round trip);
+//   T4  run heads (first window of a run sharing a minimizer), numbered by ballot + mbcnt;
+//       reverse-complement palindromes flagged through their mirrored minimizer when the index
+//       holds quirk images (-> slow kernel, which evaluates the reference's damaged key exactly);
+//   T5  one lane per run head walks the minimizer table (~5 runs per 151-bp read), 4 entries per
+//       round trip, and publishes <= 2 matching entries (text position, strand);
+//   T6a lanes = run heads: the read's two diagonals (LDS atomic minima keyed by run index); a read
+//       with a heavy / overflowing run or a third diagonal goes to the medium queue;
+//   T6b lanes = read words x 2 diagonals: text / visited / ambiguous / owner words staged in one
+//       round trip, read XOR text -> one mismatch bit per base;
+//   T6c lanes = 32-window words x 2 diagonals, one bit per window: exists & no invalid base, k clear
+//       mismatch bits (constant time), visited, ambiguous; popcounts -> per-read counters (LDS
+//       atomics).  Exact: membership is still key equality (Arcs/Arcs.h:153-156), the value comes
+//       from the position's visited / ambiguous bits and owner word;
+//   T7  lane = read: vote exactly as bestContig does (Arcs.cpp:996-1013) -- at most two distinct
+//       positive values (one per diagonal), so the ordered walk is a compare.
 // HBM traffic per read: ~5 random 8-B minimizer entries + a few text / bit words, instead of ~100
 // random 64-B lines of the hash-table design.
 // ------------------------------------------------------------------------------------------------
