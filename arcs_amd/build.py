@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     return OUT
 
 
-HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("arcs.cpp", "graph.hpp", "seqio.hpp")]
+HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("arcs.cpp", "graph.hpp", "seqio.hpp", "ingest.hpp")]
 HOST_OUT = os.path.join(HERE, "bin", "arcs")
 
 
@@ -44,7 +44,7 @@ def build_host(force=False, verbose=False):
         return HOST_OUT
     os.makedirs(os.path.dirname(HOST_OUT), exist_ok=True)
     cxx = os.environ.get("CXX", "g++")
-    cmd = [cxx, "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+    cmd = [cxx, "-O2", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "host"), HOST_SOURCES[0],
            "-L" + os.path.dirname(OUT), "-larks_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz",
            "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-o", HOST_OUT]

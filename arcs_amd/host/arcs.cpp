@@ -14,14 +14,18 @@
 // path); both are reported as errors instead of being silently ignored.
 #include "arks_hip.h"
 #include "graph.hpp"
+#include "ingest.hpp"
 #include "seqio.hpp"
 
 #include <getopt.h>
 #include <hip/hip_runtime_api.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstring>
 #include <ctime>
+#include <map>
+#include <memory>
 
 using namespace arks_host;
 
@@ -44,7 +48,7 @@ struct Params
 	unsigned dist_bin_size = 20;
 	std::string dist_samples_tsv, dist_tsv;
 	GraphParams g;
-	long batch_pairs = 2000000; // --batch-pairs (this build only): read pairs per GPU batch
+	long batch_pairs = 262144; // --batch-pairs (this build only): read pairs per GPU batch
 	int device = 0;             // --device (this build only)
 };
 
@@ -131,7 +135,7 @@ const char USAGE[] =
             "   -v, --run_verbose     verbose logging\n"
             "   -k  --k_value         size of a k-mer [30]\n"
             "   -j  --j_index         minimum fraction of read kmers matching a contigId [0.55]\n"
-            "   -t  --threads         number of threads [1] (accepted; the mapping runs on the GPU)\n"
+            "   -t  --threads         number of host ingest threads [1] (parse / pack; the mapping runs on the GPU)\n"
             "   -P, --pair            output scaffolds pairing TSV\n"
             "       --batch-pairs=N   read pairs per GPU batch [2000000]\n"
             "       --device=N        GPU ordinal [0]\n";
@@ -163,29 +167,6 @@ read_fof(const std::string& fof)
 	while (in >> s)
 		v.push_back(s);
 	return v;
-}
-
-// Arcs.cpp:243-254
-void
-strip_read_num(std::string& name)
-{
-	const size_t pos = name.rfind('/');
-	if (pos == std::string::npos || pos == 0 || pos == name.length() - 1)
-		return;
-	if (!std::isdigit((unsigned char)name.at(pos + 1)))
-		return;
-	name.resize(pos);
-}
-
-// text after "BX:Z:" up to the next space (Arcs.cpp:1227-1237); empty when the tag is absent
-std::string
-bx_barcode(const std::string& comment)
-{
-	const size_t tag = comment.find("BX:Z:");
-	if (tag == std::string::npos)
-		return std::string();
-	const size_t end = comment.find(' ', tag);
-	return end != std::string::npos ? comment.substr(tag + 5, end - tag - 5) : comment.substr(tag + 5);
 }
 
 // Arcs.cpp:336-361
@@ -411,114 +392,134 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 }
 
 // ---- read mapping (replaces readChroms / chromiumRead, Arcs.cpp:1132-1370) -------------------------
-struct MapCounters
+// device buffers of one in-flight batch
+struct DeviceSet
 {
-	uint64_t stored = 0, skipped_invalid = 0, skipped_unpaired = 0, gated = 0, invalidbarcode = 0, emptybarcode = 0;
-};
-
-struct Batch
-{
-	std::string bases;
-	std::vector<uint64_t> off;
-	std::vector<uint32_t> len;
-	std::vector<uint8_t> pair_ok;
-	std::vector<uint32_t> barcode_id;
-	void clear()
-	{
-		bases.clear();
-		off.clear();
-		len.clear();
-		pair_ok.clear();
-		barcode_id.clear();
-	}
-	size_t pairs() const { return pair_ok.size(); }
-};
-
-struct Mapper
-{
-	arks_index* idx;
-	arks_imap* imap = nullptr;
-	hipStream_t stream = nullptr;
 	DevArray<uint64_t> d_codes, d_woff;
 	DevArray<uint32_t> d_nmask, d_len, d_bid;
 	DevArray<uint8_t> d_class, d_ok, d_eval;
 	DevArray<int32_t> d_conreci;
-	uint64_t* d_stored = nullptr;
-	arks_map_stats* d_stats = nullptr;
-	std::vector<uint64_t> h_codes, h_woff;
-	std::vector<uint32_t> h_nmask;
-	std::vector<uint8_t> h_class;
+	hipStream_t stream = nullptr;
+	hipEvent_t done = nullptr;
+	PackedBatch* inflight = nullptr;
+};
 
-	explicit Mapper(arks_index* i, int64_t imap_capacity)
+// The GPU end of the ingest pipeline: two device buffer sets on two streams, so that the copies of
+// one batch overlap the kernels of the previous one.  Counters are kept per input file.
+struct Mapper
+{
+	arks_index* idx;
+	arks_imap* imap = nullptr;
+	DeviceSet sets[2];
+	size_t turn = 0;
+	uint64_t* d_stored = nullptr;    // [n_files]
+	arks_map_stats* d_stats = nullptr; // [n_files]
+	size_t n_files;
+
+	Mapper(arks_index* i, int64_t imap_capacity, size_t nfiles)
 	  : idx(i)
+	  , n_files(nfiles)
 	{
 		int rc = arks_imap_create(&imap, imap_capacity, params.device);
 		if (rc != ARKS_OK)
 			die_arks(rc, "creating the IndexMap accumulator");
-		if (hipMalloc((void**)&d_stored, sizeof(uint64_t)) != hipSuccess ||
-		    hipMalloc((void**)&d_stats, sizeof(arks_map_stats)) != hipSuccess) {
+		if (hipMalloc((void**)&d_stored, nfiles * sizeof(uint64_t)) != hipSuccess ||
+		    hipMalloc((void**)&d_stats, nfiles * sizeof(arks_map_stats)) != hipSuccess) {
 			std::cerr << PROGRAM ": out of device memory\n";
 			exit(EXIT_FAILURE);
 		}
-		(void)hipMemset(d_stored, 0, sizeof(uint64_t));
-		(void)hipMemset(d_stats, 0, sizeof(arks_map_stats));
+		(void)hipMemset(d_stored, 0, nfiles * sizeof(uint64_t));
+		(void)hipMemset(d_stats, 0, nfiles * sizeof(arks_map_stats));
+		for (auto& s : sets)
+			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+			    hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+				std::cerr << PROGRAM ": cannot create a HIP stream\n";
+				exit(EXIT_FAILURE);
+			}
 	}
 
-	void run(Batch& b, MapCounters& mc)
+	~Mapper()
 	{
-		const int64_t n = (int64_t)b.len.size(), np = (int64_t)b.pairs();
-		if (n == 0)
+		for (auto& s : sets) {
+			if (s.done)
+				(void)hipEventDestroy(s.done);
+			if (s.stream)
+				(void)hipStreamDestroy(s.stream);
+		}
+		(void)hipFree(d_stored);
+		(void)hipFree(d_stats);
+	}
+
+	// waits until the set's previous batch is through and gives its host buffers back
+	void retire(DeviceSet& s, IngestPipeline& pipe)
+	{
+		if (!s.inflight)
 			return;
-		h_woff.resize((size_t)n + 1);
-		arks_word_offsets(b.len.data(), n, h_woff.data());
-		const size_t words = (size_t)h_woff[(size_t)n] + ARKS_PAD_WORDS;
-		h_codes.assign(words, 0);
-		h_nmask.assign(words, 0);
-		h_class.resize((size_t)n);
-		b.bases.push_back('\0');
-		arks_pack_reads_host(b.bases.data(), b.off.data(), b.len.data(), h_woff.data(), n, h_codes.data(),
-		                     h_nmask.data(), h_class.data());
-		for (int64_t p = 0; p < np; ++p)
-			if (b.pair_ok[(size_t)p]) {
-				mc.gated++;
-				if (!(h_class[(size_t)(2 * p)] && h_class[(size_t)(2 * p + 1)]))
-					mc.skipped_invalid++;
-			}
-		d_codes.reserve(words);
-		d_nmask.reserve(words);
-		d_woff.reserve((size_t)n + 1);
-		d_len.reserve((size_t)n);
-		d_class.reserve((size_t)n);
-		d_eval.reserve((size_t)n);
-		d_conreci.reserve((size_t)n);
-		d_ok.reserve((size_t)np);
-		d_bid.reserve((size_t)np);
+		if (hipEventSynchronize(s.done) != hipSuccess) {
+			std::cerr << PROGRAM ": device error while mapping\n";
+			exit(EXIT_FAILURE);
+		}
+		pipe.recycle(s.inflight);
+		s.inflight = nullptr;
+	}
+
+	int submit(PackedBatch* pb, IngestPipeline& pipe)
+	{
+		const int64_t n = pb->n_reads, np = pb->n_pairs;
+		if (n == 0) {
+			pipe.recycle(pb);
+			return ARKS_OK;
+		}
+		DeviceSet& s = sets[turn++ & 1];
+		retire(s, pipe);
+		const size_t words = pb->words;
+		s.d_codes.reserve(words);
+		s.d_nmask.reserve(words);
+		s.d_woff.reserve((size_t)n + 1);
+		s.d_len.reserve((size_t)n);
+		s.d_class.reserve((size_t)n);
+		s.d_eval.reserve((size_t)n);
+		s.d_conreci.reserve((size_t)n);
+		s.d_ok.reserve((size_t)np);
+		s.d_bid.reserve((size_t)np);
 		auto up = [&](void* d, const void* h, size_t bytes) {
-			if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) {
+			if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess) {
 				std::cerr << PROGRAM ": host to device copy failed\n";
 				exit(EXIT_FAILURE);
 			}
 		};
-		up(d_codes.p, h_codes.data(), words * sizeof(uint64_t));
-		up(d_nmask.p, h_nmask.data(), words * sizeof(uint32_t));
-		up(d_woff.p, h_woff.data(), ((size_t)n + 1) * sizeof(uint64_t));
-		up(d_len.p, b.len.data(), (size_t)n * sizeof(uint32_t));
-		up(d_class.p, h_class.data(), (size_t)n);
-		up(d_ok.p, b.pair_ok.data(), (size_t)np);
-		up(d_bid.p, b.barcode_id.data(), (size_t)np * sizeof(uint32_t));
-		int rc = arks_pair_gate_device(d_ok.p, d_class.p, np, d_eval.p, params.device, stream);
+		up(s.d_codes.p, pb->codes, words * sizeof(uint64_t));
+		up(s.d_nmask.p, pb->nmask, words * sizeof(uint32_t));
+		up(s.d_woff.p, pb->woff, ((size_t)n + 1) * sizeof(uint64_t));
+		up(s.d_len.p, pb->len, (size_t)n * sizeof(uint32_t));
+		up(s.d_class.p, pb->cls, (size_t)n);
+		up(s.d_ok.p, pb->pair_ok, (size_t)np);
+		up(s.d_bid.p, pb->barcode_id, (size_t)np * sizeof(uint32_t));
+		// the copies above overlap the other set's kernels; the kernels themselves are ordered: an index
+		// has ONE set of redo queues, so only one map call per index may be in flight (arks_hip.h)
+		DeviceSet& other = sets[turn & 1];
+		if (other.inflight && hipStreamWaitEvent(s.stream, other.done, 0) != hipSuccess)
+			return ARKS_ERR_HIP;
+		int rc = arks_pair_gate_device(s.d_ok.p, s.d_class.p, np, s.d_eval.p, params.device, s.stream);
 		if (rc == ARKS_OK)
-			rc = arks_map_reads_device(idx, d_codes.p, d_nmask.p, d_woff.p, d_len.p, d_eval.p, 2 * np,
-			                           params.j_index, d_conreci.p, params.verbose ? d_stats : nullptr, stream);
+			rc = arks_map_reads_device(idx, s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, 2 * np,
+			                           params.j_index, s.d_conreci.p, params.verbose ? d_stats + pb->file : nullptr,
+			                           s.stream);
 		if (rc == ARKS_OK)
-			rc = arks_pairs_device(d_conreci.p, d_ok.p, d_bid.p, np, nullptr, imap, d_stored, params.device, stream);
+			rc = arks_pairs_device(s.d_conreci.p, s.d_ok.p, s.d_bid.p, np, nullptr, imap, d_stored + pb->file,
+			                       params.device, s.stream);
 		if (rc != ARKS_OK)
-			die_arks(rc, "mapping a read batch");
-		if (hipStreamSynchronize(stream) != hipSuccess) {
-			std::cerr << PROGRAM ": device error while mapping\n";
-			exit(EXIT_FAILURE);
-		}
-		b.clear();
+			return rc;
+		if (hipEventRecord(s.done, s.stream) != hipSuccess)
+			return ARKS_ERR_HIP;
+		s.inflight = pb;
+		return ARKS_OK;
+	}
+
+	void drain(IngestPipeline& pipe)
+	{
+		for (auto& s : sets)
+			retire(s, pipe);
 	}
 };
 
@@ -527,100 +528,80 @@ read_chroms(
     const std::vector<std::string>& files, arks_index* idx, IndexMap& imap,
     const std::unordered_map<std::string, int>& mult, const std::vector<CI>& contigRecord)
 {
-	std::unordered_map<std::string, uint32_t> barcode_id;
-	std::vector<const std::string*> barcode_name;
-	barcode_id.reserve(mult.size());
-	Mapper mapper(idx, std::max<int64_t>(1 << 16, (int64_t)mult.size() * 8));
+	const size_t nf = files.size();
+	std::vector<std::unique_ptr<SeqReader>> readers;
 	for (const auto& file : files) {
-		if (params.verbose)
-			std::cout << "Reading chrom " << file << std::endl;
-		SeqReader rd(file.c_str());
-		if (!rd.ok()) {
+		readers.emplace_back(new SeqReader(file.c_str()));
+		if (!readers.back()->ok()) {
+			if (params.verbose)
+				std::cout << "Reading chrom " << file << std::endl;
 			std::cerr << "File " << file << " cannot be opened." << std::endl;
 			exit(1);
 		}
-		std::cerr << "File " << file << " opened." << std::endl;
-		MapCounters mc;
-		Batch b;
-		size_t count = 0;
-		bool stop = false;
-		std::string n1, n2, c1, c2, s1, s2;
-		uint64_t stored_before = 0;
-		(void)hipMemcpy(&stored_before, mapper.d_stored, sizeof(uint64_t), hipMemcpyDeviceToHost);
-		arks_map_stats st_before;
-		(void)hipMemcpy(&st_before, mapper.d_stats, sizeof st_before, hipMemcpyDeviceToHost);
-		while (!stop) {
-			n1.clear(), n2.clear(), c1.clear(), c2.clear(), s1.clear(), s2.clear();
-			int l = rd.next(); // Arcs.cpp:1187-1206
-			if (l >= 0) {
-				n1 = rd.name, c1 = rd.comment, s1 = rd.seq;
-				l = rd.next();
-				if (l >= 0)
-					n2 = rd.name, c2 = rd.comment, s2 = rd.seq;
-				else
-					stop = true;
-			} else
-				stop = true;
-			strip_read_num(n1);
-			strip_read_num(n2);
-			const bool paired = n1 == n2;
-			if (!paired) {
-				std::cout << "File contains unpaired reads: " << n1 << " " << n2 << std::endl;
-				mc.skipped_unpaired++;
-			}
-			count += 2;
-			if (params.verbose && count % 10000000 == 0)
-				std::cout << "Processed " << count << " read pairs." << std::endl;
-			if (stop)
-				break;
-			const std::string b1 = bx_barcode(c1), b2 = bx_barcode(c2);
-			bool valid = false;
-			if (b1.empty() || b2.empty())
-				mc.emptybarcode++;
-			else {
-				valid = mult.find(b1) != mult.end();
-				if (!valid)
-					mc.invalidbarcode++;
-			}
-			const bool ok = paired && valid && b1 == b2; // Arcs.cpp:1264-1265 (goodmult is always true)
-			uint32_t bid = 0;
-			if (ok) {
-				auto it = barcode_id.find(b1);
-				if (it == barcode_id.end()) {
-					it = barcode_id.emplace(b1, (uint32_t)barcode_name.size()).first;
-					barcode_name.push_back(&it->first);
-				}
-				bid = it->second;
-			}
-			b.off.push_back(b.bases.size());
-			b.len.push_back((uint32_t)s1.size());
-			b.bases += s1;
-			b.off.push_back(b.bases.size());
-			b.len.push_back((uint32_t)s2.size());
-			b.bases += s2;
-			b.pair_ok.push_back(ok ? 1 : 0);
-			b.barcode_id.push_back(bid);
-			if ((long)b.pairs() >= params.batch_pairs)
-				mapper.run(b, mc);
-		}
-		mapper.run(b, mc);
+	}
+	const BarcodeDict dict(mult);
+	Mapper mapper(idx, std::max<int64_t>(1 << 16, (int64_t)mult.size() * 8), std::max<size_t>(nf, 1));
+	HostAllocator pinned;
+	pinned.alloc = [](size_t n) {
+		void* p = nullptr;
+		return hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+	};
+	pinned.release = [](void* p) { (void)hipHostFree(p); };
+	std::vector<SeqReader*> rdp;
+	for (auto& r : readers)
+		rdp.push_back(r.get());
+	IngestPipeline pipe(rdp, mult, dict, params.batch_pairs, params.verbose != 0, params.threads, pinned);
+	std::vector<FileCounters> fc(nf);
+	std::vector<std::map<int64_t, std::string>> messages(nf);
+	const int prc = pipe.run([&](PackedBatch* pb) {
+		FileCounters& f = fc[(size_t)pb->file];
+		f.skipped_unpaired += pb->fc.skipped_unpaired, f.emptybarcode += pb->fc.emptybarcode,
+		    f.invalidbarcode += pb->fc.invalidbarcode, f.gated += pb->fc.gated,
+		    f.skipped_invalid += pb->fc.skipped_invalid;
+		if (!pb->messages.empty())
+			messages[(size_t)pb->file][pb->seq].swap(pb->messages);
+		pb->messages.clear();
+		return mapper.submit(pb, pipe);
+	});
+	if (prc != ARKS_OK)
+		die_arks(prc, "mapping a read batch");
+	mapper.drain(pipe);
+	if (hipDeviceSynchronize() != hipSuccess) {
+		std::cerr << PROGRAM ": device error while mapping\n";
+		exit(EXIT_FAILURE);
+	}
+	// the log of the stage, file by file as the reference prints it (Arcs.cpp:1158-1166, 1209-1215,
+	// 1321-1349); its s_* k-mer counters are process-wide, i.e. cumulative over the files
+	std::vector<uint64_t> stored(nf);
+	std::vector<arks_map_stats> st(nf);
+	if (nf) {
+		(void)hipMemcpy(stored.data(), mapper.d_stored, nf * sizeof(uint64_t), hipMemcpyDeviceToHost);
+		(void)hipMemcpy(st.data(), mapper.d_stats, nf * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
+	}
+	arks_map_stats cum;
+	std::memset(&cum, 0, sizeof cum);
+	for (size_t f = 0; f < nf; ++f) {
+		if (params.verbose)
+			std::cout << "Reading chrom " << files[f] << std::endl;
+		std::cerr << "File " << files[f] << " opened." << std::endl;
+		for (const auto& kv : messages[f])
+			std::cout << kv.second;
+		std::cout.flush();
+		cum.total_valid += st[f].total_valid, cum.bad += st[f].bad, cum.found += st[f].found,
+		    cum.recorded += st[f].recorded, cum.dups += st[f].dups, cum.reads_pass += st[f].reads_pass,
+		    cum.reads_fail += st[f].reads_fail, cum.windows += st[f].windows;
 		if (params.verbose) {
-			uint64_t stored_after = 0;
-			arks_map_stats st;
-			(void)hipMemcpy(&stored_after, mapper.d_stored, sizeof(uint64_t), hipMemcpyDeviceToHost);
-			(void)hipMemcpy(&st, mapper.d_stats, sizeof st, hipMemcpyDeviceToHost);
-			const uint64_t stored = stored_after - stored_before;
+			const FileCounters& mc = fc[f];
 			printf("Stored read pairs: %u\nSkipped invalid read pairs: %u\nSkipped unpaired reads: "
 			       "%u\nSkipped reads pairs without a good contig: %u\n",
-			       (unsigned)stored, (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
-			       (unsigned)(mc.gated - stored));
-			// the reference's s_* counters are process-wide: cumulative over the files
+			       (unsigned)stored[f], (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
+			       (unsigned)(mc.gated - stored[f]));
 			printf("Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
 			       "%u\nNumber of kmers recorded in Ktrack: %u\nNumber of kmers found in ContigKmap but "
 			       "duplicate: %u\nNumber of reads passing jaccard threshold: %u\nNumber of reads failing "
 			       "jaccard threshold: %u\n",
-			       (unsigned)st.total_valid, (unsigned)st.bad, (unsigned)st.found, (unsigned)st.recorded,
-			       (unsigned)st.dups, (unsigned)st.reads_pass, (unsigned)st.reads_fail);
+			       (unsigned)cum.total_valid, (unsigned)cum.bad, (unsigned)cum.found, (unsigned)cum.recorded,
+			       (unsigned)cum.dups, (unsigned)cum.reads_pass, (unsigned)cum.reads_fail);
 			if (mc.emptybarcode > 0)
 				printf("WARNING:: Your chromium read file has %d readpairs that have an empty barcode.",
 				       (int)mc.emptybarcode);
@@ -628,10 +609,11 @@ read_chroms(
 				printf("WARNING:: Your chromium read file has %d read pairs that have barcodes not in the "
 				       "barcode multiplicity file.",
 				       (int)mc.invalidbarcode);
+			fflush(stdout);
 		}
-		// the reference completes the IndexMap after every file (Arcs.cpp:1304-1319); the
-		// accumulator is additive, so the rebuild below after the last file gives the same map
 	}
+	// the reference completes the IndexMap after every file (Arcs.cpp:1304-1319); the accumulator is
+	// additive, so the rebuild below after the last file gives the same map
 	const int64_t n = arks_imap_size(mapper.imap);
 	if (n < 0)
 		die_arks((int)-n, "reading the IndexMap accumulator");
@@ -640,7 +622,7 @@ read_chroms(
 	if (rc != ARKS_OK)
 		die_arks(rc, "exporting the IndexMap");
 	for (int64_t i = 0; i < n; ++i)
-		imap[*barcode_name[triples[3 * i]]][contigRecord[triples[3 * i + 1]]] += (int)triples[3 * i + 2];
+		imap[*dict.name[triples[3 * i]]][contigRecord[triples[3 * i + 1]]] += (int)triples[3 * i + 2];
 	add_opposite_ends(imap);
 	arks_imap_free(mapper.imap);
 }
@@ -668,6 +650,16 @@ run_arks(const std::vector<std::string>& filenames)
 	ContigToLength contigToLength;
 	std::vector<CI> contigRecord;
 
+	// ARKS_TIMING=1: wall time of each stage on stderr (this build only)
+	const bool timing = getenv("ARKS_TIMING") != nullptr;
+	auto t_prev = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		const auto t = std::chrono::steady_clock::now();
+		if (timing)
+			std::cerr << "[timing] " << what << ": "
+			          << std::chrono::duration_cast<std::chrono::milliseconds>(t - t_prev).count() << " ms\n";
+		t_prev = t;
+	};
 	std::cout << "\n=>Preprocessing: Gathering barcode multiplicity information..." << now();
 	if (!params.multfile.empty())
 		create_index_mult_map(params.multfile, mult);
@@ -677,10 +669,13 @@ run_arks(const std::vector<std::string>& filenames)
 		read_barcodes(filenames, mult);
 	}
 	std::cout << "\n=>Preprocessing: Gathering draft information..." << now() << "\n";
+	lap("barcode multiplicities");
 	std::cout << "\n=>Storing Kmers from Contig ends... " << now() << std::endl;
 	arks_index* idx = build_contig_index(contigRecord, contigToLength);
+	lap("contig index (read draft + device build)");
 	std::cout << "\n=>Reading Chromium FASTQ file(s)... " << now() << std::endl;
 	read_chroms(filenames, idx, imap, mult, contigRecord);
+	lap("read files -> IndexMap (ingest pipeline + GPU mapping)");
 	arks_index_free(idx);
 	std::cout << "Cumulative memory usage: " << memory_usage() << std::endl;
 

@@ -1,0 +1,135 @@
+// ingest_check.cpp -- test driver for ingest.hpp (no GPU work: parse, gate and pack only).
+//
+//   ingest_check <threads> <batch_pairs> <multiplicity.tsv> <reads.fq[.gz]>...
+//
+// Prints, per input file in file order: the stage counters, the stdout messages of the record loop,
+// and a digest of everything the GPU stage would receive (per read: length, class, packed code and
+// N-mask words; per pair: gate and barcode).  The digest is independent of thread count and batch
+// size; tests/test_host_ingest.py recomputes it from the FASTQ text.
+#include "ingest.hpp"
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+
+using namespace arks_host;
+
+namespace {
+
+struct Fnv
+{
+	uint64_t h = 1469598103934665603ull;
+	void bytes(const void* p, size_t n)
+	{
+		const unsigned char* b = (const unsigned char*)p;
+		for (size_t i = 0; i < n; ++i) {
+			h ^= b[i];
+			h *= 1099511628211ull;
+		}
+	}
+	template <typename T>
+	void pod(T v)
+	{
+		bytes(&v, sizeof v);
+	}
+};
+
+} // namespace
+
+int
+main(int argc, char** argv)
+{
+	if (argc < 5) {
+		std::cerr << "usage: ingest_check <threads> <batch_pairs> <multiplicity.tsv> <reads>...\n";
+		return 2;
+	}
+	const unsigned threads = (unsigned)std::atoi(argv[1]);
+	const long batch_pairs = std::atol(argv[2]);
+	std::unordered_map<std::string, int> mult;
+	{
+		std::ifstream in(argv[3]);
+		std::string bc;
+		int m;
+		while (in >> bc >> m)
+			mult[bc] = m;
+	}
+	std::vector<std::string> files(argv + 4, argv + argc);
+	std::vector<std::unique_ptr<SeqReader>> readers;
+	std::vector<SeqReader*> rdp;
+	for (const auto& f : files) {
+		readers.emplace_back(new SeqReader(f.c_str()));
+		if (!readers.back()->ok()) {
+			std::cerr << "File " << f << " cannot be opened.\n";
+			return 1;
+		}
+		rdp.push_back(readers.back().get());
+	}
+	const BarcodeDict dict(mult);
+	IngestPipeline pipe(rdp, mult, dict, batch_pairs, true, threads, HostAllocator());
+	const size_t nf = files.size();
+	struct PerBatch
+	{
+		std::vector<uint64_t> read_hash, pair_hash;
+		std::string messages;
+	};
+	std::vector<std::map<int64_t, PerBatch>> got(nf);
+	std::vector<FileCounters> fc(nf);
+	std::vector<uint64_t> pairs(nf), reads(nf), batches(nf);
+	const int rc = pipe.run([&](PackedBatch* pb) {
+		const size_t f = (size_t)pb->file;
+		PerBatch& out = got[f][pb->seq];
+		out.messages = pb->messages;
+		fc[f].skipped_unpaired += pb->fc.skipped_unpaired, fc[f].emptybarcode += pb->fc.emptybarcode,
+		    fc[f].invalidbarcode += pb->fc.invalidbarcode, fc[f].gated += pb->fc.gated,
+		    fc[f].skipped_invalid += pb->fc.skipped_invalid;
+		pairs[f] += (uint64_t)pb->n_pairs, reads[f] += (uint64_t)pb->n_reads, batches[f]++;
+		for (int64_t r = 0; r < pb->n_reads; ++r) {
+			Fnv h;
+			h.pod<uint32_t>(pb->len[r]);
+			h.pod<uint8_t>(pb->cls[r]);
+			for (uint64_t w = pb->woff[r]; w < pb->woff[r + 1]; ++w) {
+				h.pod<uint64_t>(pb->codes[w]);
+				h.pod<uint32_t>(pb->nmask[w]);
+			}
+			out.read_hash.push_back(h.h);
+		}
+		for (int64_t p = 0; p < pb->n_pairs; ++p) {
+			Fnv h;
+			h.pod<uint8_t>(pb->pair_ok[p]);
+			if (pb->pair_ok[p]) {
+				const std::string& name = *dict.name[pb->barcode_id[p]];
+				h.bytes(name.data(), name.size());
+			}
+			out.pair_hash.push_back(h.h);
+		}
+		pipe.recycle(pb);
+		return ARKS_OK;
+	});
+	if (rc != ARKS_OK) {
+		std::cerr << "ingest failed: " << arks_strerror(rc) << "\n";
+		return 1;
+	}
+	std::printf("threads producers=%u packers=%u\n", pipe.producers(), pipe.packers());
+	for (size_t f = 0; f < nf; ++f) {
+		Fnv d;
+		std::string messages;
+		for (const auto& kv : got[f]) {
+			for (uint64_t h : kv.second.read_hash)
+				d.pod(h);
+			messages += kv.second.messages;
+		}
+		for (const auto& kv : got[f])
+			for (uint64_t h : kv.second.pair_hash)
+				d.pod(h);
+		std::printf("file %zu pairs=%llu reads=%llu unpaired=%llu empty=%llu invalid=%llu gated=%llu "
+		            "skipped_invalid=%llu digest=%016llx multibatch=%d\n",
+		            f, (unsigned long long)pairs[f], (unsigned long long)reads[f],
+		            (unsigned long long)fc[f].skipped_unpaired, (unsigned long long)fc[f].emptybarcode,
+		            (unsigned long long)fc[f].invalidbarcode, (unsigned long long)fc[f].gated,
+		            (unsigned long long)fc[f].skipped_invalid, (unsigned long long)d.h, batches[f] > 1 ? 1 : 0);
+		std::fputs(messages.c_str(), stdout);
+	}
+	return 0;
+}

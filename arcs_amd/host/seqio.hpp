@@ -10,6 +10,7 @@
 
 #include <zlib.h>
 
+#include <cstring>
 #include <string>
 
 namespace arks_host {
@@ -21,7 +22,10 @@ class SeqReader
 
 	explicit SeqReader(const char* path)
 	  : fp_(gzopen(path, "r"))
-	{}
+	{
+		if (fp_)
+			gzbuffer(fp_, 1u << 20);
+	}
 	~SeqReader()
 	{
 		if (fp_)
@@ -71,9 +75,7 @@ class SeqReader
 			last_ = c;
 		if (c != '+')
 			return (int)seq.size();
-		while ((c = getc()) != -1 && c != '\n') {
-		}
-		if (c == -1)
+		if (!skip_line())
 			return -2;
 		while (read_line(qual, true) >= 0 && qual.size() < seq.size()) {
 		}
@@ -85,25 +87,45 @@ class SeqReader
 
   private:
 	gzFile fp_;
-	unsigned char buf_[1 << 16];
+	unsigned char buf_[1 << 18];
 	int begin_ = 0, end_ = 0;
 	bool eof_ = false;
 	int last_ = 0;
 
+	bool fill()
+	{
+		if (eof_ || !fp_)
+			return false;
+		begin_ = 0;
+		end_ = gzread(fp_, buf_, sizeof buf_);
+		if (end_ <= 0) {
+			end_ = 0;
+			eof_ = true;
+			return false;
+		}
+		return true;
+	}
+
 	int getc()
 	{
-		if (begin_ >= end_) {
-			if (eof_ || !fp_)
-				return -1;
-			begin_ = 0;
-			end_ = gzread(fp_, buf_, sizeof buf_);
-			if (end_ <= 0) {
-				end_ = 0;
-				eof_ = true;
-				return -1;
-			}
-		}
+		if (begin_ >= end_ && !fill())
+			return -1;
 		return buf_[begin_++];
+	}
+
+	// consumes up to and including the next newline; false when the stream ends first
+	bool skip_line()
+	{
+		for (;;) {
+			if (begin_ >= end_ && !fill())
+				return false;
+			const void* nl = std::memchr(buf_ + begin_, '\n', (size_t)(end_ - begin_));
+			if (nl) {
+				begin_ = (int)((const unsigned char*)nl - buf_) + 1;
+				return true;
+			}
+			begin_ = end_;
+		}
 	}
 
 	// appends (or assigns) the rest of the current line; returns the string length, or -1 when
@@ -113,12 +135,19 @@ class SeqReader
 		if (!append)
 			s.clear();
 		bool got = false;
-		int c;
-		while ((c = getc()) != -1) {
-			got = true;
-			if (c == '\n')
+		for (;;) {
+			if (begin_ >= end_ && !fill())
 				break;
-			s.push_back((char)c);
+			got = true;
+			const unsigned char* from = buf_ + begin_;
+			const void* nl = std::memchr(from, '\n', (size_t)(end_ - begin_));
+			if (nl) {
+				s.append((const char*)from, (const char*)nl);
+				begin_ = (int)((const unsigned char*)nl - buf_) + 1;
+				break;
+			}
+			s.append((const char*)from, (const char*)(buf_ + end_));
+			begin_ = end_;
 		}
 		if (!got)
 			return -1;

@@ -167,7 +167,10 @@ int arks_pack_reads_host(
  * d_out_conreci[r] = the contig end whose k-mers dominate read r (count/total > j_index, ties to
  * the smallest index, total counts NULL windows too) or 0.  d_eval (may be NULL = all) selects the
  * reads bestContig is called for (Arcs.cpp:1268); the others get 0 and touch no counter.
- * d_stats (may be NULL) points to one arks_map_stats in device memory that is ADDED to. */
+ * d_stats (may be NULL) points to one arks_map_stats in device memory that is ADDED to.
+ * Asynchronous on `stream`.  An index owns ONE set of work queues for this call: calls on the same
+ * index must be ordered with respect to each other (same stream, or stream events) -- copies and
+ * the other entry points may overlap them freely. */
 int arks_map_reads_device(
     const arks_index* idx,
     const uint64_t* d_codes,

@@ -147,3 +147,33 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
     n_unpaired = sum(1 for r in recs if _strip_read_num(r[0]) != _strip_read_num(r[3]))
     assert out.count("File contains unpaired reads:") == n_unpaired
     assert f"Skipped unpaired reads: {n_unpaired}\n" in out
+    # ---- the same reads split over three files (gz, plain, empty), more ingest threads: files are
+    #      parsed in parallel, every output and the cumulative counters stay the same -----------------
+    cut = (n_pairs // 3) | 1
+    parts = [recs[:cut], recs[cut:], []]
+    paths = [tmp_path / "part0.fq.gz", tmp_path / "part1.fq", tmp_path / "part2.fastq"]
+    for path, part in zip(paths, parts):
+        opener = gzip.open if str(path).endswith(".gz") else open
+        with opener(path, "wt") as f:
+            for (n1, c1, s1, n2, c2, s2) in part:
+                f.write(f"@{n1} {c1}\n{s1}\n+\n{'F' * len(s1)}\n@{n2} {c2}\n{s2}\n+\n{'F' * len(s2)}\n")
+    args2 = [a for a in args[:-1]]
+    args2[args2.index("-b") + 1] = str(tmp_path / "multi")
+    args2[args2.index("-t") + 1] = "5"
+    args2[args2.index("--batch-pairs") + 1] = "333"
+    args2[args2.index("--barcode-counts") + 1] = str(tmp_path / "counts2")
+    res2 = subprocess.run(args2 + [str(x) for x in paths], capture_output=True, text=True, timeout=300)
+    assert res2.returncode == 0, res2.stderr[-2000:]
+    for suffix in ("_original.gv", "_pair.tsv", "_main.tsv"):
+        assert open(str(tmp_path / "multi") + suffix).read() == open(base + suffix).read(), suffix
+    assert open(str(tmp_path / "counts2.tsv")).read() == open(str(tmp_path / "counts.tsv")).read()
+    out2 = res2.stdout
+    assert out2.count("Stored read pairs:") == 3 and out2.count("File contains unpaired reads:") == n_unpaired
+    last = out2[out2.rindex("Stored read pairs:"):]
+    assert f"Total valid kmers: {st['total_valid']}\n" in last          # s_* counters are cumulative
+    assert f"Number of reads passing jaccard threshold: {st['reads_pass']}\n" in last
+    stored_parts = [int(x.split("\n")[0]) for x in out2.split("Stored read pairs: ")[1:]]
+    assert sum(stored_parts) == stored and stored_parts[2] == 0
+    # messages keep file order
+    assert out2.index(f"Reading chrom {paths[0]}") < out2.index(f"Reading chrom {paths[1]}") < \
+        out2.index(f"Reading chrom {paths[2]}")

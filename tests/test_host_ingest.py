@@ -1,0 +1,206 @@
+"""arcs_amd/host/ingest.hpp (the pipelined ingest of `arcs --arks`: producers per file, packer pool)
+against a Python restatement of the record-pair loop of chromiumRead (Arcs/Arcs.cpp:1185-1268) and of
+the packed read layout; the result must not depend on thread count, batch size or gzip."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "arcs_amd", "host")
+MASK = (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory, arks):
+    out = str(tmp_path_factory.mktemp("bin") / "ingest_check")
+    libdir = os.path.join(ROOT, "arcs_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + HOST, os.path.join(HOST, "ingest_check.cpp"),
+                           "-L" + libdir, "-larks_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+    return out
+
+
+def fnv(h, data):
+    for b in data:
+        h = ((h ^ b) * 1099511628211) & MASK
+    return h
+
+
+FNV0 = 1469598103934665603
+CODE = {c: i for i, c in enumerate("ACGT")}
+CODE.update({c.lower(): i for c, i in list(CODE.items())})
+
+
+def read_hash(seq, cls):
+    """length, class, then per 32-base word: 2-bit codes MSB-first (u64) and invalid-base mask (u32,
+    bit 31 = first base of the word) -- the layout of include/arks_hip.h"""
+    h = fnv(FNV0, len(seq).to_bytes(4, "little") + bytes([cls]))
+    for w0 in range(0, len(seq), 32):
+        codes = nm = 0
+        for p, ch in enumerate(seq[w0:w0 + 32]):
+            if ch in CODE:
+                codes |= CODE[ch] << (62 - 2 * p)
+            else:
+                nm |= 1 << (31 - p)
+        h = fnv(h, codes.to_bytes(8, "little") + nm.to_bytes(4, "little"))
+    return h
+
+
+def strip_read_num(name):
+    pos = name.rfind("/")
+    if pos in (-1, 0, len(name) - 1) or not name[pos + 1].isdigit():
+        return name
+    return name[:pos]
+
+
+def bx(comment):
+    tag = comment.find("BX:Z:")
+    if tag < 0:
+        return ""
+    end = comment.find(" ", tag)
+    return comment[tag + 5:end] if end >= 0 else comment[tag + 5:]
+
+
+def expected(records, mult, oracle):
+    """records: (name, comment, seq) of the well-formed records in file order; `None` = a record
+    that ends the stream (kseq returns a negative length)"""
+    c = dict(pairs=0, reads=0, unpaired=0, empty=0, invalid=0, gated=0, skipped_invalid=0)
+    rh, ph, msgs = [], [], []
+    i = 0
+    while True:
+        r1 = records[i] if i < len(records) else None
+        r2 = records[i + 1] if r1 is not None and i + 1 < len(records) else None
+        i += 2
+        n1 = strip_read_num(r1[0]) if r1 else ""
+        n2 = strip_read_num(r2[0]) if r2 else ""
+        if n1 != n2:
+            msgs.append(f"File contains unpaired reads: {n1} {n2}\n")
+            c["unpaired"] += 1
+        if r1 is None or r2 is None:
+            break
+        b1, b2 = bx(r1[1]), bx(r2[1])
+        valid = False
+        if not b1 or not b2:
+            c["empty"] += 1
+        else:
+            valid = b1 in mult
+            if not valid:
+                c["invalid"] += 1
+        ok = n1 == n2 and valid and b1 == b2
+        cls = [int(oracle.check_read_sequence(r[2])) for r in (r1, r2)]
+        rh += [read_hash(r1[2], cls[0]), read_hash(r2[2], cls[1])]
+        ph.append(fnv(fnv(FNV0, bytes([1])), b1.encode()) if ok else fnv(FNV0, bytes([0])))
+        c["pairs"] += 1
+        c["reads"] += 2
+        if ok:
+            c["gated"] += 1
+            c["skipped_invalid"] += not (cls[0] and cls[1])
+    d = FNV0
+    for h in rh + ph:
+        d = fnv(d, h.to_bytes(8, "little"))
+    return c, f"{d:016x}", "".join(msgs)
+
+
+def make_records(rng, n_pairs, barcodes):
+    def rnd(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+    recs = []
+    for p in range(n_pairs):
+        kind = int(rng.integers(0, 20))
+        bc = barcodes[int(rng.integers(len(barcodes)))]
+        name = f"read{p}"
+        c1 = c2 = f"BX:Z:{bc}"
+        if kind == 0:
+            c1 = c2 = ""                                  # no comment at all
+        elif kind == 1:
+            c2 = "BX:Z:" + barcodes[(barcodes.index(bc) + 1) % len(barcodes)]   # mates disagree
+        elif kind == 2:
+            c1 = c2 = "BX:Z:NOTINTHEMAP-1"
+        elif kind == 3:
+            c1 = f"RX:Z:x BX:Z:{bc} QX:Z:y"              # tag in the middle
+            c2 = f"BX:Z:{bc} more"
+        s1, s2 = rnd(int(rng.choice([128, 151, 59, 33, 250]))), rnd(int(rng.choice([128, 151, 1, 64])))
+        if kind == 4:
+            s1 = s1[:10] + "N" + s1[11:]                  # one N: still under the 2 % rule for >= 51 b
+        if kind == 5:
+            s2 = "N" * 8 + s2[8:]
+        if kind == 6:
+            s1 = s1.lower()
+        n1, n2 = name + "/1", name + "/2"
+        if kind == 7:
+            n2 = name + "x/2"                             # names differ
+        if kind == 8:
+            n1, n2 = name, name                           # no read number suffix
+        recs.append((n1, c1, s1))
+        recs.append((n2, c2, s2))
+    return recs
+
+
+def write_fastq(path, recs, tail=""):
+    text = "".join(f"@{n}{' ' + c if c else ''}\n{s}\n+\n{'I' * len(s)}\n" for n, c, s in recs) + tail
+    if path.endswith(".gz"):
+        with gzip.open(path, "wt") as f:
+            f.write(text)
+    else:
+        with open(path, "w") as f:
+            f.write(text)
+
+
+def run(exe, threads, batch, mult_path, files):
+    out = subprocess.check_output([exe, str(threads), str(batch), mult_path] + files, text=True)
+    lines = out.splitlines(keepends=True)
+    res, cur = [], None
+    for ln in lines[1:]:
+        if ln.startswith("file "):
+            kv = dict(t.split("=") for t in ln.split()[2:])
+            cur = dict(kv=kv, msgs="")
+            res.append(cur)
+        else:
+            cur["msgs"] += ln
+    return lines[0], res
+
+
+def test_pipeline_matches_restatement(exe, oracle, tmp_path):
+    rng = np.random.Generator(np.random.PCG64(11))
+    barcodes = [f"{''.join('ACGT'[i] for i in rng.integers(0, 4, size=16))}-1" for _ in range(40)]
+    mult = {b: int(rng.integers(1, 500)) for b in barcodes[:35]}      # five barcodes are not in the map
+    mult_path = str(tmp_path / "mult.tsv")
+    with open(mult_path, "w") as f:
+        f.writelines(f"{b}\t{m}\n" for b, m in mult.items())
+    files, want = [], []
+    for fi, (n_pairs, ext, tail_kind) in enumerate([(700, ".fq", 0), (300, ".fq.gz", 1), (0, ".fastq", 0),
+                                                    (257, ".fq.gz", 2)]):
+        recs = make_records(rng, n_pairs, barcodes)
+        tail, exp_recs = "", list(recs)
+        if tail_kind == 1:     # an odd record at the end: mate missing -> "unpaired" message, stream ends
+            recs.append(("lonely/1", f"BX:Z:{barcodes[0]}", "ACGTACGTAC"))
+            exp_recs = list(recs)
+        if tail_kind == 2:     # quality shorter than the sequence: kseq returns -2, the loop stops
+            tail = "@trunc/1 BX:Z:x\nACGTACGT\n+\nIII\n"
+        path = str(tmp_path / f"reads{fi}{ext}")
+        write_fastq(path, recs, tail)
+        files.append(path)
+        want.append(expected(exp_recs, mult, oracle))
+    base = None
+    for threads, batch in [(1, 1 << 20), (2, 64), (8, 50), (3, 1), (6, 1000)]:
+        head, res = run(exe, threads, batch, mult_path, files)
+        assert len(res) == len(files)
+        for fi, r in enumerate(res):
+            c, digest, msgs = want[fi]
+            kv = r["kv"]
+            got = dict(pairs=int(kv["pairs"]), reads=int(kv["reads"]), unpaired=int(kv["unpaired"]),
+                       empty=int(kv["empty"]), invalid=int(kv["invalid"]), gated=int(kv["gated"]),
+                       skipped_invalid=int(kv["skipped_invalid"]))
+            assert got == c, (threads, batch, fi)
+            assert kv["digest"] == digest, (threads, batch, fi)
+            assert r["msgs"] == msgs, (threads, batch, fi)
+        if batch <= 64:
+            assert res[0]["kv"]["multibatch"] == "1"
+        base = base or res
+    # the thread split the front end reports
+    head, _ = run(exe, 8, 100, mult_path, files)
+    assert head.strip() == "threads producers=4 packers=4"
