@@ -280,6 +280,30 @@ done:
 	return rc;
 }
 
+// 8 bases at a time for the host packer: 2-bit codes by ((c >> 1) ^ (c >> 2)) & 3 (A, C, G, T in either
+// case -> 0..3), validity by byte-wise equality tests, the per-byte bits gathered with PEXT after a
+// byte swap so that the first base lands in the most significant position.  *codes16 = 8 codes,
+// *bad8 = bit (7 - j) set when base j is not one of ACGTacgt, *n8 = ... is N or n.
+__attribute__((target("bmi2"))) static inline void
+pack8_bmi2(const unsigned char* p, uint32_t* codes16, uint32_t* bad8, uint32_t* n8)
+{
+	uint64_t x;
+	std::memcpy(&x, p, 8);
+	x = __builtin_bswap64(x);
+	const uint64_t k01 = 0x0101010101010101ull, k7f = 0x7F7F7F7F7F7F7F7Full, k80 = 0x8080808080808080ull;
+	const uint64_t u = x & 0xDFDFDFDFDFDFDFDFull; // upper case
+	auto eq = [&](unsigned char ch) { // 0x80 in every byte of u that equals ch (exact, no carries across bytes)
+		const uint64_t v = u ^ (k01 * ch);
+		return ~(((v & k7f) + k7f) | v | k7f);
+	};
+	const uint64_t valid = eq('A') | eq('C') | eq('G') | eq('T');
+	const uint64_t isn = eq('N');
+	const uint64_t two = ((x >> 1) ^ (x >> 2)) & (k01 * 3) & ((valid >> 7) * 3);
+	*codes16 = (uint32_t)__builtin_ia32_pext_di(two, k01 * 3);
+	*bad8 = (uint32_t)__builtin_ia32_pext_di(~valid & k80, k80);
+	*n8 = (uint32_t)__builtin_ia32_pext_di(isn, k80);
+}
+
 int
 arks_pack_reads_host(
     const char* h_ascii,
@@ -308,6 +332,7 @@ arks_pack_reads_host(
 		cls['N'] = cls['n'] = 4;
 		ready = true;
 	}
+	const bool fast = __builtin_cpu_supports("bmi2");
 	for (int64_t r = 0; r < n_reads; ++r) {
 		const unsigned char* s = reinterpret_cast<const unsigned char*>(h_ascii) + h_offsets[r];
 		const uint32_t len = h_lens[r];
@@ -319,7 +344,17 @@ arks_pack_reads_host(
 			uint64_t c = 0;
 			uint32_t m = 0;
 			const uint32_t n = std::min<uint32_t>(32, len - (uint32_t)(w * 32));
-			for (uint32_t i = 0; i < n; ++i) {
+			uint32_t i = 0;
+			if (fast)
+				for (; i + 8 <= n; i += 8) {
+					uint32_t codes16, bad8, n8;
+					pack8_bmi2(s + w * 32 + i, &codes16, &bad8, &n8);
+					c |= (uint64_t)codes16 << (48 - 2 * i);
+					m |= bad8 << (24 - i);
+					nn += (uint32_t)__builtin_popcount(n8);
+					other |= bad8 & ~n8;
+				}
+			for (; i < n; ++i) {
 				const uint32_t x = cls[s[w * 32 + i]];
 				c |= (uint64_t)(x < 4 ? x : 0) << (62 - 2 * i);
 				m |= (uint32_t)(x >= 4) << (31 - i);

@@ -247,7 +247,7 @@ pack_batch(RawBatch& rb, PackedBatch& pb, const HostAllocator& a)
 // `emit` (the last one flagged, possibly empty).
 inline void
 produce_file(
-    SeqReader& rd, int file_idx, const std::unordered_map<std::string, int>& mult, const BarcodeDict& dict,
+    SeqReader& rd, int file_idx, const std::unordered_map<std::string, int>& /*mult*/, const BarcodeDict& dict,
     long batch_pairs, bool verbose, const std::function<void(RawBatch&&)>& emit)
 {
 	RawBatch b;
@@ -296,13 +296,16 @@ produce_file(
 		if (b1.empty() || b2.empty())
 			b.fc.emptybarcode++;
 		else {
-			valid = mult.find(b1) != mult.end();
+			const auto it = dict.id.find(b1); // same key set as the multiplicity map (Arcs.cpp:1258)
+			valid = it != dict.id.end();
 			if (!valid)
 				b.fc.invalidbarcode++;
+			else
+				bid = it->second;
 		}
 		const bool ok = paired && valid && b1 == b2; // Arcs.cpp:1264-1265 (goodmult is always true)
-		if (ok)
-			bid = dict.id.find(b1)->second;
+		if (!ok)
+			bid = 0;
 		b.off.push_back(b.bases.size());
 		b.len.push_back((uint32_t)s1.size());
 		b.bases += s1;
