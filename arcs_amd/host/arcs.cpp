@@ -22,6 +22,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdarg>
 #include <cstring>
 #include <ctime>
 #include <map>
@@ -303,6 +304,20 @@ memory_usage()
 	return 0;
 }
 
+// printf into a string: in the fused barcode mode (no -u) the stages do not run in the order the
+// reference prints them, so their stdout text is collected and emitted in the reference's order
+void
+appendf(std::string& out, const char* fmt, ...)
+{
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	const int n = vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (n > 0)
+		out.append(buf, (size_t)std::min<int>(n, (int)sizeof buf - 1));
+}
+
 template <typename T>
 struct DevArray
 {
@@ -329,7 +344,7 @@ struct DevArray
 
 // ---- the contig index (replaces initContigArray + getContigKmers, Arcs.cpp:451-479, 1021-1129) ----
 arks_index*
-build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength)
+build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength, std::string& log)
 {
 	// pass 1 of the reference only sizes contigRecord; it also filters on the IUPAC alphabet, which
 	// the second pass does not (Q10 of SURVEY.md): a contig with a foreign character would leave
@@ -367,7 +382,7 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 		} else
 			skipped++;
 		if (params.verbose && total % 1000 == 0)
-			printf("Finished %d Contigs...\n", total);
+			appendf(log, "Finished %d Contigs...\n", total);
 	}
 	bases.push_back('\0');
 	arks_index* idx = nullptr;
@@ -379,8 +394,8 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 		die_arks(rc, "building the contig k-mer index");
 	if (params.verbose) {
 		for (uint64_t i = 0; i < st.short_ends; ++i) // Arcs.cpp:877-882 prints one line per short end
-			std::cout << "Warning: ends of contig is shorter than k-value (no k-mers added)" << std::endl;
-		printf("%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n",
+			log += "Warning: ends of contig is shorter than k-value (no k-mers added)\n";
+		appendf(log, "%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n",
 		       "Total number of contigs in draft genome: ", (unsigned)total, "Total valid contigs: ", (unsigned)valid,
 		       "Total skipped contigs: ", (unsigned)skipped, "Total number of Kmers: ", (unsigned)st.total_kmers,
 		       "Number Null Kmers: ", (unsigned)st.null_kmers, "Number Kmers Recorded: ", (unsigned)st.recorded,
@@ -523,24 +538,62 @@ struct Mapper
 	}
 };
 
+// what the barcode pre-pass (readBarcodes, Arcs.cpp:481-547) prints, rebuilt from the per-file
+// summaries of the fused pass; `added` is its global running count of tagged reads
+void
+prepass_log(const std::vector<std::string>& files, const std::vector<PrepassInfo>& pre, std::string& out, std::string& err)
+{
+	const uint64_t step = 100000000;
+	uint64_t added = 0;
+	for (size_t f = 0; f < files.size(); ++f) {
+		if (params.verbose)
+			out += "Reading chrom " + files[f] + "\n";
+		err += "File " + files[f] + " opened.\n";
+		if (params.verbose) {
+			// the progress line appears at every record with a comment while added % step == 0
+			const PrepassInfo& pi = pre[f];
+			if (added % step == 0)
+				for (uint64_t i = 0; i < pi.lead; ++i)
+					out += std::to_string(added) + " read with valid barcode\n";
+			size_t e = 0;
+			for (uint64_t x = step - added % step; x <= pi.total; x += step) {
+				uint64_t count = 1;
+				while (e < pi.untagged_at.size() && pi.untagged_at[e] < x)
+					e++;
+				while (e < pi.untagged_at.size() && pi.untagged_at[e] == x)
+					e++, count++;
+				for (uint64_t i = 0; i < count; ++i)
+					out += std::to_string(added + x) + " read with valid barcode\n";
+			}
+		}
+		added += pre[f].total;
+	}
+}
+
+// fused == true: no multiplicity file; `mult` is an OUTPUT (reads per barcode, as readBarcodes would
+// have counted them) and *redo is set when the input needs the exact two-pass flow instead
 void
 read_chroms(
-    const std::vector<std::string>& files, arks_index* idx, IndexMap& imap,
-    const std::unordered_map<std::string, int>& mult, const std::vector<CI>& contigRecord)
+    const std::vector<std::string>& files, arks_index* idx, IndexMap& imap, std::unordered_map<std::string, int>& mult,
+    const std::vector<CI>& contigRecord, bool fused, std::string& out, std::string& err, std::string* pre_out,
+    std::string* pre_err, bool* redo)
 {
 	const size_t nf = files.size();
 	std::vector<std::unique_ptr<SeqReader>> readers;
 	for (const auto& file : files) {
 		readers.emplace_back(new SeqReader(file.c_str()));
 		if (!readers.back()->ok()) {
+			std::cout << out;
 			if (params.verbose)
 				std::cout << "Reading chrom " << file << std::endl;
 			std::cerr << "File " << file << " cannot be opened." << std::endl;
 			exit(1);
 		}
 	}
-	const BarcodeDict dict(mult);
-	Mapper mapper(idx, std::max<int64_t>(1 << 16, (int64_t)mult.size() * 8), std::max<size_t>(nf, 1));
+	std::unique_ptr<BarcodeDict> dict(fused ? nullptr : new BarcodeDict(mult));
+	// distinct (barcode, contig end) pairs: a few per barcode; unknown in the fused mode
+	const int64_t imap_cap = fused ? (int64_t)1 << 28 : std::max<int64_t>(1 << 16, (int64_t)mult.size() * 8);
+	Mapper mapper(idx, imap_cap, std::max<size_t>(nf, 1));
 	HostAllocator pinned;
 	pinned.alloc = [](size_t n) {
 		void* p = nullptr;
@@ -550,7 +603,7 @@ read_chroms(
 	std::vector<SeqReader*> rdp;
 	for (auto& r : readers)
 		rdp.push_back(r.get());
-	IngestPipeline pipe(rdp, mult, dict, params.batch_pairs, params.verbose != 0, params.threads, pinned);
+	IngestPipeline pipe(rdp, dict.get(), params.batch_pairs, params.verbose != 0, params.threads, pinned);
 	std::vector<FileCounters> fc(nf);
 	std::vector<std::map<int64_t, std::string>> messages(nf);
 	const int prc = pipe.run([&](PackedBatch* pb) {
@@ -570,6 +623,22 @@ read_chroms(
 		std::cerr << PROGRAM ": device error while mapping\n";
 		exit(EXIT_FAILURE);
 	}
+	if (fused) {
+		for (const PrepassInfo& pi : pipe.prepass())
+			if (pi.zero_len || pi.untagged_at.size() > (1u << 22)) {
+				*redo = true; // rare input shapes: let the caller run the literal two passes
+				arks_imap_free(mapper.imap);
+				return;
+			}
+		DynamicDict& dyn = pipe.dynamic();
+		for (const PrepassInfo& pi : pipe.prepass())
+			for (size_t id = 0; id < pi.counts.size(); ++id)
+				if (pi.counts[id])
+					mult[dyn.name((uint32_t)id)] += (int)pi.counts[id];
+		prepass_log(files, pipe.prepass(), *pre_out, *pre_err);
+		if (params.verbose)
+			*pre_out += "Saw " + std::to_string(mult.size()) + " distinct barcode.\n";
+	}
 	// the log of the stage, file by file as the reference prints it (Arcs.cpp:1158-1166, 1209-1215,
 	// 1321-1349); its s_* k-mer counters are process-wide, i.e. cumulative over the files
 	std::vector<uint64_t> stored(nf);
@@ -582,34 +651,32 @@ read_chroms(
 	std::memset(&cum, 0, sizeof cum);
 	for (size_t f = 0; f < nf; ++f) {
 		if (params.verbose)
-			std::cout << "Reading chrom " << files[f] << std::endl;
-		std::cerr << "File " << files[f] << " opened." << std::endl;
+			out += "Reading chrom " + files[f] + "\n";
+		err += "File " + files[f] + " opened.\n";
 		for (const auto& kv : messages[f])
-			std::cout << kv.second;
-		std::cout.flush();
+			out += kv.second;
 		cum.total_valid += st[f].total_valid, cum.bad += st[f].bad, cum.found += st[f].found,
 		    cum.recorded += st[f].recorded, cum.dups += st[f].dups, cum.reads_pass += st[f].reads_pass,
 		    cum.reads_fail += st[f].reads_fail, cum.windows += st[f].windows;
 		if (params.verbose) {
 			const FileCounters& mc = fc[f];
-			printf("Stored read pairs: %u\nSkipped invalid read pairs: %u\nSkipped unpaired reads: "
+			appendf(out, "Stored read pairs: %u\nSkipped invalid read pairs: %u\nSkipped unpaired reads: "
 			       "%u\nSkipped reads pairs without a good contig: %u\n",
 			       (unsigned)stored[f], (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
 			       (unsigned)(mc.gated - stored[f]));
-			printf("Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
+			appendf(out, "Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
 			       "%u\nNumber of kmers recorded in Ktrack: %u\nNumber of kmers found in ContigKmap but "
 			       "duplicate: %u\nNumber of reads passing jaccard threshold: %u\nNumber of reads failing "
 			       "jaccard threshold: %u\n",
 			       (unsigned)cum.total_valid, (unsigned)cum.bad, (unsigned)cum.found, (unsigned)cum.recorded,
 			       (unsigned)cum.dups, (unsigned)cum.reads_pass, (unsigned)cum.reads_fail);
 			if (mc.emptybarcode > 0)
-				printf("WARNING:: Your chromium read file has %d readpairs that have an empty barcode.",
+				appendf(out, "WARNING:: Your chromium read file has %d readpairs that have an empty barcode.",
 				       (int)mc.emptybarcode);
 			if (mc.invalidbarcode > 0)
-				printf("WARNING:: Your chromium read file has %d read pairs that have barcodes not in the "
+				appendf(out, "WARNING:: Your chromium read file has %d read pairs that have barcodes not in the "
 				       "barcode multiplicity file.",
 				       (int)mc.invalidbarcode);
-			fflush(stdout);
 		}
 	}
 	// the reference completes the IndexMap after every file (Arcs.cpp:1304-1319); the accumulator is
@@ -622,7 +689,8 @@ read_chroms(
 	if (rc != ARKS_OK)
 		die_arks(rc, "exporting the IndexMap");
 	for (int64_t i = 0; i < n; ++i)
-		imap[*dict.name[triples[3 * i]]][contigRecord[triples[3 * i + 1]]] += (int)triples[3 * i + 2];
+		imap[fused ? pipe.dynamic().name(triples[3 * i]) : *dict->name[triples[3 * i]]][contigRecord[triples[3 * i + 1]]] +=
+		    (int)triples[3 * i + 2];
 	add_opposite_ends(imap);
 	arks_imap_free(mapper.imap);
 }
@@ -661,20 +729,50 @@ run_arks(const std::vector<std::string>& filenames)
 		t_prev = t;
 	};
 	std::cout << "\n=>Preprocessing: Gathering barcode multiplicity information..." << now();
+	// Without -u the reference makes a pass of its own over the reads to count reads per barcode
+	// (Arcs.cpp:1881-1888).  Here that counting rides along with the mapping pass ("fused"); the
+	// text of the stages is emitted in the reference's order afterwards.  ARKS_TWO_PASS=1 forces
+	// the literal flow, which is also the fallback for inputs the fused pass cannot reproduce.
+	const bool fused = params.multfile.empty() && getenv("ARKS_TWO_PASS") == nullptr;
 	if (!params.multfile.empty())
 		create_index_mult_map(params.multfile, mult);
 	else {
 		std::cout << "Multiplicity information is being formed from reads as no barcode multiplicity file provided."
 		          << std::endl;
-		read_barcodes(filenames, mult);
+		if (!fused)
+			read_barcodes(filenames, mult);
 	}
-	std::cout << "\n=>Preprocessing: Gathering draft information..." << now() << "\n";
 	lap("barcode multiplicities");
-	std::cout << "\n=>Storing Kmers from Contig ends... " << now() << std::endl;
-	arks_index* idx = build_contig_index(contigRecord, contigToLength);
+	std::string mid; // stdout of the stages between the barcode pass and the read stage
+	mid += std::string("\n=>Preprocessing: Gathering draft information...") + now() + "\n";
+	mid += std::string("\n=>Storing Kmers from Contig ends... ") + now() + "\n";
+	arks_index* idx = build_contig_index(contigRecord, contigToLength, mid);
 	lap("contig index (read draft + device build)");
-	std::cout << "\n=>Reading Chromium FASTQ file(s)... " << now() << std::endl;
-	read_chroms(filenames, idx, imap, mult, contigRecord);
+	mid += std::string("\n=>Reading Chromium FASTQ file(s)... ") + now() + "\n";
+	if (!fused) {
+		std::cout << mid << std::flush;
+		mid.clear();
+	}
+	{
+		std::string out, err, pre_out, pre_err;
+		bool redo = false;
+		read_chroms(filenames, idx, imap, mult, contigRecord, fused, out, err, &pre_out, &pre_err, &redo);
+		if (fused && redo) {
+			mult.clear();
+			imap.clear();
+			out.clear();
+			err.clear();
+			read_barcodes(filenames, mult);
+			std::cout << mid << std::flush;
+			read_chroms(filenames, idx, imap, mult, contigRecord, false, out, err, nullptr, nullptr, nullptr);
+		} else if (fused) {
+			std::cout << pre_out;
+			std::cerr << pre_err;
+			std::cout << mid;
+		}
+		std::cout << out << std::flush;
+		std::cerr << err << std::flush;
+	}
 	lap("read files -> IndexMap (ingest pipeline + GPU mapping)");
 	arks_index_free(idx);
 	std::cout << "Cumulative memory usage: " << memory_usage() << std::endl;

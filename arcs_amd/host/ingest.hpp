@@ -115,6 +115,72 @@ struct BarcodeDict
 	}
 };
 
+// Without a multiplicity file (-u) the reference first counts reads per barcode in a pass of its own
+// (readBarcodes, Arcs.cpp:481-547).  The fused mode does that counting inside the mapping pass: ids
+// are handed out as barcodes appear, and every barcode that reaches the gate is by construction a
+// key of the map the pre-pass would have built -- unless a file holds a zero-length record, where
+// the pre-pass stops but the pair loop goes on (then the caller falls back to two passes).
+class DynamicDict
+{
+  public:
+	uint32_t get(const std::string& barcode)
+	{
+		std::lock_guard<std::mutex> lk(m_);
+		auto it = id_.find(barcode);
+		if (it == id_.end()) {
+			names_.push_back(barcode);
+			it = id_.emplace(barcode, (uint32_t)(names_.size() - 1)).first;
+		}
+		return it->second;
+	}
+	size_t size() const { return names_.size(); }
+	const std::string& name(uint32_t id) const { return names_[id]; }
+
+  private:
+	std::mutex m_;
+	std::unordered_map<std::string, uint32_t> id_;
+	std::deque<std::string> names_;
+};
+
+// what readBarcodes would have seen in one file
+struct PrepassInfo
+{
+	bool active = true;    // no record of length <= 0 yet
+	bool zero_len = false; // a zero-length record: pre-pass and pair loop part ways
+	uint64_t total = 0;    // reads with a BX:Z: tag
+	uint64_t lead = 0;     // records with a comment but no tag before the first tagged one
+	std::vector<uint64_t> untagged_at; // running tagged count at every later such record
+	std::vector<uint32_t> counts;      // reads per barcode id
+
+	void record(int l, const std::string& comment, DynamicDict& dict, std::unordered_map<std::string, uint32_t>& cache)
+	{
+		if (!active)
+			return;
+		if (l <= 0) {
+			active = false;
+			zero_len = l == 0;
+			return;
+		}
+		if (comment.empty())
+			return;
+		if (comment.find("BX:Z:") == std::string::npos) {
+			if (total == 0)
+				lead++;
+			else
+				untagged_at.push_back(total);
+			return;
+		}
+		const std::string bc = bx_barcode(comment);
+		auto it = cache.find(bc);
+		if (it == cache.end())
+			it = cache.emplace(bc, dict.get(bc)).first;
+		if (it->second >= counts.size())
+			counts.resize((size_t)it->second + 1 + counts.size() / 2, 0);
+		counts[it->second]++;
+		total++;
+	}
+};
+
 struct FileCounters
 {
 	uint64_t skipped_unpaired = 0, emptybarcode = 0, invalidbarcode = 0, gated = 0, skipped_invalid = 0;
@@ -247,9 +313,10 @@ pack_batch(RawBatch& rb, PackedBatch& pb, const HostAllocator& a)
 // `emit` (the last one flagged, possibly empty).
 inline void
 produce_file(
-    SeqReader& rd, int file_idx, const std::unordered_map<std::string, int>& /*mult*/, const BarcodeDict& dict,
-    long batch_pairs, bool verbose, const std::function<void(RawBatch&&)>& emit)
+    SeqReader& rd, int file_idx, const BarcodeDict* dict, DynamicDict* dyn, PrepassInfo* pre, long batch_pairs,
+    bool verbose, const std::function<void(RawBatch&&)>& emit)
 {
+	std::unordered_map<std::string, uint32_t> cache; // fused mode: this producer's view of the dictionary
 	RawBatch b;
 	int64_t seq = 0;
 	auto reset = [&](RawBatch& x) {
@@ -269,9 +336,13 @@ produce_file(
 	while (!stop) {
 		n1.clear(), n2.clear(), c1.clear(), c2.clear(), s1.clear(), s2.clear();
 		int l = rd.next(); // Arcs.cpp:1187-1206
+		if (pre)
+			pre->record(l, rd.comment, *dyn, cache);
 		if (l >= 0) {
 			n1.swap(rd.name), c1.swap(rd.comment), s1.swap(rd.seq);
 			l = rd.next();
+			if (pre)
+				pre->record(l, rd.comment, *dyn, cache);
 			if (l >= 0)
 				n2.swap(rd.name), c2.swap(rd.comment), s2.swap(rd.seq);
 			else
@@ -295,13 +366,20 @@ produce_file(
 		uint32_t bid = 0;
 		if (b1.empty() || b2.empty())
 			b.fc.emptybarcode++;
-		else {
-			const auto it = dict.id.find(b1); // same key set as the multiplicity map (Arcs.cpp:1258)
-			valid = it != dict.id.end();
+		else if (dict) {
+			const auto it = dict->id.find(b1); // same key set as the multiplicity map (Arcs.cpp:1258)
+			valid = it != dict->id.end();
 			if (!valid)
 				b.fc.invalidbarcode++;
 			else
 				bid = it->second;
+		} else {
+			// fused mode: mate 1 carries the tag, so the pre-pass has counted it: b1 is in the map
+			valid = true;
+			auto it = cache.find(b1);
+			if (it == cache.end())
+				it = cache.emplace(b1, dyn->get(b1)).first;
+			bid = it->second;
 		}
 		const bool ok = paired && valid && b1 == b2; // Arcs.cpp:1264-1265 (goodmult is always true)
 		if (!ok)
@@ -329,12 +407,14 @@ produce_file(
 class IngestPipeline
 {
   public:
+	// dict != NULL: barcodes come from a multiplicity map read beforehand; dict == NULL: fused mode,
+	// `dynamic()` and `prepass()` hold what the barcode pre-pass would have produced
 	IngestPipeline(
-	    std::vector<SeqReader*> readers, const std::unordered_map<std::string, int>& mult, const BarcodeDict& dict,
-	    long batch_pairs, bool verbose, unsigned threads, HostAllocator alloc)
+	    std::vector<SeqReader*> readers, const BarcodeDict* dict, long batch_pairs, bool verbose, unsigned threads,
+	    HostAllocator alloc)
 	  : readers_(std::move(readers))
-	  , mult_(mult)
 	  , dict_(dict)
+	  , prepass_(dict ? 0 : readers_.size())
 	  , batch_pairs_(batch_pairs)
 	  , verbose_(verbose)
 	  , alloc_(std::move(alloc))
@@ -348,6 +428,8 @@ class IngestPipeline
 		n_buffers_ = n_packers_ + 3;
 	}
 
+	DynamicDict& dynamic() { return dynamic_; }
+	const std::vector<PrepassInfo>& prepass() const { return prepass_; }
 	unsigned producers() const { return n_producers_; }
 	unsigned packers() const { return n_packers_; }
 
@@ -371,7 +453,8 @@ class IngestPipeline
 							return;
 						f = next_file++;
 					}
-					produce_file(*readers_[f], (int)f, mult_, dict_, batch_pairs_, verbose_,
+					produce_file(*readers_[f], (int)f, dict_, dict_ ? nullptr : &dynamic_,
+					             dict_ ? nullptr : &prepass_[f], batch_pairs_, verbose_,
 					             [&](RawBatch&& rb) { raw_q_.push(std::move(rb)); });
 				}
 			});
@@ -425,8 +508,9 @@ class IngestPipeline
 
   private:
 	std::vector<SeqReader*> readers_;
-	const std::unordered_map<std::string, int>& mult_;
-	const BarcodeDict& dict_;
+	const BarcodeDict* dict_;
+	DynamicDict dynamic_;
+	std::vector<PrepassInfo> prepass_;
 	long batch_pairs_;
 	bool verbose_;
 	HostAllocator alloc_;

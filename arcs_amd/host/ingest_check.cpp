@@ -1,6 +1,9 @@
 // ingest_check.cpp -- test driver for ingest.hpp (no GPU work: parse, gate and pack only).
 //
-//   ingest_check <threads> <batch_pairs> <multiplicity.tsv> <reads.fq[.gz]>...
+//   ingest_check <threads> <batch_pairs> <multiplicity.tsv | -> <reads.fq[.gz]>...
+//
+// `-` instead of a multiplicity file = the fused mode (barcode pre-pass inside the mapping pass): the
+// multiplicities and the per-file pre-pass summaries are printed as well.
 //
 // Prints, per input file in file order: the stage counters, the stdout messages of the record loop,
 // and a digest of everything the GPU stage would receive (per read: length, class, packed code and
@@ -48,7 +51,8 @@ main(int argc, char** argv)
 	const unsigned threads = (unsigned)std::atoi(argv[1]);
 	const long batch_pairs = std::atol(argv[2]);
 	std::unordered_map<std::string, int> mult;
-	{
+	const bool fused = std::string(argv[3]) == "-";
+	if (!fused) {
 		std::ifstream in(argv[3]);
 		std::string bc;
 		int m;
@@ -67,7 +71,7 @@ main(int argc, char** argv)
 		rdp.push_back(readers.back().get());
 	}
 	const BarcodeDict dict(mult);
-	IngestPipeline pipe(rdp, mult, dict, batch_pairs, true, threads, HostAllocator());
+	IngestPipeline pipe(rdp, fused ? nullptr : &dict, batch_pairs, true, threads, HostAllocator());
 	const size_t nf = files.size();
 	struct PerBatch
 	{
@@ -99,7 +103,7 @@ main(int argc, char** argv)
 			Fnv h;
 			h.pod<uint8_t>(pb->pair_ok[p]);
 			if (pb->pair_ok[p]) {
-				const std::string& name = *dict.name[pb->barcode_id[p]];
+				const std::string& name = fused ? pipe.dynamic().name(pb->barcode_id[p]) : *dict.name[pb->barcode_id[p]];
 				h.bytes(name.data(), name.size());
 			}
 			out.pair_hash.push_back(h.h);
@@ -130,6 +134,23 @@ main(int argc, char** argv)
 		            (unsigned long long)fc[f].invalidbarcode, (unsigned long long)fc[f].gated,
 		            (unsigned long long)fc[f].skipped_invalid, (unsigned long long)d.h, batches[f] > 1 ? 1 : 0);
 		std::fputs(messages.c_str(), stdout);
+	}
+	if (fused) {
+		std::map<std::string, uint64_t> counts;
+		for (const PrepassInfo& pi : pipe.prepass())
+			for (size_t id = 0; id < pi.counts.size(); ++id)
+				if (pi.counts[id])
+					counts[pipe.dynamic().name((uint32_t)id)] += pi.counts[id];
+		for (size_t f = 0; f < nf; ++f) {
+			const PrepassInfo& pi = pipe.prepass()[f];
+			std::printf("prepass %zu total=%llu lead=%llu zero_len=%d untagged_at=", f, (unsigned long long)pi.total,
+			            (unsigned long long)pi.lead, pi.zero_len ? 1 : 0);
+			for (uint64_t x : pi.untagged_at)
+				std::printf("%llu,", (unsigned long long)x);
+			std::printf("\n");
+		}
+		for (const auto& kv : counts)
+			std::printf("mult\t%s\t%llu\n", kv.first.c_str(), (unsigned long long)kv.second);
 	}
 	return 0;
 }

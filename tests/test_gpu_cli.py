@@ -177,3 +177,44 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
     # messages keep file order
     assert out2.index(f"Reading chrom {paths[0]}") < out2.index(f"Reading chrom {paths[1]}") < \
         out2.index(f"Reading chrom {paths[2]}")
+    if not use_mult_file:
+        # ---- no -u: the barcode pre-pass is fused into the mapping pass; the literal two-pass flow
+        #      (ARKS_TWO_PASS=1) must print the same log and write the same files ------------------
+        import re
+        def normalized(text, basename, countsname="counts"):
+            keep = []
+            for ln in text.split("\n"):
+                if ln.startswith(" pid ") or "Cumulative memory usage" in ln or re.search(r"\d\d:\d\d:\d\d \d{4}$", ln):
+                    continue
+                keep.append(ln.replace("/" + countsname, "/COUNTS").replace("/" + basename, "/BASE"))
+            return "\n".join(keep)
+        args3 = list(args)
+        args3[args3.index("-b") + 1] = str(tmp_path / "twopass")
+        args3[args3.index("--barcode-counts") + 1] = str(tmp_path / "counts3")
+        res3 = subprocess.run(args3, capture_output=True, text=True, timeout=300,
+                              env=dict(os.environ, ARKS_TWO_PASS="1"))
+        assert res3.returncode == 0, res3.stderr[-2000:]
+        assert normalized(res3.stdout, "twopass", "counts3") == normalized(res.stdout, "out", "counts")
+        assert res3.stdout.count("Reading chrom") == 2 and "distinct barcode." in res3.stdout
+        for suffix in ("_original.gv", "_pair.tsv", "_main.tsv"):
+            assert open(str(tmp_path / "twopass") + suffix).read() == open(base + suffix).read(), suffix
+        assert open(str(tmp_path / "counts3.tsv")).read() == open(str(tmp_path / "counts.tsv")).read()
+        # a zero-length read: readBarcodes stops counting there, the pair loop goes on -> the fused
+        # pass notices and falls back; both flows agree again
+        zl = tmp_path / "zero.fq"
+        with open(zl, "w") as f:
+            for i, (n1, c1, s1, n2, c2, s2) in enumerate(recs[:900]):
+                if i == 450:
+                    f.write(f"@z/1 {c1}\n\n+\n\n@z/2 {c1}\n\n+\n\n")
+                f.write(f"@{n1} {c1}\n{s1}\n+\n{'F' * len(s1)}\n@{n2} {c2}\n{s2}\n+\n{'F' * len(s2)}\n")
+        outs = []
+        for tag, env in (("zf", {}), ("zt", {"ARKS_TWO_PASS": "1"})):
+            a = list(args[:-1])
+            a[a.index("-b") + 1] = str(tmp_path / tag)
+            a[a.index("--barcode-counts") + 1] = str(tmp_path / (tag + "_counts"))
+            r = subprocess.run(a + [str(zl)], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append((normalized(r.stdout, tag, tag + "_counts").replace("/" + tag, "/BASE"), open(str(tmp_path / tag) + "_main.tsv").read(),
+                         open(str(tmp_path / (tag + "_counts.tsv"))).read()))
+        assert outs[0] == outs[1]
+        assert "invalid barcode" not in outs[0][0] or "barcodes not in the barcode multiplicity file" in outs[0][0]

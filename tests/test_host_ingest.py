@@ -65,7 +65,7 @@ def bx(comment):
     return comment[tag + 5:end] if end >= 0 else comment[tag + 5:]
 
 
-def expected(records, mult, oracle):
+def expected(records, mult, oracle, fused=False):
     """records: (name, comment, seq) of the well-formed records in file order; `None` = a record
     that ends the stream (kseq returns a negative length)"""
     c = dict(pairs=0, reads=0, unpaired=0, empty=0, invalid=0, gated=0, skipped_invalid=0)
@@ -87,7 +87,7 @@ def expected(records, mult, oracle):
         if not b1 or not b2:
             c["empty"] += 1
         else:
-            valid = b1 in mult
+            valid = True if fused else b1 in mult
             if not valid:
                 c["invalid"] += 1
         ok = n1 == n2 and valid and b1 == b2
@@ -152,7 +152,7 @@ def write_fastq(path, recs, tail=""):
 
 def run(exe, threads, batch, mult_path, files):
     out = subprocess.check_output([exe, str(threads), str(batch), mult_path] + files, text=True)
-    lines = out.splitlines(keepends=True)
+    lines = [ln for ln in out.splitlines(keepends=True) if not ln.startswith(("prepass ", "mult\t"))]
     res, cur = [], None
     for ln in lines[1:]:
         if ln.startswith("file "):
@@ -204,3 +204,41 @@ def test_pipeline_matches_restatement(exe, oracle, tmp_path):
     # the thread split the front end reports
     head, _ = run(exe, 8, 100, mult_path, files)
     assert head.strip() == "threads producers=4 packers=4"
+
+
+def test_fused_barcode_prepass(exe, oracle, tmp_path):
+    """no multiplicity file: the pre-pass of readBarcodes (Arcs.cpp:481-547) rides along with the pair
+    loop -- reads per barcode (every tagged record, also of pairs that fail the gate; an empty barcode
+    is a key too), the summaries its progress lines are rebuilt from, and the gate (every tagged mate
+    is in the map by construction)"""
+    rng = np.random.Generator(np.random.PCG64(12))
+    barcodes = [f"{''.join('ACGT'[i] for i in rng.integers(0, 4, size=16))}-1" for _ in range(25)]
+    files, want, all_recs = [], [], []
+    for fi, n_pairs in enumerate((400, 150)):
+        recs = make_records(rng, n_pairs, barcodes)
+        if fi == 0:   # comments without a tag before the first tagged record, an empty barcode, an odd record
+            recs = [("lead1/1", "RG:Z:a", "ACGTACGTAGCT"), ("lead1/2", "RG:Z:a", "ACGTACGTAGCTAA")] + recs
+            recs += [("eb/1", "BX:Z: x", "ACGTACGTAC"), ("eb/2", "BX:Z: x", "ACGTACGTAC"), ("odd/1", "BX:Z:" + barcodes[0], "ACGT")]
+        path = str(tmp_path / f"f{fi}.fq")
+        write_fastq(path, recs)
+        files.append(path)
+        all_recs.append(recs)
+        want.append(expected(recs, {}, oracle, fused=True))
+    counts = {}
+    for recs in all_recs:
+        for (n, c, s) in recs:
+            if "BX:Z:" in c:
+                counts[bx(c)] = counts.get(bx(c), 0) + 1
+    for threads, batch in [(1, 1 << 20), (4, 37)]:
+        out = subprocess.check_output([exe, str(threads), str(batch), "-"] + files, text=True)
+        got_mult = {ln.split("\t")[1]: int(ln.split("\t")[2]) for ln in out.splitlines() if ln.startswith("mult\t")}
+        assert got_mult == counts
+        assert "" in got_mult                      # "BX:Z: x": the empty barcode is counted like any other
+        pre = [ln for ln in out.splitlines() if ln.startswith("prepass ")]
+        assert pre[0].startswith(f"prepass 0 total={sum(1 for r in all_recs[0] if 'BX:Z:' in r[1])} lead=2 zero_len=0")
+        _, res = run(exe, threads, batch, "-", files)
+        for fi, r in enumerate(res):
+            c, digest, msgs = want[fi]
+            kv = r["kv"]
+            assert int(kv["invalid"]) == 0 and int(kv["gated"]) == c["gated"] and int(kv["empty"]) == c["empty"]
+            assert kv["digest"] == digest and r["msgs"] == msgs
