@@ -43,6 +43,8 @@ struct Params
 	int end_length = 30000;
 	int verbose = 0;
 	int k_value = 30;
+	std::string k_arg = "30"; // as given
+	std::vector<int> k_list; // -k 40,60,80 (this build only): one pass over the reads, one output set per k
 	double j_index = 0.55;
 	unsigned threads = 1;
 	bool arks = false, output_pair = false, dist_est = false;
@@ -134,7 +136,8 @@ const char USAGE[] =
             "   -e, --end_length=N    contig head/tail length for masking alignments [30000]\n"
             "   -r, --error_percent=N p-value for head/tail assignment and link orientation [0.05]\n"
             "   -v, --run_verbose     verbose logging\n"
-            "   -k  --k_value         size of a k-mer [30]\n"
+            "   -k  --k_value         size of a k-mer [30]; a list (40,60,80) maps every read batch against one\n"
+            "                         index per k in a single pass and writes one output set per k\n"
             "   -j  --j_index         minimum fraction of read kmers matching a contigId [0.55]\n"
             "   -t  --threads         number of host ingest threads [1] (parse / pack; the mapping runs on the GPU)\n"
             "   -P, --pair            output scaffolds pairing TSV\n"
@@ -343,7 +346,7 @@ struct DevArray
 };
 
 // ---- the contig index (replaces initContigArray + getContigKmers, Arcs.cpp:451-479, 1021-1129) ----
-arks_index*
+std::vector<arks_index*>
 build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength, std::string& log)
 {
 	// pass 1 of the reference only sizes contigRecord; it also filters on the IUPAC alphabet, which
@@ -385,25 +388,31 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 			appendf(log, "Finished %d Contigs...\n", total);
 	}
 	bases.push_back('\0');
-	arks_index* idx = nullptr;
-	arks_build_stats st;
-	std::memset(&st, 0, sizeof st);
-	const int rc = arks_index_build(&idx, params.k_value, bases.data(), off.data(), len.data(), (int64_t)len.size(),
-	                                params.device, params.verbose ? &st : nullptr);
-	if (rc != ARKS_OK)
-		die_arks(rc, "building the contig k-mer index");
-	if (params.verbose) {
-		for (uint64_t i = 0; i < st.short_ends; ++i) // Arcs.cpp:877-882 prints one line per short end
-			log += "Warning: ends of contig is shorter than k-value (no k-mers added)\n";
-		appendf(log, "%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n",
-		       "Total number of contigs in draft genome: ", (unsigned)total, "Total valid contigs: ", (unsigned)valid,
-		       "Total skipped contigs: ", (unsigned)skipped, "Total number of Kmers: ", (unsigned)st.total_kmers,
-		       "Number Null Kmers: ", (unsigned)st.null_kmers, "Number Kmers Recorded: ", (unsigned)st.recorded,
-		       "Number Kmer Collisions: ", (unsigned)st.collisions,
-		       "Number Times Kmers Removed (since duplicate in different contig): ", (unsigned)st.removed_dup,
-		       "Number of unique kmers (only one contig): ", (unsigned)st.unique);
+	std::vector<arks_index*> idxs;
+	for (const int k : params.k_list) {
+		arks_index* idx = nullptr;
+		arks_build_stats st;
+		std::memset(&st, 0, sizeof st);
+		const int rc = arks_index_build(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(), params.device,
+		                                params.verbose ? &st : nullptr);
+		if (rc != ARKS_OK)
+			die_arks(rc, "building the contig k-mer index");
+		if (params.verbose) {
+			if (params.k_list.size() > 1)
+				appendf(log, "k = %d:\n", k);
+			for (uint64_t i = 0; i < st.short_ends; ++i) // Arcs.cpp:877-882 prints one line per short end
+				log += "Warning: ends of contig is shorter than k-value (no k-mers added)\n";
+			appendf(log, "%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n",
+			        "Total number of contigs in draft genome: ", (unsigned)total, "Total valid contigs: ", (unsigned)valid,
+			        "Total skipped contigs: ", (unsigned)skipped, "Total number of Kmers: ", (unsigned)st.total_kmers,
+			        "Number Null Kmers: ", (unsigned)st.null_kmers, "Number Kmers Recorded: ", (unsigned)st.recorded,
+			        "Number Kmer Collisions: ", (unsigned)st.collisions,
+			        "Number Times Kmers Removed (since duplicate in different contig): ", (unsigned)st.removed_dup,
+			        "Number of unique kmers (only one contig): ", (unsigned)st.unique);
+		}
+		idxs.push_back(idx);
 	}
-	return idx;
+	return idxs;
 }
 
 // ---- read mapping (replaces readChroms / chromiumRead, Arcs.cpp:1132-1370) -------------------------
@@ -423,28 +432,33 @@ struct DeviceSet
 // one batch overlap the kernels of the previous one.  Counters are kept per input file.
 struct Mapper
 {
-	arks_index* idx;
-	arks_imap* imap = nullptr;
+	std::vector<arks_index*> idxs;  // one per k
+	std::vector<arks_imap*> imaps;  // one per k
 	DeviceSet sets[2];
 	size_t turn = 0;
-	uint64_t* d_stored = nullptr;    // [n_files]
-	arks_map_stats* d_stats = nullptr; // [n_files]
+	uint64_t* d_stored = nullptr;      // [n_k][n_files]
+	arks_map_stats* d_stats = nullptr; // [n_k][n_files]
 	size_t n_files;
 
-	Mapper(arks_index* i, int64_t imap_capacity, size_t nfiles)
-	  : idx(i)
+	Mapper(const std::vector<arks_index*>& is, int64_t imap_capacity, size_t nfiles)
+	  : idxs(is)
 	  , n_files(nfiles)
 	{
-		int rc = arks_imap_create(&imap, imap_capacity, params.device);
-		if (rc != ARKS_OK)
-			die_arks(rc, "creating the IndexMap accumulator");
-		if (hipMalloc((void**)&d_stored, nfiles * sizeof(uint64_t)) != hipSuccess ||
-		    hipMalloc((void**)&d_stats, nfiles * sizeof(arks_map_stats)) != hipSuccess) {
+		for (size_t ki = 0; ki < idxs.size(); ++ki) {
+			arks_imap* im = nullptr;
+			const int rc = arks_imap_create(&im, imap_capacity, params.device);
+			if (rc != ARKS_OK)
+				die_arks(rc, "creating the IndexMap accumulator");
+			imaps.push_back(im);
+		}
+		const size_t nc = idxs.size() * nfiles;
+		if (hipMalloc((void**)&d_stored, nc * sizeof(uint64_t)) != hipSuccess ||
+		    hipMalloc((void**)&d_stats, nc * sizeof(arks_map_stats)) != hipSuccess) {
 			std::cerr << PROGRAM ": out of device memory\n";
 			exit(EXIT_FAILURE);
 		}
-		(void)hipMemset(d_stored, 0, nfiles * sizeof(uint64_t));
-		(void)hipMemset(d_stats, 0, nfiles * sizeof(arks_map_stats));
+		(void)hipMemset(d_stored, 0, nc * sizeof(uint64_t));
+		(void)hipMemset(d_stats, 0, nc * sizeof(arks_map_stats));
 		for (auto& s : sets)
 			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
 			    hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
@@ -516,13 +530,14 @@ struct Mapper
 		if (other.inflight && hipStreamWaitEvent(s.stream, other.done, 0) != hipSuccess)
 			return ARKS_ERR_HIP;
 		int rc = arks_pair_gate_device(s.d_ok.p, s.d_class.p, np, s.d_eval.p, params.device, s.stream);
-		if (rc == ARKS_OK)
-			rc = arks_map_reads_device(idx, s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, 2 * np,
-			                           params.j_index, s.d_conreci.p, params.verbose ? d_stats + pb->file : nullptr,
-			                           s.stream);
-		if (rc == ARKS_OK)
-			rc = arks_pairs_device(s.d_conreci.p, s.d_ok.p, s.d_bid.p, np, nullptr, imap, d_stored + pb->file,
-			                       params.device, s.stream);
+		for (size_t ki = 0; ki < idxs.size() && rc == ARKS_OK; ++ki) { // the batch is resident: every k maps it
+			const size_t slot = ki * n_files + (size_t)pb->file;
+			rc = arks_map_reads_device(idxs[ki], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, 2 * np,
+			                           params.j_index, s.d_conreci.p, params.verbose ? d_stats + slot : nullptr, s.stream);
+			if (rc == ARKS_OK)
+				rc = arks_pairs_device(s.d_conreci.p, s.d_ok.p, s.d_bid.p, np, nullptr, imaps[ki], d_stored + slot,
+				                       params.device, s.stream);
+		}
 		if (rc != ARKS_OK)
 			return rc;
 		if (hipEventRecord(s.done, s.stream) != hipSuccess)
@@ -574,9 +589,9 @@ prepass_log(const std::vector<std::string>& files, const std::vector<PrepassInfo
 // have counted them) and *redo is set when the input needs the exact two-pass flow instead
 void
 read_chroms(
-    const std::vector<std::string>& files, arks_index* idx, IndexMap& imap, std::unordered_map<std::string, int>& mult,
-    const std::vector<CI>& contigRecord, bool fused, std::string& out, std::string& err, std::string* pre_out,
-    std::string* pre_err, bool* redo)
+    const std::vector<std::string>& files, const std::vector<arks_index*>& idxs, std::vector<IndexMap>& imaps,
+    std::unordered_map<std::string, int>& mult, const std::vector<CI>& contigRecord, bool fused, std::string& out,
+    std::string& err, std::string* pre_out, std::string* pre_err, bool* redo)
 {
 	const size_t nf = files.size();
 	std::vector<std::unique_ptr<SeqReader>> readers;
@@ -593,7 +608,8 @@ read_chroms(
 	std::unique_ptr<BarcodeDict> dict(fused ? nullptr : new BarcodeDict(mult));
 	// distinct (barcode, contig end) pairs: a few per barcode; unknown in the fused mode
 	const int64_t imap_cap = fused ? (int64_t)1 << 28 : std::max<int64_t>(1 << 16, (int64_t)mult.size() * 8);
-	Mapper mapper(idx, imap_cap, std::max<size_t>(nf, 1));
+	const size_t nk = idxs.size();
+	Mapper mapper(idxs, imap_cap, std::max<size_t>(nf, 1));
 	HostAllocator pinned;
 	pinned.alloc = [](size_t n) {
 		void* p = nullptr;
@@ -627,7 +643,8 @@ read_chroms(
 		for (const PrepassInfo& pi : pipe.prepass())
 			if (pi.zero_len || pi.untagged_at.size() > (1u << 22)) {
 				*redo = true; // rare input shapes: let the caller run the literal two passes
-				arks_imap_free(mapper.imap);
+				for (arks_imap* im : mapper.imaps)
+					arks_imap_free(im);
 				return;
 			}
 		DynamicDict& dyn = pipe.dynamic();
@@ -641,35 +658,40 @@ read_chroms(
 	}
 	// the log of the stage, file by file as the reference prints it (Arcs.cpp:1158-1166, 1209-1215,
 	// 1321-1349); its s_* k-mer counters are process-wide, i.e. cumulative over the files
-	std::vector<uint64_t> stored(nf);
-	std::vector<arks_map_stats> st(nf);
-	if (nf) {
-		(void)hipMemcpy(stored.data(), mapper.d_stored, nf * sizeof(uint64_t), hipMemcpyDeviceToHost);
-		(void)hipMemcpy(st.data(), mapper.d_stats, nf * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
-	}
-	arks_map_stats cum;
-	std::memset(&cum, 0, sizeof cum);
+	const size_t nfs = std::max<size_t>(nf, 1);
+	std::vector<uint64_t> stored(nk * nfs);
+	std::vector<arks_map_stats> st(nk * nfs);
+	(void)hipMemcpy(stored.data(), mapper.d_stored, nk * nfs * sizeof(uint64_t), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(st.data(), mapper.d_stats, nk * nfs * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
+	std::vector<arks_map_stats> cum(nk);
+	std::memset(cum.data(), 0, nk * sizeof(arks_map_stats));
 	for (size_t f = 0; f < nf; ++f) {
 		if (params.verbose)
 			out += "Reading chrom " + files[f] + "\n";
 		err += "File " + files[f] + " opened.\n";
 		for (const auto& kv : messages[f])
 			out += kv.second;
-		cum.total_valid += st[f].total_valid, cum.bad += st[f].bad, cum.found += st[f].found,
-		    cum.recorded += st[f].recorded, cum.dups += st[f].dups, cum.reads_pass += st[f].reads_pass,
-		    cum.reads_fail += st[f].reads_fail, cum.windows += st[f].windows;
-		if (params.verbose) {
+		for (size_t ki = 0; ki < nk; ++ki) {
+			const size_t slot = ki * nfs + f;
+			arks_map_stats& c = cum[ki];
+			c.total_valid += st[slot].total_valid, c.bad += st[slot].bad, c.found += st[slot].found,
+			    c.recorded += st[slot].recorded, c.dups += st[slot].dups, c.reads_pass += st[slot].reads_pass,
+			    c.reads_fail += st[slot].reads_fail, c.windows += st[slot].windows;
+			if (!params.verbose)
+				continue;
 			const FileCounters& mc = fc[f];
+			if (nk > 1)
+				appendf(out, "k = %d:\n", params.k_list[ki]);
 			appendf(out, "Stored read pairs: %u\nSkipped invalid read pairs: %u\nSkipped unpaired reads: "
 			       "%u\nSkipped reads pairs without a good contig: %u\n",
-			       (unsigned)stored[f], (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
-			       (unsigned)(mc.gated - stored[f]));
+			       (unsigned)stored[slot], (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
+			       (unsigned)(mc.gated - stored[slot]));
 			appendf(out, "Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
 			       "%u\nNumber of kmers recorded in Ktrack: %u\nNumber of kmers found in ContigKmap but "
 			       "duplicate: %u\nNumber of reads passing jaccard threshold: %u\nNumber of reads failing "
 			       "jaccard threshold: %u\n",
-			       (unsigned)cum.total_valid, (unsigned)cum.bad, (unsigned)cum.found, (unsigned)cum.recorded,
-			       (unsigned)cum.dups, (unsigned)cum.reads_pass, (unsigned)cum.reads_fail);
+			       (unsigned)c.total_valid, (unsigned)c.bad, (unsigned)c.found, (unsigned)c.recorded,
+			       (unsigned)c.dups, (unsigned)c.reads_pass, (unsigned)c.reads_fail);
 			if (mc.emptybarcode > 0)
 				appendf(out, "WARNING:: Your chromium read file has %d readpairs that have an empty barcode.",
 				       (int)mc.emptybarcode);
@@ -681,18 +703,59 @@ read_chroms(
 	}
 	// the reference completes the IndexMap after every file (Arcs.cpp:1304-1319); the accumulator is
 	// additive, so the rebuild below after the last file gives the same map
-	const int64_t n = arks_imap_size(mapper.imap);
-	if (n < 0)
-		die_arks((int)-n, "reading the IndexMap accumulator");
-	std::vector<uint32_t> triples((size_t)n * 3 + 3);
-	const int rc = arks_imap_export(mapper.imap, triples.data());
-	if (rc != ARKS_OK)
-		die_arks(rc, "exporting the IndexMap");
-	for (int64_t i = 0; i < n; ++i)
-		imap[fused ? pipe.dynamic().name(triples[3 * i]) : *dict->name[triples[3 * i]]][contigRecord[triples[3 * i + 1]]] +=
-		    (int)triples[3 * i + 2];
-	add_opposite_ends(imap);
-	arks_imap_free(mapper.imap);
+	imaps.assign(nk, IndexMap());
+	for (size_t ki = 0; ki < nk; ++ki) {
+		const int64_t n = arks_imap_size(mapper.imaps[ki]);
+		if (n < 0)
+			die_arks((int)-n, "reading the IndexMap accumulator");
+		std::vector<uint32_t> triples((size_t)n * 3 + 3);
+		const int rc = arks_imap_export(mapper.imaps[ki], triples.data());
+		if (rc != ARKS_OK)
+			die_arks(rc, "exporting the IndexMap");
+		IndexMap& imap = imaps[ki];
+		for (int64_t i = 0; i < n; ++i)
+			imap[fused ? pipe.dynamic().name(triples[3 * i]) : *dict->name[triples[3 * i]]]
+			    [contigRecord[triples[3 * i + 1]]] += (int)triples[3 * i + 2];
+		add_opposite_ends(imap);
+		arks_imap_free(mapper.imaps[ki]);
+	}
+}
+
+// file names of one k: with a single -k exactly the reference's (Arcs.cpp:2144-2157); with a list
+// every name carries its k (the default base name does already, explicit names get a _k<k> suffix)
+struct OutputNames
+{
+	std::string base, dist, tsv;
+};
+
+std::string
+with_k(const std::string& name, int k)
+{
+	const std::string tag = "_k" + std::to_string(k);
+	const size_t dot = name.rfind('.');
+	const size_t slash = name.rfind('/');
+	if (dot == std::string::npos || (slash != std::string::npos && dot < slash))
+		return name + tag;
+	return name.substr(0, dot) + tag + name.substr(dot);
+}
+
+OutputNames
+output_names(int k)
+{
+	const bool multi = params.k_list.size() > 1;
+	OutputNames n;
+	if (params.base_name.empty()) {
+		std::ostringstream fn;
+		fn << params.file << ".scaff"
+		   << "_arks"
+		   << "_c" << params.g.min_reads << "_k" << k << "_j" << params.j_index << "_l" << params.g.min_links << "_d"
+		   << params.g.max_degree << "_e" << params.end_length << "_r" << params.g.error_percent;
+		n.base = fn.str();
+	} else
+		n.base = multi ? params.base_name + "_k" + std::to_string(k) : params.base_name;
+	n.dist = params.dist_graph_name.empty() ? n.base + ".dist.gv" : (multi ? with_k(params.dist_graph_name, k) : params.dist_graph_name);
+	n.tsv = params.tsv_name.empty() ? n.base + "_main.tsv" : (multi ? with_k(params.tsv_name, k) : params.tsv_name);
+	return n;
 }
 
 void
@@ -702,7 +765,7 @@ run_arks(const std::vector<std::string>& filenames)
 	          << "\n -c " << params.g.min_reads << "\n -d " << params.g.max_degree << "\n -e " << params.end_length
 	          << "\n -l " << params.g.min_links << "\n -m " << params.g.min_mult << '-' << params.g.max_mult
 	          << "\n -r " << params.g.error_percent << "\n -v " << params.verbose << "\n -z " << params.min_size
-	          << "\n --gap=" << params.g.gap << "\n -k " << params.k_value << "\n -j " << params.j_index << "\n -t "
+	          << "\n --gap=" << params.g.gap << "\n -k " << params.k_arg << "\n -j " << params.j_index << "\n -t "
 	          << params.threads << "\n -b " << maybe_na(params.base_name) << "\n -g "
 	          << maybe_na(params.dist_graph_name) << "\n --barcode-counts=" << maybe_na(params.barcode_counts_name)
 	          << "\n --tsv=" << maybe_na(params.tsv_name) << "\n -a " << maybe_na(params.fofName) << "\n -f "
@@ -711,9 +774,7 @@ run_arks(const std::vector<std::string>& filenames)
 		std::cout << ' ' << f << '\n';
 	std::cout.flush();
 
-	IndexMap imap;
-	PairMap pmap;
-	ScaffoldGraph g;
+	std::vector<IndexMap> imaps;
 	std::unordered_map<std::string, int> mult;
 	ContigToLength contigToLength;
 	std::vector<CI> contigRecord;
@@ -746,7 +807,7 @@ run_arks(const std::vector<std::string>& filenames)
 	std::string mid; // stdout of the stages between the barcode pass and the read stage
 	mid += std::string("\n=>Preprocessing: Gathering draft information...") + now() + "\n";
 	mid += std::string("\n=>Storing Kmers from Contig ends... ") + now() + "\n";
-	arks_index* idx = build_contig_index(contigRecord, contigToLength, mid);
+	const std::vector<arks_index*> idxs = build_contig_index(contigRecord, contigToLength, mid);
 	lap("contig index (read draft + device build)");
 	mid += std::string("\n=>Reading Chromium FASTQ file(s)... ") + now() + "\n";
 	if (!fused) {
@@ -756,15 +817,15 @@ run_arks(const std::vector<std::string>& filenames)
 	{
 		std::string out, err, pre_out, pre_err;
 		bool redo = false;
-		read_chroms(filenames, idx, imap, mult, contigRecord, fused, out, err, &pre_out, &pre_err, &redo);
+		read_chroms(filenames, idxs, imaps, mult, contigRecord, fused, out, err, &pre_out, &pre_err, &redo);
 		if (fused && redo) {
 			mult.clear();
-			imap.clear();
+			imaps.clear();
 			out.clear();
 			err.clear();
 			read_barcodes(filenames, mult);
 			std::cout << mid << std::flush;
-			read_chroms(filenames, idx, imap, mult, contigRecord, false, out, err, nullptr, nullptr, nullptr);
+			read_chroms(filenames, idxs, imaps, mult, contigRecord, false, out, err, nullptr, nullptr, nullptr);
 		} else if (fused) {
 			std::cout << pre_out;
 			std::cerr << pre_err;
@@ -774,50 +835,59 @@ run_arks(const std::vector<std::string>& filenames)
 		std::cerr << err << std::flush;
 	}
 	lap("read files -> IndexMap (ingest pipeline + GPU mapping)");
-	arks_index_free(idx);
+	for (arks_index* idx : idxs)
+		arks_index_free(idx);
 	std::cout << "Cumulative memory usage: " << memory_usage() << std::endl;
 
-	std::cout << "\n=> Pairing scaffolds... " << now();
-	pair_contigs(imap, pmap, mult, params.g);
-	if (params.output_pair) {
-		std::cout << "\n=> Outputting Pairing information... " << now();
-		std::ofstream out((params.base_name + "_pair.tsv").c_str());
-		write_pair_map(out, pmap);
-	}
-	std::cout << "\n=> Creating the graph... " << now();
-	create_graph(pmap, g, params.g);
-	std::cout << "\n=> Writing graph file... " << now() << "\n";
-	const std::string graph_file = params.base_name + "_original.gv";
-	if (params.g.max_degree != 0) {
-		std::cout << "      Deleting nodes with degree > " << params.g.max_degree << "... \n";
-		remove_degree_nodes(g, params.g.max_degree);
-	} else
-		std::cout << "      Max Degree (-d) set to: " << params.g.max_degree
-		          << ". Will not delete any vertices from graph.\n";
-	std::cout << "      Writing graph file to " << graph_file << "...\n";
-	{
-		std::ofstream out(graph_file.c_str());
-		write_graph(out, g);
-	}
-	std::cout << "\n=> Creating the ABySS graph... " << now();
-	std::cout << "\n=> Writing the ABySS graph file... " << now() << "\n";
-	{
-		std::ofstream out(params.dist_graph_name.c_str());
-		if (!out.good()) {
-			std::cerr << "error: `" << params.dist_graph_name << "': " << strerror(errno) << std::endl;
-			exit(EXIT_FAILURE);
+	for (size_t ki = 0; ki < params.k_list.size(); ++ki) {
+		const OutputNames names = output_names(params.k_list[ki]);
+		IndexMap& imap = imaps[ki];
+		PairMap pmap;
+		ScaffoldGraph g;
+		if (params.k_list.size() > 1)
+			std::cout << "\n=> Graph stage for k = " << params.k_list[ki] << "\n";
+		std::cout << "\n=> Pairing scaffolds... " << now();
+		pair_contigs(imap, pmap, mult, params.g);
+		if (params.output_pair) {
+			std::cout << "\n=> Outputting Pairing information... " << now();
+			std::ofstream out((names.base + "_pair.tsv").c_str());
+			write_pair_map(out, pmap);
 		}
-		std::string err;
-		if (!write_dist_graph(out, contigToLength, g, params.g.gap, &err)) {
-			std::cerr << err << std::endl;
-			exit(EXIT_FAILURE);
+		std::cout << "\n=> Creating the graph... " << now();
+		create_graph(pmap, g, params.g);
+		std::cout << "\n=> Writing graph file... " << now() << "\n";
+		const std::string graph_file = names.base + "_original.gv";
+		if (params.g.max_degree != 0) {
+			std::cout << "      Deleting nodes with degree > " << params.g.max_degree << "... \n";
+			remove_degree_nodes(g, params.g.max_degree);
+		} else
+			std::cout << "      Max Degree (-d) set to: " << params.g.max_degree
+			          << ". Will not delete any vertices from graph.\n";
+		std::cout << "      Writing graph file to " << graph_file << "...\n";
+		{
+			std::ofstream out(graph_file.c_str());
+			write_graph(out, g);
 		}
-	}
-	if (!params.tsv_name.empty()) {
-		const size_t barcode_count = count_barcodes(imap, mult, params.g);
-		std::cout << "\n=> Writing TSV file... " << now();
-		std::ofstream f(params.tsv_name.c_str());
-		write_tsv(f, imap, pmap, barcode_count, params.g);
+		std::cout << "\n=> Creating the ABySS graph... " << now();
+		std::cout << "\n=> Writing the ABySS graph file... " << now() << "\n";
+		{
+			std::ofstream out(names.dist.c_str());
+			if (!out.good()) {
+				std::cerr << "error: `" << names.dist << "': " << strerror(errno) << std::endl;
+				exit(EXIT_FAILURE);
+			}
+			std::string err;
+			if (!write_dist_graph(out, contigToLength, g, params.g.gap, &err)) {
+				std::cerr << err << std::endl;
+				exit(EXIT_FAILURE);
+			}
+		}
+		if (!names.tsv.empty()) {
+			const size_t barcode_count = count_barcodes(imap, mult, params.g);
+			std::cout << "\n=> Writing TSV file... " << now();
+			std::ofstream f(names.tsv.c_str());
+			write_tsv(f, imap, pmap, barcode_count, params.g);
+		}
 	}
 	if (!params.barcode_counts_name.empty()) {
 		std::cout << "\n=> Writing reads per barcode TSV file... " << now();
@@ -840,7 +910,7 @@ main(int argc, char** argv)
 		std::istringstream arg(optarg != NULL ? optarg : "");
 		switch (c) {
 		case 'u': arg >> params.multfile; break;
-		case 'k': arg >> params.k_value; arksOnly = true; break;
+		case 'k': arg >> params.k_arg; arksOnly = true; break;
 		case 'j': arg >> params.j_index; arksOnly = true; break;
 		case 't': arg >> params.threads; arksOnly = true; break;
 		case '?': die = true; break;
@@ -934,19 +1004,28 @@ main(int argc, char** argv)
 			die = true;
 		}
 	}
-	if (params.base_name.empty()) { // Arcs.cpp:2144-2152
-		std::ostringstream fn;
-		fn << params.file << ".scaff"
-		   << "_arks"
-		   << "_c" << params.g.min_reads << "_k" << params.k_value << "_j" << params.j_index << "_l"
-		   << params.g.min_links << "_d" << params.g.max_degree << "_e" << params.end_length << "_r"
-		   << params.g.error_percent;
-		params.base_name = fn.str();
+	{ // -k: one value as in the reference, or a comma-separated list (this build only)
+		std::istringstream ks(params.k_arg);
+		std::string item;
+		while (std::getline(ks, item, ',')) {
+			std::istringstream one(item);
+			int k = 0;
+			if (!(one >> k) || !one.eof()) {
+				std::cerr << PROGRAM ": invalid option: `-k" << params.k_arg << "'\n";
+				exit(EXIT_FAILURE);
+			}
+			params.k_list.push_back(k);
+		}
+		if (params.k_list.empty())
+			params.k_list.push_back(params.k_value);
+		params.k_value = params.k_list[0];
 	}
-	if (params.dist_graph_name.empty())
-		params.dist_graph_name = params.base_name + ".dist.gv";
-	if (params.tsv_name.empty())
-		params.tsv_name = params.base_name + "_main.tsv";
+	// the run header prints -b / -g / --tsv as the reference does after filling in its defaults
+	// (Arcs.cpp:2144-2157); with a k list the per-k names are derived in output_names()
+	if (params.k_list.size() == 1) {
+		const OutputNames n = output_names(params.k_value);
+		params.base_name = n.base, params.dist_graph_name = n.dist, params.tsv_name = n.tsv;
+	}
 	if (die) {
 		std::cerr << "Try " << PROGRAM << " --help for more information.\n";
 		exit(EXIT_FAILURE);

@@ -218,3 +218,50 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
                          open(str(tmp_path / (tag + "_counts.tsv"))).read()))
         assert outs[0] == outs[1]
         assert "invalid barcode" not in outs[0][0] or "barcodes not in the barcode multiplicity file" in outs[0][0]
+
+
+def test_arcs_cli_k_list_single_pass(arks, gpu, tmp_path):
+    """-k 40,60,80: one pass over the reads against three resident indexes; every output set equals the
+    one of a single-k run (arks-long style input: pseudo-linked pairs with a multiplicity file)"""
+    from arcs_amd import build as b, synth
+    exe = b.build_host()
+    contigs = synth.make_draft(300_000, seed=91, lengths=(50000, 30000, 80000), small_frac=0.3)
+    cs = synth.contigs_to_strings(contigs)
+    fa = tmp_path / "draft.fa"
+    with open(fa, "w") as f:
+        for i, s_ in enumerate(cs):
+            f.write(f">{i + 1}\n{s_}\n")
+    n_pairs = 5000
+    batch = synth.make_read_pairs(contigs, n_pairs, seed=92, mol_len=20000, pairs_per_mol=25)
+    reads = synth.reads_to_strings(batch)
+    bid = batch["barcode_id"].numpy()
+    mult = {}
+    fq = tmp_path / "reads.fq"
+    with open(fq, "w") as f:
+        for p in range(n_pairs):
+            bc = f"{int(bid[p]) + 1}"
+            mult[bc] = mult.get(bc, 0) + 2
+            for m in (0, 1):
+                r = reads[2 * p + m]
+                f.write(f"@r{p}/{m + 1} BX:Z:{bc}\n{r}\n+\n{'F' * len(r)}\n")
+    mf = tmp_path / "mult.tsv"
+    mf.write_text("".join(f"{k}\t{v}\n" for k, v in mult.items()))
+    common = [exe, "--arks", "-v", "-f", str(fa), "-c", "3", "-m", "8-10000", "-e", "30000", "-z", "500", "-j", "0.5",
+              "-t", "4", "-u", str(mf), "-P", "--batch-pairs", "1500"]
+    r = subprocess.run(common + ["-k", "40,60,80", "-b", str(tmp_path / "multi"), str(fq)], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    differ = set()
+    for k in (40, 60, 80):
+        r1 = subprocess.run(common + ["-k", str(k), "-b", str(tmp_path / f"single{k}"), str(fq)], capture_output=True,
+                            text=True, timeout=300)
+        assert r1.returncode == 0, r1.stderr[-2000:]
+        for suffix in ("_original.gv", "_pair.tsv", "_main.tsv", ".dist.gv"):
+            a = open(str(tmp_path / f"multi_k{k}") + suffix).read()
+            assert a == open(str(tmp_path / f"single{k}") + suffix).read(), (k, suffix)
+        differ.add(open(str(tmp_path / f"single{k}") + "_main.tsv").read())
+        # the per-k counter blocks of the single pass carry the single-k numbers
+        block = r.stdout[r.stdout.index(f"k = {k}:\nStored read pairs"):]
+        line = [ln for ln in r1.stdout.split("\n") if ln.startswith("Total valid kmers:")][0]
+        assert line in block.split("k = ")[1]
+    assert len(differ) > 1, "the three k should not all give the same evidence"
