@@ -196,8 +196,7 @@ __global__ void
 insert_kernel(
     const u64* __restrict__ codes,
     const u32* __restrict__ visited,
-    const u64* __restrict__ word_off, // n_ends + 1 entries
-    long n_ends,
+    const u32* __restrict__ word_owner, // contig end (conreci) of every text word
     u64 total_words,
     KeyGeom g,
     TableView t,
@@ -215,15 +214,7 @@ insert_kernel(
 		c.w[j] = 0;
 	u64 s = 0;
 	if (active) {
-		long lo = 0, hi = n_ends - 1; // end that owns word w
-		while (lo < hi) {
-			const long mid = (lo + hi + 1) >> 1;
-			if (word_off[mid] <= w)
-				lo = mid;
-			else
-				hi = mid - 1;
-		}
-		owner = (u32)lo + 1u; // conreci
+		owner = word_owner[w]; // conreci (one load; a per-thread search over the ends costs 16 dependent ones)
 		c = reference_key(window_key_at<KW>(codes, pos, g), g);
 		s = mulhi64(key_hash(c), t.cap);
 	}
@@ -231,28 +222,38 @@ insert_kernel(
 	// loop until its whole wave has.  With a per-lane exit the compiler is free to sink the
 	// winner's key/state stores to the loop exit, which a SIMT machine reaches only after every
 	// lane has left the loop -- while the wave-mates polling the locked slot never would.
+	//
+	// Memory ordering: every access to a slot is an agent-scope ATOMIC (sc1: stores write through,
+	// loads and read-modify-writes are served at the coherence point), so no cache holds a private
+	// copy of slot data and the agent-scope acquire / release forms -- which on gfx950 invalidate /
+	// write back the whole L2 of the XCD per operation -- are not needed; what is needed is program
+	// order between the key stores and the publishing state store (and between the state load and
+	// the key loads), which a workgroup-scope fence provides (s_waitcnt).
 	bool done = !active;
 	while (__ballot(!done) != 0) {
 		if (!done) {
 			u64* slot = t.slots + s * kSlotWords;
 			u32* state = reinterpret_cast<u32*>(slot + 3);
 			u32* minown = state + 1;
-			u32 st = __hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+			u32 st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (st == kEmpty) {
 				u32 expect = kEmpty;
 				if (__hip_atomic_compare_exchange_strong(
-				        state, &expect, kLocked, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+				        state, &expect, kLocked, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
 				        __HIP_MEMORY_SCOPE_AGENT)) {
 #pragma unroll
 					for (int j = 0; j < KW; ++j)
 						__hip_atomic_store(slot + j, c.w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					__hip_atomic_store(minown, owner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					__hip_atomic_store(state, owner + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the key is written before it is published
+					__hip_atomic_store(state, owner + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					n_new = 1;
 					done = true;
 				}
 				// lost the race: look at the same slot again
 			} else if (st != kLocked) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				Key<KW> sk;
 #pragma unroll
 				for (int j = 0; j < KW; ++j)
@@ -610,19 +611,23 @@ table_put(const TableView& t, const Key<KW>& c, u32 value, bool active)
 		if (!done) {
 			u64* slot = t.slots + s * kSlotWords;
 			u32* state = reinterpret_cast<u32*>(slot + 3);
-			const u32 st = __hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+			// relaxed agent-scope atomics + program order, as in insert_kernel
+			const u32 st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (st == kEmpty) {
 				u32 expect = kEmpty;
 				if (__hip_atomic_compare_exchange_strong(
-				        state, &expect, kLocked, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+				        state, &expect, kLocked, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
 				        __HIP_MEMORY_SCOPE_AGENT)) {
 #pragma unroll
 					for (int j = 0; j < KW; ++j)
 						__hip_atomic_store(slot + j, c.w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					__hip_atomic_store(state, value + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					__hip_atomic_store(state, value + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					done = true;
 				}
 			} else if (st != kLocked) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				Key<KW> sk;
 #pragma unroll
 				for (int j = 0; j < KW; ++j)
@@ -771,16 +776,16 @@ launch_popcount(const u32* words, u64 n, u64* out, hipStream_t st)
 
 hipError_t
 launch_insert(
-    int kw, const u64* codes, const u32* visited, const u64* word_off, long n_ends, u64 total_words,
+    int kw, const u64* codes, const u32* visited, const u32* word_owner, long n_ends, u64 total_words,
     const KeyGeom& g, TableView t, u64* counters, hipStream_t st)
 {
 	if (total_words == 0 || n_ends <= 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
 	if (kw == 2)
-		insert_kernel<2><<<b, 256, 0, st>>>(codes, visited, word_off, n_ends, total_words, g, t, counters);
+		insert_kernel<2><<<b, 256, 0, st>>>(codes, visited, word_owner, total_words, g, t, counters);
 	else
-		insert_kernel<3><<<b, 256, 0, st>>>(codes, visited, word_off, n_ends, total_words, g, t, counters);
+		insert_kernel<3><<<b, 256, 0, st>>>(codes, visited, word_owner, total_words, g, t, counters);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

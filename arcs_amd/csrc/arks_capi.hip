@@ -5,6 +5,7 @@
 #include "arks_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,11 +28,17 @@ fail_hip(hipError_t e, const char* what)
 }
 
 static bool g_trace = std::getenv("ARKS_TRACE") != nullptr;
+static double
+trace_ms()
+{
+	static const auto t0 = std::chrono::steady_clock::now();
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 #define ARKS_TRACE_STEP(name)                                                                      \
 	do {                                                                                           \
 		if (g_trace) {                                                                             \
 			hipError_t te_ = hipDeviceSynchronize();                                               \
-			std::fprintf(stderr, "[arks] %s: %s\n", name, hipGetErrorString(te_));                 \
+			std::fprintf(stderr, "[arks] %10.1f ms  %s: %s\n", trace_ms(), name, hipGetErrorString(te_)); \
 			std::fflush(stderr);                                                                   \
 		}                                                                                          \
 	} while (0)
@@ -425,7 +432,7 @@ arks_index_build(
 	std::vector<uint64_t> word_off((size_t)n_ends + 1, 0), offs((size_t)n_ends + 1, 0);
 	uint64_t total_bases = 0;
 	DevBuf d_ascii, d_offs, d_lens, d_woff, d_nmask, d_counters, d_full;
-	DevBuf d_ismin, d_ispal, d_isimg, d_heavy, d_ckeys, d_ccnts;
+	DevBuf d_ismin, d_ispal, d_isimg, d_heavy, d_ckeys, d_ccnts, d_wown;
 	u64 text_words = 0, alloc_words = 0, counters[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	u64 visited_total = 0, n_min = 0, n_pal = 0, n_fb = 0, ccap = 0, mcap = 0;
 	TableView full{ nullptr, 0 };
@@ -458,12 +465,21 @@ arks_index_build(
 	w = k - mm + 1;
 	bm_bytes = sizeof(u32) * alloc_words;
 
+	ARKS_TRACE_STEP("index build: start");
 	HIP_TRY(d_ascii.alloc(total_bases + 64));
-	for (int64_t e = 0; e < n_ends; ++e) // one copy per end: the source need not be contiguous
-		if (h_lens[e])
+	// the source need not be contiguous: one copy per run of ends that are adjacent in it (a caller that
+	// concatenates its ends gets a single copy instead of one per end)
+	for (int64_t e = 0; e < n_ends;) {
+		int64_t last = e;
+		while (last + 1 < n_ends && h_offsets[last + 1] == h_offsets[last] + h_lens[last])
+			++last;
+		const uint64_t bytes = offs[(size_t)last] + h_lens[last] - offs[(size_t)e];
+		if (bytes)
 			HIP_TRY(hipMemcpy(
-			    d_ascii.as<char>() + offs[(size_t)e], h_bases + h_offsets[e], h_lens[e],
-			    hipMemcpyHostToDevice));
+			    d_ascii.as<char>() + offs[(size_t)e], h_bases + h_offsets[e], bytes, hipMemcpyHostToDevice));
+		e = last + 1;
+	}
+	ARKS_TRACE_STEP("contig ends uploaded");
 	HIP_TRY(d_offs.alloc(sizeof(u64) * ((size_t)n_ends + 1)));
 	HIP_TRY(d_lens.alloc(sizeof(u32) * ((size_t)n_ends + 1)));
 	HIP_TRY(d_woff.alloc(sizeof(u64) * ((size_t)n_ends + 1)));
@@ -503,9 +519,14 @@ arks_index_build(
 	full.cap = std::max<u64>(1024, visited_total * 2 + 64);
 	HIP_TRY(d_full.alloc(full.cap * kSlotWords * sizeof(u64)));
 	full.slots = d_full.as<u64>();
+	ARKS_TRACE_STEP("exact table allocated");
 	HIP_TRY(hipMemsetAsync(full.slots, 0, full.cap * kSlotWords * sizeof(u64), st));
+	ARKS_TRACE_STEP("exact table cleared");
+	HIP_TRY(d_wown.alloc(bm_bytes));
+	HIP_TRY(launch_word_owner(d_woff.as<u64>(), (long)n_ends, alloc_words, d_wown.as<u32>(), st));
+	ARKS_TRACE_STEP("launch_word_owner");
 	HIP_TRY(launch_insert(
-	    idx->kw, idx->codes, idx->visited, d_woff.as<u64>(), (long)n_ends, text_words, idx->geom, full,
+	    idx->kw, idx->codes, idx->visited, d_wown.as<u32>(), (long)n_ends, text_words, idx->geom, full,
 	    d_counters.as<u64>(), st));
 	ARKS_TRACE_STEP("launch_insert");
 	if (stats)
@@ -556,8 +577,7 @@ arks_index_build(
 		HIP_TRY(hipMemsetAsync(d_isimg.p, 0, bm_bytes, st));
 		HIP_TRY(hipMemsetAsync(d_heavy.p, 0, bm_bytes, st));
 		HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
-		HIP_TRY(launch_word_owner(d_woff.as<u64>(), (long)n_ends, alloc_words, idx->word_owner, st));
-	ARKS_TRACE_STEP("launch_word_owner");
+		HIP_TRY(hipMemcpyAsync(idx->word_owner, d_wown.p, bm_bytes, hipMemcpyDeviceToDevice, st));
 		HIP_TRY(launch_bmark(
 		    idx->kw, mm, idx->codes, idx->visited, text_words, idx->geom, full, w, idx->ambig,
 		    d_ismin.as<u32>(), d_ispal.as<u32>(), d_isimg.as<u32>(), st));

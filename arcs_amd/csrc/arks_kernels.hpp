@@ -15,7 +15,7 @@ hipError_t launch_visit(
     u64* counters, hipStream_t st);
 hipError_t launch_popcount(const u32* words, u64 n, u64* out, hipStream_t st);
 hipError_t launch_insert(
-    int kw, const u64* codes, const u32* visited, const u64* word_off, long n_ends, u64 total_words,
+    int kw, const u64* codes, const u32* visited, const u32* word_owner, long n_ends, u64 total_words,
     const KeyGeom& g, TableView t, u64* counters, hipStream_t st);
 hipError_t launch_build_stats(
     int kw, const u64* codes, const u32* visited, const u64* word_off, long n_ends, u64 total_words,
