@@ -355,6 +355,7 @@ struct TileLds
 	unsigned char sread[kTW + kTR + 2];
 	u32 redo;
 	u32 redo2; // reads that need the general verification (hot instantiation only)
+	u64 wstats[8]; // hot instantiation: this wave's arks_map_stats counters (registers are scarce there)
 };
 
 // lanes of one wave communicate through LDS: order the compiler's view of it
@@ -505,7 +506,8 @@ map_reads_b_kernel(
 	static_assert(2 * kSlots <= 128, "owners must stay clear of the per-read counters in S.b");
 	const int lane_id = threadIdx.x;
 	WaveStats ws = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	WaveStats ls = { 0, 0, 0, 0, 0, 0, 0, 0 }; // per-lane_id counters of the hot instantiation
+	if (STATS && lane_id < 8)
+		S.wstats[lane_id] = 0;
 	const int k = g.k, w = bx.w;
 	// the sliding minimum reads up to w - 1 + 7 positions past the tile: a constant pad
 	for (int x = lane_id; x < 96; x += 64)
@@ -1221,14 +1223,14 @@ map_reads_b_kernel(
 							const bool pass = maxj > j_index;
 							out_conreci[r] = pass ? best : 0;
 							if (STATS) {
-								ls.valid += (u64)nvalid;
-								ls.bad += (u64)(total - nvalid);
-								ls.found += (u64)(rec_a + amb_a + rec_b + amb_b);
-								ls.rec += (u64)(rec_a + rec_b);
-								ls.dup += (u64)(amb_a + amb_b);
-								ls.pass += pass;
-								ls.fail += !pass;
-								ls.win += (u64)total;
+								unsigned long long* wsp = reinterpret_cast<unsigned long long*>(S.wstats);
+								atomicAdd(wsp + 0, (unsigned long long)nvalid);
+								atomicAdd(wsp + 1, (unsigned long long)(total - nvalid));
+								atomicAdd(wsp + 2, (unsigned long long)(rec_a + amb_a + rec_b + amb_b));
+								atomicAdd(wsp + 3, (unsigned long long)(rec_a + rec_b));
+								atomicAdd(wsp + 4, (unsigned long long)(amb_a + amb_b));
+								atomicAdd(wsp + (pass ? 5 : 6), 1ull);
+								atomicAdd(wsp + 7, (unsigned long long)total);
 							}
 						}
 					}
@@ -1327,14 +1329,15 @@ map_reads_b_kernel(
 			atomicAdd(&g_sec_cycles[x], sec_acc[x]);
 #endif
 	if (STATS && !FULL) {
-		ws.valid += wave_sum_u64(ls.valid);
-		ws.bad += wave_sum_u64(ls.bad);
-		ws.found += wave_sum_u64(ls.found);
-		ws.rec += wave_sum_u64(ls.rec);
-		ws.dup += wave_sum_u64(ls.dup);
-		ws.pass += wave_sum_u64(ls.pass);
-		ws.fail += wave_sum_u64(ls.fail);
-		ws.win += wave_sum_u64(ls.win);
+		ARKS_WAVE_SYNC();
+		ws.valid += S.wstats[0];
+		ws.bad += S.wstats[1];
+		ws.found += S.wstats[2];
+		ws.rec += S.wstats[3];
+		ws.dup += S.wstats[4];
+		ws.pass += S.wstats[5];
+		ws.fail += S.wstats[6];
+		ws.win += S.wstats[7];
 	}
 	if (STATS && lane_id == 0) {
 		if (ws.valid) atomicAdd(stats + 0, ws.valid);
