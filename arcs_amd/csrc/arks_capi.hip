@@ -658,7 +658,7 @@ arks_index_build(
 	}
 	{
 		void* p = nullptr;
-		HIP_TRY(hipMalloc(&p, 4 * sizeof(u32))); // slow-queue length, work counter, medium-queue length, its work counter
+		HIP_TRY(hipMalloc(&p, kMapScratchBytes)); // slow-queue length, work counter, medium-queue length, its work counter; partial statistics
 		idx->queue_count = static_cast<u32*>(p);
 	}
 	*out = idx;

@@ -60,6 +60,12 @@ wave_sum_u64(u64 v)
 	return v;
 }
 
+// The waves of a launch add their counters into kStatRows partial rows (by block index): thousands of
+// waves adding into the same eight words serialise at the L2; a one-wave kernel folds the rows into
+// the caller's arks_map_stats afterwards.
+constexpr int kStatRows = 64; // power of two
+constexpr int kStatRow = 8;   // words per row
+
 // per-wave counters of arks_map_stats (uniform across the lanes of a wave)
 struct WaveStats
 {
@@ -257,14 +263,14 @@ map_reads_kernel(
 		}
 	}
 	if (STATS && lane == 0) {
-		if (ws.valid) atomicAdd(stats + 0, ws.valid);
-		if (ws.bad) atomicAdd(stats + 1, ws.bad);
-		if (ws.found) atomicAdd(stats + 2, ws.found);
-		if (ws.rec) atomicAdd(stats + 3, ws.rec);
-		if (ws.dup) atomicAdd(stats + 4, ws.dup);
-		if (ws.pass) atomicAdd(stats + 5, ws.pass);
-		if (ws.fail) atomicAdd(stats + 6, ws.fail);
-		if (ws.win) atomicAdd(stats + 7, ws.win);
+		if (ws.valid) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 0, ws.valid);
+		if (ws.bad) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 1, ws.bad);
+		if (ws.found) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 2, ws.found);
+		if (ws.rec) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 3, ws.rec);
+		if (ws.dup) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 4, ws.dup);
+		if (ws.pass) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 5, ws.pass);
+		if (ws.fail) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 6, ws.fail);
+		if (ws.win) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 7, ws.win);
 	}
 }
 
@@ -1186,6 +1192,7 @@ map_reads_b_kernel(
 			if (!FULL) {
 				// hot path: lane j = read j; popcounts over its window words.  At most two distinct
 				// positive values can occur (one per diagonal): the vote of Arcs.cpp:998-1004 is a compare.
+				u32 st_a = 0, st_b = 0, st_c = 0; // this read's share of the counters (hot-finished reads only)
 				if (lane < nr) {
 					const int j = lane;
 					const long r = c0 + cur + j;
@@ -1222,17 +1229,31 @@ map_reads_b_kernel(
 							const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
 							const bool pass = maxj > j_index;
 							out_conreci[r] = pass ? best : 0;
-							if (STATS) {
-								unsigned long long* wsp = reinterpret_cast<unsigned long long*>(S.wstats);
-								atomicAdd(wsp + 0, (unsigned long long)nvalid);
-								atomicAdd(wsp + 1, (unsigned long long)(total - nvalid));
-								atomicAdd(wsp + 2, (unsigned long long)(rec_a + amb_a + rec_b + amb_b));
-								atomicAdd(wsp + 3, (unsigned long long)(rec_a + rec_b));
-								atomicAdd(wsp + 4, (unsigned long long)(amb_a + amb_b));
-								atomicAdd(wsp + (pass ? 5 : 6), 1ull);
-								atomicAdd(wsp + 7, (unsigned long long)total);
+							if (STATS) { // <= 16 reads x <= 512 windows: three words of 16-bit (8-bit) fields
+								st_a = (u32)nvalid | ((u32)total << 16);
+								st_b = (u32)(rec_a + amb_a + rec_b + amb_b) | ((u32)(rec_a + rec_b) << 16);
+								st_c = (u32)(amb_a + amb_b) | (pass ? 1u << 16 : 1u << 24);
 							}
 						}
+					}
+				}
+				if (STATS) {
+					// sum over the (<= 16) read lanes with four row-shift adds, one lane updates the wave's
+					// counters: no atomics (an atomic on one address from many lanes costs a full reduction)
+#define ARKS_ROW_ADD(v, ctrl) v += (u32)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, true)
+					ARKS_ROW_ADD(st_a, 0x111); ARKS_ROW_ADD(st_b, 0x111); ARKS_ROW_ADD(st_c, 0x111); // row_shr:1
+					ARKS_ROW_ADD(st_a, 0x112); ARKS_ROW_ADD(st_b, 0x112); ARKS_ROW_ADD(st_c, 0x112); // row_shr:2
+					ARKS_ROW_ADD(st_a, 0x114); ARKS_ROW_ADD(st_b, 0x114); ARKS_ROW_ADD(st_c, 0x114); // row_shr:4
+					ARKS_ROW_ADD(st_a, 0x118); ARKS_ROW_ADD(st_b, 0x118); ARKS_ROW_ADD(st_c, 0x118); // row_shr:8
+#undef ARKS_ROW_ADD
+					if (lane == 15) {
+						S.wstats[0] += st_a & 0xFFFFu;          // valid windows
+						S.wstats[7] += st_a >> 16;              // all windows (bad = all - valid)
+						S.wstats[2] += st_b & 0xFFFFu;          // found
+						S.wstats[3] += st_b >> 16;              // recorded
+						S.wstats[4] += st_c & 0xFFFFu;          // duplicate (value 0)
+						S.wstats[5] += (st_c >> 16) & 0xFFu;    // reads passing
+						S.wstats[6] += st_c >> 24;              // reads failing
 					}
 				}
 			}
@@ -1331,7 +1352,7 @@ map_reads_b_kernel(
 	if (STATS && !FULL) {
 		ARKS_WAVE_SYNC();
 		ws.valid += S.wstats[0];
-		ws.bad += S.wstats[1];
+		ws.bad += S.wstats[7] - S.wstats[0];
 		ws.found += S.wstats[2];
 		ws.rec += S.wstats[3];
 		ws.dup += S.wstats[4];
@@ -1340,14 +1361,14 @@ map_reads_b_kernel(
 		ws.win += S.wstats[7];
 	}
 	if (STATS && lane_id == 0) {
-		if (ws.valid) atomicAdd(stats + 0, ws.valid);
-		if (ws.bad) atomicAdd(stats + 1, ws.bad);
-		if (ws.found) atomicAdd(stats + 2, ws.found);
-		if (ws.rec) atomicAdd(stats + 3, ws.rec);
-		if (ws.dup) atomicAdd(stats + 4, ws.dup);
-		if (ws.pass) atomicAdd(stats + 5, ws.pass);
-		if (ws.fail) atomicAdd(stats + 6, ws.fail);
-		if (ws.win) atomicAdd(stats + 7, ws.win);
+		if (ws.valid) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 0, ws.valid);
+		if (ws.bad) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 1, ws.bad);
+		if (ws.found) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 2, ws.found);
+		if (ws.rec) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 3, ws.rec);
+		if (ws.dup) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 4, ws.dup);
+		if (ws.pass) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 5, ws.pass);
+		if (ws.fail) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 6, ws.fail);
+		if (ws.win) atomicAdd(stats + kStatRow * (blockIdx.x & (kStatRows - 1)) + 7, ws.win);
 	}
 }
 
@@ -1464,6 +1485,19 @@ blocks_for(u64 n, unsigned bs)
 	return (unsigned)(b ? b : 1);
 }
 
+__global__ void
+fold_stats_kernel(const u64* __restrict__ rows, u64* __restrict__ stats)
+{
+	const int c = threadIdx.x;
+	if (c >= kStatRow)
+		return;
+	u64 v = 0;
+	for (int r = 0; r < kStatRows; ++r)
+		v += rows[r * kStatRow + c];
+	if (v)
+		atomicAdd(stats + c, v);
+}
+
 hipError_t
 launch_map_reads(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens,
@@ -1472,7 +1506,11 @@ launch_map_reads(
 {
 	if (n_reads <= 0)
 		return hipSuccess;
-	hipError_t e = hipMemsetAsync(queue_count, 0, 4 * sizeof(u32), st);
+	// queue_count: 4 counters, then (64 bytes in) the partial rows of the statistics
+	u64* const user_stats = stats;
+	if (stats)
+		stats = reinterpret_cast<u64*>(reinterpret_cast<char*>(queue_count) + 64);
+	hipError_t e = hipMemsetAsync(queue_count, 0, stats ? kMapScratchBytes : 4 * sizeof(u32), st);
 	if (e != hipSuccess)
 		return e;
 	// one wave per read at a time; enough resident waves to cover the memory latency
@@ -1528,6 +1566,8 @@ launch_map_reads(
 #undef ARKS_MAP_HASH
 #undef ARKS_MAP_B
 #undef ARKS_MAP_B_ST
+	if (user_stats)
+		fold_stats_kernel<<<1, 64, 0, st>>>(stats, user_stats);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }
