@@ -310,7 +310,7 @@ constexpr int kSW = 16;          // words per minimizer pass (64 lanes x 8 posit
 constexpr int kTP = kSW * 32;    // ... in base positions
 constexpr int kTW = 32;          // tile capacity in packed words: two passes, one joint back half
 constexpr int kTR = 16;          // reads per tile
-constexpr int kNH = 64;          // run heads per tile that get a published entry list
+constexpr int kNH = 128;         // run heads per tile that get a published entry list
 constexpr int kChunk = 63;       // reads handed out per device-counter grab (lane l holds read l's metadata)
 constexpr u32 kHnHeavy = 255, kHnOverflow = 254;
 
@@ -343,7 +343,7 @@ struct TileLds
 	u32 b[FULL ? kTP + 96 : 256];
 	u64 cw[kTW + 4];
 	u32 nm[kTW + 4];
-	u32 heads[kNH]; // run heads: [0] minimizer strand, [11:1] its position, [31:12] window position
+	unsigned short heads[kNH]; // run heads: [0] minimizer strand, [11:1] its position, [15:12] read of the tile
 	unsigned char hn[kNH];
 	unsigned char wread[kTW + 4];
 	u32 wmeta[kTW + 4]; // per word: read index << 16 | local end position of that read (0 = none)
@@ -565,8 +565,12 @@ map_reads_b_kernel(
 			// ---- tile = reads [cur, nxt): as many as fit --------------------------------------
 			const u64 base_w = lane_value_u64(wo, cur);
 			// first pass: reads [cur, mid) within kSW words; second pass: [mid, nxt) likewise
+			// short sliding windows mean many runs per base: keep the tile's expected run count
+			// (64 / (w + 1) per word) within kNH by capping its words (never below one read)
+			const u64 wcap = (u64)(7 * (w + 1) / 4 < kTW ? 7 * (w + 1) / 4 : kTW);
 			const u64 fit = __ballot(
-			    lane > cur && lane <= nchunk && wo - base_w <= (u64)kSW && lane - cur <= kTR);
+			    lane > cur && lane <= nchunk && wo - base_w <= (u64)kSW && lane - cur <= kTR &&
+			    (lane == cur + 1 || wo - base_w <= wcap));
 			if (fit == 0) { // a single read longer than a pass: slow kernel
 				if (lane == cur) {
 					if (rl >= 0)
@@ -582,7 +586,7 @@ map_reads_b_kernel(
 			int nxt = mid;
 			if (!FULL) {
 				const u64 fit2 = __ballot(
-				    lane > mid && lane <= nchunk && wo - mid_w <= (u64)kSW && lane - cur <= kTR);
+				    lane > mid && lane <= nchunk && wo - mid_w <= (u64)kSW && lane - cur <= kTR && wo - base_w <= wcap);
 				if (fit2)
 					nxt = 63 - __clzll((long long)fit2);
 			}
@@ -647,7 +651,8 @@ map_reads_b_kernel(
 				const int l0 = lane * 8;                      // index into the pass-local minimum arrays
 				const int i0 = (ps ? tw0 * 32 : 0) + l0;      // tile position
 				const bool in_tile = i0 < (ps ? n : tw0 * 32);
-				const int rem0 = in_tile ? (int)(S.wmeta[i0 >> 5] & 0xFFFFu) - i0 : 0; // bases of the read from i0 on
+				const u32 wm0 = in_tile ? S.wmeta[i0 >> 5] : 0u; // the lane's 8 positions lie in one word, i.e. one read
+			const int rem0 = in_tile ? (int)(wm0 & 0xFFFFu) - i0 : 0; // bases of the read from i0 on
 				u32 wmin[8]; // minimizer (order value) of the window starting at each of the 8 positions
 				{
 					u32 v[8];
@@ -753,9 +758,8 @@ map_reads_b_kernel(
 						const bool head = wc[t] != 0xFFFFFFFFu && wc[t] != (t ? wc[t - 1] : wprev);
 						const u64 hb = __ballot(head);
 						const u32 rank = (u32)nheads + mask_below(hb);
-						const u32 hv = (wc[t] & 0xFFFu) | ((u32)(i0 + t) << 12);
 						if (head && rank < (u32)kNH)
-							S.heads[rank] = hv;
+							S.heads[rank] = (unsigned short)((wc[t] & 0xFFFu) | ((wm0 >> 16) << 12));
 						nheads += __popcll(hb);
 					}
 					if (bx.has_img && !(k & 1)) { // see the comment in the FULL path below
@@ -765,7 +769,7 @@ map_reads_b_kernel(
 								const int q = (int)((wc[t] >> 1) & 2047u);
 								const int qm = 2 * (i0 + t) + (k - MM) - q;
 								if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, q))
-									atomicOr(&S.redo, 1u << (S.wmeta[i0 >> 5] >> 16));
+									atomicOr(&S.redo, 1u << (wm0 >> 16));
 							}
 						}
 					}
@@ -809,7 +813,7 @@ map_reads_b_kernel(
 						const u64 hb = __ballot(head);
 						const int hidx = nheads + (int)mask_below(hb) + (head ? 1 : 0) - 1; // run of this window
 						if (head && hidx < kNH)
-							S.heads[hidx] = (sv & 0xFFFu) | ((u32)i << 12);
+							S.heads[hidx] = (unsigned short)((sv & 0xFFFu) | ((u32)j << 12));
 						nheads += __popcll(hb);
 						int rv = is_win ? -2 : -3;
 						if (ok) {
@@ -836,7 +840,7 @@ map_reads_b_kernel(
 			// ---- T5: run heads walk the minimizer table ------------------------------------------------
 			const int nh = nheads < kNH ? nheads : kNH;
 			for (int h = lane; h < nh; h += 64) {
-				const u32 q = (S.heads[h] >> 1) & 2047u;
+				const u32 q = ((u32)S.heads[h] >> 1) & 2047u;
 				const typename Mmer<MM>::type cm = tile_canonical_mmer<MM>(S.cw, (int)q);
 				const u32 fp = mmer_fp<MM>(cm);
 				u64 slot = mtab_home<MM>(cm, bx.mtab_cap);
@@ -885,57 +889,95 @@ map_reads_b_kernel(
 			//      match).  Lanes = run heads; the "first" is an LDS atomic minimum keyed by the run index. --
 			{
 				constexpr u64 kDiagMask = (1ull << 42) - 1ull; // [39:0] D, [40] same strand, [41] valid
-				if (lane < 2 * nr)
-					(&S.pdiag[0][0])[lane] = ~0ull;
-				ARKS_WAVE_SYNC();
-				int jh = -1;
-				u64 dk0 = 0, dk1 = 0;
-				bool off = false;
-				if (lane < nh) {
-					const u32 cnt = S.hn[lane];
-					const u32 hv = S.heads[lane];
-					jh = S.wread[hv >> 17]; // window position >> 5
+				// the diagonals run h proposes (0 = none), its read, and whether it must go the general way
+				auto proposals = [&](int h, int& jh, u64& dk0, u64& dk1, bool& off) {
+					const u32 cnt = S.hn[h];
+					const u32 hv = S.heads[h];
+					jh = (int)(hv >> 12);
 					off = cnt == kHnHeavy || cnt == kHnOverflow;
+					dk0 = 0, dk1 = 0;
 					if (cnt >= 1 && cnt <= 2) {
 						const int o = (int)((hv >> 1) & 2047u) - S.rstart[jh]; // offset of the minimizer in the read
 						const u32 rstrand = hv & 1u;
 						// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
-						const u64 e0 = hc[lane][0];
+						const u64 e0 = hc[h][0];
 						const bool s0 = ((u32)(e0 >> 62) & 1u) == rstrand;
 						dk0 = (s0 ? (u64)(u32)e0 - (u64)o : (u64)(u32)e0 + (u64)(MM - 1 + o)) |
 						      ((u64)s0 << 40) | (1ull << 41);
 						if (cnt == 2) {
-							const u64 e1 = hc[lane][1];
+							const u64 e1 = hc[h][1];
 							const bool s1 = ((u32)(e1 >> 62) & 1u) == rstrand;
 							dk1 = (s1 ? (u64)(u32)e1 - (u64)o : (u64)(u32)e1 + (u64)(MM - 1 + o)) |
 							      ((u64)s1 << 40) | (1ull << 41);
 						}
-						atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][0]),
-						          (unsigned long long)(((u64)lane << 42) | dk0));
 					}
-				}
+				};
+				if (lane < 2 * nr)
+					(&S.pdiag[0][0])[lane] = ~0ull;
 				ARKS_WAVE_SYNC();
-				u64 dA = 0;
-				if (dk0) {
-					dA = S.pdiag[jh][0] & kDiagMask;
-					if (dk0 != dA)
-						atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][1]),
-						          (unsigned long long)(((u64)lane << 43) | dk0));
-					else if (dk1 && dk1 != dA)
-						atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][1]),
-						          (unsigned long long)(((u64)lane << 43) | (1ull << 42) | dk1));
-				}
-				ARKS_WAVE_SYNC();
-				if (!FULL) {
-					// hot path: a read with a run that proposes a third diagonal, sits under a heavy
-					// minimizer or had more than two entries goes to the medium queue as a whole
+				// the first 64 runs keep their proposals in registers across the three phases; further
+				// runs (short sliding windows only) recompute them
+				int jh0 = 0;
+				u64 p0 = 0, p1 = 0;
+				bool off0 = false;
+				if (lane < nh)
+					proposals(lane, jh0, p0, p1, off0);
+				auto elect_a = [&](int h, int jh, u64 dk0) {
+					if (dk0)
+						atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][0]),
+						          (unsigned long long)(((u64)h << 42) | dk0));
+				};
+				auto elect_b = [&](int h, int jh, u64 dk0, u64 dk1) {
 					if (dk0) {
+						const u64 dA = S.pdiag[jh][0] & kDiagMask;
+						if (dk0 != dA)
+							atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][1]),
+							          (unsigned long long)(((u64)h << 43) | dk0));
+						else if (dk1 && dk1 != dA)
+							atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][1]),
+							          (unsigned long long)(((u64)h << 43) | (1ull << 42) | dk1));
+					}
+				};
+				auto flag = [&](int jh, u64 dk0, u64 dk1, bool off) {
+					if (dk0) {
+						const u64 dA = S.pdiag[jh][0] & kDiagMask;
 						const u64 rb = S.pdiag[jh][1];
 						const u64 dB = rb == ~0ull ? 0ull : (rb & kDiagMask);
 						off = off || (dk0 != dA && dk0 != dB) || (dk1 && dk1 != dA && dk1 != dB);
 					}
 					if (off)
 						atomicOr(&S.redo2, 1u << jh);
+				};
+				elect_a(lane, jh0, p0);
+				for (int h = lane + 64; h < nh; h += 64) {
+					int jh;
+					u64 dk0, dk1;
+					bool off;
+					proposals(h, jh, dk0, dk1, off);
+					elect_a(h, jh, dk0);
+				}
+				ARKS_WAVE_SYNC();
+				elect_b(lane, jh0, p0, p1);
+				for (int h = lane + 64; h < nh; h += 64) {
+					int jh;
+					u64 dk0, dk1;
+					bool off;
+					proposals(h, jh, dk0, dk1, off);
+					elect_b(h, jh, dk0, dk1);
+				}
+				ARKS_WAVE_SYNC();
+				if (!FULL) {
+					// hot path: a read with a run that proposes a third diagonal, sits under a heavy
+					// minimizer or had more than two entries goes to the medium queue as a whole
+					if (lane < nh)
+						flag(jh0, p0, p1, off0);
+					for (int h = lane + 64; h < nh; h += 64) {
+						int jh;
+						u64 dk0, dk1;
+						bool off;
+						proposals(h, jh, dk0, dk1, off);
+						flag(jh, dk0, dk1, off);
+					}
 					if (nheads > kNH && lane == 0) // more runs than the tile publishes: every read
 						atomicOr(&S.redo2, 0xFFFFFFFFu);
 					ARKS_WAVE_SYNC();
