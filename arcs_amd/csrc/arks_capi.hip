@@ -454,14 +454,17 @@ arks_index_build(
 		text_words = acc;
 		alloc_words = acc + kBackPad;
 	}
-	// text positions are 32-bit in the minimizer table
-	locality = want_locality(k) && alloc_words * 32ull < 0xFFFF0000ull;
 	// minimizer length: 21-mers stay specific at any text size (a 15-mer sees ~ text / 5.4e8 chance
-	// occurrences) and leave a shorter sliding window; 15-mers only where k leaves no room.
-	// ARKS_MINIMIZER_LEN overrides (tests).
-	mm = k >= kMLong + 9 ? kMLong : kMShort;
+	// occurrences, and every chance occurrence is a third diagonal for the hot kernel); the short one
+	// (17) only where k leaves no room (k < 24).  ARKS_MINIMIZER_LEN overrides (tests).
+	mm = k >= kMLong + 3 ? kMLong : kMShort; // measured: from k = 24 on the 21-mer wins even with a 4-position window
 	if (const char* e = std::getenv("ARKS_MINIMIZER_LEN"))
 		mm = (std::atoi(e) >= 19 && k >= kMLong + 2) ? kMLong : kMShort;
+	// text positions are 32-bit in the minimizer table; and with the short minimizer (some 60 runs per
+	// read at k = 20) a text beyond ~2.5e8 positions proposes chance diagonals for nearly every read:
+	// measured at 1 Gbp, k = 20: 86 ms per 4 M pairs against 52 ms for the plain hash table
+	locality = want_locality(k) && alloc_words * 32ull < 0xFFFF0000ull &&
+	           !(mm == kMShort && alloc_words * 32ull > 250000000ull && !std::getenv("ARKS_MINIMIZER_LEN"));
 	w = k - mm + 1;
 	bm_bytes = sizeof(u32) * alloc_words;
 

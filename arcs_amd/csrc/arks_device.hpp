@@ -359,8 +359,9 @@ table_lookup(const TableView& t, const Key<KW>& c)
 // the few regular keys a palindromic query could collide with live in a small exact hash table
 // (`fallback`), reached only when the query says so.
 // ================================================================================================
-constexpr int kMShort = 15; // minimizer length for small indexes: fits 30 bits, all 32-bit arithmetic
-constexpr int kMLong = 21;  // ... for large ones (a 15-mer stops being specific near 10^8 text bases)
+constexpr int kMShort = 17; // minimizer length where k leaves no room for the long one (k < 24)
+constexpr int kMLong = 21;  // the default: specific at any text size (a 15-mer has ~ text / 5.4e8 chance
+                            // occurrences, and every chance occurrence is one more diagonal to rule out)
 constexpr u32 kFpMask = (1u << 30) - 1u;
 constexpr int kHeavy = 8;         // a minimizer with more text occurrences than this is "heavy"
 constexpr int kFrontPadWords = 16; // the text starts 512 bases into its arrays (diagonals may underrun)
@@ -372,14 +373,9 @@ struct Mmer
 {
 	typedef u64 type;
 };
-template <>
-struct Mmer<kMShort>
-{
-	typedef u32 type;
-};
 
 // minimizer-table entry: [63] occupied, [62] strand (1 = the text m-mer is the canonical one),
-// [61:32] 30-bit fingerprint of the canonical m-mer (the 15-mer itself, a hash of the 21-mer),
+// [61:32] 30-bit fingerprint (a hash) of the canonical m-mer,
 // [31:0] text position (kHeavyPos = "heavy: ask the fallback table").  A fingerprint collision only
 // proposes a diagonal that the exact verification then rejects.
 __device__ __forceinline__ u64
@@ -470,8 +466,6 @@ template <int MM>
 __device__ __forceinline__ u32
 mmer_fp(typename Mmer<MM>::type cm)
 {
-	if (MM == kMShort)
-		return (u32)cm;
 	return ((mmer_fold(cm) ^ 0x68E31DA4u) * 0xB5297A4Du) >> 2;
 }
 

@@ -408,12 +408,6 @@ template <int MM>
 __device__ __forceinline__ typename Mmer<MM>::type
 tile_mmer(const u64* cw, int i)
 {
-	if (MM == kMShort) {
-		const u32* s32 = reinterpret_cast<const u32*>(cw); // 16 bases per u32, halves swapped
-		const int hn = i >> 4, t = (i & 15) * 2;
-		const u32 hi = s32[hn ^ 1], lo = s32[(hn + 1) ^ 1];
-		return (typename Mmer<MM>::type)((t ? ((hi << t) | (lo >> (32 - t))) : hi) >> (32 - 2 * kMShort));
-	}
 	return (typename Mmer<MM>::type)(funnel_l(cw[i >> 5], cw[(i >> 5) + 1], (i & 31) * 2) >> (64 - 2 * MM));
 }
 

@@ -277,8 +277,8 @@ def test_hash_kind_still_exact(arks, gpu, oracle, golden_mini, monkeypatch):
 
 @pytest.mark.parametrize("k,mlen", [(24, 21), (30, 15), (60, 15), (64, 15), (96, 15), (40, 21)])
 def test_minimizer_length_variants(arks, gpu, oracle, golden_mini, monkeypatch, k, mlen):
-    """ARKS_MINIMIZER_LEN forces the other minimizer length (default: 21-mers from k = 30 on,
-    15-mers below): identical results, incl. the exception paths"""
+    """ARKS_MINIMIZER_LEN forces the other minimizer length (default: 21-mers from k = 24 on, the short
+    17-mers below; any value < 19 selects the short one): identical results, incl. the exception paths"""
     monkeypatch.setenv("ARKS_MINIMIZER_LEN", str(mlen))
     cs, reads = golden_mini["contigs"], golden_mini["reads"]
     ends = arks.contig_ends(cs, golden_mini["params"]["min_size"], golden_mini["params"]["end_length"])
