@@ -265,3 +265,50 @@ def test_arcs_cli_k_list_single_pass(arks, gpu, tmp_path):
         line = [ln for ln in r1.stdout.split("\n") if ln.startswith("Total valid kmers:")][0]
         assert line in block.split("k = ")[1]
     assert len(differ) > 1, "the three k should not all give the same evidence"
+
+
+def test_arks_long_pipe(arks, gpu, tmp_path):
+    """the arks-long flow of bin/arcs-make:299-313: long reads -> long-to-linked-pe (pseudo-linked pairs,
+    BX = read number) piped into `arcs --arks ... -u multiplicities /dev/stdin`; same outputs as reading
+    the materialised pairs from a file, for a k list in one pass"""
+    from arcs_amd import build as b, synth
+    exe = b.build_host()
+    feeder = os.path.join(os.path.dirname(exe), "long-to-linked-pe")
+    rng = np.random.Generator(np.random.PCG64(33))
+    contigs = synth.make_draft(600_000, seed=93, lengths=(70000, 40000, 110000), small_frac=0.2)
+    cs = synth.contigs_to_strings(contigs)
+    genome = "".join(cs)
+    fa = tmp_path / "draft.fa"
+    fa.write_text("".join(f">{i + 1}\n{s_}\n" for i, s_ in enumerate(cs)))
+    comp = str.maketrans("ACGT", "TGCA")
+    with gzip.open(tmp_path / "long.fa.gz", "wt") as f:
+        for i in range(400):
+            n = int(rng.integers(3000, 30000))
+            p0 = int(rng.integers(0, len(genome) - n))
+            r = list(genome[p0:p0 + n])
+            for q in rng.integers(0, n, size=n // 200):          # 0.5 % substitutions
+                r[q] = "ACGT"[int(rng.integers(4))]
+            r = "".join(r)
+            if i % 2:
+                r = r[::-1].translate(comp)
+            f.write(f">long{i}\n{r}\n")
+    mult = tmp_path / "bx.tsv"
+    subprocess.run([feeder, "-l", "250", "-m", "2000", "--bx-only", "-b", str(mult), str(tmp_path / "long.fa.gz")], check=True)
+    pairs = subprocess.run([feeder, "-l", "250", "-m", "2000", "-t", "2", str(tmp_path / "long.fa.gz")],
+                           capture_output=True, check=True).stdout
+    (tmp_path / "pairs.fq").write_bytes(pairs)
+    common = [exe, "--arks", "-v", "-f", str(fa), "-c", "4", "-m", "8-10000", "-e", "30000", "-z", "500", "-j", "0.05",
+              "-k", "20,40", "-t", "3", "-u", str(mult), "--batch-pairs", "2000"]
+    piped = subprocess.run(common + ["-b", str(tmp_path / "piped"), "/dev/stdin"], input=pairs, capture_output=True,
+                           timeout=300)
+    assert piped.returncode == 0, piped.stderr[-2000:]
+    filed = subprocess.run(common + ["-b", str(tmp_path / "filed"), str(tmp_path / "pairs.fq")], capture_output=True,
+                           timeout=300)
+    assert filed.returncode == 0, filed.stderr[-2000:]
+    n_edges = 0
+    for k in (20, 40):
+        for suffix in ("_original.gv", "_main.tsv", ".dist.gv"):
+            a = open(str(tmp_path / f"piped_k{k}") + suffix).read()
+            assert a == open(str(tmp_path / f"filed_k{k}") + suffix).read(), (k, suffix)
+        n_edges += open(str(tmp_path / f"piped_k{k}") + "_original.gv").read().count("--")
+    assert n_edges > 0, "long reads spanning contigs should link some ends"
