@@ -311,7 +311,8 @@ constexpr int kTP = kSW * 32;    // ... in base positions
 constexpr int kTW = 32;          // tile capacity in packed words: two passes, one joint back half
 constexpr int kTR = 16;          // reads per tile
 constexpr int kNH = 128;         // run heads per tile that get a published entry list
-constexpr int kChunk = 63;       // reads handed out per device-counter grab (lane l holds read l's metadata)
+constexpr int kChunk = 60;       // reads handed out per device-counter grab (lane l holds read l's metadata);
+                                 // divisible by the usual reads per tile (4, 6, 10, 12): no half-empty last tile
 constexpr u32 kHnHeavy = 255, kHnOverflow = 254;
 
 // Bit b of the result: none of the positions [b, b + k) of the 128-bit vector m3:m2:m1:m0 (m0 = positions
