@@ -1,0 +1,62 @@
+"""Randomised differential test: GPU path vs CPU oracle over many (k, draft, read shape) combinations."""
+import os, sys, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import arcs_amd
+from arcs_amd import synth
+from oracle import pyoracle as oracle
+oracle.build_oracle()
+COMP = str.maketrans("ACGTacgtNn", "TGCAtgcaNn")
+def rc(s): return s[::-1].translate(COMP)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120
+t_end = time.time() + budget
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+n_cases = n_reads_total = 0
+while time.time() < t_end:
+    rng = np.random.Generator(np.random.PCG64(seed)); seed += 1
+    k = int(rng.choice([20, 21, 22, 23, 24, 25, 27, 30, 31, 32, 33, 40, 45, 59, 60, 61, 63, 64, 65, 72, 80, 95, 96]))
+    def rnd(n): return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+    ends = []
+    base = rnd(int(rng.integers(2000, 20000)))
+    for e in range(int(rng.integers(2, 12))):
+        L = int(rng.choice([64, 96, 500, 1000, 3000, 320, 640, 2048]))
+        mode = int(rng.integers(0, 6))
+        if mode == 0 and len(base) > L:      # shares a segment with `base` (value 0 keys, second diagonals)
+            p = int(rng.integers(0, len(base) - L)); s = base[p:p + L]
+        elif mode == 1:                      # low complexity
+            u = rnd(int(rng.integers(1, 40))); s = (u * (L // len(u) + 1))[:L]
+        elif mode == 2:                      # palindromic stretch
+            h = rnd(L // 2); s = h + rc(h)
+        else:
+            s = rnd(L)
+        s = list(s)
+        for q in rng.integers(0, L, size=int(rng.integers(0, 4))): s[q] = "N"
+        if rng.random() < 0.2 and L > 200: s[100:100 + int(rng.integers(2, 150))] = "N" * len(s[100:100 + int(rng.integers(2, 150))])
+        ends.append("".join(s))
+    ends.append(base)
+    ox = oracle.OracleIndex(k).build(ends)
+    ix = arcs_amd.ArksIndex.build(ends, k, device=0)
+    assert {f: ix.build_stats[f] for f in ox.stats.as_dict()} == ox.stats.as_dict(), (seed, k, "build stats")
+    genome = "".join(ends)
+    reads = []
+    for i in range(int(rng.integers(200, 1500))):
+        L = int(rng.choice([k - 1, k, k + 1, 31, 32, 33, 64, 100, 128, 150, 151, 250, 300, 511, 512, 513, 700, 1]))
+        L = max(0, min(L, len(genome) - 1))
+        p = int(rng.integers(0, len(genome) - L))
+        r = list(genome[p:p + L])
+        if rng.random() < 0.15 and L > 2 * k:                      # chimera: second half from elsewhere
+            p2 = int(rng.integers(0, len(genome) - L)); r[L // 2:] = genome[p2 + L // 2:p2 + L]
+        for q in rng.integers(0, max(L, 1), size=int(rng.integers(0, 4)) if L else 0):
+            r[q] = "ACGTNacgtn"[int(rng.integers(10))]
+        r = "".join(r)
+        reads.append(rc(r) if i % 2 else r)
+    for j in (0.55, 0.0, float(rng.random())):
+        st = oracle.MapStats()
+        want = [ox.best_contig(r, j, st) for r in reads]
+        got, gst = ix.map_reads(reads, j, want_stats=True)
+        bad = [i for i, (a, b) in enumerate(zip(got.tolist(), want)) if a != b]
+        assert not bad, (seed - 1, k, j, bad[:5], [len(reads[i]) for i in bad[:5]])
+        assert gst == st.as_dict(), (seed - 1, k, j, gst, st.as_dict())
+    ix.close()
+    n_cases += 1; n_reads_total += len(reads)
+print("fuzz ok: %d cases, %d reads, last seed %d" % (n_cases, n_reads_total, seed - 1))

@@ -2,7 +2,7 @@
 shape) combinations per run -- shared segments (value 0 keys, second diagonals), low-complexity repeats
 (heavy minimizers), palindromic stretches (quirk keys), N runs (visit rule), reads of awkward lengths
 (k-1, k, k+1, word multiples, around the 512-base tile limit), chimeras, both strands.  Bit-exact:
-build counters, per-read contig end, map counters.  (scratch/fuzz.py is the open-ended version; the
+build counters, per-read contig end, map counters.  (tests/fuzz_open_ended.py <seconds> <first seed> is the open-ended version; the
 round-1 run covered 5856 cases / 5.0 M reads.)"""
 import numpy as np
 import pytest
