@@ -122,8 +122,11 @@ class OracleIndex:
         self.stats = BuildStats()
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().arks_oracle_index_free(self.h)
+        if getattr(self, "h", None) and lib is not None:   # module globals are gone at interpreter exit
+            try:
+                lib().arks_oracle_index_free(self.h)
+            except Exception:
+                pass
             self.h = None
 
     def map_kmers(self, seq, conreci):
