@@ -4,6 +4,13 @@
 #include "arks_hip.h"
 #include "arks_kernels.hpp"
 
+// minimizer-table slots per entry: the map kernel's probe is a dependent HBM round trip per group of 4
+// entries, so what matters is how often a run needs a second one (measured at C2: 2 -> 4 slots per
+// entry +6 %, 6: +8 %); 8 B per slot
+#ifndef ARKS_MTAB_LOAD_INV
+#define ARKS_MTAB_LOAD_INV 6
+#endif
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -599,7 +606,7 @@ arks_index_build(
 		(void)hipFree(d_full.p);
 		d_full.p = nullptr;
 		ccap = 2 * (n_min + 4 * n_pal) + 64;
-		mcap = 2 * (n_min + 4 * n_pal) + 64;
+		mcap = (ARKS_MTAB_LOAD_INV * (n_min + 4 * n_pal) + 64 + 3) & ~3ull; // whole groups of 4 (mtab_home)
 		HIP_TRY(d_ckeys.alloc(sizeof(u64) * ccap));
 		HIP_TRY(d_ccnts.alloc(sizeof(u32) * ccap));
 		{

@@ -473,9 +473,11 @@ template <int MM>
 __device__ __forceinline__ u64
 mtab_home(typename Mmer<MM>::type cm, u64 cap)
 {
+	// home slots are multiples of 4 (cap is one too): the map kernel reads four entries per round trip,
+	// and an aligned group is one 32-byte sector instead of a span that straddles two
 	u64 h = (u64)cm * 0x9E3779B97F4A7C15ull;
 	h ^= h >> 29;
-	return mulhi64(h * 0xD6E8FEB86659FD93ull, cap);
+	return mulhi64(h * 0xD6E8FEB86659FD93ull, cap) & ~3ull;
 }
 
 __device__ __forceinline__ u32
