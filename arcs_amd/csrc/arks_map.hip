@@ -604,9 +604,20 @@ map_reads_b_kernel(
 				if (lane < 32)
 					S.b[192 + lane] = 0u; // rmax
 			}
-			if (lane < tw + 4) {
-				S.cw[lane] = codes[base_w + (u64)lane];
-				S.nm[lane] = nmask[base_w + (u64)lane];
+			{
+				// both loads in flight before either is stored: left alone the compiler reuses one register
+				// and serialises them -- two HBM round trips at the head of every tile instead of one
+				u64 c_in = 0;
+				u32 m_in = 0;
+				if (lane < tw + 4) {
+					c_in = codes[base_w + (u64)lane];
+					m_in = nmask[base_w + (u64)lane];
+				}
+				asm volatile("" : "+v"(c_in), "+v"(m_in));
+				if (lane < tw + 4) {
+					S.cw[lane] = c_in;
+					S.nm[lane] = m_in;
+				}
 			}
 			ARKS_WAVE_SYNC();
 			if (lane < nr) {
