@@ -893,6 +893,7 @@ map_reads_b_kernel(
 			// ---- T6a: up to two diagonals per read: A = entry 0 of its first run that has entries, B = the
 			//      first entry (in run order) on another diagonal (a duplicated segment, a chance m-mer
 			//      match).  Lanes = run heads; the "first" is an LDS atomic minimum keyed by the run index. --
+			bool any_b = false; // some read of the tile has a second diagonal
 			{
 				constexpr u64 kDiagMask = (1ull << 42) - 1ull; // [39:0] D, [40] same strand, [41] valid
 				// the diagonals run h proposes (0 = none), its read, and whether it must go the general way
@@ -988,6 +989,7 @@ map_reads_b_kernel(
 						atomicOr(&S.redo2, 0xFFFFFFFFu);
 					ARKS_WAVE_SYNC();
 				}
+				bool has_b = false;
 				if (lane < nr) {
 					// strip the run index; first text word of the span [lo, lo + L) the read covers
 #pragma unroll
@@ -998,24 +1000,28 @@ map_reads_b_kernel(
 						const u64 Dv = pdv & 0xFFFFFFFFFFull;
 						const u64 lo = ((pdv >> 40) & 1ull) ? Dv : Dv - (u64)(S.rlen[lane] - 1);
 						S.tfirst[lane][d] = (u32)(lo >> 5);
+						has_b = d == 1 && pdv != 0;
 					}
 				}
+				any_b = __ballot(has_b) != 0;
 			}
 			ARKS_WAVE_SYNC();
-			// stage the text words and their visited / ambiguous / owner words (one round trip)
+			// stage the text words and their visited / ambiguous / owner words (one round trip): one lane
+			// per slot of the first diagonals; second diagonals are rare -- their pass only runs for a tile
+			// that has one (lanes = slots x 2 needed a second, almost empty trip through this code)
 			{
 				const int ns = tw + nr;
-				for (int x = lane; x < 2 * ns; x += 64) {
-					const int d = x >= ns ? 1 : 0, sl = x - d * ns;
-					const int j = S.sread[sl];
-					if (S.pdiag[j][d] >> 41) {
-						const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
-						tcodes[d][sl] = bx.codes[tw_idx];
-						tvis[d][sl] = bx.visited[tw_idx];
-						tamb[d][sl] = bx.ambig[tw_idx];
-						town[d][sl] = bx.word_owner[tw_idx];
+				for (int d = 0; d < (any_b ? 2 : 1); ++d)
+					for (int sl = lane; sl < ns; sl += 64) {
+						const int j = S.sread[sl];
+						if (S.pdiag[j][d] >> 41) {
+							const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
+							tcodes[d][sl] = bx.codes[tw_idx];
+							tvis[d][sl] = bx.visited[tw_idx];
+							tamb[d][sl] = bx.ambig[tw_idx];
+							town[d][sl] = bx.word_owner[tw_idx];
+						}
 					}
-				}
 			}
 			ARKS_WAVE_SYNC();
 			// ---- T6b: lanes = read words (x2 diagonals): XOR each word of the read with the 32 text bases
