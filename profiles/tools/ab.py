@@ -1,0 +1,73 @@
+"""(run from the repository root) interleaved A/B timing of arks_map_reads_device across several builds of libarks_hip.so
+usage: python scratch/ab.py name=path.so [name=path.so ...]"""
+import ctypes as C, os, sys, statistics
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from arcs_amd import synth, _lib
+import arcs_amd
+from arcs_amd.api import _concat
+
+variants = [a.split("=", 1) for a in sys.argv[1:]]
+k, j = 60, 0.55
+NP = int(os.environ.get("AB_PAIRS", 4_000_000))
+contigs = synth.make_draft(int(float(os.environ.get('AB_DRAFT_MBP', 50)) * 1e6), seed=synth.SEED)
+cs = synth.contigs_to_strings(contigs)
+ends = arcs_amd.contig_ends(cs) if False else None
+# contig ends without touching the default lib
+def cutoff(L, mn=500, e=30000):
+    if L < mn: return None
+    c = e
+    if c == 0 or L <= 2 * c: c = L // 2
+    return c
+ends = []
+for s_ in cs:
+    c = cutoff(len(s_))
+    if c is None: continue
+    ends.append(s_[:c]); ends.append(s_[len(s_) - c:])
+data, offsets, lens = _concat(ends)
+data = np.concatenate([data, np.zeros(1, np.uint8)])
+batch = synth.make_read_pairs(contigs, NP, seed=synth.SEED + 1, device="cuda")
+n = int(batch["lens"].numel())
+dev = torch.device("cuda", 0)
+woff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+woff[1:] = torch.cumsum((batch["lens"].to(torch.int64) + 31) // 32, 0)
+total = int(woff[-1].item())
+d_ascii = torch.cat([batch["ascii"], torch.zeros(64, dtype=torch.uint8, device=dev)])
+sp = C.c_void_p(torch.cuda.current_stream(0).cuda_stream)
+libs = []
+for name, path in variants:
+    L = C.CDLL(os.path.abspath(path))
+    L.arks_index_build.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.arks_pack_reads_device.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+    L.arks_map_reads_device.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    h = C.c_void_p()
+    assert L.arks_index_build(C.byref(h), k, data.ctypes.data, offsets.ctypes.data, lens.ctypes.data, len(lens), 0, None) == 0
+    codes = torch.zeros(total + 4, dtype=torch.int64, device=dev)
+    nmask = torch.zeros(total + 4, dtype=torch.int32, device=dev)
+    assert L.arks_pack_reads_device(d_ascii.data_ptr(), batch["offsets"].data_ptr(), batch["lens"].data_ptr(), woff.data_ptr(), n, codes.data_ptr(), nmask.data_ptr(), None, 0, sp) == 0
+    out = torch.zeros(n, dtype=torch.int32, device=dev)
+    libs.append((name, L, h, codes, nmask, out))
+torch.cuda.synchronize()
+d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
+def run(L, h, codes, nmask, out, name=""):
+    st = d_stats.data_ptr() if (os.environ.get("AB_STATS") or name.endswith("+stats")) else None
+    assert L.arks_map_reads_device(h, codes.data_ptr(), nmask.data_ptr(), woff.data_ptr(), batch["lens"].data_ptr(), None, n, j, out.data_ptr(), st, sp) == 0
+for (name, L, h, codes, nmask, out) in libs:
+    run(L, h, codes, nmask, out)
+torch.cuda.synchronize()
+ref = libs[0][5].clone()
+times = {name: [] for name, *_ in libs}
+for rnd in range(7):
+    for (name, L, h, codes, nmask, out) in libs:
+        a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+        a.record(); run(L, h, codes, nmask, out, name); b.record(); torch.cuda.synchronize()
+        times[name].append(a.elapsed_time(b))
+windows = int(torch.clamp(batch["lens"].to(torch.int64) - (k - 1), min=0).sum().item())
+for (name, L, h, codes, nmask, out) in libs:
+    t = times[name]
+    same = bool((out == ref).all().item())
+    try:
+        qc = (C.c_uint * 4)(); L.arks_debug_queue_counts.argtypes = [C.c_void_p, C.c_void_p]; L.arks_debug_queue_counts(h, qc); print("   queues: slow", qc[0], "medium", qc[2], "of", n, "reads")
+    except AttributeError:
+        pass
+    print(f"{name:14s} median {statistics.median(t):7.3f} ms  min {min(t):7.3f}  -> {windows / (statistics.median(t) * 1e-3) / 1e9:6.2f} G k-mers/s  same_as_first={same}")

@@ -31,7 +31,7 @@ while done < PAIRS:
     bid = batch["barcode_id"] + (done // 80)          # barcodes continue across chunks
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record()
-    arcs_amd.map_pairs_packed(ix, reads, 0.55, pair_ok=batch["pair_ok"], barcode_id=bid.to(torch.int32), imap=imap, stats=stats, stored=stored)
+    arcs_amd.map_pairs_packed(ix, reads, 0.55, pair_ok=batch["pair_ok"], barcode_id=bid.to(torch.int32), imap=imap, stats=(None if os.environ.get('C3_NOSTATS') else stats), stored=stored)
     b.record(); torch.cuda.synchronize()
     map_ms += a.elapsed_time(b); windows += reads.windows(60); done += n
     del batch, reads

@@ -1,0 +1,49 @@
+"""End-to-end throughput of the `arcs --arks` CLI: FASTQ(.gz) files -> .gv, by -t."""
+import gzip, os, subprocess, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from arcs_amd import build as b, synth
+exe = b.build_host()
+tmp = "/tmp/e2e"; os.makedirs(tmp, exist_ok=True)
+NF, NP = int(os.environ.get("E2E_FILES", 4)), int(os.environ.get("E2E_PAIRS", 1000000))
+contigs = synth.make_draft(20_000_000, seed=7)
+cs = synth.contigs_to_strings(contigs)
+with open(f"{tmp}/draft.fa", "w") as f:
+    for i, s in enumerate(cs):
+        f.write(f">{i+1}\n{s}\n")
+mult = {}
+t0 = time.time()
+for fi in range(NF):
+    batch = synth.make_read_pairs(contigs, NP, seed=100 + fi)
+    reads = synth.reads_to_strings(batch)
+    bid = batch["barcode_id"].numpy()
+    parts = []
+    for p in range(NP):
+        bc = f"BC{int(bid[p]):08d}-1"
+        mult[bc] = mult.get(bc, 0) + 2
+        s1, s2 = reads[2*p], reads[2*p+1]
+        parts.append(f"@r{fi}_{p}/1 BX:Z:{bc}\n{s1}\n+\n{'F'*len(s1)}\n@r{fi}_{p}/2 BX:Z:{bc}\n{s2}\n+\n{'F'*len(s2)}\n")
+    text = "".join(parts)
+    open(f"{tmp}/r{fi}.fq", "w").write(text)
+    with gzip.open(f"{tmp}/r{fi}.fq.gz", "wt", compresslevel=4) as f:
+        f.write(text)
+with open(f"{tmp}/mult.tsv", "w") as f:
+    f.writelines(f"{k}\t{v}\n" for k, v in mult.items())
+print("data generated in %.1f s; %d files x %d pairs; fq %.0f MB each" % (time.time()-t0, NF, NP, len(text)/1e6), flush=True)
+ref = None
+for ext in (".fq", ".fq.gz"):
+    files = [f"{tmp}/r{fi}{ext}" for fi in range(NF)]
+    for t in (1, 4, 16):
+        args = [exe, "--arks", "-f", f"{tmp}/draft.fa", "-u", f"{tmp}/mult.tsv", "-k", "60", "-j", "0.55", "-c", "5",
+                "-m", "50-10000", "-e", "30000", "-z", "500", "-t", str(t), "-b", f"{tmp}/out_{t}{ext.replace('.', '_')}"] + files
+        t1 = time.time()
+        out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, ARKS_TIMING='1'))
+        dt = time.time() - t1
+        if out.returncode:
+            print(out.stdout[-2000:], out.stderr[-2000:]); sys.exit(1)
+        gv = open(f"{tmp}/out_{t}{ext.replace('.', '_')}_original.gv").read()
+        ref = ref or gv
+        print(f"{ext:7s} -t {t:2d}: {dt:6.2f} s total  ({NF*NP/dt/1e6:.2f} M pairs/s whole run)  gv_same={gv == ref}", flush=True)
+        rd = [l for l in out.stderr.splitlines() if 'read files' in l]
+        ms = float(rd[0].split(':')[1].split()[0]) if rd else 0
+        print('        reads stage %.0f ms -> %.2f M pairs/s' % (ms, NF*NP/ms/1e3), flush=True)
