@@ -453,12 +453,8 @@ mmer_order(typename Mmer<MM>::type cm)
 {
 	// two 24-bit multiply-adds (full rate on CDNA; a 32-bit v_mul_lo_u32 is quarter rate and this runs
 	// for every base of every read): low 12 bases and the bases above them, mixed into the top bits
-#ifdef ARKS_OLD_HASH
-	return ((mmer_fold(cm) ^ 0x2F0B4C5Du) * 0x9E3779B1u) >> 12;
-#else
 	const u32 lo = (u32)cm, up = (u32)(cm >> 24);
 	return (__umul24(up, 0x85EBCBu) + __umul24(lo, 0x9E3779u) + 0x7F4A7C15u) >> 12;
-#endif
 }
 
 // the 30 bits of a canonical m-mer that a table entry keeps

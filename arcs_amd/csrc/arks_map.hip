@@ -51,15 +51,6 @@ lane_value_u64(u64 v, int l)
 	return ((u64)hi << 32) | lo;
 }
 
-__device__ __forceinline__ u64
-wave_sum_u64(u64 v)
-{
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1)
-		v += __shfl_xor(v, off);
-	return v;
-}
-
 // The waves of a launch add their counters into kStatRows partial rows (by block index): thousands of
 // waves adding into the same eight words serialise at the L2; a one-wave kernel folds the rows into
 // the caller's arks_map_stats afterwards.
