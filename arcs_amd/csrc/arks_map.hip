@@ -56,11 +56,6 @@ lane_value_u64(u64 v, int l)
 // the caller's arks_map_stats afterwards.
 constexpr int kStatRows = 64; // power of two
 constexpr int kStatRow = 8;   // words per row
-// work counters of the tile kernel behind those rows: kRegions of them, one cache line apart
-constexpr int kRegions = 64;       // power of two
-constexpr int kRegionStride = 32;  // u32 words between two counters (128 bytes)
-constexpr size_t kRegionCtrOffset = 64 + (size_t)kStatRows * kStatRow * sizeof(u64);
-static_assert(kRegionCtrOffset + (size_t)kRegions * kRegionStride * sizeof(u32) <= kMapScratchBytes, "scratch block");
 
 // per-wave counters of arks_map_stats (uniform across the lanes of a wave)
 struct WaveStats
@@ -515,48 +510,42 @@ map_reads_b_kernel(
 #endif
 
 	const u32 n_medium = FULL ? __hip_atomic_load(queue_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-	u32* const region_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kRegionCtrOffset);
-	const long region_reads = ((n_reads + kRegions - 1) / kRegions + kChunk - 1) / kChunk * kChunk;
-	u32 region = blockIdx.x & (u32)(kRegions - 1), misses = 0;
+	bool first_grab = true;
 	for (;;) {
 		long c0 = 0;
 		ARKS_SEC(9);
 		int nchunk;
 		if (FULL) { // one queued read per grab
-			u32 qi = 0xFFFFFFFFu;
-			if (lane_id == 0 && // a look first: thousands of idle waves then load instead of queueing atomics
-			    __hip_atomic_load(queue_count + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_medium)
-				qi = atomicAdd(queue_count + 3, 1u);
-			qi = (u32)__builtin_amdgcn_readfirstlane((int)qi);
+			// the first item of a wave is the one with its block index: no atomic, and the (many) waves
+			// beyond the queue length leave without touching the shared counter -- thousands of idle
+			// waves queueing one atomic each on the same word cost 0.1 ms
+			u32 qi = blockIdx.x;
+			if (!first_grab) {
+				if (lane_id == 0)
+					qi = gridDim.x + atomicAdd(queue_count + 3, 1u);
+				qi = (u32)__builtin_amdgcn_readfirstlane((int)qi);
+			}
+			first_grab = false;
 			if (qi >= n_medium)
 				break;
 			c0 = (long)mqueue[qi];
 			nchunk = 1;
 		} else {
-			// the reads are cut into kRegions contiguous regions, each with its own work counter (on its
-			// own cache line): one counter for all waves serialises at the L2 -- ~14 ns per grab, 1.8 ms per
-			// 8 M reads, a floor of the same order as the whole kernel.  A wave starts in region (block
-			// index mod kRegions) and moves on when a region is exhausted; it is done after kRegions
-			// misses in a row.
-			const long rbeg = (long)region * region_reads;
-			const long rend = rbeg + region_reads < n_reads ? rbeg + region_reads : n_reads;
-			u32 g0 = 0xFFFFFFFFu;
-			if (rbeg < n_reads && lane_id == 0) {
-				u32* ctr = region_ctr + region * kRegionStride;
-				// a look before the atomic: an exhausted region then costs a load, not a serialised atomic
-				if ((long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rend - rbeg)
-					g0 = atomicAdd(ctr, (u32)kChunk);
-			}
-			g0 = (u32)__builtin_amdgcn_readfirstlane((int)g0);
-			if (g0 == 0xFFFFFFFFu || rbeg + (long)g0 >= rend) {
-				region = (region + 1u) & (u32)(kRegions - 1);
-				if (++misses == (u32)kRegions)
-					break;
-				continue;
-			}
-			misses = 0;
-			c0 = rbeg + (long)g0;
-			nchunk = (int)((c0 + kChunk < rend ? c0 + kChunk : rend) - c0);
+			// likewise the first chunk of a wave is the one with its block index (no start-up queue at
+			// the counter: same-address atomics serialise at ~14 ns each); later chunks are handed out
+			// dynamically from the end of that static round on
+			u32 chunk = blockIdx.x;
+			if (!first_grab) {
+				if (lane_id == 0)
+					chunk = atomicAdd(queue_count + 1, 1u);
+				chunk = (u32)__builtin_amdgcn_readfirstlane((int)chunk);
+				c0 = ((long)gridDim.x + (long)chunk) * kChunk;
+			} else
+				c0 = (long)chunk * kChunk;
+			first_grab = false;
+			if (c0 >= n_reads)
+				break;
+			nchunk = (int)((c0 + kChunk < n_reads ? c0 + kChunk : n_reads) - c0);
 		}
 		// lane_id l holds the metadata of read c0 + l (lane_id nchunk: the end offset)
 		u64 wo = 0;
@@ -1581,7 +1570,7 @@ launch_map_reads(
 	u64* const user_stats = stats;
 	if (stats)
 		stats = reinterpret_cast<u64*>(reinterpret_cast<char*>(queue_count) + 64);
-	hipError_t e = hipMemsetAsync(queue_count, 0, kMapScratchBytes, st);
+	hipError_t e = hipMemsetAsync(queue_count, 0, stats ? kMapScratchBytes : 4 * sizeof(u32), st);
 	if (e != hipSuccess)
 		return e;
 	// one wave per read at a time; enough resident waves to cover the memory latency
