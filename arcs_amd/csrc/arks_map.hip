@@ -302,8 +302,10 @@ constexpr int kTP = kSW * 32;    // ... in base positions
 constexpr int kTW = 32;          // tile capacity in packed words: two passes, one joint back half
 constexpr int kTR = 16;          // reads per tile
 constexpr int kNH = 128;         // run heads per tile that get a published entry list
-constexpr int kChunk = 60;       // reads handed out per device-counter grab (lane l holds read l's metadata);
-                                 // divisible by the usual reads per tile (4, 6, 10, 12): no half-empty last tile
+constexpr int kChunk = 48;       // reads handed out per grab of the work counter (lane l holds read l's metadata):
+                                 // a multiple of the usual reads per tile (4, 6, 8, 12), small enough for an even
+                                 // finish, large enough for the counter (same-address atomics serialise at ~12 ns:
+                                 // 24 reads per grab made the COUNTER the kernel's run time, 20 ms at C2)
 constexpr u32 kHnHeavy = 255, kHnOverflow = 254;
 
 // Bit b of the result: none of the positions [b, b + k) of the 128-bit vector m3:m2:m1:m0 (m0 = positions
