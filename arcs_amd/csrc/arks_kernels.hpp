@@ -21,7 +21,7 @@ hipError_t launch_build_stats(
     int kw, const u64* codes, const u32* visited, const u64* word_off, long n_ends, u64 total_words,
     const KeyGeom& g, TableView t, u64* counters, hipStream_t st);
 // bytes of the scratch block behind queue_count: 4 u32 counters, pad to 64, 64 rows of 8 u64 partial statistics
-constexpr size_t kMapScratchBytes = 64 + 64 * 8 * sizeof(u64);
+constexpr size_t kMapScratchBytes = 64 + 64 * 8 * sizeof(u64) + 64 * 128; // ... and up to 64 work counters 128 bytes apart
 hipError_t launch_map_reads(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens,
     const uint8_t* eval, long n_reads, double j_index, const KeyGeom& g, TableView t,

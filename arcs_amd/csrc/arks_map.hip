@@ -56,6 +56,14 @@ lane_value_u64(u64 v, int l)
 // the caller's arks_map_stats afterwards.
 constexpr int kStatRows = 64; // power of two
 constexpr int kStatRow = 8;   // words per row
+// work counters of the tile kernel behind those rows, one cache line apart
+#ifndef ARKS_COUNTERS
+#define ARKS_COUNTERS 8
+#endif
+constexpr int kCounters = ARKS_COUNTERS; // power of two
+constexpr int kCounterStride = 32;       // u32 words between two counters (128 bytes)
+constexpr size_t kWorkCtrOffset = 64 + (size_t)kStatRows * kStatRow * sizeof(u64);
+static_assert(kWorkCtrOffset + (size_t)kCounters * kCounterStride * sizeof(u32) <= kMapScratchBytes, "scratch block");
 
 // per-wave counters of arks_map_stats (uniform across the lanes of a wave)
 struct WaveStats
@@ -513,6 +521,8 @@ map_reads_b_kernel(
 
 	const u32 n_medium = FULL ? __hip_atomic_load(queue_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 	bool first_grab = true;
+	u32* const work_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kWorkCtrOffset);
+	u32 ctr = blockIdx.x & (u32)(kCounters - 1), misses = 0;
 	for (;;) {
 		long c0 = 0;
 		ARKS_SEC(9);
@@ -536,17 +546,30 @@ map_reads_b_kernel(
 			// likewise the first chunk of a wave is the one with its block index (no start-up queue at
 			// the counter: same-address atomics serialise at ~14 ns each); later chunks are handed out
 			// dynamically from the end of that static round on
-			u32 chunk = blockIdx.x;
-			if (!first_grab) {
+			// The chunks after that static round are dealt out by kCounters counters: counter j hands out
+			// chunks j, j + kCounters, j + 2 kCounters, ... (so the waves still advance through the reads
+			// as one front) and a wave uses counter (block index mod kCounters) until that one runs past
+			// the end, then looks at the others.  One counter serialises at ~12 ns per grab -- 10 ms of
+			// the 12.4 ms the kernel takes at C2.
+			if (first_grab) {
+				c0 = (long)blockIdx.x * kChunk;
+				first_grab = false;
+				if (c0 >= n_reads)
+					break;
+			} else {
+				u32 cnt = 0;
 				if (lane_id == 0)
-					chunk = atomicAdd(queue_count + 1, 1u);
-				chunk = (u32)__builtin_amdgcn_readfirstlane((int)chunk);
-				c0 = ((long)gridDim.x + (long)chunk) * kChunk;
-			} else
-				c0 = (long)chunk * kChunk;
-			first_grab = false;
-			if (c0 >= n_reads)
-				break;
+					cnt = atomicAdd(work_ctr + ctr * kCounterStride, 1u);
+				cnt = (u32)__builtin_amdgcn_readfirstlane((int)cnt);
+				c0 = ((long)gridDim.x + (long)ctr + (long)cnt * kCounters) * kChunk;
+				if (c0 >= n_reads) {
+					ctr = (ctr + 1u) & (u32)(kCounters - 1);
+					if (++misses == (u32)kCounters)
+						break;
+					continue;
+				}
+				misses = 0;
+			}
 			nchunk = (int)((c0 + kChunk < n_reads ? c0 + kChunk : n_reads) - c0);
 		}
 		// lane_id l holds the metadata of read c0 + l (lane_id nchunk: the end offset)
@@ -1572,7 +1595,7 @@ launch_map_reads(
 	u64* const user_stats = stats;
 	if (stats)
 		stats = reinterpret_cast<u64*>(reinterpret_cast<char*>(queue_count) + 64);
-	hipError_t e = hipMemsetAsync(queue_count, 0, stats ? kMapScratchBytes : 4 * sizeof(u32), st);
+	hipError_t e = hipMemsetAsync(queue_count, 0, kMapScratchBytes, st);
 	if (e != hipSuccess)
 		return e;
 	// one wave per read at a time; enough resident waves to cover the memory latency
