@@ -783,9 +783,8 @@ map_reads_b_kernel(
 	#pragma unroll
 					for (int t = 0; t < 8; ++t)
 						wc[t] = t <= tc ? wmin[t] : 0xFFFFFFFFu;
-					u32 wprev = __shfl_up(wc[7], 1);
-					if (lane == 0)
-						wprev = 0xFFFFFFFFu;
+					// the previous lane's last window: one DPP wave shift (lane 0 keeps the "no window" value)
+					const u32 wprev = (u32)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)wc[7], 0x138, 0xF, 0xF, false);
 					// a run head = a window whose minimizer (value includes its position) differs from its
 					// predecessor's.  Heads are numbered position-class-major (all t = 0 heads of the pass,
 					// then t = 1, ...): a ballot + mbcnt per class, no per-lane serial numbering.  Which run
