@@ -1166,7 +1166,9 @@ map_reads_b_kernel(
 				}
 				{
 					// a window matched on both diagonals counts once (on A; the value is the same)
-					const u32 other = __shfl_xor(ok, 32);
+					// the first-diagonal lane of the same word is 32 lanes down: v_permlane32_swap hands the upper
+					// half of the wave the lower half's values (one VALU op; __shfl_xor is an LDS crossbar trip)
+					const u32 other = __builtin_amdgcn_permlane32_swap(ok, ok, false, false)[0];
 					if (d) {
 						ok &= ~other;
 						amb &= ok;
