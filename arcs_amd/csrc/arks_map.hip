@@ -474,6 +474,101 @@ and_window128(U128 v, int k)
 //                entries) sends its read to the "medium" queue instead, which keeps that code's
 //                registers out of the hot kernel.
 // FULL = true : the same kernel over the medium queue, one queued read per tile, every path.
+// ---- T2: order values of the 8 positions a lane owns (tile positions i0 .. i0 + 7, all in one packed
+//      word, i.e. one read).  The 8 + MM - 1 <= 32 bases their m-mers span are ONE funnel shift of two
+//      staged words; every forward m-mer is a shift + mask of that register pair, every reverse
+//      complement a shift + mask of its complement.  v[t] = mmer_order << 12 | position << 1 | strand
+//      (1 = the forward m-mer is the canonical one), or ~0 when the m-mer leaves the read (rem0 = bases
+//      of the read from i0 on) or holds an invalid base. ------------------------------------------------
+template <int MM>
+__device__ __forceinline__ void
+tile_order_values(const u64* cw, const u32* nm, int i0, int lane, int rem0, bool has_n, u32 (&v)[8])
+{
+	typedef typename Mmer<MM>::type mm_t;
+	const int wq = i0 >> 5, sft = (lane & 3) * 16;
+	const u64 x = funnel_l(cw[wq], cw[wq + 1], sft);
+	const u64 xr = ~rev_groups(x);
+	u32 nb = 0;
+	if (has_n)
+		nb = (nm[wq] << (sft >> 1)) | ((nm[wq + 1] >> 1) >> (31 - (sft >> 1)));
+	const mm_t mmask = (mm_t)((1ull << (2 * MM)) - 1ull);
+	// positions whose m-mer lies inside the read (t <= rem0 - MM) and holds no invalid base
+	const int tmax = rem0 - MM;
+	u32 okmask = tmax >= 7 ? 0xFFu : (tmax < 0 ? 0u : ((2u << tmax) - 1u));
+	if (nb) {
+#pragma unroll
+		for (int t = 0; t < 8; ++t)
+			okmask &= ((nb << t) >> (32 - MM)) ? ~(1u << t) : 0xFFFFFFFFu;
+	}
+#pragma unroll
+	for (int t = 0; t < 8; ++t) {
+		v[t] = 0xFFFFFFFFu;
+		if ((okmask >> t) & 1u) {
+			const mm_t mf = (mm_t)(x >> (64 - 2 * MM - 2 * t)) & mmask;
+			const mm_t mr = (mm_t)(xr >> (2 * t)) & mmask;
+			const mm_t cm = mf < mr ? mf : mr;
+			v[t] = (mmer_order<MM>(cm) << 12) | ((u32)(i0 + t) << 1) | (mf < mr ? 1u : 0u);
+		}
+	}
+}
+
+// ---- T3: sliding minimum over w positions for the 8 windows a lane owns.  [i, i + w) = a suffix of the
+//      lane's own 8 values, whole lanes in between, a prefix of a later lane's 8: prefix minima go through
+//      LDS (pre: kTP + pad words, the pad holds ~0), the lanes' block minima too (blk: 64 + 16 words);
+//      everything else is registers.  l0 = 8 * lane.  Ends behind a wave sync of its own; the caller must
+//      sync before anything else overwrites pre / blk. ---------------------------------------------------
+__device__ __forceinline__ void
+tile_sliding_min(u32* pre_lds, u32* blk_lds, int l0, int lane, int w, const u32 (&v)[8], u32 (&wmin)[8])
+{
+	if (w >= 9) {
+		u32 pre[8], suf[8];
+		pre[0] = v[0];
+#pragma unroll
+		for (int t = 1; t < 8; ++t)
+			pre[t] = v[t] < pre[t - 1] ? v[t] : pre[t - 1];
+		suf[7] = v[7];
+#pragma unroll
+		for (int t = 6; t >= 0; --t)
+			suf[t] = v[t] < suf[t + 1] ? v[t] : suf[t + 1];
+		uint4* pa = reinterpret_cast<uint4*>(pre_lds + l0);
+		pa[0] = make_uint4(pre[0], pre[1], pre[2], pre[3]);
+		pa[1] = make_uint4(pre[4], pre[5], pre[6], pre[7]);
+		blk_lds[lane] = pre[7];
+		if (lane < 16)
+			blk_lds[64 + lane] = 0xFFFFFFFFu;
+		ARKS_WAVE_SYNC();
+		const int e0 = (w - 1) >> 3, tb = 8 - ((w - 1) & 7);
+		u32 fa = 0xFFFFFFFFu;
+		for (int x = 1; x < e0; ++x) {
+			const u32 y = blk_lds[lane + x];
+			fa = y < fa ? y : fa;
+		}
+		u32 fb = blk_lds[lane + e0];
+		fb = fb < fa ? fb : fa;
+#pragma unroll
+		for (int t = 0; t < 8; ++t) {
+			const u32 y = pre_lds[l0 + t + w - 1];
+			const u32 f = t < tb ? fa : fb;
+			u32 m = suf[t] < y ? suf[t] : y;
+			wmin[t] = f < m ? f : m;
+		}
+	} else { // short windows: each window reads its w values
+		uint4* pa = reinterpret_cast<uint4*>(pre_lds + l0);
+		pa[0] = make_uint4(v[0], v[1], v[2], v[3]);
+		pa[1] = make_uint4(v[4], v[5], v[6], v[7]);
+		ARKS_WAVE_SYNC();
+#pragma unroll
+		for (int t = 0; t < 8; ++t) {
+			u32 m = v[t];
+			for (int o = 1; o < w; ++o) {
+				const u32 y = pre_lds[l0 + t + o];
+				m = y < m ? y : m;
+			}
+			wmin[t] = m;
+		}
+	}
+}
+
 template <int KW, bool STATS, bool FULL, int MM>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FULL ? 4 : ARKS_TILE_WAVES)))
 map_reads_b_kernel(
@@ -681,96 +776,18 @@ map_reads_b_kernel(
 			// ---- T2 .. T4 once per pass of <= kSW words; the medium kernel's single read is one pass ---------
 			const int npass = (FULL || tw0 == tw) ? 1 : 2;
 			for (int ps = 0; ps < npass; ++ps) {
-				// ---- T2: lane l owns the 8 positions 8l .. 8l+7 of the tile (16 words = 512 positions = one
-				//      pass).  The 8 + MM - 1 <= 32 bases its m-mers span are one funnel shift of two words;
-				//      every m-mer and its reverse complement is a shift + mask of that or of its complement. --
-				typedef typename Mmer<MM>::type mm_t;
+				// ---- T2 / T3: lane l owns the 8 positions 8l .. 8l+7 of the pass (16 words = 512 positions) -------
 				const int l0 = lane * 8;                      // index into the pass-local minimum arrays
 				const int i0 = (ps ? tw0 * 32 : 0) + l0;      // tile position
 				const bool in_tile = i0 < (ps ? n : tw0 * 32);
 				const u32 wm0 = in_tile ? S.wmeta[i0 >> 5] : 0u; // the lane's 8 positions lie in one word, i.e. one read
-			const int rem0 = in_tile ? (int)(wm0 & 0xFFFFu) - i0 : 0; // bases of the read from i0 on
+				const int rem0 = in_tile ? (int)(wm0 & 0xFFFFu) - i0 : 0; // bases of the read from i0 on
 				u32 wmin[8]; // minimizer (order value) of the window starting at each of the 8 positions
 				{
 					u32 v[8];
-					{
-						const int wq = i0 >> 5, sft = (lane & 3) * 16;
-						const u64 x = funnel_l(S.cw[wq], S.cw[wq + 1], sft);
-						const u64 xr = ~rev_groups(x);
-						u32 nb = 0;
-						if (has_n)
-							nb = (S.nm[wq] << (sft >> 1)) | ((S.nm[wq + 1] >> 1) >> (31 - (sft >> 1)));
-						const mm_t mmask = (mm_t)((1ull << (2 * MM)) - 1ull);
-						// positions whose m-mer lies inside the read (t <= rem0 - MM) and holds no invalid base
-						const int tmax = rem0 - MM;
-						u32 okmask = tmax >= 7 ? 0xFFu : (tmax < 0 ? 0u : ((2u << tmax) - 1u));
-						if (nb) {
-	#pragma unroll
-							for (int t = 0; t < 8; ++t)
-								okmask &= ((nb << t) >> (32 - MM)) ? ~(1u << t) : 0xFFFFFFFFu;
-						}
-	#pragma unroll
-						for (int t = 0; t < 8; ++t) {
-							v[t] = 0xFFFFFFFFu;
-							if ((okmask >> t) & 1u) {
-								const mm_t mf = (mm_t)(x >> (64 - 2 * MM - 2 * t)) & mmask;
-								const mm_t mr = (mm_t)(xr >> (2 * t)) & mmask;
-								const mm_t cm = mf < mr ? mf : mr;
-								v[t] = (mmer_order<MM>(cm) << 12) | ((u32)(i0 + t) << 1) | (mf < mr ? 1u : 0u);
-							}
-						}
-					}
+					tile_order_values<MM>(S.cw, S.nm, i0, lane, rem0, has_n, v);
 					ARKS_SEC(2);
-					// ---- T3: sliding minimum over w positions.  [i, i + w) = a suffix of the lane's own 8
-					//      values, whole lanes in between, a prefix of a later lane's 8: prefix minima go
-					//      through LDS (S.a), the lanes' block minima too (S.b); everything else is registers.
-					if (w >= 9) {
-						u32 pre[8], suf[8];
-						pre[0] = v[0];
-	#pragma unroll
-						for (int t = 1; t < 8; ++t)
-							pre[t] = v[t] < pre[t - 1] ? v[t] : pre[t - 1];
-						suf[7] = v[7];
-	#pragma unroll
-						for (int t = 6; t >= 0; --t)
-							suf[t] = v[t] < suf[t + 1] ? v[t] : suf[t + 1];
-						uint4* pa = reinterpret_cast<uint4*>(S.a + l0);
-						pa[0] = make_uint4(pre[0], pre[1], pre[2], pre[3]);
-						pa[1] = make_uint4(pre[4], pre[5], pre[6], pre[7]);
-						S.b[lane] = pre[7];
-						if (lane < 16)
-							S.b[64 + lane] = 0xFFFFFFFFu;
-						ARKS_WAVE_SYNC();
-						const int e0 = (w - 1) >> 3, tb = 8 - ((w - 1) & 7);
-						u32 fa = 0xFFFFFFFFu;
-						for (int x = 1; x < e0; ++x) {
-							const u32 y = S.b[lane + x];
-							fa = y < fa ? y : fa;
-						}
-						u32 fb = S.b[lane + e0];
-						fb = fb < fa ? fb : fa;
-	#pragma unroll
-						for (int t = 0; t < 8; ++t) {
-							const u32 y = S.a[l0 + t + w - 1];
-							const u32 f = t < tb ? fa : fb;
-							u32 m = suf[t] < y ? suf[t] : y;
-							wmin[t] = f < m ? f : m;
-						}
-					} else {
-						uint4* pa = reinterpret_cast<uint4*>(S.a + l0);
-						pa[0] = make_uint4(v[0], v[1], v[2], v[3]);
-						pa[1] = make_uint4(v[4], v[5], v[6], v[7]);
-						ARKS_WAVE_SYNC();
-	#pragma unroll
-						for (int t = 0; t < 8; ++t) {
-							u32 m = v[t];
-							for (int o = 1; o < w; ++o) {
-								const u32 y = S.a[l0 + t + o];
-								m = y < m ? y : m;
-							}
-							wmin[t] = m;
-						}
-					}
+					tile_sliding_min(S.a, S.b, l0, lane, w, v, wmin);
 				}
 				ARKS_SEC(3);
 				// ---- T4: windows, run heads --------------------------------------------------------------
