@@ -474,6 +474,78 @@ and_window128(U128 v, int k)
 //                entries) sends its read to the "medium" queue instead, which keeps that code's
 //                registers out of the hot kernel.
 // FULL = true : the same kernel over the medium queue, one queued read per tile, every path.
+// ---- T6c' helpers: 32 window starts (one packed word of a read) at a time, one bit per window ---------
+// windows of the word that exist (`left` = windows of the read from the word's first position on) and hold
+// no invalid base (nm = the tile's N masks, bit 31 = first base of a word)
+__device__ __forceinline__ u32
+word_valid_windows(const u32* nm, int wl, int left, int k, bool has_n)
+{
+	const int cexist = left < 0 ? 0 : (left > 32 ? 32 : left);
+	u32 valid = cexist == 32 ? 0xFFFFFFFFu : ((1u << cexist) - 1u);
+	if (has_n && valid) {
+		if (k >= 32) {
+			valid &= clear_spans32(__brev(nm[wl]), __brev(nm[wl + 1]), __brev(nm[wl + 2]), __brev(nm[wl + 3]), k);
+		} else {
+			U128 nf;
+			nf.lo = ~((u64)__brev(nm[wl]) | ((u64)__brev(nm[wl + 1]) << 32));
+			nf.hi = ~((u64)__brev(nm[wl + 2]) | ((u64)__brev(nm[wl + 3]) << 32));
+			valid &= (u32)and_window128(nf, k).lo;
+		}
+	}
+	return valid;
+}
+
+// Windows of word wl that match the text on the diagonal pdv ([39:0] D, [40] same strand): their k mismatch
+// bits (mm: one bit per base along the diagonal) are all clear, and the text position they map to is
+// `visited` (tvis) -- `ok`; of those, the ones whose position is `ambig` (tamb, value 0) -- `amb`; `own` =
+// contig end (town) of the others, ~0 if they span two.  p0 = first window of the word relative to the
+// read, sb / nst = first staging slot of the read and its slot count - 1, tfirst = text word of slot sb.
+__device__ __forceinline__ void
+word_match(
+    u64 pdv, const u32* mm, const u32* tvis, const u32* tamb, const u32* town, int wl, int p0, int sb, int nst,
+    u32 tfirst, int k, u32 valid, u32& ok, u32& amb, u32& own)
+{
+	if (k >= 32) {
+		ok = clear_spans32(mm[wl], mm[wl + 1], mm[wl + 2], mm[wl + 3], k) & valid;
+	} else {
+		U128 z; // match bit per base from this word on
+		z.lo = ~((u64)mm[wl] | ((u64)mm[wl + 1] << 32));
+		z.hi = ~((u64)mm[wl + 2] | ((u64)mm[wl + 3] << 32));
+		ok = (u32)and_window128(z, k).lo & valid;
+	}
+	if (!ok)
+		return;
+	const bool same = (pdv >> 40) & 1ull;
+	const u64 D = pdv & 0xFFFFFFFFFFull;
+	// text positions of the 32 window starts: same strand D + p0 + b, opposite strand (D - k + 1 - p0) - b;
+	// `lo` = the lowest of them; staged slots are sb .. sb + nst
+	const u64 lo = same ? D + (u64)p0 : D - (u64)(k - 1 + p0 + 31);
+	const int slot = sb + (int)((u32)(lo >> 5) - tfirst);
+	const int sh = (int)(lo & 31);
+	const u32 v0 = (slot >= sb && slot <= sb + nst) ? tvis[slot] : 0u;
+	const u32 v1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? tvis[slot + 1] : 0u;
+	const u32 a0 = (slot >= sb && slot <= sb + nst) ? tamb[slot] : 0u;
+	const u32 a1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? tamb[slot + 1] : 0u;
+	// 32 bits from text position lo on, most significant = lo
+	u32 vis = sh ? ((v0 << sh) | (v1 >> (32 - sh))) : v0;
+	u32 am = sh ? ((a0 << sh) | (a1 >> (32 - sh))) : a0;
+	if (same) { // bit b must be position lo + b
+		vis = __brev(vis);
+		am = __brev(am);
+	} // opposite strand: bit b is position lo + 31 - b already
+	ok &= vis;
+	amb = ok & am;
+	// contig end of the matched, unambiguous windows: the word(s) their text positions fall in.
+	// `inlo` = window bits whose position lies in `slot`.
+	const u32 recm = ok & ~amb;
+	const u32 inlo = same ? (sh ? (1u << (32 - sh)) - 1u : 0xFFFFFFFFu) : (0xFFFFFFFFu << sh);
+	const u32 o0 = (recm & inlo) ? town[slot] : 0u;
+	const u32 o1 = (recm & ~inlo) ? town[slot + 1] : 0u;
+	own = o0 ? o0 : o1;
+	if (o0 && o1 && o0 != o1)
+		own = 0xFFFFFFFFu;
+}
+
 // ---- T2: order values of the 8 positions a lane owns (tile positions i0 .. i0 + 7, all in one packed
 //      word, i.e. one read).  The 8 + MM - 1 <= 32 bases their m-mers span are ONE funnel shift of two
 //      staged words; every forward m-mer is a shift + mask of that register pair, every reverse
@@ -1119,67 +1191,10 @@ map_reads_b_kernel(
 				int j = 0;
 				if (wl < tw) {
 					j = S.wread[wl];
-					const int nwin = S.rlen[j] - k + 1;
-					const int p0 = wl * 32 - S.rstart[j]; // first window of this word, relative to the read
-					// windows that exist: p0 + b < nwin
-					int cexist = nwin - p0;
-					cexist = cexist < 0 ? 0 : (cexist > 32 ? 32 : cexist);
-					valid = cexist == 32 ? 0xFFFFFFFFu : ((1u << cexist) - 1u);
-					if (has_n && valid) { // ... and hold no invalid base: AND-window over the N-free bits
-						if (k >= 32) {
-							valid &= clear_spans32(__brev(S.nm[wl]), __brev(S.nm[wl + 1]), __brev(S.nm[wl + 2]),
-							                       __brev(S.nm[wl + 3]), k);
-						} else {
-							U128 nf;
-							nf.lo = ~((u64)__brev(S.nm[wl]) | ((u64)__brev(S.nm[wl + 1]) << 32));
-							nf.hi = ~((u64)__brev(S.nm[wl + 2]) | ((u64)__brev(S.nm[wl + 3]) << 32));
-							valid &= (u32)and_window128(nf, k).lo;
-						}
-					}
-					const u64 pdv = S.pdiag[j][d];
-					if ((pdv >> 41) && valid) {
-						if (k >= 32) {
-							ok = clear_spans32(mm32[d][wl], mm32[d][wl + 1], mm32[d][wl + 2],
-							                   mm32[d][wl + 3], k) & valid;
-						} else {
-							U128 z; // match bit per base from this word on
-							z.lo = ~((u64)mm32[d][wl] | ((u64)mm32[d][wl + 1] << 32));
-							z.hi = ~((u64)mm32[d][wl + 2] | ((u64)mm32[d][wl + 3] << 32));
-							ok = (u32)and_window128(z, k).lo & valid;
-						}
-						if (ok) {
-							const bool same = (pdv >> 40) & 1ull;
-							const u64 D = pdv & 0xFFFFFFFFFFull;
-							const int sb = (S.rstart[j] >> 5) + j, nst = (S.rlen[j] + 31) / 32; // staged: sb .. sb + nst
-							// text positions of the 32 window starts: same strand D + p0 + b, opposite
-							// strand (D - k + 1 - p0) - b; `lo` = the lowest of them
-							const u64 lo = same ? D + (u64)p0 : D - (u64)(k - 1 + p0 + 31);
-							const int slot = sb + (int)((u32)(lo >> 5) - S.tfirst[j][d]);
-							const int sh = (int)(lo & 31);
-							const u32 v0 = (slot >= sb && slot <= sb + nst) ? tvis[d][slot] : 0u;
-							const u32 v1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? tvis[d][slot + 1] : 0u;
-							const u32 a0 = (slot >= sb && slot <= sb + nst) ? tamb[d][slot] : 0u;
-							const u32 a1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? tamb[d][slot + 1] : 0u;
-							// 32 bits from text position lo on, most significant = lo
-							u32 vis = sh ? ((v0 << sh) | (v1 >> (32 - sh))) : v0;
-							u32 am = sh ? ((a0 << sh) | (a1 >> (32 - sh))) : a0;
-							if (same) { // bit b must be position lo + b
-								vis = __brev(vis);
-								am = __brev(am);
-							} // opposite strand: bit b is position lo + 31 - b already
-							ok &= vis;
-							amb = ok & am;
-							// contig end of the matched, unambiguous windows: the word(s) their text
-							// positions fall in.  `inlo` = window bits whose position lies in `slot`.
-							const u32 recm = ok & ~amb;
-							const u32 inlo = same ? (sh ? (1u << (32 - sh)) - 1u : 0xFFFFFFFFu) : (0xFFFFFFFFu << sh);
-							const u32 o0 = (recm & inlo) ? town[d][slot] : 0u;
-							const u32 o1 = (recm & ~inlo) ? town[d][slot + 1] : 0u;
-							own = o0 ? o0 : o1;
-							if (o0 && o1 && o0 != o1)
-								own = 0xFFFFFFFFu;
-						}
-					}
+					valid = word_valid_windows(S.nm, wl, S.rlen[j] - k + 1 - (wl * 32 - S.rstart[j]), k, has_n);
+					if ((S.pdiag[j][d] >> 41) && valid)
+						word_match(S.pdiag[j][d], mm32[d], tvis[d], tamb[d], town[d], wl, wl * 32 - S.rstart[j],
+						           (S.rstart[j] >> 5) + j, (S.rlen[j] + 31) / 32, S.tfirst[j][d], k, valid, ok, amb, own);
 				}
 				{
 					// a window matched on both diagonals counts once (on A; the value is the same)
