@@ -474,6 +474,78 @@ and_window128(U128 v, int k)
 //                entries) sends its read to the "medium" queue instead, which keeps that code's
 //                registers out of the hot kernel.
 // FULL = true : the same kernel over the medium queue, one queued read per tile, every path.
+// ---- T5 helper: the text occurrences of the canonical m-mer cm in the minimizer table: up to two
+//      entries are written to `entries`; returns their number, kHnOverflow for more, kHnHeavy when the
+//      table holds the "heavy: ask the fallback table" marker.  Home slots and the capacity are multiples
+//      of 4 (mtab_home): every round trip reads one aligned group of four entries. -------------------
+template <int MM>
+__device__ __forceinline__ u32
+probe_minimizer_table(const BIndexView& bx, typename Mmer<MM>::type cm, u64* entries)
+{
+	const u32 fp = mmer_fp<MM>(cm);
+	u64 slot = mtab_home<MM>(cm, bx.mtab_cap);
+	u32 cnt = 0;
+	bool end = false;
+	while (!end) {
+		u64 ev[4];
+#pragma unroll
+		for (int x = 0; x < 4; ++x)
+			ev[x] = bx.mtab[slot + x];
+#pragma unroll
+		for (int x = 0; x < 4; ++x) {
+			const u64 e = ev[x];
+			if (end)
+				continue;
+			if (!(e >> 63)) { // an empty slot ends the probe sequence
+				end = true;
+				continue;
+			}
+			if (((u32)(e >> 32) & kFpMask) != fp)
+				continue;
+			if ((u32)e == kHeavyPos) {
+				cnt = kHnHeavy;
+				end = true;
+				continue;
+			}
+			if (cnt < 2)
+				entries[cnt] = e;
+			cnt = cnt < 2 ? cnt + 1 : kHnOverflow;
+			if (cnt == kHnOverflow)
+				end = true;
+		}
+		slot += 4;
+		if (slot >= bx.mtab_cap)
+			slot = 0;
+	}
+	return cnt;
+}
+
+// ---- T6b helper: the 32 bases of one packed read word against the text they face on the diagonal pdv
+//      ([39:0] D, [40] same strand): bit b of the result = base b of the word differs.  x0 = read offset of
+//      the word's first base, sb = first staging slot of the read, tfirst = text word staged in slot sb,
+//      tcodes = the staged text words of this diagonal. -------------------------------------------------
+__device__ __forceinline__ u32
+word_mismatch_bits(u64 code_word, u64 pdv, const u64* tcodes, int x0, int sb, u32 tfirst)
+{
+	const bool same = (pdv >> 40) & 1ull;
+	const u64 D = pdv & 0xFFFFFFFFFFull;
+	// text position of the lowest-addressed base this word faces
+	const u64 tlo = same ? D + (u64)x0 : D - (u64)(x0 + 31);
+	const int slot = sb + (int)((u32)(tlo >> 5) - tfirst);
+	const u64 t0 = slot >= sb ? tcodes[slot] : 0ull;
+	const u64 t32 = funnel_l(t0, tcodes[slot + 1], (int)(tlo & 31) * 2);
+	const u64 face = same ? t32 : ~rev_groups(t32);
+	u64 x = code_word ^ face;
+	// one bit per base: OR the two bits of every group, gather the even bits
+	x = (x | (x >> 1)) & 0x5555555555555555ull;
+	x = (x | (x >> 1)) & 0x3333333333333333ull;
+	x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+	x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+	x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+	x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+	return __brev((u32)x); // base 0 of the word -> bit 0
+}
+
 // ---- T6c' helpers: 32 window starts (one packed word of a read) at a time, one bit per window ---------
 // windows of the word that exist (`left` = windows of the read from the word's first position on) and hold
 // no invalid base (nm = the tile's N masks, bit 31 = first base of a word)
@@ -966,45 +1038,7 @@ map_reads_b_kernel(
 			const int nh = nheads < kNH ? nheads : kNH;
 			for (int h = lane; h < nh; h += 64) {
 				const u32 q = ((u32)S.heads[h] >> 1) & 2047u;
-				const typename Mmer<MM>::type cm = tile_canonical_mmer<MM>(S.cw, (int)q);
-				const u32 fp = mmer_fp<MM>(cm);
-				u64 slot = mtab_home<MM>(cm, bx.mtab_cap);
-				u32 cnt = 0;
-				bool end = false;
-				while (!end) {
-					// four consecutive entries per round trip (single steps next to the wrap-around)
-					const bool wide = slot + 4 <= bx.mtab_cap;
-					u64 ev[4];
-					ev[0] = bx.mtab[slot];
-#pragma unroll
-					for (int x = 1; x < 4; ++x)
-						ev[x] = wide ? bx.mtab[slot + x] : 0ull;
-#pragma unroll
-					for (int x = 0; x < 4; ++x) {
-						const u64 e = ev[x];
-						if (end || (x > 0 && !wide))
-							continue;
-						if (!(e >> 63)) {
-							end = true;
-							continue;
-						}
-						if (((u32)(e >> 32) & kFpMask) != fp)
-							continue;
-						if ((u32)e == kHeavyPos) {
-							cnt = kHnHeavy;
-							end = true;
-							continue;
-						}
-						if (cnt < 2)
-							hc[h][cnt] = e;
-						cnt = cnt < 2 ? cnt + 1 : kHnOverflow;
-						if (cnt == kHnOverflow)
-							end = true;
-					}
-					slot += wide ? 4 : 1;
-					if (slot >= bx.mtab_cap)
-						slot -= bx.mtab_cap;
-				}
+				const u32 cnt = probe_minimizer_table<MM>(bx, tile_canonical_mmer<MM>(S.cw, (int)q), hc[h]);
 				S.hn[h] = (unsigned char)cnt;
 			}
 			ARKS_WAVE_SYNC();
@@ -1150,32 +1184,11 @@ map_reads_b_kernel(
 				if (lane < 16) // the spans of the last words read past the tile: no mismatch there
 					mm32[lane >> 3][tw + (lane & 7)] = 0u;
 				if (wl < tw) {
-					u32 mbits = 0;
-					{
-						const int j = S.wread[wl];
-						const u64 pdv = S.pdiag[j][d];
-						if (pdv >> 41) {
-							const bool same = (pdv >> 40) & 1ull;
-							const u64 D = pdv & 0xFFFFFFFFFFull;
-							const int x0 = wl * 32 - S.rstart[j]; // read offset of this word's first base
-							const int sb = (S.rstart[j] >> 5) + j;
-							// text position of the lowest-addressed base this word faces
-							const u64 tlo = same ? D + (u64)x0 : D - (u64)(x0 + 31);
-							const int slot = sb + (int)((u32)(tlo >> 5) - S.tfirst[j][d]);
-							const u64 t0 = slot >= sb ? tcodes[d][slot] : 0ull;
-							const u64 t32 = funnel_l(t0, tcodes[d][slot + 1], (int)(tlo & 31) * 2);
-							const u64 face = same ? t32 : ~rev_groups(t32);
-							u64 x = S.cw[wl] ^ face;
-							// one bit per base: OR the two bits of every group, gather the even bits
-							x = (x | (x >> 1)) & 0x5555555555555555ull;
-							x = (x | (x >> 1)) & 0x3333333333333333ull;
-							x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-							x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-							x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-							x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-							mbits = __brev((u32)x); // base 0 of the word -> bit 0
-						}
-					}
+					const int j = S.wread[wl];
+					const u64 pdv = S.pdiag[j][d];
+					const u32 mbits = (pdv >> 41) ? word_mismatch_bits(S.cw[wl], pdv, tcodes[d], wl * 32 - S.rstart[j],
+					                                                    (S.rstart[j] >> 5) + j, S.tfirst[j][d])
+					                              : 0u;
 					mm32[d][wl] = mbits;
 				}
 			}
