@@ -571,11 +571,11 @@ word_valid_windows(const u32* nm, int wl, int left, int k, bool has_n)
 // bits (mm: one bit per base along the diagonal) are all clear, and the text position they map to is
 // `visited` (tvis) -- `ok`; of those, the ones whose position is `ambig` (tamb, value 0) -- `amb`; `own` =
 // contig end (town) of the others, ~0 if they span two.  p0 = first window of the word relative to the
-// read, sb / nst = first staging slot of the read and its slot count - 1, tfirst = text word of slot sb.
+// read, sb = first staging slot of the read, tfirst = text word staged in slot sb.
 __device__ __forceinline__ void
 word_match(
-    u64 pdv, const u32* mm, const u32* tvis, const u32* tamb, const u32* town, int wl, int p0, int sb, int nst,
-    u32 tfirst, int k, u32 valid, u32& ok, u32& amb, u32& own)
+    u64 pdv, const u32* mm, const u32* tvis, const u32* tamb, const u32* town, int wl, int p0, int sb, u32 tfirst,
+    int k, u32 valid, u32& ok, u32& amb, u32& own)
 {
 	if (k >= 32) {
 		ok = clear_spans32(mm[wl], mm[wl + 1], mm[wl + 2], mm[wl + 3], k) & valid;
@@ -590,14 +590,14 @@ word_match(
 	const bool same = (pdv >> 40) & 1ull;
 	const u64 D = pdv & 0xFFFFFFFFFFull;
 	// text positions of the 32 window starts: same strand D + p0 + b, opposite strand (D - k + 1 - p0) - b;
-	// `lo` = the lowest of them; staged slots are sb .. sb + nst
+	// `lo` = the lowest of them
 	const u64 lo = same ? D + (u64)p0 : D - (u64)(k - 1 + p0 + 31);
 	const int slot = sb + (int)((u32)(lo >> 5) - tfirst);
 	const int sh = (int)(lo & 31);
-	const u32 v0 = (slot >= sb && slot <= sb + nst) ? tvis[slot] : 0u;
-	const u32 v1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? tvis[slot + 1] : 0u;
-	const u32 a0 = (slot >= sb && slot <= sb + nst) ? tamb[slot] : 0u;
-	const u32 a1 = (slot + 1 >= sb && slot + 1 <= sb + nst) ? tamb[slot + 1] : 0u;
+	// (no range checks: a slot outside the read's staged slots can only feed bits of windows that do not exist,
+	// and `ok` has lost those already; the reads stay inside the staging storage)
+	const u32 v0 = tvis[slot], v1 = tvis[slot + 1];
+	const u32 a0 = tamb[slot], a1 = tamb[slot + 1];
 	// 32 bits from text position lo on, most significant = lo
 	u32 vis = sh ? ((v0 << sh) | (v1 >> (32 - sh))) : v0;
 	u32 am = sh ? ((a0 << sh) | (a1 >> (32 - sh))) : a0;
@@ -1207,7 +1207,7 @@ map_reads_b_kernel(
 					valid = word_valid_windows(S.nm, wl, S.rlen[j] - k + 1 - (wl * 32 - S.rstart[j]), k, has_n);
 					if ((S.pdiag[j][d] >> 41) && valid)
 						word_match(S.pdiag[j][d], mm32[d], tvis[d], tamb[d], town[d], wl, wl * 32 - S.rstart[j],
-						           (S.rstart[j] >> 5) + j, (S.rlen[j] + 31) / 32, S.tfirst[j][d], k, valid, ok, amb, own);
+						           (S.rstart[j] >> 5) + j, S.tfirst[j][d], k, valid, ok, amb, own);
 				}
 				{
 					// a window matched on both diagonals counts once (on A; the value is the same)
