@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     return OUT
 
 
-HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("arcs.cpp", "graph.hpp", "seqio.hpp", "ingest.hpp")]
+HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("arcs.cpp", "graph.hpp", "seqio.hpp", "ingest.hpp", "bgzf.hpp")]
 HOST_OUT = os.path.join(HERE, "bin", "arcs")
 
 
@@ -52,7 +52,7 @@ def build_host(force=False, verbose=False):
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     # the arks-long feeder (no GPU code)
-    cmd2 = [cxx, "-O2", "-std=c++17", "-I" + os.path.join(HERE, "host"),
+    cmd2 = [cxx, "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(HERE, "host"),
             os.path.join(HERE, "host", "long_to_linked_pe.cpp"), "-lz",
             "-o", os.path.join(HERE, "bin", "long-to-linked-pe")]
     if verbose:

@@ -596,7 +596,8 @@ read_chroms(
 	const size_t nf = files.size();
 	std::vector<std::unique_ptr<SeqReader>> readers;
 	for (const auto& file : files) {
-		readers.emplace_back(new SeqReader(file.c_str()));
+		// inflate threads for bgzip'ed files: what is left of -t per file (bgzf.hpp)
+		readers.emplace_back(new SeqReader(file.c_str(), std::max(1u, params.threads / (unsigned)std::max<size_t>(files.size(), 1))));
 		if (!readers.back()->ok()) {
 			std::cout << out;
 			if (params.verbose)

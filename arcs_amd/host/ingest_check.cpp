@@ -63,7 +63,7 @@ main(int argc, char** argv)
 	std::vector<std::unique_ptr<SeqReader>> readers;
 	std::vector<SeqReader*> rdp;
 	for (const auto& f : files) {
-		readers.emplace_back(new SeqReader(f.c_str()));
+		readers.emplace_back(new SeqReader(f.c_str(), threads)); // bgzip'ed input is inflated in parallel
 		if (!readers.back()->ok()) {
 			std::cerr << "File " << f << " cannot be opened.\n";
 			return 1;

@@ -8,9 +8,12 @@
 // Written from that behaviour; no code of kseq.h is used.
 #pragma once
 
+#include "bgzf.hpp"
+
 #include <zlib.h>
 
 #include <cstring>
+#include <memory>
 #include <string>
 
 namespace arks_host {
@@ -20,11 +23,26 @@ class SeqReader
   public:
 	std::string name, comment, seq, qual;
 
-	explicit SeqReader(const char* path)
-	  : fp_(gzopen(path, "r"))
+	// bgzf_workers > 0: a BGZF (bgzip) file is inflated by that many threads (bgzf.hpp); any other input
+	// -- plain text, ordinary gzip, a pipe -- goes through zlib's gzread as the reference's kseq does
+	explicit SeqReader(const char* path, unsigned bgzf_workers = 0)
 	{
-		if (fp_)
-			gzbuffer(fp_, 1u << 20);
+		if (bgzf_workers > 0) {
+			if (FILE* f = std::fopen(path, "rb")) {
+				unsigned char h[18];
+				unsigned bsize = 0;
+				const size_t got = std::fread(h, 1, sizeof h, f);
+				if (bgzf_header(h, got, &bsize) && std::fseek(f, 0, SEEK_SET) == 0)
+					bgzf_.reset(new BgzfReader(f, bgzf_workers)); // owns f
+				else
+					std::fclose(f);
+			}
+		}
+		if (!bgzf_) {
+			fp_ = gzopen(path, "r");
+			if (fp_)
+				gzbuffer(fp_, 1u << 20);
+		}
 	}
 	~SeqReader()
 	{
@@ -33,7 +51,8 @@ class SeqReader
 	}
 	SeqReader(const SeqReader&) = delete;
 	SeqReader& operator=(const SeqReader&) = delete;
-	bool ok() const { return fp_ != nullptr; }
+	bool ok() const { return fp_ != nullptr || bgzf_ != nullptr; }
+	bool parallel_inflate() const { return bgzf_ != nullptr; }
 
 	int next()
 	{
@@ -86,7 +105,8 @@ class SeqReader
 	}
 
   private:
-	gzFile fp_;
+	gzFile fp_ = nullptr;
+	std::unique_ptr<BgzfReader> bgzf_;
 	unsigned char buf_[1 << 18];
 	int begin_ = 0, end_ = 0;
 	bool eof_ = false;
@@ -94,10 +114,10 @@ class SeqReader
 
 	bool fill()
 	{
-		if (eof_ || !fp_)
+		if (eof_ || !ok())
 			return false;
 		begin_ = 0;
-		end_ = gzread(fp_, buf_, sizeof buf_);
+		end_ = bgzf_ ? bgzf_->read(buf_, (int)sizeof buf_) : gzread(fp_, buf_, sizeof buf_);
 		if (end_ <= 0) {
 			end_ = 0;
 			eof_ = true;

@@ -27,11 +27,15 @@ for fi in range(NF):
     open(f"{tmp}/r{fi}.fq", "w").write(text)
     with gzip.open(f"{tmp}/r{fi}.fq.gz", "wt", compresslevel=4) as f:
         f.write(text)
+    if os.environ.get("E2E_BGZF"):
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from test_host_ingest import write_bgzf
+        write_bgzf(f"{tmp}/r{fi}.bgzf.fq.gz", text.encode(), level=4)
 with open(f"{tmp}/mult.tsv", "w") as f:
     f.writelines(f"{k}\t{v}\n" for k, v in mult.items())
 print("data generated in %.1f s; %d files x %d pairs; fq %.0f MB each" % (time.time()-t0, NF, NP, len(text)/1e6), flush=True)
 ref = None
-for ext in (".fq", ".fq.gz"):
+for ext in ((".fq", ".fq.gz", ".bgzf.fq.gz") if os.environ.get("E2E_BGZF") else (".fq", ".fq.gz")):
     files = [f"{tmp}/r{fi}{ext}" for fi in range(NF)]
     for t in (1, 4, 16):
         args = [exe, "--arks", "-f", f"{tmp}/draft.fa", "-u", f"{tmp}/mult.tsv", "-k", "60", "-j", "0.55", "-c", "5",

@@ -242,3 +242,55 @@ def test_fused_barcode_prepass(exe, oracle, tmp_path):
             kv = r["kv"]
             assert int(kv["invalid"]) == 0 and int(kv["gated"]) == c["gated"] and int(kv["empty"]) == c["empty"]
             assert kv["digest"] == digest and r["msgs"] == msgs
+
+
+def write_bgzf(path, data, block=0xFF00, level=6):
+    """BGZF as bgzip / htslib write it (SAM specification 4.1): independent gzip members of <= 64 KiB with a
+    'BC' extra field holding the member size, and the 28-byte empty member at the end"""
+    import struct
+    import zlib
+    def member(chunk):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(body) + 8
+        return (b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+                + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    with open(path, "wb") as f:
+        for i in range(0, len(data), block):
+            f.write(member(data[i:i + block]))
+        f.write(member(b""))
+
+
+def test_bgzf_parallel_inflate(exe, oracle, tmp_path):
+    """a bgzip'ed FASTQ is cut into its members and inflated by several threads (bgzf.hpp): same records
+    as the plain file, for every thread count; a damaged member ends the stream like a truncated gzip"""
+    rng = np.random.Generator(np.random.PCG64(13))
+    barcodes = [f"{''.join('ACGT'[i] for i in rng.integers(0, 4, size=16))}-1" for _ in range(30)]
+    mult = {b: 10 for b in barcodes}
+    mult_path = str(tmp_path / "mult.tsv")
+    with open(mult_path, "w") as f:
+        f.writelines(f"{b}\t{m}\n" for b, m in mult.items())
+    recs = make_records(rng, 3000, barcodes)
+    plain = str(tmp_path / "reads.fq")
+    write_fastq(plain, recs)
+    data = open(plain, "rb").read()
+    assert len(data) > 20 * 0xFF00                      # dozens of members
+    bg = str(tmp_path / "reads_bgzf.fq.gz")
+    write_bgzf(bg, data)
+    assert gzip.open(bg, "rb").read() == data           # a valid multi-member gzip file for anyone else
+    small = str(tmp_path / "reads_small_blocks.fq.gz")
+    write_bgzf(small, data, block=777)                  # members that end in the middle of lines
+    want = expected(recs, mult, oracle)
+    ref = None
+    for threads in (1, 2, 5, 16):
+        _, res = run(exe, threads, 500, mult_path, [plain, bg, small])
+        for r in res:
+            kv = r["kv"]
+            assert kv["digest"] == want[1] and int(kv["pairs"]) == want[0]["pairs"] and r["msgs"] == want[2], threads
+    # damage one member in the middle: the records before it arrive, the stream ends there
+    blob = bytearray(open(bg, "rb").read())
+    blob[len(blob) // 2] ^= 0x5A
+    bad = str(tmp_path / "damaged.fq.gz")
+    open(bad, "wb").write(bytes(blob))
+    _, res = run(exe, 4, 500, mult_path, [bad])
+    assert 0 < int(res[0]["kv"]["pairs"]) < want[0]["pairs"]
