@@ -237,7 +237,7 @@ read_barcodes(const std::vector<std::string>& files, std::unordered_map<std::str
 	for (const auto& f : files) {
 		if (params.verbose)
 			std::cout << "Reading chrom " << f << std::endl;
-		SeqReader rd(f.c_str());
+		SeqReader rd(f.c_str(), std::max(1u, params.threads)); // (literal two-pass flow) bgzip input inflates in parallel
 		if (!rd.ok()) {
 			std::cerr << "File " << f << " cannot be opened." << std::endl;
 			exit(1);
@@ -353,7 +353,7 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 	// the second pass does not (Q10 of SURVEY.md): a contig with a foreign character would leave
 	// contigRecord too short in the reference.  Here the record simply grows.
 	{
-		SeqReader rd(params.file.c_str());
+		SeqReader rd(params.file.c_str(), std::max(1u, params.threads));
 		size_t count = 0;
 		while (rd.next() >= 0)
 			if (check_contig_sequence(rd.seq) && (int)rd.seq.length() >= params.min_size)
@@ -367,7 +367,7 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 	int total = 0, skipped = 0, valid = 0;
 	contigRecord.clear();
 	contigRecord.push_back(CI("null contig", false));
-	SeqReader rd(params.file.c_str());
+	SeqReader rd(params.file.c_str(), std::max(1u, params.threads));
 	while (rd.next() >= 0) {
 		total++;
 		int cut = 0;

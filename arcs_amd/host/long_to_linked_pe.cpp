@@ -66,6 +66,7 @@ main(int argc, char* argv[])
 	static int help = 0, version = 0, with_fasta = 0, with_bx = 0, with_bx_only = 0;
 	bool auto_span = false, auto_dist = false, l_set = false, g_set = false;
 	size_t l = 0, g = 0, m = 2000;
+	unsigned threads = 1;
 	double cov_to_span = 0.25, dist_read_perc = 50;
 	const size_t dist_lower_bound = 1000;
 	std::string configFile("tigmint-long.params.tsv"), bxFile("barcode_multiplicity.tsv");
@@ -85,7 +86,7 @@ main(int argc, char* argv[])
 		case 'g': g_set = true; g = (size_t)std::stod(optarg); break;
 		case 'p': dist_read_perc = std::stod(optarg); break;
 		case 'c': cov_to_span = std::stod(optarg); break;
-		case 't': break; // threads: accepted, the cutter is I/O bound
+		case 't': threads = (unsigned)std::max(1L, std::atol(optarg)); break; // inflate threads for bgzip'ed input
 		case 's': auto_span = true; break;
 		case 'd': auto_dist = true; break;
 		case 'f': configFile = optarg; break;
@@ -140,7 +141,7 @@ main(int argc, char* argv[])
 		}
 	};
 	for (const auto& infile : infiles) {
-		SeqReader rd(infile.c_str());
+		SeqReader rd(infile.c_str(), threads);
 		if (!rd.ok()) {
 			std::cerr << "long-to-linked-pe v1.0: cannot open " << infile << "\n";
 			return EXIT_FAILURE;
