@@ -32,13 +32,14 @@ class SeqReader
 				unsigned char h[18];
 				unsigned bsize = 0;
 				const size_t got = std::fread(h, 1, sizeof h, f);
-				if (bgzf_header(h, got, &bsize) && std::fseek(f, 0, SEEK_SET) == 0)
-					bgzf_.reset(new BgzfReader(f, bgzf_workers)); // owns f
-				else
+				if (bgzf_header(h, got, &bsize) && std::fseek(f, 0, SEEK_SET) == 0) {
+					bgzf_file_ = f; // the inflate threads start with the first read, not for every open file
+					bgzf_workers_ = bgzf_workers;
+				} else
 					std::fclose(f);
 			}
 		}
-		if (!bgzf_) {
+		if (!bgzf_file_) {
 			fp_ = gzopen(path, "r");
 			if (fp_)
 				gzbuffer(fp_, 1u << 20);
@@ -48,11 +49,13 @@ class SeqReader
 	{
 		if (fp_)
 			gzclose(fp_);
+		if (bgzf_file_ && !bgzf_)
+			std::fclose(bgzf_file_);
 	}
 	SeqReader(const SeqReader&) = delete;
 	SeqReader& operator=(const SeqReader&) = delete;
-	bool ok() const { return fp_ != nullptr || bgzf_ != nullptr; }
-	bool parallel_inflate() const { return bgzf_ != nullptr; }
+	bool ok() const { return fp_ != nullptr || bgzf_file_ != nullptr; }
+	bool parallel_inflate() const { return bgzf_file_ != nullptr; }
 
 	int next()
 	{
@@ -107,6 +110,8 @@ class SeqReader
   private:
 	gzFile fp_ = nullptr;
 	std::unique_ptr<BgzfReader> bgzf_;
+	FILE* bgzf_file_ = nullptr;
+	unsigned bgzf_workers_ = 0;
 	unsigned char buf_[1 << 18];
 	int begin_ = 0, end_ = 0;
 	bool eof_ = false;
@@ -117,6 +122,8 @@ class SeqReader
 		if (eof_ || !ok())
 			return false;
 		begin_ = 0;
+		if (bgzf_file_ && !bgzf_)
+			bgzf_.reset(new BgzfReader(bgzf_file_, bgzf_workers_)); // owns the file from here on
 		end_ = bgzf_ ? bgzf_->read(buf_, (int)sizeof buf_) : gzread(fp_, buf_, sizeof buf_);
 		if (end_ <= 0) {
 			end_ = 0;
