@@ -28,6 +28,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -57,6 +58,17 @@ bx_barcode(const std::string& comment)
 	return end != std::string::npos ? comment.substr(tag + 5, end - tag - 5) : comment.substr(tag + 5);
 }
 
+// the same without a copy (a view into `comment`)
+inline std::string_view
+bx_barcode_view(const std::string& comment)
+{
+	const size_t tag = comment.find("BX:Z:");
+	if (tag == std::string::npos)
+		return std::string_view();
+	const size_t end = comment.find(' ', tag);
+	return std::string_view(comment).substr(tag + 5, end != std::string::npos ? end - tag - 5 : std::string::npos);
+}
+
 template <typename T>
 class BoundedQueue
 {
@@ -83,6 +95,24 @@ class BoundedQueue
 		not_full_.notify_one();
 		return true;
 	}
+	// non-blocking variants (a recycling list: nothing waits on it)
+	bool try_pop(T& out)
+	{
+		std::lock_guard<std::mutex> lk(m_);
+		if (q_.empty())
+			return false;
+		out = std::move(q_.front());
+		q_.pop_front();
+		return true;
+	}
+	bool try_push(T&& v)
+	{
+		std::lock_guard<std::mutex> lk(m_);
+		if (q_.size() >= cap_)
+			return false;
+		q_.push_back(std::move(v));
+		return true;
+	}
 	void close()
 	{
 		std::lock_guard<std::mutex> lk(m_);
@@ -102,15 +132,15 @@ class BoundedQueue
 // a key of the multiplicity map (Arcs.cpp:1258-1262), so the producers only read this table
 struct BarcodeDict
 {
-	std::unordered_map<std::string, uint32_t> id;
+	std::unordered_map<std::string_view, uint32_t> id; // views into the keys of `mult` (node-stable)
 	std::vector<const std::string*> name;
 	explicit BarcodeDict(const std::unordered_map<std::string, int>& mult)
 	{
 		id.reserve(mult.size());
 		name.reserve(mult.size());
 		for (const auto& kv : mult) {
-			auto it = id.emplace(kv.first, (uint32_t)name.size()).first;
-			name.push_back(&it->first);
+			id.emplace(std::string_view(kv.first), (uint32_t)name.size());
+			name.push_back(&kv.first);
 		}
 	}
 };
@@ -123,14 +153,17 @@ struct BarcodeDict
 class DynamicDict
 {
   public:
-	uint32_t get(const std::string& barcode)
+	// id of the barcode; *stored = the dictionary's own copy of its text (stable: usable as a cache key)
+	uint32_t get(std::string_view barcode, std::string_view* stored = nullptr)
 	{
 		std::lock_guard<std::mutex> lk(m_);
 		auto it = id_.find(barcode);
 		if (it == id_.end()) {
-			names_.push_back(barcode);
-			it = id_.emplace(barcode, (uint32_t)(names_.size() - 1)).first;
+			names_.emplace_back(barcode);
+			it = id_.emplace(std::string_view(names_.back()), (uint32_t)(names_.size() - 1)).first;
 		}
+		if (stored)
+			*stored = it->first;
 		return it->second;
 	}
 	size_t size() const { return names_.size(); }
@@ -138,7 +171,7 @@ class DynamicDict
 
   private:
 	std::mutex m_;
-	std::unordered_map<std::string, uint32_t> id_;
+	std::unordered_map<std::string_view, uint32_t> id_; // views into names_ (a deque: stable)
 	std::deque<std::string> names_;
 };
 
@@ -152,7 +185,7 @@ struct PrepassInfo
 	std::vector<uint64_t> untagged_at; // running tagged count at every later such record
 	std::vector<uint32_t> counts;      // reads per barcode id
 
-	void record(int l, const std::string& comment, DynamicDict& dict, std::unordered_map<std::string, uint32_t>& cache)
+	void record(int l, const std::string& comment, DynamicDict& dict, std::unordered_map<std::string_view, uint32_t>& cache)
 	{
 		if (!active)
 			return;
@@ -170,10 +203,13 @@ struct PrepassInfo
 				untagged_at.push_back(total);
 			return;
 		}
-		const std::string bc = bx_barcode(comment);
+		const std::string_view bc = bx_barcode_view(comment);
 		auto it = cache.find(bc);
-		if (it == cache.end())
-			it = cache.emplace(bc, dict.get(bc)).first;
+		if (it == cache.end()) {
+			std::string_view stored;
+			const uint32_t id = dict.get(bc, &stored);
+			it = cache.emplace(stored, id).first; // keyed by the dictionary's copy, not by the record's text
+		}
 		if (it->second >= counts.size())
 			counts.resize((size_t)it->second + 1 + counts.size() / 2, 0);
 		counts[it->second]++;
@@ -314,13 +350,20 @@ pack_batch(RawBatch& rb, PackedBatch& pb, const HostAllocator& a)
 inline void
 produce_file(
     SeqReader& rd, int file_idx, const BarcodeDict* dict, DynamicDict* dyn, PrepassInfo* pre, long batch_pairs,
-    bool verbose, const std::function<void(RawBatch&&)>& emit)
+    bool verbose, const std::function<void(RawBatch&&)>& emit,
+    const std::function<bool(RawBatch&)>& recycled = nullptr) // hands back a used batch (its buffers are warm)
 {
-	std::unordered_map<std::string, uint32_t> cache; // fused mode: this producer's view of the dictionary
+	std::unordered_map<std::string_view, uint32_t> cache; // fused mode: this producer's view of the dictionary
 	RawBatch b;
 	int64_t seq = 0;
 	auto reset = [&](RawBatch& x) {
-		x = RawBatch();
+		// a recycled batch keeps its capacity: a fresh 80 MB of bases costs an mmap and 20 k page faults
+		if (recycled && recycled(x)) {
+			x.bases.clear(), x.off.clear(), x.len.clear(), x.pair_ok.clear(), x.barcode_id.clear(), x.messages.clear();
+			x.fc = FileCounters();
+			x.last = false;
+		} else
+			x = RawBatch();
 		x.file = file_idx;
 		x.seq = seq++;
 		x.bases.reserve((size_t)batch_pairs * 300);
@@ -361,7 +404,7 @@ produce_file(
 			b.messages += "Processed " + std::to_string(count) + " read pairs.\n";
 		if (stop)
 			break;
-		const std::string b1 = bx_barcode(c1), b2 = bx_barcode(c2);
+		const std::string_view b1 = bx_barcode_view(c1), b2 = bx_barcode_view(c2);
 		bool valid = false;
 		uint32_t bid = 0;
 		if (b1.empty() || b2.empty())
@@ -377,8 +420,11 @@ produce_file(
 			// fused mode: mate 1 carries the tag, so the pre-pass has counted it: b1 is in the map
 			valid = true;
 			auto it = cache.find(b1);
-			if (it == cache.end())
-				it = cache.emplace(b1, dyn->get(b1)).first;
+			if (it == cache.end()) {
+				std::string_view stored;
+				const uint32_t id = dyn->get(b1, &stored);
+				it = cache.emplace(stored, id).first;
+			}
 			bid = it->second;
 		}
 		const bool ok = paired && valid && b1 == b2; // Arcs.cpp:1264-1265 (goodmult is always true)
@@ -455,7 +501,8 @@ class IngestPipeline
 					}
 					produce_file(*readers_[f], (int)f, dict_, dict_ ? nullptr : &dynamic_,
 					             dict_ ? nullptr : &prepass_[f], batch_pairs_, verbose_,
-					             [&](RawBatch&& rb) { raw_q_.push(std::move(rb)); });
+					             [&](RawBatch&& rb) { raw_q_.push(std::move(rb)); },
+					             [&](RawBatch& out) { return raw_free_.try_pop(out); });
 				}
 			});
 		for (unsigned t = 0; t < n_packers_; ++t)
@@ -472,6 +519,8 @@ class IngestPipeline
 							first_err = rc;
 					}
 					packed_q_.push(pb);
+					raw_free_.try_push(std::move(rb)); // back to the producers, buffers and all
+					rb = RawBatch();
 				}
 			});
 		std::thread closer([&] {
@@ -515,7 +564,7 @@ class IngestPipeline
 	bool verbose_;
 	HostAllocator alloc_;
 	unsigned n_producers_ = 1, n_packers_ = 1, n_buffers_ = 4;
-	BoundedQueue<RawBatch> raw_q_;
+	BoundedQueue<RawBatch> raw_q_, raw_free_{ 8 };
 	BoundedQueue<PackedBatch*> packed_q_, free_q_;
 };
 
