@@ -354,6 +354,7 @@ produce_file(
     const std::function<bool(RawBatch&)>& recycled = nullptr) // hands back a used batch (its buffers are warm)
 {
 	std::unordered_map<std::string_view, uint32_t> cache; // fused mode: this producer's view of the dictionary
+	rd.keep_qual = false; // the mapping needs no base qualities: measure them, do not copy them
 	RawBatch b;
 	int64_t seq = 0;
 	auto reset = [&](RawBatch& x) {

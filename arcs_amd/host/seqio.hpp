@@ -22,6 +22,7 @@ class SeqReader
 {
   public:
 	std::string name, comment, seq, qual;
+	bool keep_qual = true; // false: quality lines are only measured (length check), `qual` stays empty
 
 	// bgzf_workers > 0: a BGZF (bgzip) file is inflated by that many threads (bgzf.hpp); any other input
 	// -- plain text, ordinary gzip, a pipe -- goes through zlib's gzread as the reference's kseq does
@@ -99,10 +100,17 @@ class SeqReader
 			return (int)seq.size();
 		if (!skip_line())
 			return -2;
-		while (read_line(qual, true) >= 0 && qual.size() < seq.size()) {
+		size_t qlen = 0;
+		if (keep_qual) {
+			while (read_line(qual, true) >= 0 && qual.size() < seq.size()) {
+			}
+			qlen = qual.size();
+		} else {
+			while (measure_line(qlen) && qlen < seq.size()) {
+			}
 		}
 		last_ = 0;
-		if (seq.size() != qual.size())
+		if (seq.size() != qlen)
 			return -2;
 		return (int)seq.size();
 	}
@@ -153,6 +161,34 @@ class SeqReader
 			}
 			begin_ = end_;
 		}
+	}
+
+	// read_line(s, append = true) without the copy: `total` grows by the line's length under the same
+	// carriage-return rule (applied to the accumulated text); false when the stream is at its end
+	bool measure_line(size_t& total)
+	{
+		bool got = false;
+		unsigned char last = 0;
+		for (;;) {
+			if (begin_ >= end_ && !fill())
+				break;
+			got = true;
+			const unsigned char* from = buf_ + begin_;
+			const void* nl = std::memchr(from, '\n', (size_t)(end_ - begin_));
+			const unsigned char* to = nl ? (const unsigned char*)nl : buf_ + end_;
+			if (to > from) {
+				total += (size_t)(to - from);
+				last = to[-1];
+			}
+			begin_ = nl ? (int)(to - buf_) + 1 : end_;
+			if (nl)
+				break;
+		}
+		if (!got)
+			return false;
+		if (total > 1 && last == '\r')
+			total--;
+		return true;
 	}
 
 	// appends (or assigns) the rest of the current line; returns the string length, or -1 when
