@@ -46,6 +46,7 @@ SYMBOLS = {
     "arks_device_count": (_I, []),
     "arks_key_bytes": (_I, [_I]),
     "arks_index_build": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, C.POINTER(BuildStats)]),
+    "arks_index_build_shard": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I]),
     "arks_index_free": (_I, [_VP]),
     "arks_index_k": (_I, [_VP]),
     "arks_index_size": (_I64, [_VP]),
@@ -57,6 +58,8 @@ SYMBOLS = {
     "arks_pack_reads_device": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _I, _VP]),
     "arks_pack_reads_host": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
     "arks_map_reads_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
+    "arks_map_votes_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP]),
+    "arks_votes_resolve_device": (_I, [_VP, _VP, _I64, _I, _D, _VP, _I, _VP]),
     "arks_map_reads": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _VP, C.POINTER(MapStats)]),
     "arks_imap_create": (_I, [C.POINTER(_VP), _I64, _I]),
     "arks_imap_free": (_I, [_VP]),

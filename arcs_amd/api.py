@@ -93,6 +93,18 @@ class ArksIndex:
         check(rc, "arks_index_build")
         return cls(h, k, device, st.as_dict() if want_stats else None)
 
+    @classmethod
+    def build_shard(cls, ends, k, shard, n_shards, device=0):
+        """arks_index_build_shard: the k-mers of the ends e with (e // 2) % n_shards == shard, keys
+        shared with any other end of the list read 0; every shard is given the same list"""
+        data, offsets, lens = _concat(ends)
+        data = np.concatenate([data, np.zeros(1, np.uint8)])
+        h = C.c_void_p()
+        rc = lib().arks_index_build_shard(C.byref(h), k, data.ctypes.data, offsets.ctypes.data,
+                                          lens.ctypes.data, len(lens), shard, n_shards, device)
+        check(rc, "arks_index_build_shard")
+        return cls(h, k, device, None)
+
     def close(self):
         if self._h:
             lib().arks_index_free(self._h)
@@ -243,6 +255,58 @@ def map_reads_packed(index, reads, j_index, eval_mask=None, stats=None, out=None
         float(j_index), out.data_ptr(), stats.data_ptr() if stats is not None else None,
         _stream_ptr(reads.device)), "arks_map_reads_device")
     return out[:n]
+
+
+def map_votes_packed(index, reads, eval_mask=None, out=None):
+    """arks_map_votes_device against one shard of the index, on the current torch stream: int64[n]
+    (bit pattern: count << 32 | ~conreci, 0 = nothing recorded); the maximum over shards is the vote
+    of the whole index (counts stay below 2^31, so the signed maximum is the unsigned one)"""
+    torch = _torch()
+    n = reads.n_reads
+    if out is None:
+        out = torch.empty(max(n, 1), dtype=torch.int64, device=reads.codes.device)
+    check(lib().arks_map_votes_device(
+        index.handle, reads.codes.data_ptr(), reads.nmask.data_ptr(), reads.word_off.data_ptr(),
+        reads.lens.data_ptr(), eval_mask.data_ptr() if eval_mask is not None else None, n,
+        out.data_ptr(), _stream_ptr(reads.device)), "arks_map_votes_device")
+    return out[:n]
+
+
+def resolve_votes(votes, reads, k, j_index, out=None):
+    """arks_votes_resolve_device: the j_index test of bestContig over reduced votes -> int32 conreci"""
+    torch = _torch()
+    n = reads.n_reads
+    if out is None:
+        out = torch.empty(max(n, 1), dtype=torch.int32, device=reads.codes.device)
+    check(lib().arks_votes_resolve_device(votes.data_ptr(), reads.lens.data_ptr(), n, int(k),
+                                          float(j_index), out.data_ptr(), reads.device,
+                                          _stream_ptr(reads.device)), "arks_votes_resolve_device")
+    return out[:n]
+
+
+def pair_gate(reads, pair_ok=None):
+    """arks_pair_gate_device -> uint8[2 * n_pairs]"""
+    torch = _torch()
+    n_pairs = reads.n_reads // 2
+    ev = torch.empty(max(2 * n_pairs, 1), dtype=torch.uint8, device=reads.codes.device)
+    check(lib().arks_pair_gate_device(pair_ok.data_ptr() if pair_ok is not None else None,
+                                      reads.read_class.data_ptr(), n_pairs, ev.data_ptr(),
+                                      reads.device, _stream_ptr(reads.device)), "arks_pair_gate_device")
+    return ev
+
+
+def pairs_rule(conreci, reads, pair_ok=None, barcode_id=None, imap=None, stored=None):
+    """arks_pairs_device -> int32[n_pairs]"""
+    torch = _torch()
+    n_pairs = reads.n_reads // 2
+    pair = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=reads.codes.device)
+    check(lib().arks_pairs_device(conreci.data_ptr(),
+                                  pair_ok.data_ptr() if pair_ok is not None else None,
+                                  barcode_id.data_ptr() if barcode_id is not None else None,
+                                  n_pairs, pair.data_ptr(), imap.handle if imap is not None else None,
+                                  stored.data_ptr() if stored is not None else None,
+                                  reads.device, _stream_ptr(reads.device)), "arks_pairs_device")
+    return pair[:n_pairs]
 
 
 class ImapAccumulator:

@@ -287,6 +287,53 @@ insert_kernel(
 	}
 }
 
+// K2p: a shard of the index (arks_index_build_shard) holds the keys of ITS contig ends; a key that also
+// occurs in an end of another shard must read 0 here as it does in the whole map (Arcs.cpp:905-910).
+// One thread per visited window of the FOREIGN ends: a key found with an owner loses it; nothing is
+// inserted.  Runs after K2 has finished (no LOCKED states, keys and states are final), so plain
+// relaxed accesses suffice and the store is idempotent.
+template <int KW>
+__global__ void
+poison_kernel(
+    const u64* __restrict__ codes,
+    const u32* __restrict__ visited,
+    u64 total_words,
+    KeyGeom g,
+    TableView t,
+    u64* __restrict__ counter) // += keys that lost their owner to another shard
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 w = pos >> 5;
+	bool active = w < total_words;
+	if (active)
+		active = (visited[w] >> (31 - (pos & 31))) & 1u;
+	u32 n_lost = 0;
+	if (active) {
+		const Key<KW> c = reference_key(window_key_at<KW>(codes, pos, g), g);
+		u64 s = mulhi64(key_hash(c), t.cap);
+		for (;;) {
+			u64* slot = t.slots + s * kSlotWords;
+			u32* state = reinterpret_cast<u32*>(slot + 3);
+			const u32 st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (st == kEmpty)
+				break; // not a key of this shard
+			Key<KW> sk;
+#pragma unroll
+			for (int j = 0; j < KW; ++j)
+				sk.w[j] = __hip_atomic_load(slot + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (key_eq(sk, c)) {
+				if (st != 1u)
+					n_lost = __hip_atomic_exchange(state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u;
+				break;
+			}
+			s = (s + 1 == t.cap) ? 0 : s + 1;
+		}
+	}
+	const u64 b_lost = __ballot(n_lost);
+	if ((threadIdx.x & 63) == 0 && b_lost)
+		atomicAdd(counter, (u64)__popcll(b_lost));
+}
+
 // K2s: counts the visits whose end is the smallest end that visited the key; the reference's
 // "removed" counter (Arcs.cpp:909, order dependent in the serial loop, ends in ascending order) is
 // total visits minus that count.
@@ -788,6 +835,22 @@ launch_insert(
 		insert_kernel<3><<<b, 256, 0, st>>>(codes, visited, word_owner, total_words, g, t, counters);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
+}
+
+hipError_t
+launch_poison(
+    int kw, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView t,
+    u64* counter, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	const u64 n = total_words * 32;
+	const unsigned blocks = (unsigned)((n + 255) / 256);
+	if (kw == 2)
+		poison_kernel<2><<<blocks, 256, 0, st>>>(codes, visited, total_words, g, t, counter);
+	else
+		poison_kernel<3><<<blocks, 256, 0, st>>>(codes, visited, total_words, g, t, counter);
+	return hipGetLastError();
 }
 
 hipError_t

@@ -87,7 +87,13 @@ struct DevBuf
 		if (p)
 			(void)hipFree(p);
 	}
-	hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+	hipError_t alloc(size_t bytes) // a second call replaces the buffer
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		return hipMalloc(&p, bytes ? bytes : 1);
+	}
 	template <typename T>
 	T* as() const
 	{
@@ -399,20 +405,109 @@ want_locality(int k)
 	return k >= 20; // below that the minimizer window degenerates; the hash table serves
 }
 
-int
-arks_index_build(
+/* End e belongs to shard (e / 2) % n_shards: the head and the tail of a contig (conreci 2i-1, 2i,
+ * Arcs.cpp:1079-1081) stay together, contigs go round robin. */
+static inline bool
+own_end(int64_t e, int shard, int n_shards)
+{
+	return n_shards <= 1 || (int)((e / 2) % n_shards) == shard;
+}
+
+/* The ends of the OTHER shards take away the owner of every key they share with this shard's table
+ * (launch_poison): packed and scanned with the same kernels as the shard's own text, a bounded number
+ * of bases at a time, nothing of them is kept. */
+static int
+poison_with_foreign_ends(
+    const arks_index* idx, const char* h_bases, const uint64_t* h_offsets, const uint32_t* h_lens,
+    int64_t n_ends, int shard, int n_shards, TableView full, u64* d_counter, hipStream_t st)
+{
+	int rc = ARKS_OK;
+	const uint64_t kChunkBases = 1ull << 28;
+	const int kBackPad = 16;
+	std::vector<uint64_t> woff, offs, src;
+	std::vector<uint32_t> lens;
+	DevBuf d_ascii, d_offs, d_lens, d_woff, d_codes, d_nmask, d_visited, d_scratch;
+	HIP_TRY(d_scratch.alloc(sizeof(u64) * 8));
+	for (int64_t e = 0; e < n_ends;) {
+		woff.clear(), offs.clear(), src.clear(), lens.clear();
+		uint64_t acc = kFrontPadWords, bacc = 0;
+		for (; e < n_ends && (bacc == 0 || bacc + h_lens[e] <= kChunkBases); ++e) {
+			if (own_end(e, shard, n_shards) || h_lens[e] == 0)
+				continue;
+			woff.push_back(acc), offs.push_back(bacc), src.push_back(h_offsets[e]), lens.push_back(h_lens[e]);
+			acc += ((uint64_t)h_lens[e] + 31) / 32;
+			bacc += h_lens[e];
+		}
+		const size_t n = lens.size();
+		if (n == 0)
+			continue;
+		woff.push_back(acc), offs.push_back(bacc);
+		const u64 text_words = acc, alloc_words = acc + kBackPad;
+		HIP_TRY(d_ascii.alloc(bacc + 64));
+		for (size_t i = 0; i < n;) { // one copy per run of ends that are adjacent in the source
+			size_t last = i;
+			while (last + 1 < n && src[last + 1] == src[last] + lens[last])
+				++last;
+			HIP_TRY(hipMemcpy(
+			    d_ascii.as<char>() + offs[i], h_bases + src[i], offs[last] + lens[last] - offs[i],
+			    hipMemcpyHostToDevice));
+			i = last + 1;
+		}
+		lens.push_back(0);
+		HIP_TRY(d_offs.alloc(sizeof(u64) * (n + 1)));
+		HIP_TRY(d_lens.alloc(sizeof(u32) * (n + 1)));
+		HIP_TRY(d_woff.alloc(sizeof(u64) * (n + 1)));
+		HIP_TRY(d_codes.alloc(sizeof(u64) * alloc_words));
+		HIP_TRY(d_nmask.alloc(sizeof(u32) * alloc_words));
+		HIP_TRY(d_visited.alloc(sizeof(u32) * alloc_words));
+		HIP_TRY(hipMemcpy(d_offs.p, offs.data(), sizeof(u64) * (n + 1), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(d_lens.p, lens.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(d_woff.p, woff.data(), sizeof(u64) * (n + 1), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemsetAsync(d_codes.p, 0, sizeof(u64) * alloc_words, st));
+		HIP_TRY(hipMemsetAsync(d_nmask.p, 0, sizeof(u32) * alloc_words, st));
+		HIP_TRY(hipMemsetAsync(d_visited.p, 0, sizeof(u32) * alloc_words, st));
+		HIP_TRY(hipMemsetAsync(d_scratch.p, 0, sizeof(u64) * 8, st));
+		HIP_TRY(launch_pack(
+		    d_ascii.as<uint8_t>(), d_offs.as<u64>(), d_lens.as<u32>(), d_woff.as<u64>(), (long)n, text_words,
+		    d_codes.as<u64>(), d_nmask.as<u32>(), nullptr, nullptr, st));
+		HIP_TRY(launch_visit(
+		    d_nmask.as<u32>(), d_woff.as<u64>(), d_lens.as<u32>(), (long)n, idx->k, d_visited.as<u32>(),
+		    d_scratch.as<u64>(), st));
+		HIP_TRY(launch_poison(
+		    idx->kw, d_codes.as<u64>(), d_visited.as<u32>(), text_words, idx->geom, full, d_counter, st));
+		HIP_TRY(hipStreamSynchronize(st)); // the buffers are reused (or freed) next
+	}
+done:
+	return rc;
+}
+
+static int
+index_build_impl(
     arks_index** out,
     int k,
     const char* h_bases,
     const uint64_t* h_offsets,
-    const uint32_t* h_lens,
+    const uint32_t* h_all_lens,
     int64_t n_ends,
+    int shard,
+    int n_shards,
     int device,
     arks_build_stats* stats)
 {
-	if (!out || n_ends < 0 || (n_ends > 0 && (!h_bases || !h_offsets || !h_lens)))
+	if (!out || n_ends < 0 || (n_ends > 0 && (!h_bases || !h_offsets || !h_all_lens)) || n_shards < 1 ||
+	    shard < 0 || shard >= n_shards)
 		return ARKS_ERR_BAD_ARG;
 	*out = nullptr;
+	// a shard sees the other shards' ends as empty strings: same conreci numbering, none of their k-mers
+	std::vector<uint32_t> own_lens;
+	const uint32_t* h_lens = h_all_lens;
+	if (n_shards > 1) {
+		own_lens.assign(h_all_lens, h_all_lens + n_ends);
+		for (int64_t e = 0; e < n_ends; ++e)
+			if (!own_end(e, shard, n_shards))
+				own_lens[(size_t)e] = 0;
+		h_lens = own_lens.data();
+	}
 	int rc = check_k(k);
 	if (rc != ARKS_OK)
 		return rc;
@@ -539,6 +634,13 @@ arks_index_build(
 	    idx->kw, idx->codes, idx->visited, d_wown.as<u32>(), (long)n_ends, text_words, idx->geom, full,
 	    d_counters.as<u64>(), st));
 	ARKS_TRACE_STEP("launch_insert");
+	if (n_shards > 1) {
+		rc = poison_with_foreign_ends(
+		    idx, h_bases, h_offsets, h_all_lens, n_ends, shard, n_shards, full, d_counters.as<u64>() + 7, st);
+		if (rc != ARKS_OK)
+			goto done;
+		ARKS_TRACE_STEP("foreign ends");
+	}
 	if (stats)
 		HIP_TRY(launch_build_stats(
 		    idx->kw, idx->codes, idx->visited, d_woff.as<u64>(), (long)n_ends, text_words, idx->geom,
@@ -677,6 +779,35 @@ done:
 	if (idx)
 		arks_index_free(idx);
 	return rc;
+}
+
+int
+arks_index_build(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int device,
+    arks_build_stats* stats)
+{
+	return index_build_impl(out, k, h_bases, h_offsets, h_lens, n_ends, 0, 1, device, stats);
+}
+
+int
+arks_index_build_shard(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int shard,
+    int n_shards,
+    int device)
+{
+	return index_build_impl(out, k, h_bases, h_offsets, h_lens, n_ends, shard, n_shards, device, nullptr);
 }
 
 int
@@ -861,6 +992,62 @@ arks_map_reads_device(
 	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads,
 	    j_index, idx->geom, idx->table, idx->bx, d_out_conreci, reinterpret_cast<u64*>(d_stats),
 	    idx->queue, idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+int
+arks_map_votes_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    uint64_t* d_out_votes,
+    void* stream)
+{
+	if (!idx || n_reads < 0 || n_reads > 0xFFFFFFFFll)
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads == 0)
+		return ARKS_OK;
+	if (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_out_votes)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(idx->device);
+	int rc = ensure_queue(idx, n_reads);
+	if (rc != ARKS_OK)
+		return rc;
+	HIP_TRY(launch_map_reads(
+	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, 0.0,
+	    idx->geom, idx->table, idx->bx, reinterpret_cast<int*>(d_out_votes), nullptr, idx->queue,
+	    idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream), true));
+done:
+	return rc;
+}
+
+int
+arks_votes_resolve_device(
+    const uint64_t* d_votes,
+    const uint32_t* d_lens,
+    int64_t n_reads,
+    int k,
+    double j_index,
+    int32_t* d_out_conreci,
+    int device,
+    void* stream)
+{
+	if (n_reads < 0 || (n_reads > 0 && (!d_votes || !d_lens || !d_out_conreci)))
+		return ARKS_ERR_BAD_ARG;
+	int rc = check_k(k);
+	if (rc != ARKS_OK)
+		return rc;
+	rc = require_device(device);
+	if (rc != ARKS_OK)
+		return rc;
+	DeviceGuard guard(device);
+	HIP_TRY(launch_resolve_votes(
+	    (const u64*)d_votes, d_lens, (long)n_reads, k, j_index, d_out_conreci, static_cast<hipStream_t>(stream)));
 done:
 	return rc;
 }

@@ -17,6 +17,9 @@ hipError_t launch_popcount(const u32* words, u64 n, u64* out, hipStream_t st);
 hipError_t launch_insert(
     int kw, const u64* codes, const u32* visited, const u32* word_owner, long n_ends, u64 total_words,
     const KeyGeom& g, TableView t, u64* counters, hipStream_t st);
+hipError_t launch_poison(
+    int kw, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView t,
+    u64* counter, hipStream_t st);
 hipError_t launch_build_stats(
     int kw, const u64* codes, const u32* visited, const u64* word_off, long n_ends, u64 total_words,
     const KeyGeom& g, TableView t, u64* counters, hipStream_t st);
@@ -26,7 +29,7 @@ hipError_t launch_map_reads(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens,
     const uint8_t* eval, long n_reads, double j_index, const KeyGeom& g, TableView t,
     const BIndexView& bx, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu,
-    hipStream_t st);
+    hipStream_t st, bool raw = false); // raw: out is u64[n_reads], the votes of put_result<true>
 hipError_t launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner, hipStream_t st);
 hipError_t launch_bmark(
     int kw, int mm, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,
@@ -46,6 +49,8 @@ hipError_t launch_bfallback(
 hipError_t launch_bexport(
     int kw, const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner,
     u64 total_words, const KeyGeom& g, u64* out_keys, int* out_vals, u64* counter, hipStream_t st);
+hipError_t launch_resolve_votes(
+    const u64* votes, const u32* lens, long n_reads, int k, double j_index, int* out, hipStream_t st);
 hipError_t launch_pair_gate(
     const uint8_t* pair_ok, const uint8_t* read_class, long n_pairs, uint8_t* eval, hipStream_t st);
 hipError_t launch_pairs(

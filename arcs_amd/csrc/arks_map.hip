@@ -147,12 +147,35 @@ vote_long_read(
 	}
 }
 
+// What a mapping kernel writes for read r.  RAW = false: bestContig's return value (Arcs.cpp:1006-1013).
+// RAW = true (sharded index, arks_map_votes_device): the winner of the walk of Arcs.cpp:998-1004 before
+// the j_index test, as one u64 whose unsigned maximum over index shards is the winner over all of them:
+// count in the high word, ~conreci in the low word (a tie keeps the smaller conreci); 0 = nothing recorded.
+template <bool RAW>
+__device__ __forceinline__ void
+put_result(int* __restrict__ out, long r, int best, int best_cnt, bool pass)
+{
+	if (RAW)
+		reinterpret_cast<u64*>(out)[r] = best_cnt > 0 ? (((u64)(u32)best_cnt << 32) | (u64)(~(u32)best)) : 0ull;
+	else
+		out[r] = pass ? best : 0;
+}
+template <bool RAW>
+__device__ __forceinline__ void
+put_none(int* __restrict__ out, long r)
+{
+	if (RAW)
+		reinterpret_cast<u64*>(out)[r] = 0ull;
+	else
+		out[r] = 0;
+}
+
 // FAST = true : the hot kernel.  Grid-stride over all reads; a read that needs one of the rare
 //               paths (a reverse-complement palindrome window, whose key takes the reference's
 //               damaged branch; or more than 64 * kMaxPass windows) is appended to `queue`
 //               untouched, which keeps those paths' registers out of this kernel.
 // FAST = false: the same algorithm with every path, over the reads listed in `queue`.
-template <int KW, bool STATS, bool FAST, bool BMODE, int MM>
+template <int KW, bool STATS, bool FAST, bool BMODE, int MM, bool RAW = false>
 __global__ void __launch_bounds__(256)
 map_reads_kernel(
     const u64* __restrict__ codes,
@@ -180,7 +203,7 @@ map_reads_kernel(
 		const long r = FAST ? it : (long)queue[it];
 		if (FAST && eval && !eval[r]) {
 			if (lane == 0)
-				out_conreci[r] = 0;
+				put_none<RAW>(out_conreci, r);
 			continue;
 		}
 		const int nwin = (int)lens[r] - g.k + 1; // <= 0: the loop of Arcs.cpp:959 never runs
@@ -249,7 +272,7 @@ map_reads_kernel(
 		const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
 		const bool pass = maxj > j_index;
 		if (lane == 0)
-			out_conreci[r] = pass ? best : 0;
+			put_result<RAW>(out_conreci, r, best, best_cnt, pass);
 		if (STATS) {
 			ws.valid += rs.valid;
 			ws.bad += rs.bad;
@@ -713,7 +736,7 @@ tile_sliding_min(u32* pre_lds, u32* blk_lds, int l0, int lane, int w, const u32 
 	}
 }
 
-template <int KW, bool STATS, bool FULL, int MM>
+template <int KW, bool STATS, bool FULL, int MM, bool RAW = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FULL ? 4 : ARKS_TILE_WAVES)))
 map_reads_b_kernel(
     const u64* __restrict__ codes,
@@ -841,7 +864,7 @@ map_reads_b_kernel(
 					if (rl >= 0)
 						queue[atomicAdd(queue_count, 1u)] = (u32)(c0 + cur);
 					else
-						out_conreci[c0 + cur] = 0;
+						put_none<RAW>(out_conreci, c0 + cur);
 				}
 				cur++;
 				continue;
@@ -1329,7 +1352,7 @@ map_reads_b_kernel(
 					const long r = c0 + cur + j;
 					const int L = S.rlen[j];
 					if (L < 0) {
-						out_conreci[r] = 0;
+						put_none<RAW>(out_conreci, r);
 					} else if ((redo_mask >> j) & 1u) {
 						queue[atomicAdd(queue_count, 1u)] = (u32)r;
 					} else {
@@ -1359,7 +1382,7 @@ map_reads_b_kernel(
 							const int total = nwin > 0 ? nwin : 0;
 							const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
 							const bool pass = maxj > j_index;
-							out_conreci[r] = pass ? best : 0;
+							put_result<RAW>(out_conreci, r, best, best_cnt, pass);
 							if (STATS) { // <= 16 reads x <= 512 windows: three words of 16-bit (8-bit) fields
 								st_a = (u32)nvalid | ((u32)total << 16);
 								st_b = (u32)(rec_a + amb_a + rec_b + amb_b) | ((u32)(rec_a + rec_b) << 16);
@@ -1393,7 +1416,7 @@ map_reads_b_kernel(
 				const int L = S.rlen[j];
 				if (L < 0) {
 					if (lane == 0)
-						out_conreci[r] = 0;
+						put_none<RAW>(out_conreci, r);
 					continue;
 				}
 				if ((redo_mask >> j) & 1u) {
@@ -1463,7 +1486,7 @@ map_reads_b_kernel(
 				const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
 				const bool pass = maxj > j_index;
 				if (lane == 0)
-					out_conreci[r] = pass ? best : 0;
+					put_result<RAW>(out_conreci, r, best, best_cnt, pass);
 				if (STATS) {
 					ws.pass += pass;
 					ws.fail += !pass;
@@ -1633,10 +1656,13 @@ hipError_t
 launch_map_reads(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens,
     const uint8_t* eval, long n_reads, double j_index, const KeyGeom& g, TableView t,
-    const BIndexView& bx, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st)
+    const BIndexView& bx, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st,
+    bool raw)
 {
 	if (n_reads <= 0)
 		return hipSuccess;
+	if (raw && stats)
+		return hipErrorInvalidValue; // the window counters of a shard are not the reference's
 	// queue_count: 4 counters, then (64 bytes in) the partial rows of the statistics
 	u64* const user_stats = stats;
 	if (stats)
@@ -1649,38 +1675,46 @@ launch_map_reads(
 	const u64 cap = (u64)(n_cu > 0 ? n_cu : 256) * 8ull;
 	const unsigned b = (unsigned)(want < cap ? want : cap);
 	const unsigned bs = (unsigned)(want < 256 ? want : 256); // slow path: the queue is short
-#define ARKS_MAP_HASH(KWV, ST)                                                                     \
+#define ARKS_MAP_HASH(KWV, ST, RAWV)                                                               \
 	do {                                                                                           \
-		map_reads_kernel<KWV, ST, true, false, kMShort><<<b, 256, 0, st>>>(                        \
+		map_reads_kernel<KWV, ST, true, false, kMShort, RAWV><<<b, 256, 0, st>>>(                  \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, t, bx, out, stats, queue,     \
 		    queue_count);                                                                          \
-		map_reads_kernel<KWV, ST, false, false, kMShort><<<bs, 256, 0, st>>>(                      \
+		map_reads_kernel<KWV, ST, false, false, kMShort, RAWV><<<bs, 256, 0, st>>>(                \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, t, bx, out, stats, queue,     \
 		    queue_count);                                                                          \
 	} while (0)
-#define ARKS_MAP_B(KWV, ST, MMV)                                                                   \
+#define ARKS_MAP_B(KWV, ST, MMV, RAWV)                                                             \
 	do {                                                                                           \
 		int per_cu = 0;                                                                            \
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                          \
-		        &per_cu, map_reads_b_kernel<KWV, ST, false, MMV>, 64, 0) != hipSuccess ||          \
+		        &per_cu, map_reads_b_kernel<KWV, ST, false, MMV, RAWV>, 64, 0) != hipSuccess ||    \
 		    per_cu <= 0)                                                                           \
 			per_cu = 8;                                                                            \
 		const u64 res = (u64)(n_cu > 0 ? n_cu : 256) * (u64)per_cu;                                \
 		const u64 wantw = ((u64)n_reads + 3) / 4;                                                  \
 		const unsigned bb = (unsigned)(wantw < res ? wantw : res);                                 \
-		map_reads_b_kernel<KWV, ST, false, MMV><<<bb, 64, 0, st>>>(                                \
+		map_reads_b_kernel<KWV, ST, false, MMV, RAWV><<<bb, 64, 0, st>>>(                          \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue + n_reads, queue_count);                                                         \
-		map_reads_b_kernel<KWV, ST, true, MMV><<<bb, 64, 0, st>>>(                                 \
+		map_reads_b_kernel<KWV, ST, true, MMV, RAWV><<<bb, 64, 0, st>>>(                           \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue + n_reads, queue_count);                                                         \
-		map_reads_kernel<KWV, ST, false, true, MMV><<<bs, 256, 0, st>>>(                           \
+		map_reads_kernel<KWV, ST, false, true, MMV, RAWV><<<bs, 256, 0, st>>>(                     \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, t, bx, out, stats, queue,     \
 		    queue_count);                                                                          \
 	} while (0)
 #define ARKS_MAP_B_ST(KWV, MMV)                                                                    \
 	do {                                                                                           \
-		if (stats) ARKS_MAP_B(KWV, true, MMV); else ARKS_MAP_B(KWV, false, MMV);                   \
+		if (raw) ARKS_MAP_B(KWV, false, MMV, true);                                                \
+		else if (stats) ARKS_MAP_B(KWV, true, MMV, false);                                         \
+		else ARKS_MAP_B(KWV, false, MMV, false);                                                   \
+	} while (0)
+#define ARKS_MAP_HASH_ST(KWV)                                                                      \
+	do {                                                                                           \
+		if (raw) ARKS_MAP_HASH(KWV, false, true);                                                  \
+		else if (stats) ARKS_MAP_HASH(KWV, true, false);                                           \
+		else ARKS_MAP_HASH(KWV, false, false);                                                     \
 	} while (0)
 	if (bx.enabled) {
 		if (kw == 2 && bx.m == kMShort) ARKS_MAP_B_ST(2, kMShort);
@@ -1688,17 +1722,46 @@ launch_map_reads(
 		else if (bx.m == kMShort) ARKS_MAP_B_ST(3, kMShort);
 		else ARKS_MAP_B_ST(3, kMLong);
 	} else {
-		if (kw == 2) {
-			if (stats) ARKS_MAP_HASH(2, true); else ARKS_MAP_HASH(2, false);
-		} else {
-			if (stats) ARKS_MAP_HASH(3, true); else ARKS_MAP_HASH(3, false);
-		}
+		if (kw == 2) ARKS_MAP_HASH_ST(2);
+		else ARKS_MAP_HASH_ST(3);
 	}
+#undef ARKS_MAP_HASH_ST
 #undef ARKS_MAP_HASH
 #undef ARKS_MAP_B
 #undef ARKS_MAP_B_ST
 	if (user_stats)
 		fold_stats_kernel<<<1, 64, 0, st>>>(stats, user_stats);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+// The tail of bestContig (Arcs.cpp:996-1013) over votes that were gathered from index shards
+// (put_result<true>; the caller has taken the maximum over the shards): total = every window of the
+// read, NULL ones included (:962); accepted iff count / total > j_index in double (:1006).
+__global__ void
+resolve_votes_kernel(
+    const u64* __restrict__ votes, const u32* __restrict__ lens, long n_reads, int k, double j_index,
+    int* __restrict__ out)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads)
+		return;
+	const u64 v = votes[r];
+	const int best_cnt = (int)(v >> 32);
+	const int best = best_cnt > 0 ? (int)~(u32)v : 0;
+	const int nwin = (int)lens[r] - k + 1;
+	const int total = nwin > 0 ? nwin : 0;
+	const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
+	out[r] = maxj > j_index ? best : 0;
+}
+
+hipError_t
+launch_resolve_votes(
+    const u64* votes, const u32* lens, long n_reads, int k, double j_index, int* out, hipStream_t st)
+{
+	if (n_reads <= 0)
+		return hipSuccess;
+	resolve_votes_kernel<<<blocks_for((u64)n_reads, 256), 256, 0, st>>>(votes, lens, n_reads, k, j_index, out);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

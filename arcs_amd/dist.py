@@ -2,7 +2,12 @@
 "gloo" in the CPU tests).  The path shards over reads: every rank holds a replica of the contig
 k-mer index and maps its own slice of the read pairs; the only exchange is the final merge of the
 per-rank IndexMap triples (a sum), which mirrors `imap[barcode][end]++` being commutative
-(Arcs/Arcs.cpp:1282-1285).  No data-path collective."""
+(Arcs/Arcs.cpp:1282-1285).  No data-path collective.
+
+The sharded-index configuration (BASELINE configs[3]; a draft whose index should not live on one GPU)
+is the second half of this file: rank r holds shard r of the index (arks_index_build_shard), every
+rank maps the SAME read batch against its shard, and the one data-path collective is an
+all-reduce(MAX) of the 8-byte per-read votes -- see include/arks_hip.h, arks_map_votes_device."""
 import numpy as np
 
 
@@ -54,3 +59,39 @@ def sum_stats(stats, group=None):
     t = torch.as_tensor(np.asarray(stats, dtype=np.int64)).to(dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()
+
+
+# ---- sharded index ------------------------------------------------------------------------------
+
+def pack_vote(count, conreci):
+    """the 64-bit vote of arks_map_votes_device as a Python int"""
+    return ((int(count) << 32) | (~int(conreci) & 0xFFFFFFFF)) if count > 0 else 0
+
+
+def unpack_vote(v):
+    """(count, conreci) of one vote"""
+    v = int(v)
+    return (v >> 32, (~v) & 0xFFFFFFFF) if (v >> 32) > 0 else (0, 0)
+
+
+def reduce_votes(votes, group=None):
+    """in-place all-reduce(MAX) of the per-read votes (int64 tensor; on the GPU with RCCL, on the
+    CPU with gloo): the vote of the end that wins bestContig's walk over the whole index"""
+    import torch.distributed as dist
+    dist.all_reduce(votes, op=dist.ReduceOp.MAX, group=group)
+    return votes
+
+
+def map_pairs_sharded(shard_index, reads, j_index, pair_ok=None, barcode_id=None, imap=None,
+                      stored=None, group=None):
+    """The per-pair flow of chromiumRead (Arcs/Arcs.cpp:1264-1292) with the index sharded over the
+    ranks of `group`: every rank calls this with the same resident batch and its own shard; all get
+    the same (conreci, pair) tensors.  Only one rank should pass `imap` (or the triples of all ranks
+    must not be summed): each rank would record every stored pair."""
+    from . import api
+    ev = api.pair_gate(reads, pair_ok)
+    votes = api.map_votes_packed(shard_index, reads, eval_mask=ev)
+    reduce_votes(votes, group)
+    conreci = api.resolve_votes(votes, reads, shard_index.k, j_index)
+    pair = api.pairs_rule(conreci, reads, pair_ok, barcode_id, imap, stored)
+    return conreci, pair

@@ -110,6 +110,26 @@ int arks_index_build(
     int device,
     arks_build_stats* stats);
 
+/* One shard of the index for a draft whose whole index should not (or cannot) live on one GPU --
+ * BASELINE config "contig k-mer index hash-sharded across 8 GPUs".  Shard `shard` of `n_shards` holds the
+ * k-mers of the ends e with (e / 2) % n_shards == shard (a contig's head and tail together, contigs
+ * round robin); every rank passes the SAME end list, conreci numbering is that of the whole list.
+ * A key that also occurs in an end of another shard reads 0 in this shard, as it does in the one map of
+ * Arcs/Arcs.cpp:903-920: the foreign ends are streamed through the shard's table once while it is
+ * built (no exchange between ranks).  Every conreci therefore lives in exactly one shard, and the
+ * winner of bestContig's walk (Arcs.cpp:998-1004) over the whole map is the maximum over shards of the
+ * per-shard winners -- see arks_map_votes_device.  n_shards == 1 is arks_index_build. */
+int arks_index_build_shard(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int shard,
+    int n_shards,
+    int device);
+
 int arks_index_free(arks_index* idx);
 int arks_index_k(const arks_index* idx);
 /* number of distinct keys (== kmap.size()) */
@@ -182,6 +202,36 @@ int arks_map_reads_device(
     double j_index,
     int32_t* d_out_conreci,
     arks_map_stats* d_stats,
+    void* stream);
+
+/* bestContig (Arcs/Arcs.cpp:939-1004) up to, not including, the j_index test, against ONE shard:
+ * d_out_votes[r] = (count << 32) | ~conreci of the end that won the walk of :998-1004 in this shard
+ * (0 = nothing recorded, or d_eval[r] == 0).  The unsigned 64-bit MAXIMUM of a read's votes over all
+ * shards is the vote of the whole map: the larger count wins and a tie keeps the smaller conreci
+ * (:1000, strict <).  That maximum is the only data-path exchange of the sharded configuration (one
+ * 8-byte all-reduce(MAX) per read; reads are replicated to every shard), arks_votes_resolve_device
+ * finishes the call.  Same ordering rule per index as arks_map_reads_device. */
+int arks_map_votes_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    uint64_t* d_out_votes,
+    void* stream);
+
+/* The tail of bestContig (Arcs/Arcs.cpp:996,1006-1013) over reduced votes: d_out_conreci[r] = conreci
+ * if count / (len - k + 1 windows, NULL ones included, :962) > j_index in double, else 0. */
+int arks_votes_resolve_device(
+    const uint64_t* d_votes,
+    const uint32_t* d_lens,
+    int64_t n_reads,
+    int k,
+    double j_index,
+    int32_t* d_out_conreci,
+    int device,
     void* stream);
 
 /* Host convenience over the above (pack + map + copy back); mirrors calling bestContig on every

@@ -1,7 +1,10 @@
 """world_size-2 `gloo` test of the multi-GPU driver logic on CPU: the reads are sharded over two
 ranks, each rank maps its slice (here through the CPU oracle -- the device kernels need a GPU; what
 is under test is the sharding and the triple/counter merge), and the merged IndexMap equals the
-single-process result."""
+single-process result.  Second half: the sharded-index configuration -- each rank votes with the
+part of the contig k-mer map that its shard holds, all-reduce(MAX) of the votes, j_index test.  It also
+checks the claim the device code rests on: the winner over the whole map is the maximum of the
+per-shard winners."""
 import os
 import socket
 import sys
@@ -79,3 +82,83 @@ def test_sum_triples():
     rows = np.array([[5, 2, 1], [1, 9, 4], [5, 2, 3], [1, 3, 1]], dtype=np.uint32)
     assert adist.sum_triples(rows).tolist() == [[1, 3, 1], [1, 9, 4], [5, 2, 4]]
     assert adist.sum_triples(np.zeros((0, 3))).shape == (0, 3)
+
+
+def _shard_votes(O, ox, reads, k, shard, n_shards):
+    """per-read vote (dist.pack_vote) of the ends of one shard: bestContig's walk (Arcs.cpp:959-1004)
+    restricted to the conreci the shard owns -- the values are those of the whole map, which is what a
+    shard built by arks_index_build_shard holds"""
+    from arcs_amd import dist as adist
+    out = np.zeros(len(reads), dtype=np.int64)
+    for r, read in enumerate(reads):
+        hist = {}
+        for i in range(len(read) - k + 1):
+            key = O.key(read, i, k)
+            if key is None:
+                continue
+            c = ox.get(key)
+            if c > 0 and ((c - 1) // 2) % n_shards == shard:
+                hist[c] = hist.get(c, 0) + 1
+        best, cnt = 0, 0
+        for c in sorted(hist):
+            if hist[c] > cnt:
+                best, cnt = c, hist[c]
+        out[r] = adist.pack_vote(cnt, best)
+    return out
+
+
+def _sharded_case(O):
+    from arcs_amd import synth
+    k = 40
+    contigs = synth.make_draft(60000, seed=51, lengths=(5000, 8000, 3000), inject=False)
+    cs = synth.contigs_to_strings(contigs)
+    batch = synth.make_read_pairs(contigs, 150, seed=52, mol_len=4000, pairs_per_mol=10)
+    reads = synth.reads_to_strings(batch)
+    ends = O.contig_ends(cs, 500, 2000)
+    ends += [ends[0][100:160] + "A", "C" + ends[3][5:75]]        # keys shared between shards read 0
+    # 21 windows each of ends 4 and 1 (two shards): the smaller conreci wins; 22 v 21: the larger count
+    reads = reads + [ends[3][200:260] + "N" + ends[0][300:360], ends[2][200:261] + "N" + ends[5][300:360]]
+    return k, ends, reads
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from arcs_amd import dist as adist
+    from oracle import pyoracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, ends, reads = _sharded_case(O)
+    ox = O.OracleIndex(k).build(ends)
+    votes = torch.from_numpy(_shard_votes(O, ox, reads, k, rank, world))
+    adist.reduce_votes(votes)
+    np.save(os.path.join(out_dir, f"votes{rank}.npy"), votes.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_index_votes(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    from arcs_amd import dist as adist
+    assert adist.unpack_vote(adist.pack_vote(7, 12)) == (7, 12) and adist.pack_vote(0, 5) == 0
+    assert adist.pack_vote(7, 3) > adist.pack_vote(7, 4) > adist.pack_vote(6, 1)      # tie -> smaller conreci
+    world = 2
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    k, ends, reads = _sharded_case(oracle)
+    ox = oracle.OracleIndex(k).build(ends)
+    v0 = np.load(os.path.join(str(tmp_path), "votes0.npy"))
+    v1 = np.load(os.path.join(str(tmp_path), "votes1.npy"))
+    assert v0.tolist() == v1.tolist()
+    for j in (0.55, 0.2, 0.0):
+        got = []
+        for v, read in zip(v0, reads):
+            cnt, c = adist.unpack_vote(v)
+            total = max(len(read) - k + 1, 0)
+            got.append(c if cnt > 0 and cnt / total > j else 0)
+        want = [ox.best_contig(r, j) for r in reads]
+        assert got == want, j
+    assert len({c for c in want if c}) > 5
+    assert want[-2] == 1 and want[-1] == 3

@@ -1,0 +1,166 @@
+"""The sharded index (arks_index_build_shard / arks_map_votes_device / arks_votes_resolve_device,
+BASELINE configs[3]) against the whole index and the CPU oracle.  One GPU holds all shards here, one
+after the other; what is under test is that (1) a shard is exactly the part of the whole map that its
+contig ends touch, with the values of the WHOLE map (keys shared with another shard read 0), and
+(2) the maximum of the per-shard votes followed by the j_index test is bestContig over the whole map."""
+import os
+
+import numpy as np
+import pytest
+
+from util import index_digest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGTacgtNn", "TGCAtgcaNn"))
+
+
+def _draft(k, seed):
+    from arcs_amd import synth
+    contigs = synth.make_draft(70000, seed=seed, lengths=(4000, 9000, 2500, 12000), small_frac=0.2,
+                               inject=False)
+    big = [c for c in contigs if len(c) >= 2500]
+    big[0][300:400] = ord("N")
+    big[1][50] = ord("N"); big[1][55] = ord("N")
+    big[2][200:900] = big[3][100:800]            # the same 700 bases in two contigs (two shards)
+    big[4][1000:1400] = big[1][600:1000]         # ... and in contigs two shards apart
+    big[5][20:20 + 300] = big[0][900:1200]
+    if k % 2 == 0:
+        big[4][100:100 + 3 * k] = np.frombuffer((b"AT" * (2 * k))[:3 * k], dtype=np.uint8)
+        big[6][700:700 + 2 * k] = np.frombuffer((b"AT" * (2 * k))[:2 * k], dtype=np.uint8)
+    return synth.contigs_to_strings(contigs)
+
+
+def _reads(cs, ends, k, seed, n=1200):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    genome = "".join(cs)
+    reads = []
+    for i in range(n):
+        L = int(rng.choice([128, 151, 250, k - 1, k, k + 1, 64 + k, 700]))
+        p = int(rng.integers(0, len(genome) - L))
+        r = list(genome[p:p + L])
+        for q in rng.integers(0, L, size=int(rng.integers(0, 3))):
+            r[q] = "ACGTNacgtn"[int(rng.integers(10))]
+        r = "".join(r)
+        reads.append(_rc(r) if i % 2 else r)
+    # chimeras of ends that live in different shards: equal counts (the smaller conreci wins), one more
+    # window on either side, three-way
+    w = k + 9
+    for a, b in ((3, 1), (1, 3), (2, 5), (7, 0), (4, 6)):
+        reads.append(ends[a][100:100 + w] + ends[b][100:100 + w])
+        reads.append(ends[a][100:100 + w + 1] + ends[b][100:100 + w])
+        reads.append(ends[a][100:100 + w] + ends[b][100:100 + w + 1])
+        reads.append(_rc(ends[a][200:200 + w]) + ends[b][300:300 + w] + ends[(a + b) % 8][50:50 + w])
+    reads += ["", "A", "N" * 200, ("AT" * 400)[:k + 70], genome[:k].lower(),
+              ends[2][:1000] + ends[1][:1000], ends[2][:1000] + "N" * 500 + ends[1][:1001]]
+    return reads
+
+
+@pytest.mark.parametrize("k,n_shards", [(16, 2), (20, 3), (30, 2), (31, 3), (60, 2), (60, 3), (60, 8), (80, 2)])
+def test_shards_equal_whole_index(arks, gpu, oracle, k, n_shards):
+    import torch
+    cs = _draft(k, 500 + k)
+    ends = arks.contig_ends(cs, 500, 1500)
+    assert len(ends) >= 16
+    ox = oracle.OracleIndex(k).build(ends)
+    ok, ov = ox.dump()
+    whole = {bytes(kk): int(v) for kk, v in zip(ok, ov)}
+    ix = arks.ArksIndex.build(ends, k, device=gpu)
+    shards = [arks.ArksIndex.build_shard(ends, k, s, n_shards, device=gpu) for s in range(n_shards)]
+
+    # (1) content: the keys its own ends visit, with the values of the whole map
+    n_zeroed = 0
+    for s, sh in enumerate(shards):
+        own = [e if (i // 2) % n_shards == s else "" for i, e in enumerate(ends)]
+        oxs = oracle.OracleIndex(k).build(own)
+        keys, local_vals = oxs.dump()
+        want_vals = np.array([whole[bytes(kk)] for kk in keys], dtype=np.int32)
+        n_zeroed += int(np.count_nonzero((want_vals == 0) & (local_vals != 0)))
+        gk, gv = sh.export()
+        assert len(sh) == len(keys)
+        assert index_digest(gk, gv) == index_digest(keys, want_vals), (k, n_shards, s)
+        assert sh.kind == ix.kind
+    assert n_zeroed > 100        # the draft does have keys shared between shards
+
+    # (2) mapping: max of the shard votes == the whole index == the oracle
+    reads = _reads(cs, ends, k, 900 + k)
+    packed = arks.PackedReads.from_ascii(reads, device=gpu)
+    ev = torch.ones(len(reads), dtype=torch.uint8, device="cuda")
+    ev[5::17] = 0                                         # reads bestContig is not called for
+    votes = None
+    for sh in shards:
+        v = arks.map_votes_packed(sh, packed, eval_mask=ev).clone()
+        votes = v if votes is None else torch.maximum(votes, v)
+    whole_votes = arks.map_votes_packed(ix, packed, eval_mask=ev)
+    assert torch.equal(votes, whole_votes)
+    evh = ev.cpu().numpy()
+    for j in (0.55, 0.05, 0.0, -1.0):
+        got = arks.resolve_votes(votes, packed, k, j).cpu().tolist()
+        plain = arks.map_reads_packed(ix, packed, j, eval_mask=ev).cpu().tolist()
+        want = [ox.best_contig(r, j) if evh[i] else 0 for i, r in enumerate(reads)]
+        assert plain == want, (k, j)
+        assert got == want, (k, n_shards, j)
+    assert len({c for c in want if c}) > 8
+    for sh in shards:
+        sh.close()
+    ix.close()
+
+
+def test_hash_layout_shards(arks, gpu, oracle, monkeypatch):
+    """the exact hash table layout (ARKS_INDEX_KIND=hash) shards the same way"""
+    import torch
+    monkeypatch.setenv("ARKS_INDEX_KIND", "hash")
+    k, n_shards = 40, 3
+    cs = _draft(k, 77)
+    ends = arks.contig_ends(cs, 500, 1500)
+    ox = oracle.OracleIndex(k).build(ends)
+    shards = [arks.ArksIndex.build_shard(ends, k, s, n_shards, device=gpu) for s in range(n_shards)]
+    assert all(sh.kind == 0 for sh in shards)
+    reads = _reads(cs, ends, k, 78, n=600)
+    packed = arks.PackedReads.from_ascii(reads, device=gpu)
+    votes = None
+    for sh in shards:
+        v = arks.map_votes_packed(sh, packed).clone()
+        votes = v if votes is None else torch.maximum(votes, v)
+    for j in (0.55, 0.0):
+        got = arks.resolve_votes(votes, packed, k, j).cpu().tolist()
+        assert got == [ox.best_contig(r, j) for r in reads], j
+
+
+def test_one_rank_group_end_to_end(arks, gpu, oracle):
+    """dist.map_pairs_sharded through a real RCCL process group of one rank (what a GPU box offers):
+    gate -> votes -> all-reduce(MAX) -> j_index test -> pair rule -> imap, equal to the plain path"""
+    import torch
+    import torch.distributed as dist
+    from arcs_amd import dist as adist, synth
+    from util import oracle_pairs
+    k, j = 60, 0.55
+    contigs = synth.make_draft(200000, seed=41, lengths=(9000, 14000, 30000))
+    cs = synth.contigs_to_strings(contigs)
+    ends = arks.contig_ends(cs, 500, 4000)
+    batch = synth.make_read_pairs(contigs, 3000, seed=42, mol_len=8000, pairs_per_mol=10)
+    reads = synth.reads_to_strings(batch)
+    ox = oracle.OracleIndex(k).build(ends)
+    _, want_pair, _, want_triples = oracle_pairs(oracle, ox, reads, batch["pair_ok"].numpy(),
+                                                 batch["barcode_id"].numpy(), j)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29641")
+    torch.cuda.set_device(gpu)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        sh = arks.ArksIndex.build_shard(ends, k, dist.get_rank(), dist.get_world_size(), device=gpu)
+        packed = arks.PackedReads.from_ascii(reads, device=gpu)
+        imap = arks.ImapAccumulator(1 << 16, device=gpu)
+        conreci, pair = adist.map_pairs_sharded(
+            sh, packed, j, pair_ok=batch["pair_ok"].cuda(), barcode_id=batch["barcode_id"].cuda(), imap=imap)
+        torch.cuda.synchronize()
+        assert pair.cpu().tolist() == list(want_pair)
+        assert imap.triples().tolist() == want_triples
+        assert len(want_triples) > 20
+    finally:
+        if created:
+            dist.destroy_process_group()
