@@ -95,3 +95,32 @@ def map_pairs_sharded(shard_index, reads, j_index, pair_ok=None, barcode_id=None
     conreci = api.resolve_votes(votes, reads, shard_index.k, j_index)
     pair = api.pairs_rule(conreci, reads, pair_ok, barcode_id, imap, stored)
     return conreci, pair
+
+
+class ShardedPairStep:
+    """map_pairs_sharded with every buffer preallocated (bench.py --sharded-index)"""
+
+    def __init__(self, shard_index, reads, j_index, pair_ok=None, barcode_id=None, imap=None, group=None):
+        import torch
+        dev = reads.codes.device
+        self.index, self.reads, self.j, self.group = shard_index, reads, float(j_index), group
+        self.pair_ok, self.barcode_id, self.imap = pair_ok, barcode_id, imap
+        self.n_pairs = reads.n_reads // 2
+        self.votes = torch.empty(max(reads.n_reads, 1), dtype=torch.int64, device=dev)
+        self.conreci = torch.empty(max(reads.n_reads, 1), dtype=torch.int32, device=dev)
+        self.pair = None
+
+    def run(self, stats=None, stored=None, map_events=None):
+        import torch.distributed as dist
+        from . import api
+        assert stats is None, "the window counters of a shard are not the reference's"
+        ev = api.pair_gate(self.reads, self.pair_ok)
+        if map_events is not None:
+            map_events[0].record()
+        api.map_votes_packed(self.index, self.reads, eval_mask=ev, out=self.votes)
+        if map_events is not None:
+            map_events[1].record()
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            reduce_votes(self.votes, self.group)
+        api.resolve_votes(self.votes, self.reads, self.index.k, self.j, out=self.conreci)
+        self.pair = api.pairs_rule(self.conreci, self.reads, self.pair_ok, self.barcode_id, self.imap, stored)
