@@ -4,6 +4,7 @@ after the other; what is under test is that (1) a shard is exactly the part of t
 contig ends touch, with the values of the WHOLE map (keys shared with another shard read 0), and
 (2) the maximum of the per-shard votes followed by the j_index test is bestContig over the whole map."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -129,38 +130,75 @@ def test_hash_layout_shards(arks, gpu, oracle, monkeypatch):
         assert got == [ox.best_contig(r, j) for r in reads], j
 
 
-def test_one_rank_group_end_to_end(arks, gpu, oracle):
-    """dist.map_pairs_sharded through a real RCCL process group of one rank (what a GPU box offers):
-    gate -> votes -> all-reduce(MAX) -> j_index test -> pair rule -> imap, equal to the plain path"""
-    import torch
-    import torch.distributed as dist
-    from arcs_amd import dist as adist, synth
-    from util import oracle_pairs
-    k, j = 60, 0.55
+def _one_rank_case():
+    from arcs_amd import synth
     contigs = synth.make_draft(200000, seed=41, lengths=(9000, 14000, 30000))
     cs = synth.contigs_to_strings(contigs)
-    ends = arks.contig_ends(cs, 500, 4000)
     batch = synth.make_read_pairs(contigs, 3000, seed=42, mol_len=8000, pairs_per_mol=10)
-    reads = synth.reads_to_strings(batch)
+    return cs, batch, synth.reads_to_strings(batch)
+
+
+def _one_rank_worker(want_path):
+    """runs in its own process (a hung RCCL start-up must not take the test session with it)"""
+    import json
+    import torch
+    import torch.distributed as dist
+    import arcs_amd as arks
+    from arcs_amd import dist as adist
+    want = json.load(open(want_path))
+    k, j = want["k"], want["j"]
+    cs, batch, reads = _one_rank_case()
+    ends = arks.contig_ends(cs, 500, 4000)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(want["port"]))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    sh = arks.ArksIndex.build_shard(ends, k, dist.get_rank(), dist.get_world_size(), device=0)
+    packed = arks.PackedReads.from_ascii(reads, device=0)
+    imap = arks.ImapAccumulator(1 << 16, device=0)
+    step = adist.ShardedPairStep(sh, packed, j, pair_ok=batch["pair_ok"].cuda(),
+                                 barcode_id=batch["barcode_id"].cuda(), imap=imap)
+    step.run()
+    votes = step.votes.clone()
+    adist.reduce_votes(votes)                       # the collective itself, on one rank: identity
+    torch.cuda.synchronize()
+    assert torch.equal(votes, step.votes)
+    assert step.pair.cpu().tolist() == want["pair"]
+    assert imap.triples().tolist() == want["triples"]
+    conreci, pair = adist.map_pairs_sharded(sh, packed, j, pair_ok=batch["pair_ok"].cuda())
+    assert pair.cpu().tolist() == want["pair"]
+    dist.destroy_process_group()
+    print("one-rank ok")
+
+
+def test_one_rank_group_end_to_end(arks, gpu, oracle, tmp_path):
+    """dist.map_pairs_sharded / ShardedPairStep under a real RCCL process group of one rank (what a
+    single-GPU box offers): gate -> votes -> all-reduce(MAX) -> j_index test -> pair rule -> imap,
+    equal to the oracle's pair flow"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from util import oracle_pairs
+    k, j = 60, 0.55
+    cs, batch, reads = _one_rank_case()
+    ends = arks.contig_ends(cs, 500, 4000)
     ox = oracle.OracleIndex(k).build(ends)
     _, want_pair, _, want_triples = oracle_pairs(oracle, ox, reads, batch["pair_ok"].numpy(),
                                                  batch["barcode_id"].numpy(), j)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29641")
-    torch.cuda.set_device(gpu)
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1)
-    try:
-        sh = arks.ArksIndex.build_shard(ends, k, dist.get_rank(), dist.get_world_size(), device=gpu)
-        packed = arks.PackedReads.from_ascii(reads, device=gpu)
-        imap = arks.ImapAccumulator(1 << 16, device=gpu)
-        conreci, pair = adist.map_pairs_sharded(
-            sh, packed, j, pair_ok=batch["pair_ok"].cuda(), barcode_id=batch["barcode_id"].cuda(), imap=imap)
-        torch.cuda.synchronize()
-        assert pair.cpu().tolist() == list(want_pair)
-        assert imap.triples().tolist() == want_triples
-        assert len(want_triples) > 20
-    finally:
-        if created:
-            dist.destroy_process_group()
+    assert len(want_triples) > 20
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    wp = tmp_path / "want.json"
+    wp.write_text(json.dumps({"k": k, "j": j, "port": port, "pair": [int(x) for x in want_pair],
+                              "triples": [[int(a), int(b), int(c)] for a, b, c in want_triples]}))
+    res = subprocess.run([sys.executable, os.path.abspath(__file__), "one-rank-worker", str(wp)],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "one-rank ok" in res.stdout, res.stderr[-3000:]
+
+
+if __name__ == "__main__" and len(sys.argv) == 3 and sys.argv[1] == "one-rank-worker":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    _one_rank_worker(sys.argv[2])
