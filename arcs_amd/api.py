@@ -272,6 +272,13 @@ def map_votes_packed(index, reads, eval_mask=None, out=None):
     return out[:n]
 
 
+def max_votes(acc, votes, device=0):
+    """arks_votes_max_device: acc = max(acc, votes) in place"""
+    check(lib().arks_votes_max_device(acc.data_ptr(), votes.data_ptr(), int(acc.numel()), device,
+                                      _stream_ptr(device)), "arks_votes_max_device")
+    return acc
+
+
 def resolve_votes(votes, reads, k, j_index, out=None):
     """arks_votes_resolve_device: the j_index test of bestContig over reduced votes -> int32 conreci"""
     torch = _torch()

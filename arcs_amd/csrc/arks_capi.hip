@@ -1027,6 +1027,20 @@ done:
 }
 
 int
+arks_votes_max_device(uint64_t* d_acc, const uint64_t* d_in, int64_t n_reads, int device, void* stream)
+{
+	if (n_reads < 0 || (n_reads > 0 && (!d_acc || !d_in)))
+		return ARKS_ERR_BAD_ARG;
+	int rc = require_device(device);
+	if (rc != ARKS_OK)
+		return rc;
+	DeviceGuard guard(device);
+	HIP_TRY(launch_max_votes((u64*)d_acc, (const u64*)d_in, (long)n_reads, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+int
 arks_votes_resolve_device(
     const uint64_t* d_votes,
     const uint32_t* d_lens,

@@ -49,6 +49,7 @@ hipError_t launch_bfallback(
 hipError_t launch_bexport(
     int kw, const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner,
     u64 total_words, const KeyGeom& g, u64* out_keys, int* out_vals, u64* counter, hipStream_t st);
+hipError_t launch_max_votes(u64* acc, const u64* in, long n, hipStream_t st);
 hipError_t launch_resolve_votes(
     const u64* votes, const u32* lens, long n_reads, int k, double j_index, int* out, hipStream_t st);
 hipError_t launch_pair_gate(

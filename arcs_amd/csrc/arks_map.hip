@@ -1755,6 +1755,29 @@ resolve_votes_kernel(
 	out[r] = maxj > j_index ? best : 0;
 }
 
+// acc[r] = max(acc[r], in[r]): folds the votes of another shard in (single-process drivers that copy
+// votes between GPUs themselves; with one process per GPU the all-reduce(MAX) of RCCL does this)
+__global__ void
+max_votes_kernel(u64* __restrict__ acc, const u64* __restrict__ in, long n)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < n) {
+		const u64 a = acc[r], b = in[r];
+		if (b > a)
+			acc[r] = b;
+	}
+}
+
+hipError_t
+launch_max_votes(u64* acc, const u64* in, long n, hipStream_t st)
+{
+	if (n <= 0)
+		return hipSuccess;
+	max_votes_kernel<<<blocks_for((u64)n, 256), 256, 0, st>>>(acc, in, n);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
 hipError_t
 launch_resolve_votes(
     const u64* votes, const u32* lens, long n_reads, int k, double j_index, int* out, hipStream_t st)

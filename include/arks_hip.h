@@ -222,6 +222,10 @@ int arks_map_votes_device(
     uint64_t* d_out_votes,
     void* stream);
 
+/* d_acc[r] = max(d_acc[r], d_in[r]) (unsigned): folds another shard's votes in, for a driver that
+ * moves votes between GPUs itself (hipMemcpyPeerAsync) instead of calling RCCL's all-reduce(MAX). */
+int arks_votes_max_device(uint64_t* d_acc, const uint64_t* d_in, int64_t n_reads, int device, void* stream);
+
 /* The tail of bestContig (Arcs/Arcs.cpp:996,1006-1013) over reduced votes: d_out_conreci[r] = conreci
  * if count / (len - k + 1 windows, NULL ones included, :962) > j_index in double, else 0. */
 int arks_votes_resolve_device(

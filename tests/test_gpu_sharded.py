@@ -124,7 +124,7 @@ def test_hash_layout_shards(arks, gpu, oracle, monkeypatch):
     votes = None
     for sh in shards:
         v = arks.map_votes_packed(sh, packed).clone()
-        votes = v if votes is None else torch.maximum(votes, v)
+        votes = v if votes is None else arks.max_votes(votes, v, device=gpu)      # arks_votes_max_device
     for j in (0.55, 0.0):
         got = arks.resolve_votes(votes, packed, k, j).cpu().tolist()
         assert got == [ox.best_contig(r, j) for r in reads], j
