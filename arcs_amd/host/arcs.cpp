@@ -52,6 +52,7 @@ struct Params
 	std::string dist_samples_tsv, dist_tsv;
 	GraphParams g;
 	long batch_pairs = 262144; // --batch-pairs (this build only): read pairs per GPU batch
+	int index_shards = 1;      // --index-shards (this build only): the contig k-mer index in N parts
 	int device = 0;             // --device (this build only)
 };
 
@@ -72,7 +73,8 @@ enum
 	OPT_DIST_UPPER,
 	OPT_ARKS_METHOD,
 	OPT_BATCH_PAIRS,
-	OPT_DEVICE
+	OPT_DEVICE,
+	OPT_INDEX_SHARDS
 };
 
 const char shortopts[] = "f:a:B:s:c:Dl:z:b:g:m:d:e:r:vt:u:j:k:P";
@@ -112,6 +114,7 @@ const struct option longopts[] = {
 	{ "pair", no_argument, NULL, 'P' },
 	{ "batch-pairs", required_argument, NULL, OPT_BATCH_PAIRS },
 	{ "device", required_argument, NULL, OPT_DEVICE },
+	{ "index-shards", required_argument, NULL, OPT_INDEX_SHARDS },
 	{ NULL, 0, NULL, 0 }
 };
 
@@ -142,6 +145,7 @@ const char USAGE[] =
             "   -t  --threads         number of host ingest threads [1] (parse / pack; the mapping runs on the GPU)\n"
             "   -P, --pair            output scaffolds pairing TSV\n"
             "       --batch-pairs=N   read pairs per GPU batch [2000000]\n"
+            "       --index-shards=N  build and map the contig k-mer index in N parts (very large drafts) [1]\n"
             "       --device=N        GPU ordinal [0]\n";
 
 void
@@ -389,10 +393,27 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 	}
 	bases.push_back('\0');
 	std::vector<arks_index*> idxs;
+	const int n_shards = std::max(1, params.index_shards);
 	for (const int k : params.k_list) {
 		arks_index* idx = nullptr;
 		arks_build_stats st;
 		std::memset(&st, 0, sizeof st);
+		if (n_shards > 1) {
+			// --index-shards: N indexes of 1/N of the contigs each (a draft beyond one index's 2^32 text
+			// positions, or whose build scratch does not fit); the reads are mapped against each in turn
+			for (int s = 0; s < n_shards; ++s) {
+				const int rc = arks_index_build_shard(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(),
+				                                      s, n_shards, params.device);
+				if (rc != ARKS_OK)
+					die_arks(rc, "building a shard of the contig k-mer index");
+				idxs.push_back(idx);
+			}
+			if (params.verbose)
+				appendf(log, "%s %u\n%s %u\n%s %u\n(index in %d shards: the k-mer counters are not collected)\n",
+				        "Total number of contigs in draft genome: ", (unsigned)total, "Total valid contigs: ", (unsigned)valid,
+				        "Total skipped contigs: ", (unsigned)skipped, n_shards);
+			continue;
+		}
 		const int rc = arks_index_build(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(), params.device,
 		                                params.verbose ? &st : nullptr);
 		if (rc != ARKS_OK)
@@ -423,6 +444,7 @@ struct DeviceSet
 	DevArray<uint32_t> d_nmask, d_len, d_bid;
 	DevArray<uint8_t> d_class, d_ok, d_eval;
 	DevArray<int32_t> d_conreci;
+	DevArray<uint64_t> d_votes, d_votes2; // --index-shards only
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;
 	PackedBatch* inflight = nullptr;
@@ -432,8 +454,9 @@ struct DeviceSet
 // one batch overlap the kernels of the previous one.  Counters are kept per input file.
 struct Mapper
 {
-	std::vector<arks_index*> idxs;  // one per k
+	std::vector<arks_index*> idxs;  // n_k x n_shards, the shards of one k together
 	std::vector<arks_imap*> imaps;  // one per k
+	size_t n_shards, n_k;
 	DeviceSet sets[2];
 	size_t turn = 0;
 	uint64_t* d_stored = nullptr;      // [n_k][n_files]
@@ -442,16 +465,18 @@ struct Mapper
 
 	Mapper(const std::vector<arks_index*>& is, int64_t imap_capacity, size_t nfiles)
 	  : idxs(is)
+	  , n_shards((size_t)std::max(1, params.index_shards))
+	  , n_k(is.size() / (size_t)std::max(1, params.index_shards))
 	  , n_files(nfiles)
 	{
-		for (size_t ki = 0; ki < idxs.size(); ++ki) {
+		for (size_t ki = 0; ki < n_k; ++ki) {
 			arks_imap* im = nullptr;
 			const int rc = arks_imap_create(&im, imap_capacity, params.device);
 			if (rc != ARKS_OK)
 				die_arks(rc, "creating the IndexMap accumulator");
 			imaps.push_back(im);
 		}
-		const size_t nc = idxs.size() * nfiles;
+		const size_t nc = n_k * nfiles;
 		if (hipMalloc((void**)&d_stored, nc * sizeof(uint64_t)) != hipSuccess ||
 		    hipMalloc((void**)&d_stats, nc * sizeof(arks_map_stats)) != hipSuccess) {
 			std::cerr << PROGRAM ": out of device memory\n";
@@ -530,10 +555,26 @@ struct Mapper
 		if (other.inflight && hipStreamWaitEvent(s.stream, other.done, 0) != hipSuccess)
 			return ARKS_ERR_HIP;
 		int rc = arks_pair_gate_device(s.d_ok.p, s.d_class.p, np, s.d_eval.p, params.device, s.stream);
-		for (size_t ki = 0; ki < idxs.size() && rc == ARKS_OK; ++ki) { // the batch is resident: every k maps it
+		if (n_shards > 1) {
+			s.d_votes.reserve((size_t)n);
+			s.d_votes2.reserve((size_t)n);
+		}
+		for (size_t ki = 0; ki < n_k && rc == ARKS_OK; ++ki) { // the batch is resident: every k maps it
 			const size_t slot = ki * n_files + (size_t)pb->file;
-			rc = arks_map_reads_device(idxs[ki], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, 2 * np,
-			                           params.j_index, s.d_conreci.p, params.verbose ? d_stats + slot : nullptr, s.stream);
+			if (n_shards > 1) {
+				// per shard the votes of bestContig's walk, folded with a maximum, then the j_index test
+				for (size_t sh = 0; sh < n_shards && rc == ARKS_OK; ++sh) {
+					rc = arks_map_votes_device(idxs[ki * n_shards + sh], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p,
+					                           s.d_eval.p, 2 * np, sh ? s.d_votes2.p : s.d_votes.p, s.stream);
+					if (rc == ARKS_OK && sh)
+						rc = arks_votes_max_device(s.d_votes.p, s.d_votes2.p, 2 * np, params.device, s.stream);
+				}
+				if (rc == ARKS_OK)
+					rc = arks_votes_resolve_device(s.d_votes.p, s.d_len.p, 2 * np, params.k_list[ki], params.j_index,
+					                               s.d_conreci.p, params.device, s.stream);
+			} else
+				rc = arks_map_reads_device(idxs[ki], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, 2 * np,
+				                           params.j_index, s.d_conreci.p, params.verbose ? d_stats + slot : nullptr, s.stream);
 			if (rc == ARKS_OK)
 				rc = arks_pairs_device(s.d_conreci.p, s.d_ok.p, s.d_bid.p, np, nullptr, imaps[ki], d_stored + slot,
 				                       params.device, s.stream);
@@ -609,7 +650,7 @@ read_chroms(
 	std::unique_ptr<BarcodeDict> dict(fused ? nullptr : new BarcodeDict(mult));
 	// distinct (barcode, contig end) pairs: a few per barcode; unknown in the fused mode
 	const int64_t imap_cap = fused ? (int64_t)1 << 28 : std::max<int64_t>(1 << 16, (int64_t)mult.size() * 8);
-	const size_t nk = idxs.size();
+	const size_t nk = idxs.size() / (size_t)std::max(1, params.index_shards);
 	Mapper mapper(idxs, imap_cap, std::max<size_t>(nf, 1));
 	HostAllocator pinned;
 	pinned.alloc = [](size_t n) {
@@ -937,6 +978,7 @@ main(int argc, char** argv)
 		case OPT_ARKS_METHOD: params.arks = true; break;
 		case OPT_BATCH_PAIRS: arg >> params.batch_pairs; break;
 		case OPT_DEVICE: arg >> params.device; break;
+		case OPT_INDEX_SHARDS: arg >> params.index_shards; break;
 		case 'm': {
 			std::string first, second;
 			std::getline(arg, first, '-');
@@ -1004,6 +1046,10 @@ main(int argc, char** argv)
 			          << ". Exiting... \n";
 			die = true;
 		}
+	}
+	if (params.index_shards < 1 || params.index_shards > 4096) {
+		std::cerr << PROGRAM ": --index-shards must be between 1 and 4096\n";
+		die = true;
 	}
 	{ // -k: one value as in the reference, or a comma-separated list (this build only)
 		std::istringstream ks(params.k_arg);

@@ -177,6 +177,18 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
     # messages keep file order
     assert out2.index(f"Reading chrom {paths[0]}") < out2.index(f"Reading chrom {paths[1]}") < \
         out2.index(f"Reading chrom {paths[2]}")
+    # ---- the contig k-mer index in three parts (--index-shards): per batch the votes of every part,
+    #      their maximum, then the j_index test -- same files, same stored pairs ----------------------
+    args4 = list(args)
+    args4[args4.index("-b") + 1] = str(tmp_path / "sharded")
+    args4[args4.index("--barcode-counts") + 1] = str(tmp_path / "counts4")
+    args4[-1:-1] = ["--index-shards", "3"]
+    res4 = subprocess.run(args4, capture_output=True, text=True, timeout=300)
+    assert res4.returncode == 0, res4.stderr[-2000:]
+    for suffix in ("_original.gv", "_pair.tsv", "_main.tsv"):
+        assert open(str(tmp_path / "sharded") + suffix).read() == open(base + suffix).read(), suffix
+    assert f"Stored read pairs: {stored}\n" in res4.stdout
+    assert "(index in 3 shards: the k-mer counters are not collected)" in res4.stdout
     if not use_mult_file:
         # ---- no -u: the barcode pre-pass is fused into the mapping pass; the literal two-pass flow
         #      (ARKS_TWO_PASS=1) must print the same log and write the same files ------------------
