@@ -78,7 +78,13 @@ def reduce_votes(votes, group=None):
     """in-place all-reduce(MAX) of the per-read votes (int64 tensor; on the GPU with RCCL, on the
     CPU with gloo): the vote of the end that wins bestContig's walk over the whole index"""
     import torch.distributed as dist
-    dist.all_reduce(votes, op=dist.ReduceOp.MAX, group=group)
+    if votes.is_cuda and dist.get_backend(group) != "nccl":
+        # gloo (ranks sharing one GPU in the tests): through host memory
+        host = votes.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        votes.copy_(host)
+    else:
+        dist.all_reduce(votes, op=dist.ReduceOp.MAX, group=group)
     return votes
 
 

@@ -199,6 +199,59 @@ def test_one_rank_group_end_to_end(arks, gpu, oracle, tmp_path):
     assert res.returncode == 0 and "one-rank ok" in res.stdout, res.stderr[-3000:]
 
 
+def _two_rank_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    import arcs_amd as arks
+    from arcs_amd import dist as adist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    cs, batch, reads = _one_rank_case()
+    ends = arks.contig_ends(cs, 500, 4000)
+    sh = arks.ArksIndex.build_shard(ends, 60, rank, world, device=0)          # this rank's part only
+    packed = arks.PackedReads.from_ascii(reads, device=0)
+    imap = arks.ImapAccumulator(1 << 16, device=0) if rank == 0 else None
+    step = adist.ShardedPairStep(sh, packed, 0.55, pair_ok=batch["pair_ok"].cuda(),
+                                 barcode_id=batch["barcode_id"].cuda(), imap=imap)
+    step.run()
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"pair{rank}.npy"), step.pair.cpu().numpy())
+    np.save(os.path.join(out_dir, f"keys{rank}.npy"), np.array([len(sh)]))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "triples.npy"), imap.triples())
+    dist.destroy_process_group()
+
+
+def test_three_ranks_share_the_gpu(arks, gpu, oracle, tmp_path):
+    """the multi-process flow of the sharded configuration with the device kernels: three ranks (gloo;
+    they share the one GPU of the box), rank r builds and holds only shard r, all map the same batch,
+    all-reduce(MAX) of the votes -- every rank ends with the oracle's pairs, rank 0 with its IndexMap"""
+    import socket
+    import torch.multiprocessing as mp
+    from util import oracle_pairs
+    world = 3
+    cs, batch, reads = _one_rank_case()
+    ends = arks.contig_ends(cs, 500, 4000)
+    ox = oracle.OracleIndex(60).build(ends)
+    _, want_pair, _, want_triples = oracle_pairs(oracle, ox, reads, batch["pair_ok"].numpy(),
+                                                 batch["barcode_id"].numpy(), 0.55)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sizes = []
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"pair{r}.npy"))
+        assert got.tolist() == [int(x) for x in want_pair], r
+        sizes.append(int(np.load(os.path.join(str(tmp_path), f"keys{r}.npy"))[0]))
+    assert np.load(os.path.join(str(tmp_path), "triples.npy")).tolist() == want_triples
+    assert sum(sizes) >= len(ox) and max(sizes) < len(ox)       # nobody holds the whole map
+
+
 if __name__ == "__main__" and len(sys.argv) == 3 and sys.argv[1] == "one-rank-worker":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     _one_rank_worker(sys.argv[2])
