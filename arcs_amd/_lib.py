@@ -46,6 +46,7 @@ SYMBOLS = {
     "arks_device_count": (_I, []),
     "arks_key_bytes": (_I, [_I]),
     "arks_index_build": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, C.POINTER(BuildStats)]),
+    "arks_shard_of_ends": (_I, [_VP, _I64, _I, _VP]),
     "arks_index_build_shard": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I]),
     "arks_index_free": (_I, [_VP]),
     "arks_index_k": (_I, [_VP]),

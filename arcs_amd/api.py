@@ -71,6 +71,15 @@ def pack_reads_host(seqs):
             "read_class": cls[:len(lens)]}
 
 
+def shard_of_ends(lens, n_shards):
+    """arks_shard_of_ends: int32[n_ends], the shard that holds each contig end"""
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    out = np.zeros(max(len(lens), 1), dtype=np.int32)
+    check(lib().arks_shard_of_ends(lens.ctypes.data, len(lens), int(n_shards), out.ctypes.data),
+          "arks_shard_of_ends")
+    return out[:len(lens)]
+
+
 class ArksIndex:
     """Device-resident contig-end k-mer index: ContigKMap (Arcs/Arcs.h:158) built the way
     getContigKmers/mapKmers do (Arcs/Arcs.cpp:869-929, 1021-1129)."""
@@ -95,7 +104,7 @@ class ArksIndex:
 
     @classmethod
     def build_shard(cls, ends, k, shard, n_shards, device=0):
-        """arks_index_build_shard: the k-mers of the ends e with (e // 2) % n_shards == shard, keys
+        """arks_index_build_shard: the k-mers of the ends that shard_of_ends gives to `shard`, keys
         shared with any other end of the list read 0; every shard is given the same list"""
         data, offsets, lens = _concat(ends)
         data = np.concatenate([data, np.zeros(1, np.uint8)])

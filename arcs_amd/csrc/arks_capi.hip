@@ -405,12 +405,29 @@ want_locality(int k)
 	return k >= 20; // below that the minimizer window degenerates; the hash table serves
 }
 
-/* End e belongs to shard (e / 2) % n_shards: the head and the tail of a contig (conreci 2i-1, 2i,
- * Arcs.cpp:1079-1081) stay together, contigs go round robin. */
-static inline bool
-own_end(int64_t e, int shard, int n_shards)
+/* Which shard holds which contig end (arks_shard_of_ends): the head and the tail of a contig (ends 2i and
+ * 2i + 1, conreci 2i + 1 and 2i + 2, Arcs.cpp:1079-1081) stay together; contigs are dealt in list order,
+ * each to the shard that holds the fewest bases so far (ties: the lowest shard) -- the shards differ by
+ * less than one contig whatever the order of the draft, and every rank derives the same assignment. */
+static void
+assign_shards(const uint32_t* h_lens, int64_t n_ends, int n_shards, std::vector<int32_t>& shard_of)
 {
-	return n_shards <= 1 || (int)((e / 2) % n_shards) == shard;
+	shard_of.assign((size_t)n_ends, 0);
+	if (n_shards <= 1)
+		return;
+	std::vector<uint64_t> load((size_t)n_shards, 0);
+	for (int64_t e = 0; e < n_ends; e += 2) {
+		int best = 0;
+		for (int s = 1; s < n_shards; ++s)
+			if (load[(size_t)s] < load[(size_t)best])
+				best = s;
+		load[(size_t)best] += h_lens[e];
+		shard_of[(size_t)e] = best;
+		if (e + 1 < n_ends) {
+			load[(size_t)best] += h_lens[e + 1];
+			shard_of[(size_t)e + 1] = best;
+		}
+	}
 }
 
 /* The ends of the OTHER shards take away the owner of every key they share with this shard's table
@@ -419,7 +436,8 @@ own_end(int64_t e, int shard, int n_shards)
 static int
 poison_with_foreign_ends(
     const arks_index* idx, const char* h_bases, const uint64_t* h_offsets, const uint32_t* h_lens,
-    int64_t n_ends, int shard, int n_shards, TableView full, u64* d_counter, hipStream_t st)
+    int64_t n_ends, int shard, const std::vector<int32_t>& shard_of, TableView full, u64* d_counter,
+    hipStream_t st)
 {
 	int rc = ARKS_OK;
 	const uint64_t kChunkBases = 1ull << 28;
@@ -432,7 +450,7 @@ poison_with_foreign_ends(
 		woff.clear(), offs.clear(), src.clear(), lens.clear();
 		uint64_t acc = kFrontPadWords, bacc = 0;
 		for (; e < n_ends && (bacc == 0 || bacc + h_lens[e] <= kChunkBases); ++e) {
-			if (own_end(e, shard, n_shards) || h_lens[e] == 0)
+			if (shard_of[(size_t)e] == shard || h_lens[e] == 0)
 				continue;
 			woff.push_back(acc), offs.push_back(bacc), src.push_back(h_offsets[e]), lens.push_back(h_lens[e]);
 			acc += ((uint64_t)h_lens[e] + 31) / 32;
@@ -500,11 +518,13 @@ index_build_impl(
 	*out = nullptr;
 	// a shard sees the other shards' ends as empty strings: same conreci numbering, none of their k-mers
 	std::vector<uint32_t> own_lens;
+	std::vector<int32_t> shard_of;
 	const uint32_t* h_lens = h_all_lens;
 	if (n_shards > 1) {
+		assign_shards(h_all_lens, n_ends, n_shards, shard_of);
 		own_lens.assign(h_all_lens, h_all_lens + n_ends);
 		for (int64_t e = 0; e < n_ends; ++e)
-			if (!own_end(e, shard, n_shards))
+			if (shard_of[(size_t)e] != shard)
 				own_lens[(size_t)e] = 0;
 		h_lens = own_lens.data();
 	}
@@ -636,7 +656,7 @@ index_build_impl(
 	ARKS_TRACE_STEP("launch_insert");
 	if (n_shards > 1) {
 		rc = poison_with_foreign_ends(
-		    idx, h_bases, h_offsets, h_all_lens, n_ends, shard, n_shards, full, d_counters.as<u64>() + 7, st);
+		    idx, h_bases, h_offsets, h_all_lens, n_ends, shard, shard_of, full, d_counters.as<u64>() + 7, st);
 		if (rc != ARKS_OK)
 			goto done;
 		ARKS_TRACE_STEP("foreign ends");
@@ -793,6 +813,18 @@ arks_index_build(
     arks_build_stats* stats)
 {
 	return index_build_impl(out, k, h_bases, h_offsets, h_lens, n_ends, 0, 1, device, stats);
+}
+
+int
+arks_shard_of_ends(const uint32_t* h_lens, int64_t n_ends, int n_shards, int32_t* h_shard)
+{
+	if (n_ends < 0 || n_shards < 1 || (n_ends > 0 && (!h_lens || !h_shard)))
+		return ARKS_ERR_BAD_ARG;
+	std::vector<int32_t> shard_of;
+	assign_shards(h_lens, n_ends, n_shards, shard_of);
+	for (int64_t e = 0; e < n_ends; ++e)
+		h_shard[e] = shard_of[(size_t)e];
+	return ARKS_OK;
 }
 
 int

@@ -209,7 +209,7 @@ def main():
                        "index_keys": len(index),
                        "index_kind": "locality (text + minimizer table)" if index.kind == 1 else "hash table",
                        "index_bytes": index.device_bytes,
-                       "parallelism": (f"index sharded x{world} (contig ends round robin), reads replicated, "
+                       "parallelism": (f"index sharded x{world} (contigs dealt to the lightest shard), reads replicated, "
                                        "all-reduce(MAX) of votes") if args.sharded_index
                        else f"index replica x{world}, reads sharded"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -112,13 +112,15 @@ int arks_index_build(
 
 /* One shard of the index for a draft whose whole index should not (or cannot) live on one GPU --
  * BASELINE config "contig k-mer index hash-sharded across 8 GPUs".  Shard `shard` of `n_shards` holds the
- * k-mers of the ends e with (e / 2) % n_shards == shard (a contig's head and tail together, contigs
- * round robin); every rank passes the SAME end list, conreci numbering is that of the whole list.
+ * k-mers of the ends that arks_shard_of_ends assigns to it (a contig's head and tail together; contigs
+ * dealt in list order to the shard with the fewest bases so far); every rank passes the SAME end list,
+ * conreci numbering is that of the whole list.
  * A key that also occurs in an end of another shard reads 0 in this shard, as it does in the one map of
  * Arcs/Arcs.cpp:903-920: the foreign ends are streamed through the shard's table once while it is
  * built (no exchange between ranks).  Every conreci therefore lives in exactly one shard, and the
  * winner of bestContig's walk (Arcs.cpp:998-1004) over the whole map is the maximum over shards of the
  * per-shard winners -- see arks_map_votes_device.  n_shards == 1 is arks_index_build. */
+int arks_shard_of_ends(const uint32_t* h_lens, int64_t n_ends, int n_shards, int32_t* h_shard);
 int arks_index_build_shard(
     arks_index** out,
     int k,

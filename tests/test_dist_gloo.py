@@ -97,7 +97,7 @@ def _shard_votes(O, ox, reads, k, shard, n_shards):
             if key is None:
                 continue
             c = ox.get(key)
-            if c > 0 and ((c - 1) // 2) % n_shards == shard:
+            if c > 0 and ((c - 1) // 2) % n_shards == shard:       # any partition of the contigs serves here
                 hist[c] = hist.get(c, 0) + 1
         best, cnt = 0, 0
         for c in sorted(hist):

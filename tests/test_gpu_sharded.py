@@ -73,8 +73,12 @@ def test_shards_equal_whole_index(arks, gpu, oracle, k, n_shards):
 
     # (1) content: the keys its own ends visit, with the values of the whole map
     n_zeroed = 0
+    owner = arks.shard_of_ends([len(e) for e in ends], n_shards)
+    assert all(owner[i] == owner[i + 1] for i in range(0, len(ends), 2))      # head and tail together
+    load = np.bincount(owner, weights=[len(e) for e in ends], minlength=n_shards)
+    assert load.max() - load.min() <= 2 * max(len(e) for e in ends)           # balanced to within one contig
     for s, sh in enumerate(shards):
-        own = [e if (i // 2) % n_shards == s else "" for i, e in enumerate(ends)]
+        own = [e if owner[i] == s else "" for i, e in enumerate(ends)]
         oxs = oracle.OracleIndex(k).build(own)
         keys, local_vals = oxs.dump()
         want_vals = np.array([whole[bytes(kk)] for kk in keys], dtype=np.int32)
