@@ -57,6 +57,21 @@ while time.time() < t_end:
         bad = [i for i, (a, b) in enumerate(zip(got.tolist(), want)) if a != b]
         assert not bad, (seed - 1, k, j, bad[:5], [len(reads[i]) for i in bad[:5]])
         assert gst == st.as_dict(), (seed - 1, k, j, gst, st.as_dict())
+    if os.environ.get("FUZZ_SHARDS"):      # the same reads through 2..5 index shards: votes, maximum, j_index test
+        n_sh = int(rng.integers(2, 6))
+        packed = arcs_amd.PackedReads.from_ascii(reads, device=0)
+        votes = None
+        for sidx in range(n_sh):
+            sh = arcs_amd.ArksIndex.build_shard(ends, k, sidx, n_sh, device=0)
+            v = arcs_amd.map_votes_packed(sh, packed).clone()
+            votes = v if votes is None else arcs_amd.max_votes(votes, v)
+            torch.cuda.synchronize(); sh.close()
+        assert torch.equal(votes, arcs_amd.map_votes_packed(ix, packed)), (seed - 1, k, n_sh, "votes")
+        for j in (0.55, 0.0):
+            got = arcs_amd.resolve_votes(votes, packed, k, j).cpu().tolist()
+            want = [ox.best_contig(r, j) for r in reads]
+            bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+            assert not bad, (seed - 1, k, j, n_sh, "sharded", bad[:5])
     ix.close()
     n_cases += 1; n_reads_total += len(reads)
 print("fuzz ok: %d cases, %d reads, last seed %d" % (n_cases, n_reads_total, seed - 1))
