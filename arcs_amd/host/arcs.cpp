@@ -13,6 +13,7 @@
 // Not offered: the alignment (SAM/BAM) mode and -D distance estimation (outside the ARKS k-mer
 // path); both are reported as errors instead of being silently ignored.
 #include "arks_hip.h"
+#include "dist_est.hpp"
 #include "graph.hpp"
 #include "ingest.hpp"
 #include "seqio.hpp"
@@ -122,7 +123,7 @@ const char USAGE[] =
     PROGRAM " " PACKAGE_VERSION "\n\n"
             "Usage: arcs [Options] --arks -f <contig sequence file> <list of linked read files>\n\n"
             "MI355X build of the ARKS method of bcgsc/arcs: same options and output files as the\n"
-            "reference for --arks; the alignment (SAM/BAM) method and -D are not part of this build.\n\n"
+            "reference for --arks; the alignment (SAM/BAM) method is not part of this build.\n\n"
             "   -a, --fofName=FILE    text file listing input filenames\n"
             "   -u, --multfile        tsv or csv file listing barcode multiplicities [optional]\n"
             "   -f, --file=FILE       FASTA file of contig sequences to scaffold\n"
@@ -144,6 +145,13 @@ const char USAGE[] =
             "   -j  --j_index         minimum fraction of read kmers matching a contigId [0.55]\n"
             "   -t  --threads         number of host ingest threads [1] (parse / pack; the mapping runs on the GPU)\n"
             "   -P, --pair            output scaffolds pairing TSV\n"
+            "   -D, --dist_est        enable distance estimation\n"
+            "       --no_dist_est     disable distance estimation [default]\n"
+            "       --dist_median     use median distance in ABySS dist.gv [default]\n"
+            "       --dist_upper      use upper bound distance in ABySS dist.gv\n"
+            "   -B, --bin_size=N      estimate distance using N closest Jaccard scores [20]\n"
+            "       --dist_tsv=FILE   write min/max distance estimates to FILE\n"
+            "       --samples_tsv=FILE  write intra-contig distance/barcode samples to FILE\n"
             "       --batch-pairs=N   read pairs per GPU batch [2000000]\n"
             "       --index-shards=N  build and map the contig k-mer index in N parts (very large drafts) [1]\n"
             "       --device=N        GPU ordinal [0]\n";
@@ -895,8 +903,34 @@ run_arks(const std::vector<std::string>& filenames)
 			std::ofstream out((names.base + "_pair.tsv").c_str());
 			write_pair_map(out, pmap);
 		}
-		std::cout << "\n=> Creating the graph... " << now();
+		const std::string t_graph = now(); // the reference reuses this time stamp for the next heading (Arcs.cpp:1917-1924)
+		std::cout << "\n=> Creating the graph... " << t_graph;
 		create_graph(pmap, g, params.g);
+		if (params.dist_est) { // calcDistanceEstimates, Arcs.cpp:1767-1808
+			const bool multi = params.k_list.size() > 1;
+			std::cout << "\n=> Calculating distance estimates... " << t_graph;
+			std::cout << "\n\t=> Measuring intra-contig distances / shared barcodes... " << now();
+			DistSampleMap samples;
+			calc_dist_samples(imap, contigToLength, mult, params.g, samples);
+			std::cout << "\n\t=> Writing intra-contig distance samples to TSV... " << now();
+			if (!params.dist_samples_tsv.empty()) {
+				std::ofstream f((multi ? with_k(params.dist_samples_tsv, params.k_list[ki]) : params.dist_samples_tsv).c_str());
+				write_dist_samples_tsv(f, samples);
+			}
+			std::cout << "\n\t=> Building Jaccard to distance map... " << now();
+			JaccardToDist j2d;
+			build_jaccard_to_dist(samples, j2d);
+			std::cout << "\n\t=> Calculating barcode stats for scaffold pairs... " << now();
+			PairToBarcodeStats pair_stats;
+			build_pair_to_barcode_stats(imap, mult, contigToLength, params.g, pair_stats);
+			std::cout << "\n\t=> Adding edge distances... " << now();
+			add_edge_distances(pair_stats, j2d, params.g, g);
+			if (!params.dist_tsv.empty()) {
+				std::cout << "\n\t=> Writing distance estimates to TSV... " << now();
+				std::ofstream f((multi ? with_k(params.dist_tsv, params.k_list[ki]) : params.dist_tsv).c_str());
+				write_dist_tsv(f, pair_stats, g);
+			}
+		}
 		std::cout << "\n=> Writing graph file... " << now() << "\n";
 		const std::string graph_file = names.base + "_original.gv";
 		if (params.g.max_degree != 0) {
@@ -919,7 +953,7 @@ run_arks(const std::vector<std::string>& filenames)
 				exit(EXIT_FAILURE);
 			}
 			std::string err;
-			if (!write_dist_graph(out, contigToLength, g, params.g.gap, &err)) {
+			if (!write_dist_graph(out, contigToLength, g, params.g.gap, &err, params.dist_est, params.g.dist_upper)) {
 				std::cerr << err << std::endl;
 				exit(EXIT_FAILURE);
 			}
@@ -973,8 +1007,8 @@ main(int argc, char** argv)
 		case OPT_SAMPLES_TSV: arg >> params.dist_samples_tsv; break;
 		case OPT_DIST_TSV: arg >> params.dist_tsv; break;
 		case OPT_NO_DIST_EST: params.dist_est = false; break;
-		case OPT_DIST_MEDIAN:
-		case OPT_DIST_UPPER: break;
+		case OPT_DIST_MEDIAN: params.g.dist_upper = false; break;
+		case OPT_DIST_UPPER: params.g.dist_upper = true; break;
 		case OPT_ARKS_METHOD: params.arks = true; break;
 		case OPT_BATCH_PAIRS: arg >> params.batch_pairs; break;
 		case OPT_DEVICE: arg >> params.device; break;
@@ -1007,10 +1041,6 @@ main(int argc, char** argv)
 	if (!params.arks) {
 		std::cerr << PROGRAM ": error: this build provides the ARKS method only (--arks); the alignment "
 		                     "(SAM/BAM) method is not part of it.\n";
-		die = true;
-	}
-	if (params.dist_est) {
-		std::cerr << PROGRAM ": error: -D/--dist_est (distance estimation) is not part of this build.\n";
 		die = true;
 	}
 	std::vector<std::string> filenames(argv + optind, argv + argc);
@@ -1047,6 +1077,9 @@ main(int argc, char** argv)
 			die = true;
 		}
 	}
+	params.g.end_length = params.end_length;
+	params.g.dist_bin_size = params.dist_bin_size;
+	params.g.dist_est = params.dist_est;
 	if (params.index_shards < 1 || params.index_shards > 4096) {
 		std::cerr << PROGRAM ": --index-shards must be between 1 and 4096\n";
 		die = true;

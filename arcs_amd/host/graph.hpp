@@ -25,6 +25,7 @@
 #include <sstream>
 #include <string>
 #include <unordered_map>
+#include <limits>
 #include <vector>
 
 namespace arks_host {
@@ -44,6 +45,10 @@ struct GraphParams
 	int max_degree = 0;
 	float error_percent = 0.05f;
 	unsigned gap = 100;
+	int end_length = 30000;      // -e, used by the distance estimates only
+	bool dist_est = false;       // -D
+	bool dist_upper = false;     // --dist_upper: the .dist.gv carries the upper bound instead of the median
+	unsigned dist_bin_size = 20; // -B
 };
 
 // Arcs.cpp:833-839.  The mixed widths are part of the behaviour: mean and sd are floats, the
@@ -104,6 +109,11 @@ struct Edge
 	int u, v; // vertex slots
 	int orientation;
 	int weight;
+	// distance estimate (-D, dist_est.hpp); unset as in EdgeProperties, Arcs/Arcs.h:166-183
+	int min_dist = std::numeric_limits<int>::min();
+	int dist = std::numeric_limits<int>::max();
+	int max_dist = std::numeric_limits<int>::max();
+	float jaccard = -1.0f;
 };
 
 // what boost::undirected_graph<VertexProperties, EdgeProperties> amounts to for this program:
@@ -185,8 +195,12 @@ write_graph(std::ostream& out, const ScaffoldGraph& g)
 		if (g.alive[v])
 			out << index[v] << " [id=" << g.id[v] << "];\n";
 	for (const Edge& e : g.edges)
-		out << index[e.u] << "--" << index[e.v] << " [label=" << e.orientation << ", weight=" << e.weight
-		    << "];\n";
+	{
+		out << index[e.u] << "--" << index[e.v] << " [label=" << e.orientation << ", weight=" << e.weight;
+		if (e.min_dist != std::numeric_limits<int>::min()) // Arcs.h:204-211
+			out << ", d=" << e.dist << ", maxd=" << e.max_dist;
+		out << "];\n";
+	}
 	out << "}\n";
 }
 
@@ -195,7 +209,7 @@ write_graph(std::ostream& out, const ScaffoldGraph& g)
 // vertex in insertion order.  Returns false on a duplicate edge (the reference exits).
 inline bool
 write_dist_graph(std::ostream& out, const ContigToLength& lengths, const ScaffoldGraph& g, unsigned gap,
-                 std::string* err)
+                 std::string* err, bool dist_est = false, bool dist_upper = false)
 {
 	std::vector<std::string> names;
 	std::vector<int> len;
@@ -205,34 +219,36 @@ write_dist_graph(std::ostream& out, const ContigToLength& lengths, const Scaffol
 		names.push_back(it.first);
 		len.push_back(it.second);
 	}
-	struct Out { int v; int weight; };
+	struct Out { int v; int weight; int d; };
 	std::vector<std::vector<Out>> adj(2 * names.size());
 	auto vname = [&](int v) { return names[(size_t)(v >> 1)] + ((v & 1) ? "-" : "+"); };
-	auto add = [&](int u, int v, int w) {
+	auto add = [&](int u, int v, int w, int d) {
 		for (const Out& o : adj[(size_t)u])
 			if (o.v == v)
 				return false;
-		adj[(size_t)u].push_back(Out{ v, w });
+		adj[(size_t)u].push_back(Out{ v, w, d });
 		return true;
 	};
 	for (const Edge& e : g.edges) {
 		// sense = true is the '-' vertex: u sense = orientation < 2, v sense = orientation % 2
 		const int u = 2 * dict.at(g.id[(size_t)e.u]) + (e.orientation < 2 ? 1 : 0);
 		const int v = 2 * dict.at(g.id[(size_t)e.v]) + (e.orientation % 2);
-		if (!add(u, v, e.weight)) {
+		// Arcs.cpp:1636-1648: with -D the estimate replaces the gap (an edge without one keeps INT_MAX)
+		const int d = dist_est ? (dist_upper ? e.max_dist : e.dist) : (int)gap;
+		if (!add(u, v, e.weight, d)) {
 			if (err)
 				*err = "error: Duplicate edge: \"" + vname(u) + "\" -> \"" + vname(v) + "\"";
 			return false;
 		}
 		if (u != (v ^ 1))
-			add(v ^ 1, u ^ 1, e.weight);
+			add(v ^ 1, u ^ 1, e.weight, d);
 	}
 	out << "digraph arcs {\n";
 	for (size_t v = 0; v < adj.size(); ++v)
 		out << '"' << vname((int)v) << "\" [l=" << len[v >> 1] << "]\n";
 	for (size_t u = 0; u < adj.size(); ++u)
 		for (const Out& o : adj[u])
-			out << '"' << vname((int)u) << "\" -> \"" << vname(o.v) << "\" [d=" << (int)gap
+			out << '"' << vname((int)u) << "\" -> \"" << vname(o.v) << "\" [d=" << o.d
 			    << " e=" << std::fixed << std::setprecision(1) << (float)gap << " n=" << o.weight << "]\n";
 	out << "}\n";
 	return true;

@@ -1,9 +1,12 @@
 // graph_check.cpp -- test driver for graph.hpp (no GPU): runs the graph stage on an IndexMap given as
 // text and writes the reference's output files.  Built and used by tests/test_host_graph.py only.
-//   graph_check imap  <imap.tsv> <mult.tsv> <lengths.tsv> <out_base> c l m_lo m_hi d r gap
+//   graph_check imap  <imap.tsv> <mult.tsv> <lengths.tsv> <out_base> c l m_lo m_hi d r gap x [e B upper]
 //       imap.tsv: barcode \t contig \t H|T \t count   (the post-pass for missing ends is applied)
+//       with e (end length), B (bin size) and upper (0|1): -D distance estimates as well
+//       (<out_base>_dist.tsv, <out_base>_samples.tsv, d= / maxd= in the graph files)
 //   graph_check gv    <original.gv> <lengths.tsv> <out.dist.gv> gap
 //       rebuilds the scaffold graph from an _original.gv and writes the ABySS dist.gv for it
+#include "dist_est.hpp"
 #include "graph.hpp"
 
 #include <cstring>
@@ -84,6 +87,25 @@ main(int argc, char** argv)
 		}
 		ScaffoldGraph g;
 		create_graph(pmap, g, P);
+		if (argc >= 17) { // calcDistanceEstimates runs on the graph before the degree filter (Arcs.cpp:1921-1931)
+			P.dist_est = true;
+			P.end_length = std::atoi(argv[14]);
+			P.dist_bin_size = (unsigned)std::atoi(argv[15]);
+			P.dist_upper = std::atoi(argv[16]) != 0;
+			DistSampleMap samples;
+			calc_dist_samples(imap, len, mult, P, samples);
+			{
+				std::ofstream f(base + "_samples.tsv");
+				write_dist_samples_tsv(f, samples);
+			}
+			JaccardToDist j2d;
+			build_jaccard_to_dist(samples, j2d);
+			PairToBarcodeStats stats;
+			build_pair_to_barcode_stats(imap, mult, len, P, stats);
+			add_edge_distances(stats, j2d, P, g);
+			std::ofstream f(base + "_dist.tsv");
+			write_dist_tsv(f, stats, g);
+		}
 		if (P.max_degree != 0)
 			remove_degree_nodes(g, P.max_degree);
 		{
@@ -93,7 +115,7 @@ main(int argc, char** argv)
 		{
 			std::ofstream out(base + ".dist.gv");
 			std::string err;
-			if (!write_dist_graph(out, len, g, P.gap, &err)) {
+			if (!write_dist_graph(out, len, g, P.gap, &err, P.dist_est, P.dist_upper)) {
 				std::cerr << err << "\n";
 				return 1;
 			}

@@ -12,6 +12,13 @@
  */
 #include "ReadsProcessor.h" /* the reference header, via -I<reference>/Common */
 
+/* Two more std-only reference headers, for the -D distance estimates (the host graph stage's tests):
+ * closestKeys and quantile as the reference defines them. */
+#include <cassert>
+#include "MapUtil.h"
+#include "StatUtil.h"
+#include <vector>
+
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -214,6 +221,27 @@ ref_index_best_contig(void* h, const char* read, int len, double j_index, uint64
 	if (counters)
 		counters[6]++;
 	return 0;
+}
+
+/* closestKeys(map<double, int>, key, n) of Common/MapUtil.h over the sorted, distinct keys[0..n_keys):
+ * the positions [first, last) of the returned iterator range */
+void
+ref_closest_keys(const double* keys, int n_keys, double key, int n, int* first, int* last)
+{
+	std::map<double, int> m;
+	for (int i = 0; i < n_keys; ++i)
+		m[keys[i]] = i;
+	auto r = closestKeys(m, key, (size_t)n);
+	*first = r.first == m.end() ? n_keys : r.first->second;
+	*last = r.second == m.end() ? n_keys : r.second->second;
+}
+
+/* quantile() of Common/StatUtil.h over a sorted vector<unsigned>, as estimateDistance calls it */
+double
+ref_quantile(const unsigned* vals, int n, double q)
+{
+	std::vector<unsigned> v(vals, vals + n);
+	return quantile(v.begin(), v.end(), q);
 }
 
 } /* extern "C" */

@@ -1,6 +1,8 @@
 """Python restatement (test infrastructure) of the stages after the read mapping: IndexMap -> PairMap
 -> scaffold graph -> output files (Arcs/Arcs.cpp:833-861, 1378-1526, 1549-1757; Arcs/Arcs.h:185-229;
-Graph/DotIO.h:82-114).  numpy float32 reproduces the reference's float arithmetic."""
+Graph/DotIO.h:82-114) and of the -D distance estimates (Arcs/DistanceEst.h, Common/MapUtil.h,
+Common/StatUtil.h).  numpy float32 reproduces the reference's float arithmetic."""
+import bisect
 import math
 
 import numpy as np
@@ -145,3 +147,163 @@ def pair_text(pmap):
 def counts_text(mult):
     rows = sorted(mult.items(), key=lambda x: (-x[1], x[0]))
     return "".join(f"{b}\t{m}\n" for b, m in rows)
+
+
+# ---- -D: distance estimates (Arcs/DistanceEst.h) ------------------------------------------------
+
+def dist_samples(imap, lengths, mult, P):
+    """DistanceEst.h:101-173 -> {contig: [distance, barcodes_head, barcodes_tail, union, intersect]}"""
+    out = {}
+    for bc, sm in imap.items():
+        if not (P["min_mult"] <= mult[bc] <= P["max_mult"]):
+            continue
+        for (ctg, head), pairs in sm.items():
+            if pairs < P["min_reads"] or lengths[ctg] < 2 * P["end_length"]:
+                continue
+            s = out.setdefault(ctg, [0, 0, 0, 0, 0])
+            s[0] = lengths[ctg] - 2 * P["end_length"]
+            s[1 if head else 2] += 1
+            found_other = sm.get((ctg, not head), -1) >= P["min_reads"] and (ctg, not head) in sm
+            if found_other and head:
+                s[4] += 1
+                s[3] += 1
+            elif not found_other:
+                s[3] += 1
+    return dict(sorted(out.items()))
+
+
+def jaccard_to_dist(samples):
+    """DistanceEst.h:181-189 with this build's tie rule: of equal Jaccard indices the sample of the
+    smallest contig id stays (the reference keeps whichever its unordered_map yields first)"""
+    j2d = {}
+    for ctg, s in samples.items():           # sorted by contig id
+        j2d.setdefault(s[4] / s[3], s[0])
+    keys = sorted(j2d)
+    return keys, [j2d[k] for k in keys]
+
+
+def closest_key(keys, key):
+    """Common/MapUtil.h:8-44 -> position"""
+    it = bisect.bisect_left(keys, key)
+    if it == 0:
+        return 0
+    if it == len(keys):
+        return it - 1
+    return it if abs(key - keys[it - 1]) > abs(key - keys[it]) else it - 1
+
+
+def closest_keys(keys, key, n):
+    """Common/MapUtil.h:47-93 -> [first, last)"""
+    if not keys:
+        return 0, 0
+    first = closest_key(keys, key)
+    last = first + 1
+    count = 1
+    while count < n:
+        if first == 0 and last == len(keys):
+            break
+        if first == 0:
+            last += 1
+        elif last == len(keys):
+            first -= 1
+        elif abs(key - keys[first - 1]) < abs(key - keys[last]):
+            first -= 1
+        else:
+            last += 1
+        count += 1
+    return first, last
+
+
+def quantile(sorted_vals, q):
+    """Common/StatUtil.h:8-32 (the reference's weights: the fraction goes to the LOWER element)"""
+    last = len(sorted_vals) - 1
+    bpos, apos = math.floor(q * last), math.ceil(q * last)
+    w = q * last - bpos
+    return w * sorted_vals[bpos] + (1.0 - w) * sorted_vals[apos]
+
+
+def pair_barcode_stats(imap, mult, lengths, P):
+    """DistanceEst.h:220-334 -> {(id1, id2): [[barcodes1, barcodes2, union, intersect] x HH,HT,TH,TT]}"""
+    def valid(ctg, pairs):
+        return pairs >= P["min_reads"] and lengths[ctg] >= 2 * P["end_length"]
+    per_end, out = {}, {}
+    for bc, sm in imap.items():
+        if not (P["min_mult"] <= mult[bc] <= P["max_mult"]):
+            continue
+        for (c1, h1), p1 in sm.items():
+            if not valid(c1, p1):
+                continue
+            per_end[(c1, h1)] = per_end.get((c1, h1), 0) + 1
+            for (c2, h2), p2 in sm.items():
+                if not valid(c2, p2) or c1 > c2:
+                    continue
+                st = out.setdefault((c1, c2), [[0, 0, 0, 0] for _ in range(4)])
+                st[(0 if h1 else 2) + (0 if h2 else 1)][3] += 1
+    for (c1, c2), arr in out.items():
+        for o in range(4):
+            n1 = per_end.get((c1, o < 2))
+            if n1 is None:
+                continue
+            arr[o][0] = n1
+            n2 = per_end.get((c2, o % 2 == 0))
+            if n2 is None:
+                continue
+            arr[o][1] = n2
+            arr[o][2] = n1 + n2 - arr[o][3]
+    return out
+
+
+def edge_distances(ids, edges, stats, j2d, P):
+    """DistanceEst.h:337-430 -> per edge None or (min_dist, dist, max_dist)"""
+    keys, dists = j2d
+    out = []
+    for (u, v, o, w) in edges:
+        st = stats.get((ids[u], ids[v]))
+        if not keys or st is None or st[o][2] == 0:
+            out.append(None)
+            continue
+        first, last = closest_keys(keys, st[o][3] / st[o][2], P["dist_bin_size"])
+        d = sorted(dists[first:last])
+        # C's round(): half away from zero (values are non-negative here)
+        out.append((math.floor(quantile(d, 0.01)), int(math.floor(quantile(d, 0.5) + 0.5)),
+                    math.ceil(quantile(d, 0.99))))
+    return out
+
+
+def graph_text_with_distances(ids, edges, est, dead=()):
+    index, n = {}, 0
+    for v in range(len(ids)):
+        if v not in dead:
+            index[v] = n
+            n += 1
+    out = ["graph G {"]
+    out += [f"{index[v]} [id={ids[v]}];" for v in range(len(ids)) if v not in dead]
+    for (u, v, o, w), e in zip(edges, est):
+        if u in dead or v in dead:
+            continue
+        extra = f", d={e[1]}, maxd={e[2]}" if e is not None else ""
+        out.append(f"{index[u]}--{index[v]} [label={o}, weight={w}{extra}];")
+    out.append("}")
+    return "\n".join(out) + "\n"
+
+
+def dist_tsv_text(ids, edges, est, stats, dead=()):
+    out = ["contig1\tcontig2\tmin_dist\tdist\tmax_dist\tbarcodes1\tbarcodes2\tbarcodes_union\tbarcodes_intersect"]
+    for (u, v, o, w), e in zip(edges, est):
+        if u in dead or v in dead:
+            continue
+        st = stats.get((ids[u], ids[v]))
+        if st is None:
+            continue
+        s1, s2 = o < 2, bool(o % 2)
+        d = "\t".join(map(str, e)) if e is not None else "NA\tNA\tNA"
+        b1, b2, un, it = st[o]
+        out.append(f"{ids[u]}{'-' if s1 else '+'}\t{ids[v]}{'-' if s2 else '+'}\t{d}\t{b1}\t{b2}\t{un}\t{it}")
+        out.append(f"{ids[v]}{'+' if s2 else '-'}\t{ids[u]}{'+' if s1 else '-'}\t{d}\t{b2}\t{b1}\t{un}\t{it}")
+    return "\n".join(out) + "\n"
+
+
+def samples_text(samples):
+    out = ["contig_id\tdistance\tbarcodes_head\tbarcodes_tail\tbarcodes_union\tbarcodes_intersect"]
+    out += [f"{c}\t{s[0]}\t{s[1]}\t{s[2]}\t{s[3]}\t{s[4]}" for c, s in samples.items()]
+    return "\n".join(out) + "\n"

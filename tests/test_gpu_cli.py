@@ -189,6 +189,30 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
         assert open(str(tmp_path / "sharded") + suffix).read() == open(base + suffix).read(), suffix
     assert f"Stored read pairs: {stored}\n" in res4.stdout
     assert "(index in 3 shards: the k-mer counters are not collected)" in res4.stdout
+    # ---- -D: distance estimates (dist_est.hpp) on the same run: d= / maxd= on the edges, --dist_tsv,
+    #      --samples_tsv, d= of the ABySS graph ------------------------------------------------------------
+    args5 = list(args)
+    args5[args5.index("-b") + 1] = str(tmp_path / "dist")
+    args5[args5.index("--barcode-counts") + 1] = str(tmp_path / "counts5")
+    args5[-1:-1] = ["-D", "-B", "3", "--dist_upper", "--dist_tsv", str(tmp_path / "dist.tsv"), "--samples_tsv",
+                    str(tmp_path / "samples.tsv")]
+    res5 = subprocess.run(args5, capture_output=True, text=True, timeout=300)
+    assert res5.returncode == 0, res5.stderr[-2000:]
+    PD = dict(P, end_length=30000, dist_bin_size=3)
+    ids_d, all_edges = G.create_graph(pmap, P)
+    samples = G.dist_samples(imap, lengths, mult, PD)
+    pstats = G.pair_barcode_stats(imap, mult, lengths, PD)
+    est = G.edge_distances(ids_d, all_edges, pstats, G.jaccard_to_dist(samples), PD)
+    assert len(samples) >= 2
+    assert open(str(tmp_path / "samples.tsv")).read() == G.samples_text(samples)
+    assert open(str(tmp_path / "dist.tsv")).read() == G.dist_tsv_text(ids_d, all_edges, est, pstats)
+    assert open(str(tmp_path / "dist") + "_original.gv").read() == G.graph_text_with_distances(ids_d, all_edges, est, dead)
+    dl = open(str(tmp_path / "dist") + ".dist.gv").read()
+    for (u, v, o, w), e in zip(all_edges, est):
+        if u not in dead and v not in dead:
+            dd = e[2] if e is not None else 2**31 - 1                # --dist_upper
+            assert f'"{ids_d[u]}{"-" if o < 2 else "+"}" -> "{ids_d[v]}{"-" if o % 2 else "+"}" [d={dd} e=100.0 n={w}]' in dl
+    assert "=> Calculating distance estimates..." in res5.stdout and "=> Adding edge distances..." in res5.stdout
     if not use_mult_file:
         # ---- no -u: the barcode pre-pass is fused into the mapping pass; the literal two-pass flow
         #      (ARKS_TWO_PASS=1) must print the same log and write the same files ------------------

@@ -106,6 +106,103 @@ def test_graph_stage_vs_python(graph_check, tmp_path, seed, c, l, d, r):
         assert body[i].split('"')[1][-1] == "+" and body[i + 1].split('"')[1][-1] == "-"
 
 
+@pytest.mark.parametrize("seed,c,d,end_length,bin_size,upper", [(11, 3, 0, 20000, 20, 0), (12, 2, 0, 5000, 3, 1),
+                                                                 (13, 4, 3, 30000, 7, 0), (14, 1, 0, 100000, 20, 0),
+                                                                 (15, 2, 2, 1000, 1, 1)])
+def test_distance_estimates_vs_python(graph_check, tmp_path, seed, c, d, end_length, bin_size, upper):
+    """-D (dist_est.hpp) against the Python restatement of Arcs/DistanceEst.h: samples, Jaccard map with
+    this build's tie rule, pair statistics, closest keys, the reference's quantile, edge attributes in
+    _original.gv, the --dist_tsv and --samples_tsv files and the d= of the ABySS graph"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    contigs = [str(x) for x in rng.permutation(60)[:30] + 1] + ["ctgA", "scaf_10", "9"]
+    lengths = {x: int(rng.choice([900, 30000, 45000, 61000, 90000, 150000, 400000])) + int(rng.integers(0, 50))
+               for x in contigs}
+    imap, mult = {}, {}
+    # the contigs form a chain with random orientations; a barcode is a molecule that covers the joint of
+    # two neighbours (the facing ends get the read pairs) and now and then both ends of a contig
+    facing = [bool(rng.random() < 0.5) for _ in contigs]       # which end of contig i faces contig i + 1
+    for b in range(900):
+        bc = "".join(rng.choice(list("ACGT"), size=16)) + "-1"
+        mult[bc] = int(rng.integers(1, 300))
+        sm = {}
+        for _ in range(int(rng.integers(1, 3))):
+            i = int(rng.integers(len(contigs) - 1))
+            sm[(contigs[i], facing[i])] = int(rng.integers(4, 30))
+            sm[(contigs[i + 1], not facing[i + 1])] = int(rng.integers(4, 30))
+            if rng.random() < 0.35 and i % 4:                    # a long molecule: the far end of contig i too
+                # (never for every fourth contig: their Jaccard index is 0 and the samples collide)
+                sm[(contigs[i], not facing[i])] = int(rng.integers(1, 8))
+            if rng.random() < 0.1:
+                sm[(contigs[int(rng.integers(len(contigs)))], bool(rng.random() < 0.5))] = int(rng.integers(1, 6))
+        imap[bc] = sm
+    P = {"min_reads": c, "min_links": 0, "min_mult": 20, "max_mult": 250, "max_degree": d, "error_percent": 0.05,
+         "gap": 77, "end_length": end_length, "dist_bin_size": bin_size}
+    (tmp_path / "imap.tsv").write_text("".join(
+        f"{bc}\t{ctg}\t{'H' if h else 'T'}\t{n}\n" for bc, sm in imap.items() for (ctg, h), n in sm.items()))
+    (tmp_path / "mult.tsv").write_text("".join(f"{b}\t{m}\n" for b, m in mult.items()))
+    (tmp_path / "len.tsv").write_text("".join(f"{k}\t{v}\n" for k, v in lengths.items()))
+    base = str(tmp_path / "out")
+    subprocess.check_call([graph_check, "imap", str(tmp_path / "imap.tsv"), str(tmp_path / "mult.tsv"),
+                           str(tmp_path / "len.tsv"), base, str(c), "0", "20", "250", str(d), "0.05", "77", "x",
+                           str(end_length), str(bin_size), str(upper)], stdout=subprocess.DEVNULL)
+    G.add_opposite_ends(imap)
+    pmap = G.pair_contigs(imap, mult, P)
+    ids, all_edges = G.create_graph(pmap, P)
+    assert len(all_edges) > 5
+    samples = G.dist_samples(imap, lengths, mult, P)
+    j2d = G.jaccard_to_dist(samples)
+    stats = G.pair_barcode_stats(imap, mult, lengths, P)
+    est = G.edge_distances(ids, all_edges, stats, j2d, P)
+    if end_length <= 30000:
+        assert len(samples) > 5 and sum(e is not None for e in est) > 3
+        assert len(j2d[0]) < len(samples)           # equal Jaccard indices do collide
+    else:
+        assert len(samples) < 8                      # only the 400 kbp contigs are two end lengths long
+    dead = set()
+    if d:
+        dead, _ = G.remove_degree_nodes(ids, all_edges, d)
+    assert open(base + "_samples.tsv").read() == G.samples_text(samples)
+    assert open(base + "_dist.tsv").read() == G.dist_tsv_text(ids, all_edges, est, stats)
+    assert open(base + "_original.gv").read() == G.graph_text_with_distances(ids, all_edges, est, dead)
+    # the ABySS graph: d = median (or upper bound) of the estimate; an edge without one keeps INT_MAX
+    lines = open(base + ".dist.gv").read().split("\n")
+    want = set()
+    for (u, v, o, w), e in zip(all_edges, est):
+        if u in dead or v in dead:
+            continue
+        dd = (e[2] if upper else e[1]) if e is not None else 2**31 - 1
+        un, vn = ids[u] + ("-" if o < 2 else "+"), ids[v] + ("-" if o % 2 else "+")
+        flip = lambda s: s[:-1] + ("+" if s[-1] == "-" else "-")
+        want.add(f'"{un}" -> "{vn}" [d={dd} e=77.0 n={w}]')
+        if un != flip(vn):
+            want.add(f'"{flip(vn)}" -> "{flip(un)}" [d={dd} e=77.0 n={w}]')
+    assert set(lines[1 + 2 * len(lengths):-2]) == want
+
+
+def test_closest_keys_and_quantile_vs_reference_headers(oracle):
+    """the restatements of Common/MapUtil.h and Common/StatUtil.h against those headers themselves,
+    compiled where they lie into oracle/_ref (this container only)"""
+    if not oracle.have_ref() or not hasattr(oracle.ref(), "ref_closest_keys"):
+        pytest.skip("oracle/_ref is not built here")
+    import ctypes as C
+    R = oracle.ref()
+    rng = np.random.Generator(np.random.PCG64(5))
+    for case in range(3000):
+        n = int(rng.integers(1, 40))
+        keys = sorted(set(np.round(rng.random(n) * (1 if case % 3 else 0.2), int(rng.integers(1, 4))).tolist()))
+        arr = (C.c_double * len(keys))(*keys)
+        key = float(rng.choice(keys)) if case % 4 == 0 else float(rng.random())
+        nn = int(rng.integers(1, 25))
+        first, last = C.c_int(), C.c_int()
+        R.ref_closest_keys(arr, len(keys), C.c_double(key), nn, C.byref(first), C.byref(last))
+        assert (first.value, last.value) == G.closest_keys(keys, key, nn), (keys, key, nn)
+        vals = sorted(int(x) for x in rng.integers(0, 400000, size=int(rng.integers(1, 30))))
+        varr = (C.c_uint * len(vals))(*vals)
+        for q in (0.01, 0.5, 0.99, float(rng.random())):
+            R.ref_quantile.restype = C.c_double
+            assert R.ref_quantile(varr, len(vals), C.c_double(q)) == G.quantile(vals, q), (vals, q)
+
+
 def test_normal_estimation_cases():
     """headOrTail / checkSignificance edge cases: sum below -c, all on one end, even split"""
     P = {"min_reads": 5, "error_percent": 0.05}
