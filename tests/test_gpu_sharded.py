@@ -203,7 +203,7 @@ def test_one_rank_group_end_to_end(arks, gpu, oracle, tmp_path):
     assert res.returncode == 0 and "one-rank ok" in res.stdout, res.stderr[-3000:]
 
 
-def _two_rank_worker(rank, world, port, out_dir):
+def _shared_gpu_worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     import torch.distributed as dist
@@ -246,7 +246,7 @@ def test_three_ranks_share_the_gpu(arks, gpu, oracle, tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_shared_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     sizes = []
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"pair{r}.npy"))
