@@ -95,6 +95,20 @@ class BoundedQueue
 		not_full_.notify_one();
 		return true;
 	}
+	// like pop, but the element pushed LAST: for a pool of buffers that are allocated on first use, so
+	// that a buffer that has just come back (allocated, warm) is taken before one that was never used --
+	// the pool then grows to the number of buffers in flight, not to its capacity
+	bool pop_newest(T& out)
+	{
+		std::unique_lock<std::mutex> lk(m_);
+		not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+		if (q_.empty())
+			return false;
+		out = std::move(q_.back());
+		q_.pop_back();
+		not_full_.notify_one();
+		return true;
+	}
 	// non-blocking variants (a recycling list: nothing waits on it)
 	bool try_pop(T& out)
 	{
@@ -511,7 +525,7 @@ class IngestPipeline
 				RawBatch rb;
 				while (raw_q_.pop(rb)) {
 					PackedBatch* pb = nullptr;
-					if (!free_q_.pop(pb))
+					if (!free_q_.pop_newest(pb))
 						return;
 					const int rc = pack_batch(rb, *pb, alloc_);
 					if (rc != ARKS_OK) {
