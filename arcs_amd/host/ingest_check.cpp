@@ -81,7 +81,12 @@ main(int argc, char** argv)
 	std::vector<std::map<int64_t, PerBatch>> got(nf);
 	std::vector<FileCounters> fc(nf);
 	std::vector<uint64_t> pairs(nf), reads(nf), batches(nf);
+	const bool null_consumer = std::getenv("INGEST_NULL") != nullptr; // timing runs: parse + pack only
 	const int rc = pipe.run([&](PackedBatch* pb) {
+		if (null_consumer) {
+			pipe.recycle(pb);
+			return ARKS_OK;
+		}
 		const size_t f = (size_t)pb->file;
 		PerBatch& out = got[f][pb->seq];
 		out.messages = pb->messages;

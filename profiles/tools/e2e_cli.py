@@ -36,7 +36,7 @@ with open(f"{tmp}/mult.tsv", "w") as f:
 print("data generated in %.1f s; %d files x %d pairs; fq %.0f MB each" % (time.time()-t0, NF, NP, len(text)/1e6), flush=True)
 ref = None
 for ext in ((".fq", ".fq.gz", ".bgzf.fq.gz") if os.environ.get("E2E_BGZF") else (".fq", ".fq.gz")):
-    files = [f"{tmp}/r{fi}{ext}" for fi in range(NF)]
+    files = [f"{tmp}/r{fi}{ext}" for fi in range(NF)] * int(os.environ.get("E2E_REPEAT", 1))
     for t in (1, 4, 16):
         args = [exe, "--arks", "-f", f"{tmp}/draft.fa", "-u", f"{tmp}/mult.tsv", "-k", "60", "-j", "0.55", "-c", "5",
                 "-m", "50-10000", "-e", "30000", "-z", "500", "-t", str(t), "-b", f"{tmp}/out_{t}{ext.replace('.', '_')}"] + files
@@ -47,7 +47,7 @@ for ext in ((".fq", ".fq.gz", ".bgzf.fq.gz") if os.environ.get("E2E_BGZF") else 
             print(out.stdout[-2000:], out.stderr[-2000:]); sys.exit(1)
         gv = open(f"{tmp}/out_{t}{ext.replace('.', '_')}_original.gv").read()
         ref = ref or gv
-        print(f"{ext:7s} -t {t:2d}: {dt:6.2f} s total  ({NF*NP/dt/1e6:.2f} M pairs/s whole run)  gv_same={gv == ref}", flush=True)
+        print(f"{ext:7s} -t {t:2d}: {dt:6.2f} s total  ({len(files)*NP/dt/1e6:.2f} M pairs/s whole run)  gv_same={gv == ref}", flush=True)
         rd = [l for l in out.stderr.splitlines() if 'read files' in l]
         ms = float(rd[0].split(':')[1].split()[0]) if rd else 0
-        print('        reads stage %.0f ms -> %.2f M pairs/s' % (ms, NF*NP/ms/1e3), flush=True)
+        print('        reads stage %.0f ms -> %.2f M pairs/s' % (ms, len(files)*NP/ms/1e3), flush=True)
