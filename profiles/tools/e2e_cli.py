@@ -35,10 +35,12 @@ with open(f"{tmp}/mult.tsv", "w") as f:
     f.writelines(f"{k}\t{v}\n" for k, v in mult.items())
 print("data generated in %.1f s; %d files x %d pairs; fq %.0f MB each" % (time.time()-t0, NF, NP, len(text)/1e6), flush=True)
 ref = None
-for ext in ((".fq", ".fq.gz", ".bgzf.fq.gz") if os.environ.get("E2E_BGZF") else (".fq", ".fq.gz")):
+EXTS = os.environ.get("E2E_EXTS")
+PREFIX = os.environ.get("E2E_PREFIX", "").split()
+for ext in (EXTS.split(",") if EXTS else (".fq", ".fq.gz", ".bgzf.fq.gz") if os.environ.get("E2E_BGZF") else (".fq", ".fq.gz")):
     files = [f"{tmp}/r{fi}{ext}" for fi in range(NF)] * int(os.environ.get("E2E_REPEAT", 1))
     for t in (1, 4, 16):
-        args = [exe, "--arks", "-f", f"{tmp}/draft.fa", "-u", f"{tmp}/mult.tsv", "-k", "60", "-j", "0.55", "-c", "5",
+        args = PREFIX + [exe, "--arks", "-f", f"{tmp}/draft.fa", "-u", f"{tmp}/mult.tsv", "-k", "60", "-j", "0.55", "-c", "5",
                 "-m", "50-10000", "-e", "30000", "-z", "500", "-t", str(t), "-b", f"{tmp}/out_{t}{ext.replace('.', '_')}"] + files
         t1 = time.time()
         out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, ARKS_TIMING='1'))
