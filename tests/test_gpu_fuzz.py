@@ -3,7 +3,7 @@ shape) combinations per run -- shared segments (value 0 keys, second diagonals),
 (heavy minimizers), palindromic stretches (quirk keys), N runs (visit rule), reads of awkward lengths
 (k-1, k, k+1, word multiples, around the 512-base tile limit), chimeras, both strands.  Bit-exact:
 build counters, per-read contig end, map counters.  (tests/fuzz_open_ended.py <seconds> <first seed> is the open-ended version; the
-round-1 runs covered 220 000 cases / 188 M reads over the last builds, 159 416 cases / 135.5 M reads with the final kernel; 6 576 cases / 5.6 M reads
+round-1 runs covered 220 000 cases / 188 M reads over the last builds, 159 416 cases / 135.5 M reads with the final kernel; 9 239 cases / 7.9 M reads
 also went through 2..5 index shards (FUZZ_SHARDS=1): votes, maximum, j_index test.)"""
 import numpy as np
 import pytest
