@@ -152,7 +152,7 @@ const char USAGE[] =
             "   -B, --bin_size=N      estimate distance using N closest Jaccard scores [20]\n"
             "       --dist_tsv=FILE   write min/max distance estimates to FILE\n"
             "       --samples_tsv=FILE  write intra-contig distance/barcode samples to FILE\n"
-            "       --batch-pairs=N   read pairs per GPU batch [2000000]\n"
+            "       --batch-pairs=N   read pairs per GPU batch [262144]\n"
             "       --index-shards=N  build and map the contig k-mer index in N parts (very large drafts) [1]\n"
             "       --device=N        GPU ordinal [0]\n";
 
