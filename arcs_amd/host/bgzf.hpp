@@ -8,6 +8,8 @@
 // file order.  The bytes delivered are exactly those gzread would deliver.
 #pragma once
 
+#include "crc32_fold.hpp"
+
 #include <zlib.h>
 
 #include <condition_variable>
@@ -184,7 +186,7 @@ class BgzfReader
 				const int rc = inflate(&z, Z_FINISH);
 				s->out_len = (uint32_t)(s->out.size() - z.avail_out);
 				bad = rc != Z_STREAM_END || s->out_len != want_len ||
-				      (uint32_t)crc32(crc32(0L, Z_NULL, 0), s->out.data(), s->out_len) != want_crc;
+				      crc32_fast(0u, s->out.data(), s->out_len) != want_crc;
 			}
 			{
 				std::lock_guard<std::mutex> lk(m_);

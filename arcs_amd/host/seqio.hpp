@@ -9,9 +9,11 @@
 #pragma once
 
 #include "bgzf.hpp"
+#include "fast_inflate.hpp"
 
 #include <zlib.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -24,23 +26,29 @@ class SeqReader
 	std::string name, comment, seq, qual;
 	bool keep_qual = true; // false: quality lines are only measured (length check), `qual` stays empty
 
-	// bgzf_workers > 0: a BGZF (bgzip) file is inflated by that many threads (bgzf.hpp); any other input
-	// -- plain text, ordinary gzip, a pipe -- goes through zlib's gzread as the reference's kseq does
+	// bgzf_workers > 0: a BGZF (bgzip) file is inflated by that many threads (bgzf.hpp); an ordinary gzip file
+	// by fast_inflate.hpp; plain text and pipes go through zlib's gzread as the reference's kseq does
 	explicit SeqReader(const char* path, unsigned bgzf_workers = 0)
 	{
-		if (bgzf_workers > 0) {
-			if (FILE* f = std::fopen(path, "rb")) {
-				unsigned char h[18];
-				unsigned bsize = 0;
-				const size_t got = std::fread(h, 1, sizeof h, f);
-				if (bgzf_header(h, got, &bsize) && std::fseek(f, 0, SEEK_SET) == 0) {
+		// a seekable file that starts like a gzip member: BGZF goes to the inflate threads, any other gzip file
+		// to the fast single-stream inflater (fast_inflate.hpp; ARKS_ZLIB_INFLATE=1 keeps zlib's)
+		if (FILE* f = std::fopen(path, "rb")) {
+			unsigned char h[18];
+			unsigned bsize = 0;
+			const size_t got = std::fread(h, 1, sizeof h, f);
+			const bool gz = got >= 3 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8;
+			if (gz && std::fseek(f, 0, SEEK_SET) == 0) {
+				if (bgzf_workers > 0 && bgzf_header(h, got, &bsize)) {
 					bgzf_file_ = f; // the inflate threads start with the first read, not for every open file
 					bgzf_workers_ = bgzf_workers;
-				} else
+				} else if (!std::getenv("ARKS_ZLIB_INFLATE"))
+					fast_.reset(new GzInflater(f)); // owns the file
+				else
 					std::fclose(f);
-			}
+			} else
+				std::fclose(f);
 		}
-		if (!bgzf_file_) {
+		if (!bgzf_file_ && !fast_) {
 			fp_ = gzopen(path, "r");
 			if (fp_)
 				gzbuffer(fp_, 1u << 20);
@@ -55,7 +63,7 @@ class SeqReader
 	}
 	SeqReader(const SeqReader&) = delete;
 	SeqReader& operator=(const SeqReader&) = delete;
-	bool ok() const { return fp_ != nullptr || bgzf_file_ != nullptr; }
+	bool ok() const { return fp_ != nullptr || bgzf_file_ != nullptr || fast_ != nullptr; }
 	bool parallel_inflate() const { return bgzf_file_ != nullptr; }
 
 	int next()
@@ -118,6 +126,7 @@ class SeqReader
   private:
 	gzFile fp_ = nullptr;
 	std::unique_ptr<BgzfReader> bgzf_;
+	std::unique_ptr<GzInflater> fast_;
 	FILE* bgzf_file_ = nullptr;
 	unsigned bgzf_workers_ = 0;
 	unsigned char buf_[1 << 18];
@@ -132,7 +141,8 @@ class SeqReader
 		begin_ = 0;
 		if (bgzf_file_ && !bgzf_)
 			bgzf_.reset(new BgzfReader(bgzf_file_, bgzf_workers_)); // owns the file from here on
-		end_ = bgzf_ ? bgzf_->read(buf_, (int)sizeof buf_) : gzread(fp_, buf_, sizeof buf_);
+		end_ = bgzf_ ? bgzf_->read(buf_, (int)sizeof buf_)
+		             : fast_ ? fast_->read(buf_, (int)sizeof buf_) : gzread(fp_, buf_, sizeof buf_);
 		if (end_ <= 0) {
 			end_ = 0;
 			eof_ = true;

@@ -297,3 +297,122 @@ def test_bgzf_parallel_inflate(exe, oracle, tmp_path):
     open(bad, "wb").write(bytes(blob))
     _, res = run(exe, 4, 500, mult_path, [bad])
     assert 0 < int(res[0]["kv"]["pairs"]) < want[0]["pairs"]
+
+
+# ---- fast_inflate.hpp / crc32_fold.hpp ---------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def inflate_check(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("bin") / "inflate_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + HOST, os.path.join(HOST, "inflate_check.cpp"), "-lz",
+                           "-o", out])
+    return out
+
+
+def _gz(data, level=6, strategy=0, mem=8):
+    import zlib
+    c = zlib.compressobj(level, zlib.DEFLATED, 31, mem, strategy)
+    return c.compress(data) + c.flush()
+
+
+def test_fast_inflate_equals_zlib(inflate_check, tmp_path):
+    """GzInflater against zlib's gzread, byte for byte: FASTQ text at every level, the three block types
+    (stored / fixed / dynamic), codes longer than the primary tables, runs and short periods, members back
+    to back (an empty one among them), every optional header field, trailing garbage; read sizes 1 .. 256 Ki"""
+    import zlib
+    rng = np.random.Generator(np.random.PCG64(9))
+    fastq = "".join(
+        f"@r{i}/1 BX:Z:{''.join(rng.choice(list('ACGT'), size=16))}-1\n{''.join(rng.choice(list('ACGTN'), size=int(rng.integers(50, 160)), p=[.24, .24, .24, .24, .04]))}\n+\n"
+        f"{''.join(rng.choice(list('FFFFF:,#'), size=int(rng.integers(50, 160))))}\n" for i in range(6000)).encode()
+    skew = bytes(rng.geometric(0.08, size=400000).clip(1, 255).astype(np.uint8))       # long Huffman codes
+    noise = rng.integers(0, 256, size=300000, dtype=np.uint8).tobytes()                  # stored blocks
+    runs = b"".join(bytes([int(rng.integers(65, 70))]) * int(rng.integers(1, 700)) for _ in range(3000))
+    periods = b"".join((bytes(rng.integers(65, 91, size=int(p), dtype=np.uint8)) * 400)[:int(rng.integers(1, 1500))]
+                       for p in rng.integers(1, 12, size=2000))
+    cases = {}
+    for lvl in range(0, 10):
+        cases[f"fastq{lvl}"] = _gz(fastq, lvl)
+    cases["fixed"] = _gz(fastq[:200000], 6, zlib.Z_FIXED)
+    cases["huffman_only"] = _gz(fastq[:200000] + skew, 6, zlib.Z_HUFFMAN_ONLY)
+    cases["rle"] = _gz(runs + fastq[:100000], 6, zlib.Z_RLE)
+    cases["skew"] = _gz(skew, 9)
+    cases["noise"] = _gz(noise, 6)
+    cases["runs"] = _gz(runs, 9)
+    cases["periods"] = _gz(periods, 9, mem=9)
+    cases["tiny"] = _gz(b"A", 6)
+    cases["empty_member"] = _gz(b"", 6)
+    cases["members"] = _gz(fastq[:70000], 1) + _gz(b"", 6) + _gz(noise[:70000], 6) + _gz(runs[:99999], 9) + _gz(b"x", 6)
+    cases["garbage_after"] = _gz(fastq[:50000], 6) + b"\0\0\0not gzip"
+    # every optional header field (RFC 1952): FEXTRA, FNAME, FCOMMENT, FHCRC
+    body = _gz(fastq[:30000], 6)[10:]
+    hdr = bytes([0x1f, 0x8b, 8, 2 | 4 | 8 | 16, 0, 0, 0, 0, 0, 3]) + bytes([5, 0]) + b"EXTRA" + b"name.fq\0" + b"a comment\0"
+    cases["all_header_fields"] = hdr + (zlib.crc32(hdr) & 0xffff).to_bytes(2, "little") + body
+    for name, blob in cases.items():
+        path = tmp_path / (name + ".gz")
+        path.write_bytes(blob)
+        for chunk in ((1 << 18, 1, 7, 4096) if len(blob) < 5000 else (1 << 18, 4099)):
+            out = subprocess.run([inflate_check, str(path), str(chunk)], capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0 and out.stdout.startswith("same "), (name, chunk, out.stdout)
+    assert zlib.decompress(cases["all_header_fields"], 31) == fastq[:30000]
+
+
+def test_fast_inflate_damaged_input(inflate_check, tmp_path):
+    """truncated and corrupted files: no crash, no hang, a truncated file delivers exactly what zlib delivers,
+    and a failure is reported whenever zlib reports one"""
+    rng = np.random.Generator(np.random.PCG64(10))
+    data = ("".join(f"@r{i}\n{''.join(rng.choice(list('ACGT'), size=100))}\n+\n{'F' * 100}\n" for i in range(3000))).encode()
+    blob = _gz(data, 6) + _gz(data[:5000], 1)
+    # (the reader hands a file to GzInflater only when it starts with the three bytes 1f 8b 08)
+    cuts = [3, 4, 9, 10, 11, 17, 100, len(blob) // 3, len(blob) // 2, len(blob) - 9, len(blob) - 8, len(blob) - 1]
+    n_err = 0
+    for i, cut in enumerate(cuts):
+        path = tmp_path / f"cut{i}.gz"
+        path.write_bytes(blob[:cut])
+        out = subprocess.run([inflate_check, str(path)], capture_output=True, text=True, timeout=60)
+        assert out.stdout.split()[0] in ("same", "DIFFERENT"), out.stdout          # ran to the end
+        rc = out.stdout.split("rc ")[1].split()[0].split("/")
+        # gzread's return value calls a truncated stream a plain end of file (only gzerror tells); what counts for
+        # the reader is that the same bytes were delivered before it
+        sizes = out.stdout.split(" bytes (zlib ")
+        assert sizes[0].split()[-1] == sizes[1].split(")")[0], (cut, out.stdout)
+        assert int(rc[1]) >= 0 or int(rc[0]) < 0
+        n_err += int(rc[0]) < 0
+    assert n_err >= 8
+    for i in range(60):
+        bad = bytearray(blob)
+        pos = int(rng.integers(0, len(bad)))
+        bad[pos] ^= 1 << int(rng.integers(8))
+        path = tmp_path / f"flip{i}.gz"
+        path.write_bytes(bytes(bad))
+        out = subprocess.run([inflate_check, str(path)], capture_output=True, text=True, timeout=60)
+        assert out.stdout.split()[0] in ("same", "DIFFERENT"), (pos, out.stdout, out.stderr)
+        rc = out.stdout.split("rc ")[1].split()[0].split("/")
+        if int(rc[1]) < 0:                     # zlib saw the damage: so must we (CRC-32 and length are checked)
+            assert int(rc[0]) < 0, (pos, out.stdout)
+
+
+def test_crc32_fold_equals_zlib(tmp_path):
+    src = tmp_path / "crc_check.cpp"
+    src.write_text(r'''
+#include "crc32_fold.hpp"
+#include <cstdio>
+#include <vector>
+int main() {
+	std::vector<unsigned char> b(1 << 22);
+	unsigned s = 12345;
+	for (auto& x : b) { s = s * 1664525u + 1013904223u; x = (unsigned char)(s >> 24); }
+	int bad = 0;
+	for (int t = 0; t < 30000; ++t) {
+		s = s * 1664525u + 1013904223u; const size_t off = s % 1000;
+		s = s * 1664525u + 1013904223u; const size_t len = t < 300 ? (size_t)t : s % 9000;
+		s = s * 1664525u + 1013904223u; const uint32_t init = (t % 3) ? s : 0;
+		bad += (uint32_t)crc32(init, b.data() + off, (uInt)len) != arks_host::crc32_fast(init, b.data() + off, len);
+	}
+	bad += (uint32_t)crc32(0, b.data(), (uInt)b.size()) != arks_host::crc32_fast(0, b.data(), b.size());
+	std::printf("bad=%d\n", bad);
+	return bad != 0;
+}
+''')
+    exe = str(tmp_path / "crc_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + HOST, str(src), "-lz", "-o", exe])
+    assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == "bad=0"
