@@ -64,7 +64,7 @@ class GzInflater
 	}
 
   private:
-	static constexpr size_t kInSize = 1u << 20, kHistory = 32768, kChunk = 1u << 19, kSlack = 320;
+	static constexpr size_t kInSize = 1u << 20, kHistory = 32768, kChunk = 1u << 19, kSlack = 320; // slack: one match + the literals and word copies around it
 	static constexpr int kLitBits = 11, kDistBits = 8;
 	enum State { HEADER, BLOCK_START, STORED, HUFFMAN, TRAILER_PENDING, DONE, FAILED };
 	// table entry: bits 0-7 code length (bits to drop), 8-12 extra bits (or subtable bits), 13-15 kind,
@@ -430,40 +430,68 @@ class GzInflater
 
 	bool inflate_huffman(size_t out_limit)
 	{
+		// the loop's state lives in locals: every store to `out` is a char store, which the compiler must
+		// assume may alias the members
 		unsigned char* const out = out_.data();
-		size_t op = out_pos_;
+		const uint32_t* const lit = lit_;
+		const uint32_t* const dist = dist_;
+		const unsigned char* in = in_.data();
+		size_t ip = in_pos_, ie = in_end_, op = out_pos_;
+		uint64_t bb = bitbuf_;
+		int bc = bitcnt_;
+		const uint64_t before = member_out_; // bytes of this member in front of out_pos_
+		const size_t op0 = op;
 		bool ok = true;
 		while (op < out_limit) {
-			if (in_end_ - in_pos_ < 16) {
+			if (ie - ip < 16 && !in_eof_) {
+				in_pos_ = ip;
 				refill_input();
+				ip = in_pos_, ie = in_end_;
 			}
-			refill_bits();
-			uint32_t e = lit_[bitbuf_ & ((1u << kLitBits) - 1)];
+			if (ie - ip >= 8) { // refill_bits()
+				uint64_t v;
+				std::memcpy(&v, in + ip, 8);
+				bb |= v << bc;
+				const int n = (63 - bc) >> 3;
+				ip += (size_t)n;
+				bc += n * 8;
+			} else
+				while (bc <= 56 && ip < ie) {
+					bb |= (uint64_t)in[ip++] << bc;
+					bc += 8;
+				}
+			uint32_t e = lit[bb & ((1u << kLitBits) - 1)];
 			if ((e >> 13 & 7) == SUBTABLE) {
-				e = lit_[(e >> 16) + ((bitbuf_ >> kLitBits) & ((1u << (e >> 8 & 31)) - 1))];
-				bitbuf_ >>= kLitBits;
-				bitcnt_ -= kLitBits;
+				e = lit[(e >> 16) + ((bb >> kLitBits) & ((1u << (e >> 8 & 31)) - 1))];
+				bb >>= kLitBits;
+				bc -= kLitBits;
 			}
-			bitbuf_ >>= (e & 0xff);
-			bitcnt_ -= (int)(e & 0xff);
+			bb >>= (e & 0xff);
+			bc -= (int)(e & 0xff);
 			const uint32_t kind = e >> 13 & 7;
 			if (kind == LITERAL) {
 				out[op++] = (unsigned char)(e >> 16);
-				// a second literal from the same refill (two codes are at most 30 bits)
-				uint32_t e2 = lit_[bitbuf_ & ((1u << kLitBits) - 1)];
-				if ((e2 >> 13 & 7) == LITERAL && bitcnt_ >= (int)(e2 & 0xff)) {
-					bitbuf_ >>= (e2 & 0xff);
-					bitcnt_ -= (int)(e2 & 0xff);
+				// up to two more literals from the same refill (three codes are at most 45 of >= 56 bits)
+				uint32_t e2 = lit[bb & ((1u << kLitBits) - 1)];
+				if ((e2 >> 13 & 7) == LITERAL && bc >= (int)(e2 & 0xff)) {
+					bb >>= (e2 & 0xff);
+					bc -= (int)(e2 & 0xff);
 					out[op++] = (unsigned char)(e2 >> 16);
+					e2 = lit[bb & ((1u << kLitBits) - 1)];
+					if ((e2 >> 13 & 7) == LITERAL && bc >= (int)(e2 & 0xff)) {
+						bb >>= (e2 & 0xff);
+						bc -= (int)(e2 & 0xff);
+						out[op++] = (unsigned char)(e2 >> 16);
+					}
 				}
-				if (bitcnt_ < 0) {
+				if (bc < 0) {
 					ok = false;
 					break;
 				}
 				continue;
 			}
 			if (kind == END_OF_BLOCK) {
-				if (bitcnt_ < 0)
+				if (bc < 0)
 					ok = false;
 				state_ = last_block_ ? TRAILER_PENDING : BLOCK_START;
 				break;
@@ -473,26 +501,26 @@ class GzInflater
 				break;
 			}
 			const uint32_t lx = e >> 8 & 31;
-			const uint32_t length = (e >> 16) + (uint32_t)(bitbuf_ & ((1u << lx) - 1));
-			bitbuf_ >>= lx;
-			bitcnt_ -= (int)lx;
-			uint32_t d = dist_[bitbuf_ & ((1u << kDistBits) - 1)];
+			const uint32_t length = (e >> 16) + (uint32_t)(bb & ((1u << lx) - 1));
+			bb >>= lx;
+			bc -= (int)lx;
+			uint32_t d = dist[bb & ((1u << kDistBits) - 1)];
 			if ((d >> 13 & 7) == SUBTABLE) {
-				d = dist_[(d >> 16) + ((bitbuf_ >> kDistBits) & ((1u << (d >> 8 & 31)) - 1))];
-				bitbuf_ >>= kDistBits;
-				bitcnt_ -= kDistBits;
+				d = dist[(d >> 16) + ((bb >> kDistBits) & ((1u << (d >> 8 & 31)) - 1))];
+				bb >>= kDistBits;
+				bc -= kDistBits;
 			}
 			if ((d >> 13 & 7) != BASE) {
 				ok = false;
 				break;
 			}
-			bitbuf_ >>= (d & 0xff);
-			bitcnt_ -= (int)(d & 0xff);
+			bb >>= (d & 0xff);
+			bc -= (int)(d & 0xff);
 			const uint32_t dx = d >> 8 & 31;
-			const size_t distance = (d >> 16) + (size_t)(bitbuf_ & ((1u << dx) - 1));
-			bitbuf_ >>= dx;
-			bitcnt_ -= (int)dx;
-			if (bitcnt_ < 0 || distance > kHistory || distance > member_out_ + (op - out_pos_)) {
+			const size_t distance = (d >> 16) + (size_t)(bb & ((1u << dx) - 1));
+			bb >>= dx;
+			bc -= (int)dx;
+			if (bc < 0 || distance > kHistory || distance > before + (op - op0)) {
 				ok = false;
 				break;
 			}
@@ -523,7 +551,10 @@ class GzInflater
 				}
 			}
 		}
-		member_out_ += op - out_pos_;
+		in_pos_ = ip;
+		bitbuf_ = bb;
+		bitcnt_ = bc;
+		member_out_ += op - op0;
 		out_pos_ = op;
 		return ok;
 	}
