@@ -12,9 +12,14 @@
 
 #include "crc32_fold.hpp"
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace arks_host {
@@ -591,6 +596,115 @@ class GzInflater
 				return true;
 			default:
 				return true;
+			}
+		}
+	}
+};
+
+// Runs a GzInflater one step ahead of its consumer on a thread of its own, so that the record parser and the
+// inflate loop of ONE .gz file work at the same time (the file's rate becomes the slower of the two instead
+// of their harmonic sum).  Four buffers in a ring; the thread starts with the first read.
+class InflateAhead
+{
+  public:
+	explicit InflateAhead(std::unique_ptr<GzInflater> src)
+	  : src_(std::move(src))
+	{
+		for (auto& b : ring_)
+			b.data.resize(kBuf);
+	}
+	~InflateAhead()
+	{
+		{
+			std::lock_guard<std::mutex> lk(m_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		if (th_.joinable())
+			th_.join();
+	}
+	InflateAhead(const InflateAhead&) = delete;
+	InflateAhead& operator=(const InflateAhead&) = delete;
+
+	int read(unsigned char* dst, int cap)
+	{
+		if (!th_.joinable())
+			th_ = std::thread([this] { run(); });
+		Buf& b = ring_[tail_ % kRing];
+		if (pos_ == 0) { // wait for the next buffer
+			std::unique_lock<std::mutex> lk(m_);
+			cv_.wait(lk, [&] { return tail_ < head_ || stop_; });
+			if (tail_ >= head_)
+				return -1;
+		}
+		if (b.len <= 0)
+			return b.len; // end of the stream (0) or a damaged one (-1): stays
+		const int n = std::min(cap, b.len - pos_);
+		std::memcpy(dst, b.data.data() + pos_, (size_t)n);
+		pos_ += n;
+		if (pos_ == b.len) {
+			pos_ = 0;
+			{
+				std::lock_guard<std::mutex> lk(m_);
+				tail_++;
+			}
+			cv_.notify_all();
+		}
+		return n;
+	}
+
+  private:
+	static constexpr size_t kBuf = 1u << 18, kRing = 4;
+	struct Buf
+	{
+		std::vector<unsigned char> data;
+		int len = 0;
+	};
+	std::unique_ptr<GzInflater> src_;
+	Buf ring_[kRing];
+	uint64_t head_ = 0, tail_ = 0; // produced / consumed buffers
+	int pos_ = 0;
+	bool stop_ = false;
+	std::mutex m_;
+	std::condition_variable cv_;
+	std::thread th_;
+
+	void run()
+	{
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(m_);
+				cv_.wait(lk, [&] { return head_ - tail_ < kRing || stop_; });
+				if (stop_)
+					return;
+			}
+			Buf& b = ring_[head_ % kRing];
+			int got = 0, n = 0; // fill the buffer: the source hands out at most what it has decoded
+			while (got < (int)kBuf && (n = src_->read(b.data.data() + got, (int)kBuf - got)) > 0)
+				got += n;
+			const bool last = n <= 0;
+			b.len = got > 0 ? got : n;
+			{
+				std::lock_guard<std::mutex> lk(m_);
+				head_++;
+			}
+			cv_.notify_all();
+			if (last) {
+				if (got > 0) { // the end marker (or the error) goes into a buffer of its own
+					{
+						std::unique_lock<std::mutex> lk(m_);
+						cv_.wait(lk, [&] { return head_ - tail_ < kRing || stop_; });
+						if (stop_)
+							return;
+					}
+					ring_[head_ % kRing].len = n;
+					{
+						std::lock_guard<std::mutex> lk(m_);
+						head_++;
+					}
+					cv_.notify_all();
+				}
+				return;
 			}
 		}
 	}

@@ -416,3 +416,20 @@ int main() {
     exe = str(tmp_path / "crc_check")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + HOST, str(src), "-lz", "-o", exe])
     assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == "bad=0"
+
+
+def test_inflate_thread_same_stream(exe, tmp_path):
+    """ARKS_INFLATE_THREAD=1 (InflateAhead: the .gz inflate on its own thread) delivers the same records"""
+    rng = np.random.Generator(np.random.PCG64(21))
+    path = str(tmp_path / "reads.fq.gz")
+    with gzip.open(path, "wt", compresslevel=4) as f:
+        for i in range(40000):
+            s1 = "".join(rng.choice(list("ACGTN"), size=int(rng.integers(30, 200)), p=[.245, .245, .245, .245, .02]))
+            f.write(f"@r{i}/1 BX:Z:BC{i // 50:06d}-1\n{s1}\n+\n{'F' * len(s1)}\n@r{i}/2 BX:Z:BC{i // 50:06d}-1\n{s1[::-1]}\n+\n{'F' * len(s1)}\n")
+    outs = []
+    for env in ({}, {"ARKS_INFLATE_THREAD": "1"}, {"ARKS_ZLIB_INFLATE": "1"}):
+        r = subprocess.run([exe, "4", "3000", "-", path], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2] and "pairs=40000" in outs[0]
