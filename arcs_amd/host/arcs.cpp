@@ -364,15 +364,6 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 	// pass 1 of the reference only sizes contigRecord; it also filters on the IUPAC alphabet, which
 	// the second pass does not (Q10 of SURVEY.md): a contig with a foreign character would leave
 	// contigRecord too short in the reference.  Here the record simply grows.
-	{
-		SeqReader rd(params.file.c_str(), std::max(1u, params.threads));
-		size_t count = 0;
-		while (rd.next() >= 0)
-			if (check_contig_sequence(rd.seq) && (int)rd.seq.length() >= params.min_size)
-				count++;
-		if (params.verbose)
-			std::cerr << "Number of contigs:" << count << "\nSize of Contig Array:" << count * 2 + 1 << std::endl;
-	}
 	std::string bases;
 	std::vector<uint64_t> off;
 	std::vector<uint32_t> len;
@@ -380,8 +371,11 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 	contigRecord.clear();
 	contigRecord.push_back(CI("null contig", false));
 	SeqReader rd(params.file.c_str(), std::max(1u, params.threads));
+	size_t count = 0; // what initContigArray (Arcs.cpp:451-479) counts in a pass of its own; here in the same pass
 	while (rd.next() >= 0) {
 		total++;
+		if (params.verbose && check_contig_sequence(rd.seq) && (int)rd.seq.length() >= params.min_size)
+			count++;
 		int cut = 0;
 		if (arks_end_cutoff((int)rd.seq.length(), params.min_size, params.end_length, &cut)) {
 			contigToLength[rd.name] = (int)rd.seq.length();
@@ -400,6 +394,8 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 			appendf(log, "Finished %d Contigs...\n", total);
 	}
 	bases.push_back('\0');
+	if (params.verbose)
+		std::cerr << "Number of contigs:" << count << "\nSize of Contig Array:" << count * 2 + 1 << std::endl;
 	std::vector<arks_index*> idxs;
 	const int n_shards = std::max(1, params.index_shards);
 	for (const int k : params.k_list) {
