@@ -111,3 +111,24 @@ def test_product_does_not_reach_into_oracle():
                 assert "oracle" not in text.lower() or f == "synth.py", os.path.join(dirpath, f)
     out = subprocess.check_output(["ldd", os.path.join(ROOT, "arcs_amd", "lib", "libarks_hip.so")]).decode()
     assert "arks_oracle" not in out and "arks_ref" not in out
+
+
+def test_shard_of_ends_is_host_only_and_balanced(arks):
+    """arks_shard_of_ends needs no device: head and tail of a contig stay together, the shards differ by
+    less than one contig whatever the order of the draft, n_shards = 1 puts everything in shard 0"""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(3))
+    for pattern in ("cycle", "sorted", "random"):
+        per_contig = {"cycle": np.tile([20000, 50000, 100000, 230000], 50),
+                      "sorted": np.sort(rng.integers(500, 300000, size=200))[::-1],
+                      "random": rng.integers(500, 300000, size=201)}[pattern]
+        lens = np.repeat(np.minimum(per_contig // 2, 30000), 2).astype(np.uint32)
+        for n in (1, 2, 3, 8):
+            owner = arks.shard_of_ends(lens, n)
+            assert owner.min() >= 0 and owner.max() < n
+            assert (owner[0::2] == owner[1::2]).all()
+            load = np.bincount(owner, weights=lens, minlength=n)
+            assert load.max() - load.min() <= 2 * int(lens.max()), (pattern, n, load)
+            assert (arks.shard_of_ends(lens, n) == owner).all()            # a function of its input
+    assert arks.shard_of_ends(np.array([7, 7, 9], dtype=np.uint32), 2).tolist() == [0, 0, 1]   # odd count: last end alone
+    assert len(arks.shard_of_ends(np.zeros(0, np.uint32), 4)) == 0
