@@ -11,6 +11,7 @@
 #include "bgzf.hpp"
 #include "fast_inflate.hpp"
 
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <cstdlib>
@@ -32,7 +33,11 @@ class SeqReader
 	{
 		// a seekable file that starts like a gzip member: BGZF goes to the inflate threads, any other gzip file
 		// to the fast single-stream inflater (fast_inflate.hpp; ARKS_ZLIB_INFLATE=1 keeps zlib's)
-		if (FILE* f = std::fopen(path, "rb")) {
+		// (regular files only: looking at the first bytes of a pipe -- /dev/stdin in the arks-long pipeline --
+		// would take them away from the reader that follows)
+		struct stat st;
+		FILE* f = (::stat(path, &st) == 0 && S_ISREG(st.st_mode)) ? std::fopen(path, "rb") : nullptr;
+		if (f) {
 			unsigned char h[18];
 			unsigned bsize = 0;
 			const size_t got = std::fread(h, 1, sizeof h, f);

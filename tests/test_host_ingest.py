@@ -433,3 +433,19 @@ def test_inflate_thread_same_stream(exe, tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout)
     assert outs[0] == outs[1] == outs[2] and "pairs=40000" in outs[0]
+
+
+def test_reads_from_a_pipe(exe, tmp_path):
+    """/dev/stdin fed through a real pipe (how arcs-make runs arks-long, bin/arcs-make:305-313), plain and
+    gzip'ed: the reader must not look at the first bytes of a stream it cannot rewind"""
+    rng = np.random.Generator(np.random.PCG64(22))
+    text = "".join(f"@r{i}/1 BX:Z:BC{i // 20:05d}-1\n{s}\n+\n{'F' * len(s)}\n@r{i}/2 BX:Z:BC{i // 20:05d}-1\n{s[::-1]}\n+\n{'F' * len(s)}\n"
+                   for i, s in ((i, "".join(rng.choice(list("ACGT"), size=int(rng.integers(40, 160))))) for i in range(3000))).encode()
+    plain = tmp_path / "reads.fq"
+    plain.write_bytes(text)
+    want = subprocess.run([exe, "4", "700", "-", str(plain)], capture_output=True, text=True, timeout=120).stdout
+    assert "pairs=3000" in want
+    for blob in (text, gzip.compress(text, 4)):
+        p = subprocess.Popen([exe, "4", "700", "-", "/dev/stdin"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=False)
+        out, _ = p.communicate(blob, timeout=120)
+        assert p.returncode == 0 and out.decode() == want
