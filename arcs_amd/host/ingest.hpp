@@ -180,11 +180,21 @@ class DynamicDict
 			*stored = it->first;
 		return it->second;
 	}
-	size_t size() const { return names_.size(); }
-	const std::string& name(uint32_t id) const { return names_[id]; }
+	// (locked: a producer may be growing the deque's block map at the same time; the strings themselves
+	// never move)
+	size_t size() const
+	{
+		std::lock_guard<std::mutex> lk(m_);
+		return names_.size();
+	}
+	const std::string& name(uint32_t id) const
+	{
+		std::lock_guard<std::mutex> lk(m_);
+		return names_[id];
+	}
 
   private:
-	std::mutex m_;
+	mutable std::mutex m_;
 	std::unordered_map<std::string_view, uint32_t> id_; // views into names_ (a deque: stable)
 	std::deque<std::string> names_;
 };

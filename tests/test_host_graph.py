@@ -17,7 +17,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 @pytest.fixture(scope="module")
 def graph_check(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("bin") / "graph_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "arcs_amd", "host"),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-I" + os.path.join(ROOT, "arcs_amd", "host"),
                            os.path.join(ROOT, "arcs_amd", "host", "graph_check.cpp"), "-o", out])
     return out
 

@@ -17,7 +17,7 @@ MASK = (1 << 64) - 1
 def exe(tmp_path_factory, arks):
     out = str(tmp_path_factory.mktemp("bin") / "ingest_check")
     libdir = os.path.join(ROOT, "arcs_amd", "lib")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+    subprocess.check_call(["g++", "-O1", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                            "-I" + os.path.join(ROOT, "include"), "-I" + HOST, os.path.join(HOST, "ingest_check.cpp"),
                            "-L" + libdir, "-larks_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
@@ -304,7 +304,7 @@ def test_bgzf_parallel_inflate(exe, oracle, tmp_path):
 @pytest.fixture(scope="module")
 def inflate_check(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("bin") / "inflate_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + HOST, os.path.join(HOST, "inflate_check.cpp"), "-lz",
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-I" + HOST, os.path.join(HOST, "inflate_check.cpp"), "-lz",
                            "-o", out])
     return out
 
@@ -414,7 +414,7 @@ int main() {
 }
 ''')
     exe = str(tmp_path / "crc_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + HOST, str(src), "-lz", "-o", exe])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-I" + HOST, str(src), "-lz", "-o", exe])
     assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == "bad=0"
 
 
