@@ -67,6 +67,8 @@ SYMBOLS = {
     "arks_imap_free": (_I, [_VP]),
     "arks_imap_size": (_I64, [_VP]),
     "arks_imap_export": (_I, [_VP, _VP]),
+    "arks_imap_set_pair_base": (_I, [_VP, C.c_uint64]),
+    "arks_imap_export_ordered": (_I, [_VP, _VP, _VP]),
     "arks_pair_gate_device": (_I, [_VP, _VP, _I64, _VP, _I, _VP]),
     "arks_pairs_device": (_I, [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _I, _VP]),
 }

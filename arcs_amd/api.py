@@ -349,14 +349,31 @@ class ImapAccumulator:
         except Exception:
             pass
 
-    def triples(self):
-        """uint32[n, 3] (barcode id, conreci, count) sorted by (barcode id, conreci)"""
+    def __len__(self):
         n = lib().arks_imap_size(self._h)
         if n < 0:
             raise _lib.ArksError(int(-n), "arks_imap_size")
+        return int(n)
+
+    def triples(self):
+        """uint32[n, 3] (barcode id, conreci, count) sorted by (barcode id, conreci)"""
+        n = len(self)
         out = np.zeros((max(n, 1), 3), dtype=np.uint32)
         check(lib().arks_imap_export(self._h, out.ctypes.data), "arks_imap_export")
         return out[:n]
+
+    def set_pair_base(self, first_pair):
+        """sequence number of pair 0 of the next batch (arks_imap_set_pair_base)"""
+        check(lib().arks_imap_set_pair_base(self._h, int(first_pair)), "arks_imap_set_pair_base")
+
+    def triples_ordered(self):
+        """(triples, uint64[n]: sequence number of the first stored pair of each entry)"""
+        n = len(self)
+        out = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        first = np.zeros(max(n, 1), dtype=np.uint64)
+        check(lib().arks_imap_export_ordered(self._h, out.ctypes.data, first.ctypes.data),
+              "arks_imap_export_ordered")
+        return out[:n], first[:n]
 
 
 def map_pairs_packed(index, reads, j_index, pair_ok=None, barcode_id=None, imap=None,

@@ -150,10 +150,11 @@ struct arks_index
 struct arks_imap
 {
 	int device = 0;
-	u64* keys = nullptr;
-	u32* counts = nullptr;
-	u32* overflow = nullptr;
-	u64 cap = 0;
+	ImapView v{ nullptr, nullptr, nullptr, 0, nullptr, nullptr };
+	// host-side bound of the occupied slots: the last exact count plus the pairs submitted since (a pair
+	// adds at most one entry); the table is rebuilt larger before the bound could pass half the slots
+	u64 bound = 0;
+	u64 seq_base = 0; // arks_imap_set_pair_base
 };
 
 extern "C" {
@@ -1182,6 +1183,93 @@ done:
 /* pairs and the IndexMap accumulator                                                             */
 /* ---------------------------------------------------------------------------------------------- */
 
+static void
+imap_release(ImapView& v)
+{
+	if (v.keys)
+		(void)hipFree(v.keys);
+	if (v.counts)
+		(void)hipFree(v.counts);
+	if (v.first)
+		(void)hipFree(v.first);
+	if (v.n_entries)
+		(void)hipFree(v.n_entries);
+	v = ImapView{ nullptr, nullptr, nullptr, 0, nullptr, nullptr };
+}
+
+// an empty table of `slots` slots (n_entries and overflow share one allocation)
+static int
+imap_alloc(ImapView& v, u64 slots)
+{
+	int rc = ARKS_OK;
+	void* p = nullptr;
+	v = ImapView{ nullptr, nullptr, nullptr, slots, nullptr, nullptr };
+	HIP_TRY(hipMalloc(&p, slots * sizeof(u64)));
+	v.keys = static_cast<u64*>(p);
+	HIP_TRY(hipMalloc(&p, slots * sizeof(u32)));
+	v.counts = static_cast<u32*>(p);
+	HIP_TRY(hipMalloc(&p, slots * sizeof(u64)));
+	v.first = static_cast<u64*>(p);
+	HIP_TRY(hipMalloc(&p, 2 * sizeof(u32)));
+	v.n_entries = static_cast<u32*>(p);
+	v.overflow = v.n_entries + 1;
+	HIP_TRY(hipMemset(v.keys, 0, slots * sizeof(u64)));
+	HIP_TRY(hipMemset(v.counts, 0, slots * sizeof(u32)));
+	HIP_TRY(hipMemset(v.first, 0xFF, slots * sizeof(u64)));
+	HIP_TRY(hipMemset(v.n_entries, 0, 2 * sizeof(u32)));
+	HIP_TRY(hipDeviceSynchronize()); // the caller's streams need not be ordered behind the null stream
+done:
+	if (rc != ARKS_OK)
+		imap_release(v);
+	return rc;
+}
+
+// exact number of entries (waits for the device)
+static int
+imap_count(const arks_imap* m, u64* n)
+{
+	int rc = ARKS_OK;
+	u32 h[2] = { 0, 0 };
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(h, m->v.n_entries, sizeof h, hipMemcpyDeviceToHost));
+	if (h[1])
+		return ARKS_ERR_FULL;
+	*n = h[0];
+done:
+	return rc;
+}
+
+// makes room for `incoming` more pairs: load <= 1/2 afterwards whatever they hold
+static int
+imap_reserve(arks_imap* m, u64 incoming)
+{
+	if ((m->bound + incoming) * 2 <= m->v.cap)
+		return ARKS_OK;
+	u64 n = 0;
+	int rc = imap_count(m, &n); // the bound counted every pair as a new entry: take the exact figure
+	if (rc != ARKS_OK)
+		return rc;
+	m->bound = n;
+	if ((n + 8 * incoming) * 2 <= m->v.cap) // room for at least eight more launches of this size
+		return ARKS_OK;
+	u64 slots = m->v.cap;
+	while ((n + 8 * incoming) * 2 > slots)
+		slots *= 2;
+	ImapView to;
+	rc = imap_alloc(to, slots);
+	if (rc != ARKS_OK) { // no room for the larger table: go on while the exact bound allows it
+		return (n + incoming) * 2 <= m->v.cap ? ARKS_OK : rc;
+	}
+	HIP_TRY(launch_imap_rehash(m->v, to, nullptr));
+	HIP_TRY(hipDeviceSynchronize());
+	imap_release(m->v);
+	m->v = to;
+	return ARKS_OK;
+done:
+	imap_release(to);
+	return rc;
+}
+
 int
 arks_imap_create(arks_imap** out, int64_t capacity_entries, int device)
 {
@@ -1196,23 +1284,17 @@ arks_imap_create(arks_imap** out, int64_t capacity_entries, int device)
 	if (!m)
 		return ARKS_ERR_OOM;
 	m->device = device;
-	m->cap = (u64)capacity_entries * 2 + 64; // load factor <= 0.5
-	void* p = nullptr;
-	HIP_TRY(hipMalloc(&p, m->cap * sizeof(u64)));
-	m->keys = static_cast<u64*>(p);
-	HIP_TRY(hipMalloc(&p, m->cap * sizeof(u32)));
-	m->counts = static_cast<u32*>(p);
-	HIP_TRY(hipMalloc(&p, sizeof(u32)));
-	m->overflow = static_cast<u32*>(p);
-	HIP_TRY(hipMemset(m->keys, 0, m->cap * sizeof(u64)));
-	HIP_TRY(hipMemset(m->counts, 0, m->cap * sizeof(u32)));
-	HIP_TRY(hipMemset(m->overflow, 0, sizeof(u32)));
+	// a starting size only (the table grows): at most 2^24 slots up front
+	u64 slots = 1024;
+	while (slots < (u64)capacity_entries * 2 && slots < ((u64)1 << 24))
+		slots *= 2;
+	rc = imap_alloc(m->v, slots);
+	if (rc != ARKS_OK) {
+		delete m;
+		return rc;
+	}
 	*out = m;
-	m = nullptr;
-done:
-	if (m)
-		arks_imap_free(m);
-	return rc;
+	return ARKS_OK;
 }
 
 int
@@ -1221,41 +1303,18 @@ arks_imap_free(arks_imap* m)
 	if (!m)
 		return ARKS_OK;
 	DeviceGuard guard(m->device);
-	if (m->keys)
-		(void)hipFree(m->keys);
-	if (m->counts)
-		(void)hipFree(m->counts);
-	if (m->overflow)
-		(void)hipFree(m->overflow);
+	imap_release(m->v);
 	delete m;
 	return ARKS_OK;
 }
 
-static int
-imap_download(const arks_imap* m, std::vector<std::pair<u64, u32>>& ent)
+int
+arks_imap_set_pair_base(arks_imap* m, uint64_t first_pair)
 {
-	int rc = ARKS_OK;
-	std::vector<u64> keys;
-	std::vector<u32> counts;
-	u32 overflow = 0;
-	try {
-		keys.resize(m->cap);
-		counts.resize(m->cap);
-	} catch (const std::bad_alloc&) {
-		return ARKS_ERR_OOM;
-	}
-	HIP_TRY(hipDeviceSynchronize());
-	HIP_TRY(hipMemcpy(&overflow, m->overflow, sizeof(u32), hipMemcpyDeviceToHost));
-	if (overflow)
-		return ARKS_ERR_FULL;
-	HIP_TRY(hipMemcpy(keys.data(), m->keys, m->cap * sizeof(u64), hipMemcpyDeviceToHost));
-	HIP_TRY(hipMemcpy(counts.data(), m->counts, m->cap * sizeof(u32), hipMemcpyDeviceToHost));
-	for (u64 s = 0; s < m->cap; ++s)
-		if (keys[s] != 0)
-			ent.emplace_back(keys[s], counts[s]);
-	std::sort(ent.begin(), ent.end());
-done:
-	return rc;
+	if (!m)
+		return ARKS_ERR_BAD_ARG;
+	m->seq_base = first_pair;
+	return ARKS_OK;
 }
 
 int64_t
@@ -1264,9 +1323,52 @@ arks_imap_size(const arks_imap* m)
 	if (!m)
 		return 0;
 	DeviceGuard guard(m->device);
-	std::vector<std::pair<u64, u32>> ent;
-	const int rc = imap_download(m, ent);
-	return rc == ARKS_OK ? (int64_t)ent.size() : -(int64_t)rc;
+	u64 n = 0;
+	const int rc = imap_count(m, &n);
+	return rc == ARKS_OK ? (int64_t)n : -(int64_t)rc;
+}
+
+// the entries sorted by (barcode id, conreci): compacted on the device, sorted on the host
+static int
+imap_download(const arks_imap* m, uint32_t* h_triples, uint64_t* h_first)
+{
+	int rc = ARKS_OK;
+	u64 n = 0;
+	rc = imap_count(m, &n);
+	if (rc != ARKS_OK || n == 0)
+		return rc;
+	DevBuf dk, df, dc, cur;
+	std::vector<u64> keys, first;
+	std::vector<u32> counts, order;
+	try {
+		keys.resize(n), first.resize(n), counts.resize(n), order.resize(n);
+	} catch (const std::bad_alloc&) {
+		return ARKS_ERR_OOM;
+	}
+	HIP_TRY(dk.alloc(n * sizeof(u64)));
+	HIP_TRY(df.alloc(n * sizeof(u64)));
+	HIP_TRY(dc.alloc(n * sizeof(u32)));
+	HIP_TRY(cur.alloc(sizeof(u32)));
+	HIP_TRY(hipMemset(cur.p, 0, sizeof(u32)));
+	HIP_TRY(launch_imap_compact(m->v, dk.as<u64>(), df.as<u64>(), dc.as<u32>(), cur.as<u32>(), nullptr));
+	HIP_TRY(hipMemcpy(keys.data(), dk.p, n * sizeof(u64), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(first.data(), df.p, n * sizeof(u64), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(counts.data(), dc.p, n * sizeof(u32), hipMemcpyDeviceToHost));
+	for (u64 i = 0; i < n; ++i)
+		order[i] = (u32)i;
+	std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return keys[a] < keys[b]; });
+	for (u64 i = 0; i < n; ++i) {
+		const u32 s = order[i];
+		if (h_triples) {
+			h_triples[3 * i + 0] = (uint32_t)(keys[s] >> 32);
+			h_triples[3 * i + 1] = (uint32_t)keys[s];
+			h_triples[3 * i + 2] = counts[s];
+		}
+		if (h_first)
+			h_first[i] = first[s];
+	}
+done:
+	return rc;
 }
 
 int
@@ -1275,16 +1377,16 @@ arks_imap_export(const arks_imap* m, uint32_t* h_triples)
 	if (!m || !h_triples)
 		return ARKS_ERR_BAD_ARG;
 	DeviceGuard guard(m->device);
-	std::vector<std::pair<u64, u32>> ent;
-	const int rc = imap_download(m, ent);
-	if (rc != ARKS_OK)
-		return rc;
-	for (size_t i = 0; i < ent.size(); ++i) {
-		h_triples[3 * i + 0] = (uint32_t)(ent[i].first >> 32);
-		h_triples[3 * i + 1] = (uint32_t)ent[i].first;
-		h_triples[3 * i + 2] = ent[i].second;
-	}
-	return ARKS_OK;
+	return imap_download(m, h_triples, nullptr);
+}
+
+int
+arks_imap_export_ordered(const arks_imap* m, uint32_t* h_triples, uint64_t* h_first_pair)
+{
+	if (!m || !h_triples || !h_first_pair)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(m->device);
+	return imap_download(m, h_triples, h_first_pair);
 }
 
 int
@@ -1333,10 +1435,20 @@ arks_pairs_device(
 	if (rc != ARKS_OK)
 		return rc;
 	DeviceGuard guard(device);
-	HIP_TRY(launch_pairs(
-	    d_conreci, d_pair_ok, d_barcode_id, (long)n_pairs, d_out_pair, imap ? imap->keys : nullptr,
-	    imap ? imap->counts : nullptr, imap ? imap->cap : 0, imap ? imap->overflow : nullptr,
-	    (u64*)d_stored, static_cast<hipStream_t>(stream)));
+	{
+		ImapView none{ nullptr, nullptr, nullptr, 0, nullptr, nullptr };
+		if (imap) {
+			rc = imap_reserve(imap, (u64)n_pairs);
+			if (rc != ARKS_OK)
+				return rc;
+			imap->bound += (u64)n_pairs;
+		}
+		HIP_TRY(launch_pairs(
+		    d_conreci, d_pair_ok, d_barcode_id, (long)n_pairs, d_out_pair, imap ? imap->v : none,
+		    imap ? imap->seq_base : 0, (u64*)d_stored, static_cast<hipStream_t>(stream)));
+		if (imap)
+			imap->seq_base += (u64)n_pairs; // the next batch continues the numbering unless the caller sets it
+	}
 done:
 	return rc;
 }

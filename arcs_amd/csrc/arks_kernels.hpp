@@ -54,9 +54,24 @@ hipError_t launch_resolve_votes(
     const u64* votes, const u32* lens, long n_reads, int k, double j_index, int* out, hipStream_t st);
 hipError_t launch_pair_gate(
     const uint8_t* pair_ok, const uint8_t* read_class, long n_pairs, uint8_t* eval, hipStream_t st);
+// the IndexMap accumulator (arks_imap.hip): open-addressed (barcode id << 32 | conreci) -> count, plus the
+// sequence number of the first stored pair of the entry (the order in which a single-threaded reference
+// run would have created it)
+struct ImapView
+{
+	u64* keys;      // 0 = empty
+	u32* counts;
+	u64* first;     // ~0 until set
+	u64 cap;        // slots
+	u32* n_entries; // occupied slots
+	u32* overflow;  // set when an insert found no slot (the growth rule of arks_pairs_device excludes it)
+};
 hipError_t launch_pairs(
     const int* conreci, const uint8_t* pair_ok, const u32* barcode_id, long n_pairs, int* out_pair,
-    u64* imap_keys, u32* imap_counts, u64 imap_cap, u32* imap_overflow, u64* stored, hipStream_t st);
+    const ImapView& im, u64 seq_base, u64* stored, hipStream_t st);
+hipError_t launch_imap_rehash(const ImapView& from, const ImapView& to, hipStream_t st);
+hipError_t launch_imap_compact(
+    const ImapView& im, u64* out_keys, u64* out_first, u32* out_counts, u32* cursor, hipStream_t st);
 
 #ifdef ARKS_PROFILE_SECTIONS
 void read_section_cycles(unsigned long long* out16);

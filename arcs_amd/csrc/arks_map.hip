@@ -1544,84 +1544,6 @@ pair_gate_kernel(
 	eval[2 * p + 1] = e;
 }
 
-__device__ __forceinline__ u64
-mix64(u64 x)
-{
-	x ^= x >> 33;
-	x *= 0xff51afd7ed558ccdull;
-	x ^= x >> 33;
-	x *= 0xc4ceb9fe1a85ec53ull;
-	x ^= x >> 33;
-	return x;
-}
-
-// imap[(barcode, conreci)] += n   (keys are never 0 because conreci >= 1)
-__device__ inline bool
-imap_add(u64* keys, u32* counts, u64 cap, u64 key, u32 n)
-{
-	u64 s = mulhi64(mix64(key), cap);
-	for (u64 probes = 0; probes < cap; ++probes) {
-		u64 cur = __hip_atomic_load(keys + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (cur == 0) {
-			u64 expect = 0;
-			if (__hip_atomic_compare_exchange_strong(
-			        keys + s, &expect, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-				cur = key;
-			else
-				cur = expect;
-		}
-		if (cur == key) {
-			atomicAdd(counts + s, n);
-			return true;
-		}
-		s = (s + 1 == cap) ? 0 : s + 1;
-	}
-	return false;
-}
-
-// One thread per pair.  Runs of equal (barcode, conreci) in adjacent lanes -- the normal case,
-// linked-read files are grouped by barcode -- are folded with a ballot before touching the table.
-__global__ void
-pairs_kernel(
-    const int* __restrict__ conreci,
-    const uint8_t* __restrict__ pair_ok,
-    const u32* __restrict__ barcode_id,
-    long n_pairs,
-    int* __restrict__ out_pair,
-    u64* __restrict__ imap_keys,
-    u32* __restrict__ imap_counts,
-    u64 imap_cap,
-    u32* __restrict__ imap_overflow,
-    u64* __restrict__ stored)
-{
-	const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	const int lane = threadIdx.x & 63;
-	int agreed = 0;
-	bool ok = false;
-	if (p < n_pairs) {
-		const int c1 = conreci[2 * p], c2 = conreci[2 * p + 1];
-		agreed = (c1 != 0 && c1 == c2) ? c1 : 0; // Arcs.cpp:1280
-		if (out_pair)
-			out_pair[p] = agreed;
-		ok = agreed != 0 && (pair_ok ? pair_ok[p] != 0 : true);
-	}
-	const u64 okmask = __ballot(ok);
-	if (stored && lane == 0 && okmask)
-		atomicAdd(stored, (u64)__popcll(okmask));
-	if (imap_keys == nullptr)
-		return;
-	const u64 key = ok ? (((u64)barcode_id[p] << 32) | (u32)agreed) : 0ull;
-	const u64 prev = __shfl_up(key, 1);
-	const bool head = lane == 0 || key != prev;
-	const u64 heads = __ballot(head);
-	if (head && key != 0) {
-		const u64 later = lane == 63 ? 0ull : (heads >> (lane + 1));
-		const int run = later ? (__ffsll((long long)later)) : (64 - lane);
-		if (!imap_add(imap_keys, imap_counts, imap_cap, key, (u32)run))
-			atomicOr(imap_overflow, 1u);
-	}
-}
-
 // ------------------------------------------------------------------------------------------------
 // launchers (called from arks_capi.cpp through arks_kernels.hpp)
 // ------------------------------------------------------------------------------------------------
@@ -1795,20 +1717,6 @@ launch_pair_gate(const uint8_t* pair_ok, const uint8_t* read_class, long n_pairs
 	if (n_pairs <= 0)
 		return hipSuccess;
 	pair_gate_kernel<<<blocks_for((u64)n_pairs, 256), 256, 0, st>>>(pair_ok, read_class, n_pairs, eval);
-	ARKS_LAUNCH_CHECK();
-	return hipSuccess;
-}
-
-hipError_t
-launch_pairs(
-    const int* conreci, const uint8_t* pair_ok, const u32* barcode_id, long n_pairs, int* out_pair,
-    u64* imap_keys, u32* imap_counts, u64 imap_cap, u32* imap_overflow, u64* stored, hipStream_t st)
-{
-	if (n_pairs <= 0)
-		return hipSuccess;
-	pairs_kernel<<<blocks_for((u64)n_pairs, 256), 256, 0, st>>>(
-	    conreci, pair_ok, barcode_id, n_pairs, out_pair, imap_keys, imap_counts, imap_cap,
-	    imap_overflow, stored);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

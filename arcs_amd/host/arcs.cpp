@@ -10,8 +10,8 @@
 //   read pairs -> IndexMap   host parse (chromiumRead :1185-1262) + GPU (gate, bestContig x2,
 //                            pair rule, imap accumulation)
 //   graph stage and writers  host  (graph.hpp)
-// Not offered: the alignment (SAM/BAM) mode and -D distance estimation (outside the ARKS k-mer
-// path); both are reported as errors instead of being silently ignored.
+// Not offered: the alignment (SAM/BAM) mode (outside the ARKS k-mer path), reported as an error
+// instead of being silently ignored.  -D distance estimation is offered (dist_est.hpp).
 #include "arks_hip.h"
 #include "dist_est.hpp"
 #include "graph.hpp"
@@ -579,9 +579,13 @@ struct Mapper
 			} else
 				rc = arks_map_reads_device(idxs[ki], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, 2 * np,
 				                           params.j_index, s.d_conreci.p, params.verbose ? d_stats + slot : nullptr, s.stream);
-			if (rc == ARKS_OK)
+			if (rc == ARKS_OK) {
+				// pairs are numbered in input order (file, batch, pair): the order in which a single-threaded
+				// chromiumRead creates the IndexMap's barcodes (Arcs.cpp:1282-1285)
+				arks_imap_set_pair_base(imaps[ki], ((uint64_t)pb->file << 48) | ((uint64_t)pb->seq << 24));
 				rc = arks_pairs_device(s.d_conreci.p, s.d_ok.p, s.d_bid.p, np, nullptr, imaps[ki], d_stored + slot,
 				                       params.device, s.stream);
+			}
 		}
 		if (rc != ARKS_OK)
 			return rc;
@@ -652,8 +656,8 @@ read_chroms(
 		}
 	}
 	std::unique_ptr<BarcodeDict> dict(fused ? nullptr : new BarcodeDict(mult));
-	// distinct (barcode, contig end) pairs: a few per barcode; unknown in the fused mode
-	const int64_t imap_cap = fused ? (int64_t)1 << 28 : std::max<int64_t>(1 << 16, (int64_t)mult.size() * 8);
+	// distinct (barcode, contig end) pairs: a few per barcode; a starting size only, the accumulator grows
+	const int64_t imap_cap = fused ? (int64_t)1 << 20 : std::max<int64_t>(1 << 16, (int64_t)mult.size() * 4);
 	const size_t nk = idxs.size() / (size_t)std::max(1, params.index_shards);
 	Mapper mapper(idxs, imap_cap, std::max<size_t>(nf, 1));
 	HostAllocator pinned;
@@ -677,10 +681,9 @@ read_chroms(
 			messages[(size_t)pb->file][pb->seq].swap(pb->messages);
 		pb->messages.clear();
 		return mapper.submit(pb, pipe);
-	});
+	}, [&] { mapper.drain(pipe); }); // the in-flight batches are retired before their pinned buffers go
 	if (prc != ARKS_OK)
 		die_arks(prc, "mapping a read batch");
-	mapper.drain(pipe);
 	if (hipDeviceSynchronize() != hipSuccess) {
 		std::cerr << PROGRAM ": device error while mapping\n";
 		exit(EXIT_FAILURE);
@@ -755,13 +758,27 @@ read_chroms(
 		if (n < 0)
 			die_arks((int)-n, "reading the IndexMap accumulator");
 		std::vector<uint32_t> triples((size_t)n * 3 + 3);
-		const int rc = arks_imap_export(mapper.imaps[ki], triples.data());
+		std::vector<uint64_t> first((size_t)n + 1);
+		const int rc = arks_imap_export_ordered(mapper.imaps[ki], triples.data(), first.data());
 		if (rc != ARKS_OK)
 			die_arks(rc, "exporting the IndexMap");
 		IndexMap& imap = imaps[ki];
-		for (int64_t i = 0; i < n; ++i)
-			imap[fused ? pipe.dynamic().name(triples[3 * i]) : *dict->name[triples[3 * i]]]
-			    [contigRecord[triples[3 * i + 1]]] += (int)triples[3 * i + 2];
+		// Barcodes enter the unordered IndexMap in the order of their first stored pair, as in a
+		// single-threaded reference run: the container's iteration order (which -D's tie handling sees,
+		// Arcs/DistanceEst.h:230-262) is then the reference's for the same libstdc++.  The triples are
+		// sorted by barcode id: one group per barcode.
+		std::vector<std::pair<uint64_t, int64_t>> groups; // (first stored pair of the barcode, first triple)
+		for (int64_t i = 0; i < n; ++i) {
+			if (i == 0 || triples[3 * i] != triples[3 * (i - 1)])
+				groups.emplace_back(first[(size_t)i], i);
+			else
+				groups.back().first = std::min(groups.back().first, first[(size_t)i]);
+		}
+		std::sort(groups.begin(), groups.end());
+		for (const auto& g : groups)
+			for (int64_t i = g.second; i < n && triples[3 * i] == triples[3 * g.second]; ++i)
+				imap[fused ? pipe.dynamic().name(triples[3 * i]) : *dict->name[triples[3 * i]]]
+				    [contigRecord[triples[3 * i + 1]]] += (int)triples[3 * i + 2];
 		add_opposite_ends(imap);
 		arks_imap_free(mapper.imaps[ki]);
 	}
@@ -1006,7 +1023,10 @@ main(int argc, char** argv)
 		case OPT_DIST_MEDIAN: params.g.dist_upper = false; break;
 		case OPT_DIST_UPPER: params.g.dist_upper = true; break;
 		case OPT_ARKS_METHOD: params.arks = true; break;
-		case OPT_BATCH_PAIRS: arg >> params.batch_pairs; break;
+		case OPT_BATCH_PAIRS:
+			arg >> params.batch_pairs;
+			params.batch_pairs = std::min(params.batch_pairs, (1L << 24) - 1); // pair numbering: 24 bits per batch
+			break;
 		case OPT_DEVICE: arg >> params.device; break;
 		case OPT_INDEX_SHARDS: arg >> params.index_shards; break;
 		case 'm': {

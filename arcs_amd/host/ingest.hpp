@@ -504,7 +504,10 @@ class IngestPipeline
 	unsigned producers() const { return n_producers_; }
 	unsigned packers() const { return n_packers_; }
 
-	int run(const std::function<int(PackedBatch*)>& consume)
+	// `finish` (may be empty) runs after the last batch was handed to `consume` and before the batch
+	// buffers are released: a consumer that keeps batches in flight (asynchronous copies out of the
+	// pinned buffers) retires them there and gives them back with recycle()
+	int run(const std::function<int(PackedBatch*)>& consume, const std::function<void()>& finish = nullptr)
 	{
 		std::vector<PackedBatch> pool(n_buffers_);
 		for (auto& pb : pool)
@@ -571,6 +574,8 @@ class IngestPipeline
 				recycle(pb);
 		}
 		closer.join();
+		if (finish)
+			finish();
 		free_q_.close();
 		for (auto& b : pool)
 			packed_free(b, alloc_);

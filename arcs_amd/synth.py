@@ -18,8 +18,10 @@ def revcomp_ascii(a):
 
 
 def make_draft(total_bp, seed=SEED, lengths=(20000, 50000, 100000, 230000), small_frac=0.005,
-               inject=True):
-    """list of uint8 ASCII arrays (contigs, FASTA order)"""
+               inject=True, dup_events=None, touched=None):
+    """list of uint8 ASCII arrays (contigs, FASTA order).  dup_events (a list) receives the
+    (source contig, destination contig) of every copied segment, so that a caller can find the
+    contigs that share k-mers with a given set (closed_contig_set)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     contigs = []
     acc = 0
@@ -40,11 +42,15 @@ def make_draft(total_bp, seed=SEED, lengths=(20000, 50000, 100000, 230000), smal
             j = big[int(rng.integers(len(big)))]
             p = int(rng.integers(0, len(contigs[j]) - 200))
             contigs[j][p:p + 100] = ord("N")
+            if touched is not None:
+                touched.add(j)
             # one N pair 5 bp apart (the i += k rule then skips valid windows)
             j = big[int(rng.integers(len(big)))]
             p = int(rng.integers(0, len(contigs[j]) - 200))
             contigs[j][p] = ord("N")
             contigs[j][p + 5] = ord("N")
+            if touched is not None:
+                touched.add(j)
             # one 5-kbp segment copied into another contig (forces value 0), placed near an end so
             # that it lands inside the indexed 30-kbp region
             a, b = big[int(rng.integers(len(big)))], big[int(rng.integers(len(big)))]
@@ -52,11 +58,38 @@ def make_draft(total_bp, seed=SEED, lengths=(20000, 50000, 100000, 230000), smal
                 pa = int(rng.integers(0, min(len(contigs[a]) - 5000, 20000)))
                 pb = int(rng.integers(0, min(len(contigs[b]) - 5000, 20000)))
                 contigs[b][pb:pb + 5000] = contigs[a][pa:pa + 5000]
+                if dup_events is not None:
+                    dup_events.append((a, b))
+                if touched is not None:
+                    touched.update((a, b))
             # one (AT)x40 microsatellite: reverse-complement palindromes at every even k
             j = big[int(rng.integers(len(big)))]
             p = int(rng.integers(0, min(len(contigs[j]) - 100, 25000)))
             contigs[j][p:p + 80] = np.frombuffer(b"AT" * 40, dtype=np.uint8)
+            if touched is not None:
+                touched.add(j)
     return contigs
+
+
+def closed_contig_set(n_first, dup_events):
+    """sorted indices of the first n_first contigs plus every contig connected to one of them through
+    copied segments (transitively): a k-mer of these contigs occurs in no contig outside the set,
+    except by chance or inside the (AT)n microsatellites, so an index of the set's ends gives the
+    whole index's answers for reads drawn from the first n_first contigs (which is what a CPU check
+    of a human-scale index needs: the oracle cannot hold 1.4 G keys in a test's time)."""
+    parent = {}
+
+    def find(x):
+        while parent.setdefault(x, x) != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    for a, b in dup_events:
+        parent[find(a)] = find(b)
+    roots = {find(i) for i in range(n_first)}
+    extra = {x for x in list(parent) if find(x) in roots}
+    return sorted(set(range(n_first)) | extra)
 
 
 def contigs_to_strings(contigs):
@@ -65,21 +98,26 @@ def contigs_to_strings(contigs):
 
 def make_read_pairs(contigs, n_pairs, seed=SEED, device="cpu", r1_len=128, r2_len=151,
                     frag=350, mol_len=50000, pairs_per_mol=40, sub_rate=0.005, one_n_rate=0.01,
-                    many_n_rate=0.001, unpaired_rate=0.001, chunk=2_000_000):
-    """Linked read pairs sampled from the concatenated draft, generated with torch on `device`.
+                    many_n_rate=0.001, unpaired_rate=0.001, chunk=2_000_000, want_origin=False):
+    """Linked read pairs sampled from the concatenated draft (a list of contigs, or the uint8
+    tensor of their concatenation), generated with torch on `device`.
 
     Returns a dict of torch tensors on `device`:
       ascii   uint8[n_pairs * (r1_len + r2_len)]  reads back to back (R1 of pair 0, R2 of pair 0, ...)
       offsets int64[2 n_pairs + 1], lens int32[2 n_pairs]
       barcode_id int32[n_pairs]   (one barcode per two molecules)
       pair_ok uint8[n_pairs]      0 for the pairs whose mate names would not match
+      origin  int64[n_pairs]      (want_origin) position of R1's first base in the concatenated draft;
+                                  R2 is the reverse complement of [origin + frag - r2_len, origin + frag)
     """
     import torch
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    genome_np = np.concatenate(contigs)
-    genome = torch.from_numpy(genome_np).to(dev)
+    if isinstance(contigs, torch.Tensor):      # the concatenated draft, already where it is needed
+        genome = contigs.to(dev)
+    else:
+        genome = torch.from_numpy(np.concatenate(contigs)).to(dev)
     G = genome.numel()
     comp = torch.from_numpy(_COMP).to(dev)
     n_mol = (n_pairs + pairs_per_mol - 1) // pairs_per_mol
@@ -90,12 +128,15 @@ def make_read_pairs(contigs, n_pairs, seed=SEED, device="cpu", r1_len=128, r2_le
     ar1 = torch.arange(r1_len, device=dev)
     ar2 = torch.arange(r2_len, device=dev)
     mol_eff = min(mol_len, G)
+    origin = torch.empty(n_pairs, dtype=torch.int64, device=dev) if want_origin else None
     for lo in range(0, n_pairs, chunk):
         hi = min(n_pairs, lo + chunk)
         n = hi - lo
         mol = torch.arange(lo, hi, device=dev) // pairs_per_mol
         u = mol_start[mol] + torch.randint(0, max(mol_eff - frag, 1), (n,), generator=g, device=dev)
         u = torch.clamp(u, max=G - frag)
+        if origin is not None:
+            origin[lo:hi] = u
         r1 = genome[u[:, None] + ar1[None, :]]
         # R2: reverse complement of the r2_len bases that end at u + frag
         r2 = comp[genome[(u + frag - 1)[:, None] - ar2[None, :]].long()]
@@ -125,8 +166,35 @@ def make_read_pairs(contigs, n_pairs, seed=SEED, device="cpu", r1_len=128, r2_le
     offsets[1:] = torch.cumsum(lens.to(torch.int64), 0)
     barcode_id = (torch.arange(n_pairs, device=dev) // (2 * pairs_per_mol)).to(torch.int32)
     pair_ok = (torch.rand((n_pairs,), generator=g, device=dev) >= unpaired_rate).to(torch.uint8)
-    return {"ascii": out, "offsets": offsets, "lens": lens, "barcode_id": barcode_id,
-            "pair_ok": pair_ok}
+    res = {"ascii": out, "offsets": offsets, "lens": lens, "barcode_id": barcode_id, "pair_ok": pair_ok}
+    if origin is not None:
+        res["origin"] = origin
+    return res
+
+
+def pairs_touching_microsatellite(batch, r1_len=128, r2_len=151, run=14, chunk=500_000):
+    """bool[n_pairs]: a mate holds `run` alternating A/T bases, i.e. reaches >= run bases into one of
+    the injected (AT)n microsatellites.  K-mers made of a short flank plus (AT)n collide by chance
+    between microsatellite sites, so their index value depends on the WHOLE draft; every other k-mer of
+    a read depends on its own contig and the contigs it shares copied segments with
+    (closed_contig_set).  A CPU check against a sub-draft leaves these pairs out."""
+    import torch
+    L = r1_len + r2_len
+    a = batch["ascii"]
+    n = a.numel() // L
+    out = torch.zeros(n, dtype=torch.bool, device=a.device)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        x = a[lo * L:hi * L].reshape(hi - lo, L)
+        isa, ist = x == ord("A"), x == ord("T")
+        alt = (isa[:, :-1] & ist[:, 1:]) | (ist[:, :-1] & isa[:, 1:])     # positions i with x[i]x[i+1] in {AT, TA}
+        alt[:, r1_len - 1] = False                                         # not across the mates
+        c = torch.cumsum(alt.to(torch.int16), 1)
+        z = torch.zeros((hi - lo, 1), dtype=torch.int16, device=a.device)
+        c = torch.cat([z, c], 1)
+        w = run - 1
+        out[lo:hi] = ((c[:, w:] - c[:, :-w]) == w).any(1)
+    return out
 
 
 def reads_to_strings(batch):

@@ -2,18 +2,22 @@
 """bench.py -- throughput of the ARKS read->contig k-mer mapping hot path on MI355X.
 
 One "step" = one pass of the hot path (pair gate -> per-read k-mer window keys -> contig k-mer
-table probe -> per-read vote -> pair rule + (barcode, contig end) accumulation) over one resident
-batch of synthetic linked-read pairs.  Workload at N=1: BASELINE.json configs[1] -- synthetic 50 Mbp
-draft + 20 M linked-read pairs (R1 128 bp / R2 151 bp), k=60, j=0.55.  With N > 1 every rank holds a
-replica of the index and its own 20 M pairs (the path shards over reads with no data-path
-collective; weak scaling).
+index lookup -> per-read vote -> pair rule + (barcode, contig end) accumulation) over the whole
+resident read set.  Workload at N=1: BASELINE.json configs[2] -- synthetic 3 Gbp draft + 500 M
+linked-read pairs (R1 128 bp / R2 151 bp), k=60, j=0.55, everything resident in HBM (packed reads
+~55 GB, index ~2 GB); the read set is mapped in launches of 20 M pairs.  With N > 1 every rank
+holds a replica of the index; by default every rank maps its own 500 M pairs (weak scaling: the
+path shards over reads with no data-path collective), with --strong the 500 M pairs are split
+over the ranks.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--draft-mbp M]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--draft-mbp M] [--strong]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -31,6 +35,7 @@ from arcs_amd import synth  # noqa: E402
 
 METRIC = "read k-mers hashed+probed/sec at k=60; 1/2/4/8 GPU; bit-exact .gv"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+STAT_NAMES = ("total_valid", "bad", "found", "recorded", "dups", "reads_pass", "reads_fail", "windows")
 
 
 def alg_bytes_per_window(k, bases, windows):
@@ -38,53 +43,264 @@ def alg_bytes_per_window(k, bases, windows):
     return 2.0 * bases / (8.0 * windows) + (2 * k + 7) // 8 + 4
 
 
-def pmc_traffic(args):
+def kernel_build_id():
+    """digest of the kernel sources the loaded library was built from; profiles/traffic_r*.json
+    carries the id of the build its counters were taken on"""
+    h = hashlib.sha256()
+    for f in ("arks_device.hpp", "arks_kernels.hpp", "arks_map.hip"):
+        h.update(open(os.path.join(ROOT, "arcs_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this
-    very workload (profiles/traffic_r*.json, written from separate --pmc passes by profiles/prof.sh);
-    None when no summary matches the workload being run."""
-    import glob
+    very workload AND this very kernel build (profiles/traffic_r*.json, written from separate --pmc
+    passes by profiles/prof.sh); None when there is none -- a stale summary is never reported."""
+    bid = kernel_build_id()
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        wl = d.get("workload", {})
-        if wl.get("pairs_per_gpu") == args.pairs and wl.get("draft_mbp") == args.draft_mbp and wl.get("k") == args.k:
+        if d.get("workload") == workload and d.get("kernel_build_id") == bid:
             best = d
     return best
 
 
-def cpu_baseline(cs, batch, k, j, n_pairs_total, log):
-    """the CPU oracle (a literal port of the reference path: per-window O(k) re-encode, exact
-    hash map, ordered histogram; OpenMP over pairs) timed on the host cores, on a bounded sample
-    of the same reads.  Test infrastructure, never the product path."""
+# ---- host topology (for the CPU baseline) --------------------------------------------------------
+
+def cpu_topology():
+    """(model name, {socket: [one logical cpu per physical core]}) restricted to the cpus this
+    process may run on"""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    allowed = sorted(os.sched_getaffinity(0))
+    sockets = {}
+    seen = set()
+    for c in allowed:
+        base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+        try:
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except (OSError, ValueError):
+            pkg, core = 0, c
+        if (pkg, core) in seen:
+            continue
+        seen.add((pkg, core))
+        sockets.setdefault(pkg, []).append(c)
+    return model, sockets
+
+
+# ---- workload ------------------------------------------------------------------------------------
+
+class Workload:
+    """a draft, its index, and a resident read set cut into launches"""
+
+    def __init__(self, draft_mbp, pairs, chunk, k, j, dev, local, rank, seed_salt, log, want_stats=True,
+                 keep_draft=False):
+        self.k, self.j = k, j
+        t0 = time.time()
+        self.dup_events = []
+        contigs = synth.make_draft(int(draft_mbp * 1e6), seed=synth.SEED, dup_events=self.dup_events)
+        self.n_contigs = len(contigs)
+        ends = []
+        self.valid = []          # contig index of every contig that has ends, in conreci order
+        for i, c in enumerate(contigs):
+            cut = arcs_amd.end_cutoff(len(c))
+            if cut is None:
+                continue
+            self.valid.append(i)
+            ends.append(c[:cut].tobytes())
+            ends.append(c[len(c) - cut:].tobytes())
+        log(f"draft: {len(contigs)} contigs, {sum(map(len, contigs))} bp, {len(ends)} ends in {time.time() - t0:.1f}s")
+        t0 = time.time()
+        self.index = arcs_amd.ArksIndex.build(ends, k, device=local, want_stats=want_stats)
+        del ends
+        log(f"index: {len(self.index)} keys, {self.index.device_bytes / 2**30:.2f} GiB, built in "
+            f"{time.time() - t0:.1f}s {self.index.build_stats}")
+        t0 = time.time()
+        self.genome = torch.from_numpy(np.concatenate(contigs)).to(dev)
+        self.contigs = contigs if keep_draft else None
+        self.steps = []
+        self.windows_all = 0
+        self.bases = 0
+        n_barcodes = 0
+        done = 0
+        while done < pairs:
+            n = min(chunk, pairs - done)
+            batch = synth.make_read_pairs(self.genome, n, seed=synth.SEED + 1 + seed_salt + done // chunk, device=dev)
+            reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"],
+                                                            device=local)
+            bid = (batch["barcode_id"] + done // 80).to(torch.int32)      # barcodes continue across launches
+            n_barcodes = int(bid[-1].item()) + 1
+            self.windows_all += reads.windows(k)
+            self.bases += int(batch["lens"].to(torch.int64).sum().item())
+            self.steps.append((reads, batch["pair_ok"], bid))
+            done += n
+            del batch
+        self.pairs = pairs
+        self.imap = arcs_amd.ImapAccumulator(max(1 << 16, 8 * n_barcodes), device=local)
+        self.steps = [arcs_amd.PairStep(self.index, r, j, pair_ok=ok, barcode_id=b, imap=self.imap)
+                      for r, ok, b in self.steps]
+        log(f"reads: {pairs} pairs in {len(self.steps)} launches, {self.windows_all} windows, resident in "
+            f"{time.time() - t0:.1f}s")
+
+    def run(self, stats=None, stored=None, events=None):
+        for i, s in enumerate(self.steps):
+            s.run(stats=stats, stored=stored, map_events=None if events is None else events[i])
+
+    def timed(self, steps, warmup, barrier):
+        dev = self.genome.device
+        stats = torch.zeros(8, dtype=torch.int64, device=dev)
+        stored = torch.zeros(1, dtype=torch.int64, device=dev)
+        for _ in range(warmup):
+            self.run()
+        self.run(stats=stats, stored=stored)          # the counters, outside the timed region
+        barrier()
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in self.steps] for _ in range(steps)]
+        t0 = time.perf_counter()
+        for s in range(steps):
+            self.run(events=ev[s])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        launch_ms = [a.elapsed_time(b) for row in ev for a, b in row]
+        st = dict(zip(STAT_NAMES, stats.cpu().tolist()))
+        return elapsed, launch_ms, st, int(stored.item())
+
+
+def cpu_baseline(wl, dev, local, log, sub_mbp=50.0):
+    """The CPU oracle (a literal port of the reference path: per-window O(k) re-encode, exact hash map,
+    ordered histogram; OpenMP over pairs, Arcs.cpp:1169) timed at t=1 and on the physical cores of ONE
+    socket, on a bounded sample of reads of the workload's shape drawn from the first `sub_mbp` of the
+    draft; the oracle indexes the ends of those contigs plus the contigs they share copied segments
+    with (the whole 1.4 G-key map does not fit a bench run), numbered as in the whole draft.  The GPU
+    maps the same reads against the WHOLE index and must agree read for read.  Test infrastructure,
+    never the product path."""
     from oracle import pyoracle as O
     O.build_oracle()
-    cores = os.cpu_count() or 1
-    t0 = time.time()
-    ox = O.OracleIndex(k).build(O.contig_ends(cs))
-    log(f"cpu oracle index: {len(ox)} keys in {time.time() - t0:.1f}s")
-    L = int(batch["lens"][0].item()) + int(batch["lens"][1].item())
+    k, j = wl.k, wl.j
+    contigs = wl.contigs
+    acc, n_first = 0, 0
+    while n_first < len(contigs) and acc < sub_mbp * 1e6:
+        acc += len(contigs[n_first])
+        n_first += 1
+    members = set(synth.closed_contig_set(n_first, wl.dup_events))
+    model, sockets = cpu_topology()
+    sock = sorted(sockets)[0]
+    cores = sockets[sock]
+    saved = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, cores)             # OpenMP workers are created after this and inherit it
+    try:
+        t0 = time.time()
+        ox = O.sub_draft_index(k, contigs, members)
+        log(f"cpu oracle index: ends of {len(members)} contigs, {len(ox)} keys in {time.time() - t0:.1f}s")
+        sub_genome = wl.genome[:acc]
+        probe = 20000
+        n_max = 4_000_000
+        batch = synth.make_read_pairs(sub_genome, n_max, seed=synth.SEED + 777, device=dev)
+        # k-mers of a short flank + (AT)n collide by chance between microsatellite sites all over the
+        # draft: the few pairs that reach into one are left out (pair_ok = 0) on both sides
+        batch["pair_ok"][synth.pairs_touching_microsatellite(batch)] = 0
+        a_all = np.concatenate([batch["ascii"].cpu().numpy(), np.zeros(1, np.uint8)])
+        lens_all = batch["lens"].cpu().numpy().astype(np.uint32)
+        offs_all = batch["offsets"].cpu().numpy().astype(np.uint64)
+        ok_all = batch["pair_ok"].cpu().numpy()
 
-    def run(n_pairs, threads):
-        a = batch["ascii"][: n_pairs * L].cpu().numpy()
-        lens = batch["lens"][: 2 * n_pairs].cpu().numpy().astype(np.uint32)
-        offs = batch["offsets"][: 2 * n_pairs].cpu().numpy().astype(np.uint64)
-        ok = batch["pair_ok"][:n_pairs].cpu().numpy()
-        a = np.concatenate([a, np.zeros(1, np.uint8)])
-        t = time.time()
-        c, p, st = ox.map_pairs(a, offs, lens, j, pair_ok=ok, threads=threads)
-        return time.time() - t, c, p, st
+        def run(n_pairs, threads):
+            t = time.time()
+            c, p, st = ox.map_pairs(a_all, offs_all[: 2 * n_pairs], lens_all[: 2 * n_pairs], j,
+                                    pair_ok=ok_all[:n_pairs], threads=threads)
+            return time.time() - t, c, p, st
 
-    probe = min(20000, n_pairs_total)
-    dt, _, _, st = run(probe, cores)
-    rate = st["windows"] / max(dt, 1e-9)
-    n = int(min(n_pairs_total, max(probe, 15.0 * rate / (st["windows"] / probe))))
-    dt, c, p, st = run(n, cores)
-    return {"value": st["windows"] / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} pairs ({st['windows']} windows) of the rank-0 batch, "
-                      f"{dt:.1f}s, OpenMP {cores} threads, index resident in host RAM"}, (n, c, p, st)
+        def measure(threads, seconds):
+            dt, _, _, st = run(probe, threads)
+            per_pair = dt / probe
+            n = int(min(n_max, max(probe, seconds / max(per_pair, 1e-9))))
+            dt, c, p, st = run(n, threads)
+            return n, dt, c, p, st
+
+        n1, dt1, _, _, st1 = measure(1, 10.0)
+        ns, dts, c, p, sts = measure(len(cores), 12.0)
+    finally:
+        os.sched_setaffinity(0, saved)
+    # the GPU on the same reads, against the whole index
+    reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
+    got_c, got_p = arcs_amd.map_pairs_packed(wl.index, reads, j, pair_ok=batch["pair_ok"])
+    torch.cuda.synchronize(dev)
+    parity = bool((got_c[: 2 * ns].cpu().numpy() == c).all() and (got_p[:ns].cpu().numpy() == p).all())
+    out = {"value": sts["windows"] / dts, "unit": "k-mers/s", "cores": len(cores), "kind": "port",
+           "cpu_model": model, "sockets_visible": len(sockets),
+           "physical_cores_visible": sum(len(v) for v in sockets.values()),
+           "t1": {"value": st1["windows"] / dt1, "unit": "k-mers/s", "cores": 1,
+                  "sample": f"first {n1} pairs ({st1['windows']} windows), {dt1:.1f}s"},
+           "sample": f"{ns} pairs ({sts['windows']} windows) of the workload's shape drawn from the first "
+                     f"{acc / 1e6:.0f} Mbp of the draft, {dts:.1f}s, OpenMP {len(cores)} threads pinned one per "
+                     f"physical core of socket {sock}; oracle index = the ends of those contigs ({len(ox)} keys, "
+                     f"host RAM); the GPU mapped the same reads against the whole index: "
+                     f"{'identical' if parity else 'DIFFERENT'}"}
+    return out, parity
+
+
+def end_to_end(wl, dev, local, n_batches=8, pairs=2_000_000):
+    """packed batches start in pinned HOST memory; per batch H2D (codes, N mask, offsets,
+    lengths, class, pair_ok, barcode ids) -> gate / map / pair rule -> D2H (pair results), double-buffered
+    on two streams.  The PCIe-inclusive rate, never `value`."""
+    host = []
+    windows = 0
+    for b in range(2):
+        s = wl.steps[b % len(wl.steps)]
+        r = s.reads
+        n = min(pairs, s.n_pairs)
+        w = int(r.word_off[2 * n].item())
+        host.append({nm: t.cpu().pin_memory() for nm, t in
+                     dict(codes=r.codes[: w + 4], nmask=r.nmask[: w + 4], woff=r.word_off[: 2 * n + 1],
+                          lens=r.lens[: 2 * n], cls=r.read_class[: 2 * n], ok=s.pair_ok[:n],
+                          bid=s.barcode_id[:n]).items()})
+        windows = int(torch.clamp(r.lens[: 2 * n].to(torch.int64) - (wl.k - 1), min=0).sum().item())
+    pairs = host[0]["ok"].numel()
+    if host[1]["ok"].numel() != pairs:
+        host[1] = host[0]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    dbuf = [{nm: torch.empty_like(t, device=dev) for nm, t in host[0].items()} for _ in range(2)]
+    outs = [torch.empty(pairs, dtype=torch.int32).pin_memory() for _ in range(2)]
+    steps = []
+    for s in range(2):
+        d = dbuf[s]
+        reads = arcs_amd.PackedReads(d["codes"], d["nmask"], d["woff"], d["lens"], d["cls"], local)
+        steps.append(arcs_amd.PairStep(wl.index, reads, wl.j, pair_ok=d["ok"], barcode_id=d["bid"]))
+    bytes_in = sum(t.numel() * t.element_size() for t in host[0].values())
+    done = [None, None]          # the index's work queues take one map call at a time
+
+    def run(nb):
+        for b in range(nb):
+            s = b & 1
+            with torch.cuda.stream(streams[s]):
+                for nm, t in host[s].items():
+                    dbuf[s][nm].copy_(t, non_blocking=True)
+                if done[s ^ 1] is not None:
+                    streams[s].wait_event(done[s ^ 1])
+                steps[s].run()
+                done[s] = torch.cuda.Event()
+                done[s].record(streams[s])
+                outs[s].copy_(steps[s].pair[:pairs], non_blocking=True)
+        torch.cuda.synchronize(dev)
+
+    run(2)
+    t0 = time.perf_counter()
+    run(n_batches)
+    dt = time.perf_counter() - t0
+    return {"value": n_batches * windows / dt, "unit": "k-mers/s",
+            "h2d_GBps": n_batches * bytes_in / dt / 1e9, "ms_per_batch": 1e3 * dt / n_batches,
+            "what": f"{n_batches} packed batches of {pairs} pairs from pinned host memory: H2D {bytes_in / 1e6:.0f} MB "
+                    f"+ gate/map/pairs + D2H of the pair results per batch, two streams"}
 
 
 def main():
@@ -92,11 +308,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=20_000_000, help="read pairs per GPU")
-    ap.add_argument("--draft-mbp", type=float, default=50.0)
+    ap.add_argument("--pairs", type=int, default=500_000_000, help="read pairs (per GPU; in total with --strong)")
+    ap.add_argument("--chunk", type=int, default=20_000_000, help="read pairs per launch")
+    ap.add_argument("--draft-mbp", type=float, default=3000.0)
     ap.add_argument("--k", type=int, default=60)
     ap.add_argument("--j", type=float, default=0.55)
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: split the --pairs read pairs over the ranks (fixed total work) instead of giving "
+                         "every rank its own --pairs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] line and the end-to-end figure")
     ap.add_argument("--sharded-index", action="store_true",
                     help="BASELINE configs[3]: rank r holds shard r of the index, every rank maps the SAME "
                          "batch, one all-reduce(MAX) of the per-read votes per step (default: index replicas, "
@@ -125,113 +346,147 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    assert arcs_amd.device_count() >= 1, "libarks_hip sees no gfx950 device (no CPU fallback)"
-    k, j = args.k, args.j
-
-    # ---- draft + index replica -----------------------------------------------------------------
-    t0 = time.time()
-    contigs = synth.make_draft(int(args.draft_mbp * 1e6), seed=synth.SEED)
-    cs = synth.contigs_to_strings(contigs)
-    ends = arcs_amd.contig_ends(cs)
-    log(f"draft: {len(contigs)} contigs, {sum(map(len, cs))} bp, {len(ends)} ends in {time.time() - t0:.1f}s")
-    t0 = time.time()
-    if args.sharded_index:
-        index = arcs_amd.ArksIndex.build_shard(ends, k, rank, world, device=local)
-    else:
-        index = arcs_amd.ArksIndex.build(ends, k, device=local, want_stats=(rank == 0))
-    log(f"index: {len(index)} keys, {index.device_bytes / 2**30:.2f} GiB, built in {time.time() - t0:.1f}s "
-        f"{index.build_stats}")
-
-    # ---- reads, resident in HBM before the timed region ------------------------------------------
-    t0 = time.time()
-    batch = synth.make_read_pairs(contigs, args.pairs, seed=synth.SEED + 1 + (0 if args.sharded_index else rank),
-                                  device=dev)
-    reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
-    windows = reads.windows(k)
-    bases = int(batch["lens"].to(torch.int64).sum().item())
-    log(f"reads: {args.pairs} pairs, {windows} windows, packed in {time.time() - t0:.1f}s")
-    b_alg = alg_bytes_per_window(k, bases, windows)
-
-    stats = torch.zeros(8, dtype=torch.int64, device=dev)
-    stored = torch.zeros(1, dtype=torch.int64, device=dev)
-    n_barcodes = int(batch["barcode_id"].max().item()) + 1
-    imap = arcs_amd.ImapAccumulator(max(1 << 16, 8 * n_barcodes), device=local)
-    if args.sharded_index:
-        from arcs_amd.dist import ShardedPairStep
-        step = ShardedPairStep(index, reads, j, pair_ok=batch["pair_ok"], barcode_id=batch["barcode_id"], imap=imap)
-    else:
-        step = arcs_amd.PairStep(index, reads, j, pair_ok=batch["pair_ok"], barcode_id=batch["barcode_id"],
-                                 imap=imap)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step.run()
-    # one instrumented pass for the counters (outside the timed region)
-    step.run(stats=None if args.sharded_index else stats, stored=stored)
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step.run(map_events=ev[s])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    map_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    assert arcs_amd.device_count() >= 1, "libarks_hip sees no gfx950 device (no CPU fallback)"
+    k, j = args.k, args.j
+    if args.sharded_index:
+        return sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier)
+
+    if args.strong and world > 1:
+        from arcs_amd.dist import shard_pairs
+        lo, hi = shard_pairs(args.pairs, rank, world)
+        my_pairs = hi - lo
+    else:
+        my_pairs = args.pairs
+    cpu_leg = (not args.no_cpu_baseline) and world == 1
+    wl = Workload(args.draft_mbp, my_pairs, args.chunk, k, j, dev, local, rank, 1000 * rank, log,
+                  want_stats=(rank == 0), keep_draft=cpu_leg)
+    elapsed, launch_ms, st, stored = wl.timed(args.steps, args.warmup, barrier)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    win = torch.tensor([float(windows)], dtype=torch.float64, device=red_dev)
+    win = torch.tensor([float(st["windows"])], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        if not args.sharded_index:      # sharded index: every rank worked on the same windows
-            dist.all_reduce(win, op=dist.ReduceOp.SUM)
-    elapsed_max, windows_all = float(el.item()), float(win.item())
-    value = windows_all * args.steps / elapsed_max
+        dist.all_reduce(win, op=dist.ReduceOp.SUM)
+    elapsed_max, windows_job = float(el.item()), float(win.item())
+    # the unit (Arcs.cpp:959-962): windows of the reads that reach bestContig
+    value = windows_job * args.steps / elapsed_max
 
     if rank == 0:
-        st = dict(zip(("total_valid", "bad", "found", "recorded", "dups", "reads_pass", "reads_fail",
-                       "windows"), stats.cpu().tolist()))
-        assert st["windows"] <= windows
-        achieved = windows * b_alg / (map_ms * 1e-3) / 1e9
-        traffic = pmc_traffic(args)
+        assert st["windows"] <= wl.windows_all
+        b_alg = alg_bytes_per_window(k, wl.bases, wl.windows_all)
+        n_launch = len(wl.steps)
+        kernel_ms = float(np.mean(launch_ms))                     # mean launch of the map stage
+        win_per_launch = st["windows"] / n_launch
+        achieved = win_per_launch * b_alg / (kernel_ms * 1e-3) / 1e9
+        workload = {"draft_mbp": args.draft_mbp, "pairs_per_launch": min(args.chunk, my_pairs), "k": k}
+        traffic = pmc_traffic(workload)
+        scaling = "strong" if (args.strong and world > 1) else "weak"
         out = {
             "metric": METRIC, "value": value, "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps,
-            "higher_is_better": True, "scaling": "strong" if args.sharded_index else "weak",
+            "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": f"synthetic {args.draft_mbp:g} Mbp draft + {args.pairs} linked-read "
-                                   f"pairs per GPU (R1 128 / R2 151 bp), k={k} j={j}",
-                       "k": k, "j": j, "pairs_per_gpu": args.pairs, "windows_per_gpu": windows,
-                       "index_keys": len(index),
-                       "index_kind": "locality (text + minimizer table)" if index.kind == 1 else "hash table",
-                       "index_bytes": index.device_bytes,
-                       "parallelism": (f"index sharded x{world} (contigs dealt to the lightest shard), reads replicated, "
-                                       "all-reduce(MAX) of votes") if args.sharded_index
-                       else f"index replica x{world}, reads sharded"},
+            "config": {"workload": f"synthetic {args.draft_mbp:g} Mbp draft + {args.pairs} linked-read pairs "
+                                   f"{'in total' if scaling == 'strong' else 'per GPU'} (R1 128 / R2 151 bp), "
+                                   f"k={k} j={j}, resident in HBM, mapped in launches of {min(args.chunk, my_pairs)} pairs"
+                                   + (" [BASELINE configs[2]]" if args.draft_mbp == 3000 and args.pairs == 500_000_000 else ""),
+                       "k": k, "j": j, "pairs_per_gpu": my_pairs, "launches_per_step": n_launch,
+                       "windows_per_gpu": st["windows"], "windows_incl_gated_reads": wl.windows_all,
+                       "index_keys": len(wl.index),
+                       "index_kind": "locality (text + minimizer table)" if wl.index.kind == 1 else "hash table",
+                       "index_bytes": wl.index.device_bytes,
+                       "parallelism": f"index replica x{world}, reads sharded"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic["hbm_bytes_per_launch"] / 1e9) if traffic else None,
                          "traffic_unit": "GB per launch (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE)",
                          "traffic_source": traffic["source"] if traffic else None,
-                         "alg_bytes_per_launch_GB": windows * b_alg / 1e9,
-                         "kernel": "map_reads_b_kernel" if index.kind == 1 else "map_reads_kernel",
-                         "kernel_ms": map_ms, "alg_bytes_per_window": b_alg},
-            "counters": st, "stored_pairs": int(stored.item()),
+                         "kernel_build_id": kernel_build_id(),
+                         "alg_bytes_per_launch_GB": win_per_launch * b_alg / 1e9,
+                         "kernel": "map_reads_b_kernel" if wl.index.kind == 1 else "map_reads_kernel",
+                         "kernel_ms": kernel_ms, "launches_timed": len(launch_ms),
+                         "alg_bytes_per_window": b_alg},
+            "counters": st, "stored_pairs": stored,
         }
-        if not args.no_cpu_baseline and world == 1:
-            cb, (n, c, p, cst) = cpu_baseline(cs, batch, k, j, args.pairs, log)
+        if cpu_leg:
+            cb, parity = cpu_baseline(wl, dev, local, log)
             out["cpu_baseline"] = cb
-            # parity guard on the sample: the GPU results of the same pairs must be identical
-            got_c = step.conreci[: 2 * n].cpu().numpy()
-            got_p = step.pair[:n].cpu().numpy()
-            out["sample_parity"] = bool((got_c == c).all() and (got_p == p).all())
-            assert out["sample_parity"], "GPU results differ from the CPU oracle on the sample"
-            out["gpu_over_cpu"] = value / cb["value"]
+            out["sample_parity"] = parity
+            out["gpu_over_cpu_socket"] = value / cb["value"]
+            out["gpu_over_cpu_t1"] = value / cb["t1"]["value"]
+        if world == 1 and not args.no_extras:
+            out["end_to_end"] = end_to_end(wl, dev, local)
+            del wl
+            torch.cuda.empty_cache()
+            # BASELINE configs[1] (last round's headline), same build, same box
+            c2 = Workload(50.0, 20_000_000, 20_000_000, k, j, dev, local, 0, 0, log, want_stats=False)
+            e2, l2, s2, _ = c2.timed(args.steps, args.warmup, barrier)
+            b2 = alg_bytes_per_window(k, c2.bases, c2.windows_all)
+            out["configs1"] = {"workload": "synthetic 50 Mbp draft + 20000000 linked-read pairs, k=60 j=0.55",
+                               "value": s2["windows"] * args.steps / e2, "unit": "k-mers/s",
+                               "kernel_ms": float(np.mean(l2)),
+                               "frac": s2["windows"] * b2 / (float(np.mean(l2)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         print(json.dumps(out), flush=True)
+        if cpu_leg:
+            assert out["sample_parity"], "GPU results differ from the CPU oracle on the sample"
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
+    """BASELINE configs[3] (kept from round 1): see DESIGN.md 6"""
+    import torch.distributed as dist
+    from arcs_amd.dist import ShardedPairStep
+    k, j = args.k, args.j
+    pairs = min(args.pairs, args.chunk)
+    contigs = synth.make_draft(int(args.draft_mbp * 1e6), seed=synth.SEED)
+    ends = []
+    for c in contigs:
+        cut = arcs_amd.end_cutoff(len(c))
+        if cut is not None:
+            ends.append(c[:cut].tobytes())
+            ends.append(c[len(c) - cut:].tobytes())
+    index = arcs_amd.ArksIndex.build_shard(ends, k, rank, world, device=local)
+    del ends
+    batch = synth.make_read_pairs(contigs, pairs, seed=synth.SEED + 1, device=dev)
+    reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
+    windows = reads.windows(k)
+    bases = int(batch["lens"].to(torch.int64).sum().item())
+    imap = arcs_amd.ImapAccumulator(max(1 << 16, 8 * (int(batch["barcode_id"].max().item()) + 1)), device=local)
+    step = ShardedPairStep(index, reads, j, pair_ok=batch["pair_ok"], barcode_id=batch["barcode_id"], imap=imap)
+    for _ in range(args.warmup):
+        step.run()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step.run(map_events=ev[s])
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if rank == 0:
+        map_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        b_alg = alg_bytes_per_window(k, bases, windows)
+        achieved = windows * b_alg / (map_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": METRIC, "value": windows * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.draft_mbp:g} Mbp draft + {pairs} linked-read pairs (R1 128 / R2 151 bp), "
+                                   f"k={k} j={j}", "k": k, "j": j, "index_keys_this_shard": len(index),
+                       "parallelism": f"index sharded x{world} (contigs dealt to the lightest shard), reads replicated, "
+                                      "all-reduce(MAX) of votes"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "map_reads_b_kernel",
+                         "kernel_ms": map_ms, "alg_bytes_per_window": b_alg}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -47,8 +47,8 @@ extern "C" {
 #define ARKS_ERR_HIP 4          /* a HIP runtime call / kernel launch failed (arks_last_error_string) */
 #define ARKS_ERR_NO_DEVICE 5    /* no usable gfx950 device: the product has no CPU fallback */
 #define ARKS_ERR_BAD_ARG 6      /* NULL pointer, negative count, ... */
-#define ARKS_ERR_RESERVED_7 7      /* (unused) */
-#define ARKS_ERR_FULL 8         /* accumulator table full */
+/* 7 was never assigned */
+#define ARKS_ERR_FULL 8         /* an accumulator insert found no slot (the growth rule excludes it: a bug) */
 
 #define ARKS_MAX_K 96
 
@@ -255,13 +255,27 @@ int arks_map_reads(
 /* ---- pairs and the IndexMap ------------------------------------------------------------------ */
 
 /* Device accumulator for `IndexMap imap` (Arcs/Arcs.h:108-113) as (barcode id, conreci) -> count;
- * the caller keeps the barcode string <-> id dictionary. */
+ * the caller keeps the barcode string <-> id dictionary.  `capacity_entries` is a starting size only:
+ * the table grows (arks_pairs_device rebuilds it larger before a launch could fill it beyond one half;
+ * that is the one place where the call waits for the device), so no input can overflow it.
+ * Calls that use one accumulator must be ordered with respect to each other, like the map calls of
+ * one index. */
 typedef struct arks_imap arks_imap;
 int arks_imap_create(arks_imap** out, int64_t capacity_entries, int device);
 int arks_imap_free(arks_imap* m);
+/* number of distinct (barcode id, conreci) entries, negative status on error; waits for the device */
 int64_t arks_imap_size(const arks_imap* m);
 /* h_triples = size * 3 uint32 (barcode id, conreci, count), sorted by (barcode id, conreci). */
 int arks_imap_export(const arks_imap* m, uint32_t* h_triples);
+/* The same plus, per triple, the sequence number of the FIRST stored pair that created the entry:
+ * pair p of a batch has number base + p, where base is what arks_imap_set_pair_base set before the
+ * batch's arks_pairs_device call (default: batches continue each other's numbering).  With numbers that
+ * follow the input order, sorting the barcodes by their smallest number gives the order in which
+ * chromiumRead's `imap[barcode][...]++` (Arcs.cpp:1282-1285) creates them in a single-threaded run --
+ * which decides the iteration order of the reference's unordered_map and so the vertex order of
+ * `.dist.gv` and the tie order of -D. */
+int arks_imap_set_pair_base(arks_imap* m, uint64_t first_pair);
+int arks_imap_export_ordered(const arks_imap* m, uint32_t* h_triples, uint64_t* h_first_pair);
 
 /* The gate of chromiumRead, Arcs/Arcs.cpp:1264-1268: d_eval[2p] = d_eval[2p+1] =
  * pair_ok[p] && class[2p] && class[2p+1]  (goodmult is always true, :1267). */

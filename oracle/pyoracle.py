@@ -183,6 +183,27 @@ class OracleIndex:
         return out_c, out_p, d
 
 
+def sub_draft_index(k, contigs, members, min_size=500, end_length=30000):
+    """OracleIndex over the ends of the contigs whose index is in `members` (contigs: uint8 arrays or
+    bytes, FASTA order), numbered as getContigKmers numbers them in the WHOLE draft (head of the n-th
+    valid contig = 2n-1, tail = 2n): what a human-scale index is checked against when the whole map
+    (1.4 G keys) is out of a test's reach -- see arcs_amd.synth.closed_contig_set for which contigs a
+    set of reads needs."""
+    members = set(members)
+    ox = OracleIndex(k)
+    n = 0
+    for ci, c in enumerate(contigs):
+        cut = end_cutoff(len(c), min_size, end_length)
+        if cut is None:
+            continue
+        n += 1
+        if ci in members:
+            b = c.tobytes() if hasattr(c, "tobytes") else bytes(c)
+            ox.map_kmers(b[:cut], 2 * n - 1)
+            ox.map_kmers(b[len(b) - cut:], 2 * n)
+    return ox
+
+
 # ------------------------------------------------------------------------------------------------
 # reference-encoder shim (this container only)
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,36 @@
+"""profiles/traffic_<round>.json from the FETCH_SIZE / WRITE_SIZE passes of profiles/prof.sh: HBM bytes per
+launch of the dominant kernel, stamped with the workload and the id of the kernel build the counters were
+taken on (bench.py reports `roofline.traffic` only when both match what it is running).
+usage: make_traffic.py <tag> [bench args of the profiled run...]"""
+import argparse, csv, json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+
+tag = sys.argv[1]
+ap = argparse.ArgumentParser()
+ap.add_argument("--pairs", type=int, default=500_000_000)
+ap.add_argument("--chunk", type=int, default=20_000_000)
+ap.add_argument("--draft-mbp", type=float, default=3000.0)
+ap.add_argument("--k", type=int, default=60)
+a, _ = ap.parse_known_args(sys.argv[2:])
+
+
+def mean_of(path, counter):
+    best = None
+    for r in csv.DictReader(open(path)):
+        if r["counter"] == counter and "map_reads_b_kernel" in r["kernel"] and "false, false" in r["kernel"]:
+            v = float(r["mean_per_dispatch"])
+            best = v if best is None else max(best, v)
+    return best
+
+
+f = mean_of(f"gpurun_out/{tag}_pmc_FETCH_SIZE.csv", "FETCH_SIZE")
+w = mean_of(f"gpurun_out/{tag}_pmc_WRITE_SIZE.csv", "WRITE_SIZE")
+out = {"workload": {"draft_mbp": a.draft_mbp, "pairs_per_launch": min(a.chunk, a.pairs), "k": a.k},
+       "kernel_build_id": bench.kernel_build_id(),
+       "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
+       "hbm_bytes_per_launch": (f + w) * 1024.0,
+       "note": "x1: random 8..64-byte gathers, not a wide coalesced stream (the guide's x2 applies to those)",
+       "source": f"profiles/{tag}_pmc_FETCH_SIZE.csv + {tag}_pmc_WRITE_SIZE.csv (rocprofv3 --pmc, separate passes)"}
+json.dump(out, open(f"gpurun_out/traffic_{tag.split('_')[0]}.json", "w"), indent=1)
+print(json.dumps(out))

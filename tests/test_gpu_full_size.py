@@ -1,6 +1,8 @@
 """Full-size checks (BASELINE configs[1]: 50 Mbp draft + 20 M pairs is the bench; here a 10 Mbp /
 2 M-pair cut of the same generator keeps the suite short) through size-independent properties of
 the path, plus an oracle comparison on a slice."""
+import os
+
 import numpy as np
 import pytest
 
@@ -67,3 +69,196 @@ def test_properties_at_scale(arks, gpu, oracle):
     assert ix.map_reads(strs[:2000], j).tolist() == want
     imap.close()
     ix.close()
+
+
+STAT_NAMES = ("total_valid", "bad", "found", "recorded", "dups", "reads_pass", "reads_fail", "windows")
+
+
+def _ends_of(arks, contigs, end_length=30000):
+    ends = []
+    for c in contigs:
+        cut = arks.end_cutoff(len(c), 500, end_length)
+        if cut is not None:
+            ends.append(c[:cut].tobytes())
+            ends.append(c[len(c) - cut:].tobytes())
+    return ends
+
+
+def _sub_draft(synth, contigs, dup_events, sub_mbp):
+    """(bases of the first contigs that make up sub_mbp, the contigs an oracle index for reads drawn
+    from them needs)"""
+    acc, n_first = 0, 0
+    while n_first < len(contigs) and acc < sub_mbp * 1e6:
+        acc += len(contigs[n_first])
+        n_first += 1
+    return acc, synth.closed_contig_set(n_first, dup_events)
+
+
+def _expected_ends(arks, contigs, touched, origin, r1_len=128, r2_len=151, frag=350, end_length=30000):
+    """for error-free pairs with known origin: the contig end (conreci) that holds R1 / R2 completely, or -1
+    where the mate is not wholly inside one end of a contig that no injection touched"""
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    starts = np.zeros(len(contigs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=starts[1:])
+    cut = np.array([arks.end_cutoff(int(n), 500, end_length) or 0 for n in lens], dtype=np.int64)
+    valid = cut > 0
+    rank = np.cumsum(valid)                      # 1-based rank among the contigs that have ends
+    plain = valid & ~np.isin(np.arange(len(contigs)), np.fromiter(touched, dtype=np.int64, count=len(touched)))
+    out = []
+    for lo, n in ((origin, r1_len), (origin + frag - r2_len, r2_len)):
+        ci = np.searchsorted(starts, lo, side="right") - 1
+        off = lo - starts[ci]
+        inside = off + n <= lens[ci]
+        head = inside & (off + n <= cut[ci])
+        tail = inside & (off >= lens[ci] - cut[ci])
+        e = np.where(head, 2 * rank[ci] - 1, np.where(tail, 2 * rank[ci], -1))   # head wins where both hold (L <= 2e)
+        out.append(np.where(plain[ci] & (head != tail), e, -1))
+    return out
+
+
+def test_human_scale_draft(arks, gpu, oracle):
+    """BASELINE configs[2]'s index -- 3 Gbp draft, 1.4 G keys -- built on the device, then (1) an oracle
+    comparison on 4 M pairs drawn from a sub-draft whose ends the CPU can index (conreci, pair rule, all
+    eight counters, IndexMap), (2) known answers for error-free reads of known origin all over the draft,
+    (3) the size-independent properties of the path."""
+    import torch
+    from arcs_amd import synth
+    k, j = 60, 0.55
+    dup_events, touched = [], set()
+    contigs = synth.make_draft(3_000_000_000, seed=synth.SEED, dup_events=dup_events, touched=touched)
+    ix = arks.ArksIndex.build(_ends_of(arks, contigs), k, device=gpu)
+    st = ix.build_stats
+    assert ix.kind == 1
+    assert st["recorded"] + st["collisions"] == st["total_kmers"] and len(ix) == st["recorded"]
+    assert st["unique"] <= st["recorded"] and st["removed_dup"] <= st["collisions"]
+    assert len(ix) > 1_400_000_000
+    genome = torch.from_numpy(np.concatenate(contigs)).cuda()
+
+    # (1) oracle on a sub-draft slice
+    acc, members = _sub_draft(synth, contigs, dup_events, 40.0)
+    ox = oracle.sub_draft_index(k, contigs, members)
+    n_pairs = 4_000_000
+    batch = synth.make_read_pairs(genome[:acc], n_pairs, seed=4242, device="cuda")
+    batch["pair_ok"][synth.pairs_touching_microsatellite(batch)] = 0
+    reads = arks.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=gpu)
+    stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+    imap = arks.ImapAccumulator(1 << 20, device=gpu)
+    conreci, pair = arks.map_pairs_packed(ix, reads, j, pair_ok=batch["pair_ok"], barcode_id=batch["barcode_id"],
+                                          imap=imap, stats=stats)
+    torch.cuda.synchronize()
+    ok = batch["pair_ok"].cpu().numpy()
+    a = np.concatenate([batch["ascii"].cpu().numpy(), np.zeros(1, np.uint8)])
+    want_c, want_p, want_st = ox.map_pairs(a, batch["offsets"].cpu().numpy().astype(np.uint64)[:-1],
+                                           batch["lens"].cpu().numpy().astype(np.uint32), j, pair_ok=ok,
+                                           threads=min(64, os.cpu_count() or 1))
+    assert (conreci.cpu().numpy() == want_c).all()
+    assert (pair.cpu().numpy() == want_p).all()
+    assert dict(zip(STAT_NAMES, stats.cpu().tolist())) == {f: want_st[f] for f in STAT_NAMES}
+    sel = (want_p != 0) & (ok != 0)
+    key = batch["barcode_id"].cpu().numpy().astype(np.int64)[sel] * (1 << 32) + want_p[sel]
+    uk, cnt = np.unique(key, return_counts=True)
+    t = imap.triples()
+    assert len(t) == len(uk) and (t[:, 0].astype(np.int64) * (1 << 32) + t[:, 1] == uk).all() and (t[:, 2] == cnt).all()
+    imap.close()
+    del batch, reads, a
+
+    # (2) error-free pairs from all over the draft: a mate wholly inside one end of an untouched contig is
+    # made of that end's k-mers only, every one of them unique in the draft -> count / total = 1 > j
+    batch = synth.make_read_pairs(genome, n_pairs, seed=4243, device="cuda", sub_rate=0.0, one_n_rate=0.0,
+                                  many_n_rate=0.0, unpaired_rate=0.0, want_origin=True)
+    reads = arks.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=gpu)
+    c = arks.map_reads_packed(ix, reads, j).cpu().numpy()
+    e1, e2 = _expected_ends(arks, contigs, touched, batch["origin"].cpu().numpy())
+    assert (e1 >= 0).sum() > n_pairs // 10 and (e2 >= 0).sum() > n_pairs // 10
+    assert (c[0::2][e1 >= 0] == e1[e1 >= 0]).all()
+    assert (c[1::2][e2 >= 0] == e2[e2 >= 0]).all()
+    # the conreci of any read is one of the (at most four) ends of the contigs its bases come from, or 0
+    assert c.max() <= 2 * sum(1 for x in contigs if len(x) >= 500)
+
+    # (3) properties on ordinary reads (errors, Ns, unpaired names)
+    batch = synth.make_read_pairs(genome, n_pairs, seed=4244, device="cuda")
+    reads = arks.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=gpu)
+    stats.zero_()
+    stored = torch.zeros(1, dtype=torch.int64, device="cuda")
+    imap = arks.ImapAccumulator(1 << 20, device=gpu)
+    conreci, pair = arks.map_pairs_packed(ix, reads, j, pair_ok=batch["pair_ok"], barcode_id=batch["barcode_id"],
+                                          imap=imap, stats=stats, stored=stored)
+    torch.cuda.synchronize()
+    s = dict(zip(STAT_NAMES, stats.cpu().tolist()))
+    assert s["total_valid"] + s["bad"] == s["windows"] and s["found"] == s["recorded"] + s["dups"]
+    c, p = conreci.cpu().numpy(), pair.cpu().numpy()
+    ok = batch["pair_ok"].cpu().numpy().astype(bool)
+    assert ((p != 0) == ((c[0::2] != 0) & (c[0::2] == c[1::2]))).all()
+    assert (c[0::2][~ok] == 0).all() and (c[1::2][~ok] == 0).all()
+    assert s["reads_pass"] == int((c != 0).sum()) and int(stored.item()) == int((p != 0).sum())
+    t = imap.triples()
+    assert int(t[:, 2].sum()) == int((p != 0).sum())
+    # strand symmetry: the reverse complement of a read names the same end (same multiset of canonical keys)
+    strs = synth.reads_to_strings({"ascii": batch["ascii"][: 279 * 5000], "offsets": batch["offsets"][:10001]})
+    comp = str.maketrans("ACGTN", "TGCAN")
+    assert ix.map_reads(strs, j).tolist() == ix.map_reads([x[::-1].translate(comp) for x in strs], j).tolist()
+    # order independence: the same reads in another order give the permuted result
+    perm = np.random.default_rng(1).permutation(len(strs))
+    assert ix.map_reads([strs[i] for i in perm], j).tolist() == ix.map_reads(strs, j)[perm].tolist()
+    imap.close()
+    ix.close()
+
+
+def test_beyond_one_index_in_shards(arks, gpu, oracle):
+    """A draft whose contig-end text exceeds what one locality index addresses (2^32 positions: 4.6 Gbp with
+    -e 120000, the ends cover every contig) mapped through two index shards (arks_index_build_shard,
+    arks_map_votes_device, arks_votes_max_device, arks_votes_resolve_device), compared with the oracle on
+    reads drawn from a sub-draft -- not with another sharding."""
+    import ctypes as C
+    import torch
+    from arcs_amd import synth
+    from arcs_amd._lib import check, lib
+    k, j, END = 60, 0.55, 120000
+    dup_events = []
+    contigs = synth.make_draft(4_600_000_000, seed=synth.SEED, dup_events=dup_events)
+    parts, lens = [], []
+    for c in contigs:
+        cut = arks.end_cutoff(len(c), 500, END)
+        if cut is None:
+            continue
+        parts += [c[:cut], c[len(c) - cut:]]
+        lens += [cut, cut]
+    lens = np.array(lens, dtype=np.uint32)
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    assert int(offs[-1]) > 2**32
+    data = np.concatenate(parts + [np.zeros(1, np.uint8)])
+    del parts
+    acc, members = _sub_draft(synth, contigs, dup_events, 30.0)
+    ox = oracle.sub_draft_index(k, contigs, members, end_length=END)
+    n_pairs = 2_000_000
+    n_sub = 0
+    while sum(len(c) for c in contigs[:n_sub]) < acc:
+        n_sub += 1
+    genome_sub = torch.from_numpy(np.concatenate(contigs[:n_sub])).cuda()
+    assert genome_sub.numel() == acc
+    batch = synth.make_read_pairs(genome_sub, n_pairs, seed=4343, device="cuda")
+    batch["pair_ok"][synth.pairs_touching_microsatellite(batch)] = 0
+    reads = arks.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=gpu)
+    ev = arks.pair_gate(reads, batch["pair_ok"])
+    votes = None
+    for s in range(2):
+        h = C.c_void_p()
+        check(lib().arks_index_build_shard(C.byref(h), k, data.ctypes.data, offs.ctypes.data, lens.ctypes.data,
+                                           len(lens), s, 2, gpu), "arks_index_build_shard")
+        sh = arks.ArksIndex(h, k, gpu, None)
+        assert sh.kind == 1
+        v = arks.map_votes_packed(sh, reads, eval_mask=ev)
+        votes = v.clone() if votes is None else arks.max_votes(votes, v)
+        torch.cuda.synchronize()
+        sh.close()
+    conreci = arks.resolve_votes(votes, reads, k, j)
+    pair = arks.pairs_rule(conreci, reads, batch["pair_ok"])
+    torch.cuda.synchronize()
+    a = np.concatenate([batch["ascii"].cpu().numpy(), np.zeros(1, np.uint8)])
+    want_c, want_p, _ = ox.map_pairs(a, batch["offsets"].cpu().numpy().astype(np.uint64)[:-1],
+                                     batch["lens"].cpu().numpy().astype(np.uint32), j,
+                                     pair_ok=batch["pair_ok"].cpu().numpy(), threads=min(64, os.cpu_count() or 1))
+    assert (conreci.cpu().numpy() == want_c).all()
+    assert (pair.cpu().numpy() == want_p).all()
+    assert int((want_p != 0).sum()) > n_pairs // 10
