@@ -466,7 +466,7 @@ template <int KW, int MM>
 __global__ void
 bmark_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ visited, u64 total_words, KeyGeom g,
-    TableView full, int w, u32* __restrict__ ambig, u32* __restrict__ is_min,
+    TableView full, int w, int dense, u32* __restrict__ ambig, u32* __restrict__ is_min,
     u32* __restrict__ is_pal, u32* __restrict__ is_img)
 {
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -492,6 +492,8 @@ bmark_kernel(
 		atomicOr(is_pal + word, bit);
 	else if (is_quirk_image(c, g))
 		atomicOr(is_img + word, bit);
+	if (dense)
+		return; // seed index: every m-mer position of a visited window is registered (bdilate_kernel)
 	typedef typename Mmer<MM>::type mm_t;
 	u32 min_h;
 	int off;
@@ -504,6 +506,47 @@ bmark_kernel(
 			atomicOr(is_min + (q >> 5), 1u << (31 - (u32)(q & 31)));
 		}
 	}
+}
+
+// out bit q = OR of the in bits q - w + 1 .. q (bit 31 of a word = its first position): the m-mer start
+// positions inside a visited window (seed index), one thread per 32-position word.  The text is
+// front-padded (kFrontPadWords), so the words before the first one read as zeros.
+__global__ void
+bdilate_kernel(const u32* __restrict__ in, u64 total_words, int w, u32* __restrict__ out)
+{
+	const u64 word = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (word >= total_words)
+		return;
+	// the 32 + w - 1 <= 127 positions that end with this word, as a 128-bit stream (position word*32 - 96 first)
+	u32 x[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+		x[j] = word + (u64)j >= 3 ? in[word + (u64)j - 3] : 0u;
+	u32 acc = 0;
+	for (int s = 0; s < w; ++s) {
+		// 32 bits from position word*32 - s on
+		const int first = 96 - s, wi = first >> 5, sh = first & 31;
+		acc |= sh ? ((x[wi] << sh) | (x[wi + 1] >> (32 - sh))) : x[wi];
+	}
+	out[word] = acc;
+}
+
+// bit of window pos = some position of [pos, pos + w) is set in `bits`
+__device__ __forceinline__ bool
+any_bit_in_span(const u32* __restrict__ bits, u64 pos, int w)
+{
+	u64 q = pos;
+	int left = w;
+	while (left > 0) {
+		const u32 sh = (u32)(q & 31);
+		const int take = left < 32 - (int)sh ? left : 32 - (int)sh;
+		const u32 m = (0xFFFFFFFFu >> sh) & (take + (int)sh == 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (sh + (u32)take)));
+		if (bits[q >> 5] & m)
+			return true;
+		q += (u64)take;
+		left -= take;
+	}
+	return false;
 }
 
 // ---- minimizer occurrence counts: open-addressed u64 key (canonical m-mer | 1 << 63) -> u32 counter
@@ -569,7 +612,7 @@ key_mmer(const Key<KW>& x, int o)
 template <int KW, int MM, int PHASE>
 __global__ void
 bforce_kernel(
-    const u64* __restrict__ codes, const u32* __restrict__ is_pal, u64 total_words, KeyGeom g, int w,
+    const u64* __restrict__ codes, const u32* __restrict__ is_pal, u64 total_words, KeyGeom g, int w, int dense,
     u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap)
 {
 	typedef typename Mmer<MM>::type mm_t;
@@ -590,7 +633,7 @@ bforce_kernel(
 	for (int o = 0; o < w; ++o) {
 		const mm_t mf = key_mmer<KW, MM>(x, o), mr = mmer_rc<MM>(mf);
 		const mm_t cm = mf < mr ? mf : mr;
-		if (mmer_order<MM>(cm) != min_h)
+		if (!dense && mmer_order<MM>(cm) != min_h) // seed index: a query may come through any m-mer of X'
 			continue;
 		u32* cnt = ctab_slot<MM>(ckeys, ccnts, ccap, cm, true);
 		if (PHASE == 0)
@@ -696,7 +739,7 @@ __global__ void
 bfallback_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ visited, const u32* __restrict__ ambig,
     const u32* __restrict__ is_pal, const u32* __restrict__ is_img, const u32* __restrict__ heavy_min,
-    const u32* __restrict__ word_owner, u64 total_words, KeyGeom g, int w, TableView fb,
+    const u32* __restrict__ word_owner, u64 total_words, KeyGeom g, int w, int dense, TableView fb,
     u64* __restrict__ counter)
 {
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -705,7 +748,9 @@ bfallback_kernel(
 	const u32 sh = 31 - (u32)(pos & 31);
 	if (word < total_words && ((visited[word] >> sh) & 1u)) {
 		take = ((is_pal[word] | is_img[word]) >> sh) & 1u;
-		if (!take) {
+		if (!take && dense) {
+			take = any_bit_in_span(heavy_min, pos, w); // a query may come through any m-mer of the window
+		} else if (!take) {
 			typedef typename Mmer<MM>::type mm_t;
 			u32 min_h;
 			int off;
@@ -900,16 +945,20 @@ launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner,
 hipError_t
 launch_bmark(
     int kw, int mm, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,
-    int w, u32* ambig, u32* is_min, u32* is_pal, u32* is_img, hipStream_t st)
+    int w, bool dense, u32* ambig, u32* is_min, u32* is_pal, u32* is_img, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
 #define ARKS_CALL(KWV, MMV)                                                                        \
-	bmark_kernel<KWV, MMV><<<b, 256, 0, st>>>(codes, visited, total_words, g, full, w, ambig, is_min, is_pal, is_img)
+	bmark_kernel<KWV, MMV><<<b, 256, 0, st>>>(codes, visited, total_words, g, full, w, dense ? 1 : 0, ambig, is_min, is_pal, is_img)
 	ARKS_KM_DISPATCH(kw, mm, ARKS_CALL);
 #undef ARKS_CALL
 	ARKS_LAUNCH_CHECK();
+	if (dense) {
+		bdilate_kernel<<<blocks_for(total_words, 256), 256, 0, st>>>(visited, total_words, w, is_min);
+		ARKS_LAUNCH_CHECK();
+	}
 	return hipSuccess;
 }
 
@@ -930,15 +979,15 @@ launch_bcount(int mm, const u64* codes, const u32* is_min, u64 total_words, u64*
 hipError_t
 launch_bforce(
     int kw, int mm, int phase, const u64* codes, const u32* is_pal, u64 total_words, const KeyGeom& g, int w,
-    u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st)
+    bool dense, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
 #define ARKS_CALL0(KWV, MMV)                                                                       \
-	bforce_kernel<KWV, MMV, 0><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)
+	bforce_kernel<KWV, MMV, 0><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, dense ? 1 : 0, ckeys, ccnts, ccap, mtab, mcap)
 #define ARKS_CALL1(KWV, MMV)                                                                       \
-	bforce_kernel<KWV, MMV, 1><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, ckeys, ccnts, ccap, mtab, mcap)
+	bforce_kernel<KWV, MMV, 1><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, dense ? 1 : 0, ckeys, ccnts, ccap, mtab, mcap)
 	if (phase == 0)
 		ARKS_KM_DISPATCH(kw, mm, ARKS_CALL0);
 	else
@@ -969,17 +1018,17 @@ hipError_t
 launch_bfallback(
     int kw, int mm, bool insert, const u64* codes, const u32* visited, const u32* ambig, const u32* is_pal,
     const u32* is_img, const u32* heavy_min, const u32* word_owner, u64 total_words, const KeyGeom& g,
-    int w, TableView fb, u64* counter, hipStream_t st)
+    int w, bool dense, TableView fb, u64* counter, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
 #define ARKS_FB_T(KWV, MMV)                                                                        \
 	bfallback_kernel<KWV, MMV, true><<<b, 256, 0, st>>>(                                           \
-	    codes, visited, ambig, is_pal, is_img, heavy_min, word_owner, total_words, g, w, fb, counter)
+	    codes, visited, ambig, is_pal, is_img, heavy_min, word_owner, total_words, g, w, dense ? 1 : 0, fb, counter)
 #define ARKS_FB_F(KWV, MMV)                                                                        \
 	bfallback_kernel<KWV, MMV, false><<<b, 256, 0, st>>>(                                          \
-	    codes, visited, ambig, is_pal, is_img, heavy_min, word_owner, total_words, g, w, fb, counter)
+	    codes, visited, ambig, is_pal, is_img, heavy_min, word_owner, total_words, g, w, dense ? 1 : 0, fb, counter)
 	if (insert)
 		ARKS_KM_DISPATCH(kw, mm, ARKS_FB_T);
 	else

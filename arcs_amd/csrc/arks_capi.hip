@@ -10,6 +10,11 @@
 #ifndef ARKS_MTAB_LOAD_INV
 #define ARKS_MTAB_LOAD_INV 6
 #endif
+// the same for the seed index, whose table holds every m-mer position of the text (8 B per slot:
+// 32 B per text position at 4) and is probed by far fewer lanes per tile
+#ifndef ARKS_SEED_LOAD_INV
+#define ARKS_SEED_LOAD_INV 4
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -406,6 +411,27 @@ want_locality(int k)
 	return k >= 20; // below that the minimizer window degenerates; the hash table serves
 }
 
+// Seed index (every m-mer position in the table, fixed-position seeds on the read side) or minimizer
+// index (minimizer positions only, ~20x smaller table, the read side computes its minimizers)?  The
+// seed index is the fast one; it is chosen when its table fits comfortably: ARKS_INDEX_KIND=minimizer /
+// =seeds force one or the other.
+static bool
+want_seeds(u64 text_positions, int device)
+{
+	const char* e = std::getenv("ARKS_INDEX_KIND");
+	if (e && std::strcmp(e, "minimizer") == 0)
+		return false;
+	if (e && std::strcmp(e, "seeds") == 0)
+		return true;
+	size_t free_b = 0, total_b = 0;
+	(void)device;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+		return false;
+	// the table (ARKS_SEED_LOAD_INV slots of 8 B per position) plus the count table of the build (24 B per
+	// position) within half of what is free now
+	return (double)text_positions * (8.0 * ARKS_SEED_LOAD_INV + 24.0) < 0.5 * (double)free_b;
+}
+
 /* Which shard holds which contig end (arks_shard_of_ends): the head and the tail of a contig (ends 2i and
  * 2i + 1, conreci 2i + 1 and 2i + 2, Arcs.cpp:1079-1081) stay together; contigs are dealt in list order,
  * each to the shard that holds the fewest bases so far (ties: the lowest shard) -- the shards differ by
@@ -560,7 +586,7 @@ index_build_impl(
 	u64 visited_total = 0, n_min = 0, n_pal = 0, n_fb = 0, ccap = 0, mcap = 0;
 	TableView full{ nullptr, 0 };
 	int mm = kMShort, w = 0;
-	bool locality = false;
+	bool locality = false, dense = false;
 	size_t bm_bytes = 0;
 
 	{
@@ -692,7 +718,10 @@ index_build_impl(
 		idx->codes = nullptr;
 		idx->visited = nullptr;
 	} else {
-		idx->kind = 1;
+		// (decided here, with the exact table of the build -- 64 B per visited window -- still allocated: what
+		// is free now is a lower bound of what the index may use)
+		dense = want_seeds(visited_total + (u64)w * (u64)n_ends, device);
+		idx->kind = dense ? 2 : 1;
 		{
 			void* p = nullptr;
 			HIP_TRY(hipMalloc(&p, bm_bytes));
@@ -712,7 +741,7 @@ index_build_impl(
 		HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
 		HIP_TRY(hipMemcpyAsync(idx->word_owner, d_wown.p, bm_bytes, hipMemcpyDeviceToDevice, st));
 		HIP_TRY(launch_bmark(
-		    idx->kw, mm, idx->codes, idx->visited, text_words, idx->geom, full, w, idx->ambig,
+		    idx->kw, mm, idx->codes, idx->visited, text_words, idx->geom, full, w, dense, idx->ambig,
 		    d_ismin.as<u32>(), d_ispal.as<u32>(), d_isimg.as<u32>(), st));
 	ARKS_TRACE_STEP("launch_bmark");
 		HIP_TRY(launch_popcount(d_ismin.as<u32>(), text_words, d_counters.as<u64>() + 0, st));
@@ -729,7 +758,7 @@ index_build_impl(
 		(void)hipFree(d_full.p);
 		d_full.p = nullptr;
 		ccap = 2 * (n_min + 4 * n_pal) + 64;
-		mcap = (ARKS_MTAB_LOAD_INV * (n_min + 4 * n_pal) + 64 + 3) & ~3ull; // whole groups of 4 (mtab_home)
+		mcap = ((u64)(dense ? ARKS_SEED_LOAD_INV : ARKS_MTAB_LOAD_INV) * (n_min + 4 * n_pal) + 64 + 3) & ~3ull; // whole groups of 4 (mtab_home)
 		HIP_TRY(d_ckeys.alloc(sizeof(u64) * ccap));
 		HIP_TRY(d_ccnts.alloc(sizeof(u32) * ccap));
 		{
@@ -743,7 +772,7 @@ index_build_impl(
 		HIP_TRY(launch_bcount(mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap, st));
 	ARKS_TRACE_STEP("launch_bcount");
 		HIP_TRY(launch_bforce(
-		    idx->kw, mm, 0, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, d_ckeys.as<u64>(),
+		    idx->kw, mm, 0, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense, d_ckeys.as<u64>(),
 		    d_ccnts.as<u32>(), ccap, idx->mtab, mcap, st));
 	ARKS_TRACE_STEP("launch_bforce");
 		HIP_TRY(launch_bfill_mtab(
@@ -751,13 +780,13 @@ index_build_impl(
 		    idx->mtab, mcap, d_heavy.as<u32>(), st));
 	ARKS_TRACE_STEP("launch_bfill_mtab");
 		HIP_TRY(launch_bforce(
-		    idx->kw, mm, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, d_ckeys.as<u64>(),
+		    idx->kw, mm, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense, d_ckeys.as<u64>(),
 		    d_ccnts.as<u32>(), ccap, idx->mtab, mcap, st));
 	ARKS_TRACE_STEP("launch_bforce");
 		HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
 		HIP_TRY(launch_bfallback(
 		    idx->kw, mm, false, idx->codes, idx->visited, idx->ambig, d_ispal.as<u32>(), d_isimg.as<u32>(),
-		    d_heavy.as<u32>(), idx->word_owner, text_words, idx->geom, w, idx->table,
+		    d_heavy.as<u32>(), idx->word_owner, text_words, idx->geom, w, dense, idx->table,
 		    d_counters.as<u64>(), st));
 	ARKS_TRACE_STEP("launch_bfallback");
 		HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
@@ -772,7 +801,7 @@ index_build_impl(
 		HIP_TRY(hipMemsetAsync(idx->table.slots, 0, idx->table.cap * kSlotWords * sizeof(u64), st));
 		HIP_TRY(launch_bfallback(
 		    idx->kw, mm, true, idx->codes, idx->visited, idx->ambig, d_ispal.as<u32>(), d_isimg.as<u32>(),
-		    d_heavy.as<u32>(), idx->word_owner, text_words, idx->geom, w, idx->table,
+		    d_heavy.as<u32>(), idx->word_owner, text_words, idx->geom, w, dense, idx->table,
 		    d_counters.as<u64>(), st));
 	ARKS_TRACE_STEP("launch_bfallback");
 		HIP_TRY(hipStreamSynchronize(st));
@@ -788,6 +817,7 @@ index_build_impl(
 		idx->bx.m = mm;
 		idx->bx.w = w;
 		idx->bx.enabled = 1;
+		idx->bx.dense = dense ? 1 : 0;
 	}
 	{
 		void* p = nullptr;
@@ -887,7 +917,7 @@ arks_index_device_bytes(const arks_index* idx)
 	if (!idx)
 		return 0;
 	int64_t b = (int64_t)(idx->table.cap * kSlotWords * sizeof(u64)) + idx->queue_cap * (int64_t)sizeof(u32);
-	if (idx->kind == 1)
+	if (idx->kind >= 1)
 		b += (int64_t)(idx->alloc_words * (sizeof(u64) + 3 * sizeof(u32))) + (int64_t)(idx->bx.mtab_cap * sizeof(u64));
 	return b;
 }

@@ -397,6 +397,9 @@ struct BIndexView
 	int w;       // minimizer window: k - m + 1
 	int enabled; // 0 => the plain hash table `TableView` is the index (small k)
 	int has_img; // the index holds regular keys that are quirk images (a palindromic query could hit them)
+	int dense;   // 1: the table holds EVERY m-mer position inside a visited window ("seed index"): a query
+	             // window may be looked up through any m-mer it contains, so a read needs one fixed-position
+	             // seed per w windows and no minimizers at all; 0: minimizer positions only
 };
 
 // the m-mer starting at base `pos` of a packed stream, right-aligned in 2*MM bits
@@ -521,8 +524,9 @@ bindex_lookup_serial(
 {
 	typedef typename Mmer<MM>::type mm_t;
 	u32 min_h;
-	int off;
-	window_minimizer<MM>(codes, pos, bx.w, min_h, off);
+	int off = 0; // seed index: any m-mer of the window will do, the first one is as good as any
+	if (!bx.dense)
+		window_minimizer<MM>(codes, pos, bx.w, min_h, off);
 	const mm_t mf = mmer_fw<MM>(codes, pos + (u64)off);
 	const mm_t mr = mmer_rc<MM>(mf);
 	const mm_t cm = mf < mr ? mf : mr;

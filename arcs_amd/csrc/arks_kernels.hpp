@@ -33,19 +33,19 @@ hipError_t launch_map_reads(
 hipError_t launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner, hipStream_t st);
 hipError_t launch_bmark(
     int kw, int mm, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,
-    int w, u32* ambig, u32* is_min, u32* is_pal, u32* is_img, hipStream_t st);
+    int w, bool dense, u32* ambig, u32* is_min, u32* is_pal, u32* is_img, hipStream_t st);
 hipError_t launch_bcount(
     int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, hipStream_t st);
 hipError_t launch_bforce(
     int kw, int mm, int phase, const u64* codes, const u32* is_pal, u64 total_words, const KeyGeom& g, int w,
-    u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st);
+    bool dense, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st);
 hipError_t launch_bfill_mtab(
     int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab,
     u64 mcap, u32* heavy_min, hipStream_t st);
 hipError_t launch_bfallback(
     int kw, int mm, bool insert, const u64* codes, const u32* visited, const u32* ambig, const u32* is_pal,
     const u32* is_img, const u32* heavy_min, const u32* word_owner, u64 total_words, const KeyGeom& g,
-    int w, TableView fb, u64* counter, hipStream_t st);
+    int w, bool dense, TableView fb, u64* counter, hipStream_t st);
 hipError_t launch_bexport(
     int kw, const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner,
     u64 total_words, const KeyGeom& g, u64* out_keys, int* out_vals, u64* counter, hipStream_t st);

@@ -3,6 +3,9 @@
 // (barcode, contig end) accumulation.  Reference behaviour restated, never its code.
 #include "arks_kernels.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace arks {
 
 // ------------------------------------------------------------------------------------------------
@@ -384,6 +387,7 @@ struct TileLds
 	u32 town_f[FULL ? 2 * (kTW + kTR + 2) : 1];
 	u32 mm32_f[FULL ? 2 * (kTW + 8) : 1]; // mismatch bit per base along the diagonals
 	unsigned char sread[kTW + kTR + 2];
+	int hbase[FULL ? kTR : 1]; // seed index, medium kernel: first seed (head) of every read
 	u32 redo;
 	u32 redo2; // reads that need the general verification (hot instantiation only)
 	u64 wstats[8]; // hot instantiation: this wave's arks_map_stats counters (registers are scarce there)
@@ -641,6 +645,14 @@ word_match(
 		own = 0xFFFFFFFFu;
 }
 
+// does one of the `len` (<= 32) bases from tile position q on hold an invalid character?
+__device__ __forceinline__ bool
+tile_span_has_n(const u32* nm, int q, int len)
+{
+	const u64 two = ((u64)nm[q >> 5] << 32) | (u64)nm[(q >> 5) + 1];
+	return ((two << (q & 31)) >> (64 - len)) != 0;
+}
+
 // ---- T2: order values of the 8 positions a lane owns (tile positions i0 .. i0 + 7, all in one packed
 //      word, i.e. one read).  The 8 + MM - 1 <= 32 bases their m-mers span are ONE funnel shift of two
 //      staged words; every forward m-mer is a shift + mask of that register pair, every reverse
@@ -736,7 +748,14 @@ tile_sliding_min(u32* pre_lds, u32* blk_lds, int l0, int lane, int w, const u32 
 	}
 }
 
-template <int KW, bool STATS, bool FULL, int MM, bool RAW = false>
+// DENSE = true: the seed index (BIndexView::dense).  Every m-mer position of the text is in the table, so
+//                a window may be looked up through ANY m-mer it contains: the windows of a read are cut
+//                into groups of w = k - MM + 1 consecutive ones, the m-mer at the start of a group's last
+//                window lies inside every window of the group and is the group's seed (its "run head").
+//                No order values, no sliding minimum, no run detection (T2-T4 -- 44 % of the minimizer
+//                kernel's time); 2-3 probes per 10x read instead of 5-6.  Exact for the same reason: a
+//                window that is in the index brings its seed's text position into the seed's entry list.
+template <int KW, bool STATS, bool FULL, int MM, bool RAW = false, bool DENSE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FULL ? 4 : ARKS_TILE_WAVES)))
 map_reads_b_kernel(
     const u64* __restrict__ codes,
@@ -855,7 +874,9 @@ map_reads_b_kernel(
 			// first pass: reads [cur, mid) within kSW words; second pass: [mid, nxt) likewise
 			// short sliding windows mean many runs per base: keep the tile's expected run count
 			// (64 / (w + 1) per word) within kNH by capping its words (never below one read)
-			const u64 wcap = (u64)(7 * (w + 1) / 4 < kTW ? 7 * (w + 1) / 4 : kTW);
+			// (seed index: one head per w windows and one more per read -- 7 w / 2 words stay within kNH)
+			const u64 wcap = DENSE ? (u64)(7 * w / 2 < kTW ? 7 * w / 2 : kTW)
+			                       : (u64)(7 * (w + 1) / 4 < kTW ? 7 * (w + 1) / 4 : kTW);
 			const u64 fit = __ballot(
 			    lane > cur && lane <= nchunk && wo - base_w <= (u64)kSW && lane - cur <= kTR &&
 			    (lane == cur + 1 || wo - base_w <= wcap));
@@ -940,8 +961,101 @@ map_reads_b_kernel(
 			u32* const rmax = dst + 192; // [kTR][2]
 			static_assert(kTR * 2 <= 32, "per-read counters");
 			int nheads = 0;
+			if (DENSE) {
+				// ---- seeds: lane j = read j: groups of w windows, one seed each (the m-mer at the start of the
+				//      group's last window); heads are numbered read-major ---------------------------------
+				const u32 wrecip = (65536u + (u32)w - 1u) / (u32)w; // x / w == (x * wrecip) >> 16 for x < 65536 / w
+				int G = 0, nwin = 0, rs = 0;
+				if (lane < nr) {
+					nwin = S.rlen[lane] - k + 1; // a read that is not evaluated has rlen < 0
+					G = nwin > 0 ? (int)(((u32)(nwin + w - 1) * wrecip) >> 16) : 0;
+					rs = S.rstart[lane];
+				}
+				int incl = G;
+#define ARKS_ROW_ADD(v, ctrl) v += __builtin_amdgcn_update_dpp(0, (v), ctrl, 0xF, 0xF, true)
+				ARKS_ROW_ADD(incl, 0x111); // row_shr:1 (kTR <= 16 reads: one row)
+				ARKS_ROW_ADD(incl, 0x112);
+				ARKS_ROW_ADD(incl, 0x114);
+				ARKS_ROW_ADD(incl, 0x118);
+#undef ARKS_ROW_ADD
+				nheads = __builtin_amdgcn_readlane(incl, nr - 1);
+				const int hb = incl - G;
+				if (FULL && lane < nr)
+					S.hbase[lane] = hb;
+				for (int gi = 0; __ballot(gi < G) != 0; ++gi) {
+					if (gi < G && hb + gi < kNH) {
+						int q = (gi + 1) * w - 1;
+						q = q < nwin - 1 ? q : nwin - 1;
+						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)lane << 12));
+					}
+				}
+				if (FULL) {
+					// window records of the medium path: pending (seed position, seed strand, head)
+					for (int base = 0; base < n; base += 64) {
+						const int i = base + lane;
+						// (n is a multiple of 32, not of 64: positions beyond the tile see stale metadata)
+						const u32 wm = i < n ? S.wmeta[i >> 5] : 0u;
+						const int j = (int)(wm >> 16);
+						const int rem = (int)(wm & 0xFFFFu) - i;
+						const bool is_win = i < n && rem >= k;
+						bool bad = false;
+						if (has_n && is_win) {
+							const int tn = i & 31, e = tn + k;
+							u32 any = 0;
+#pragma unroll
+							for (int x = 0; x <= KW; ++x) {
+								int lo = tn - 32 * x, hi = e - 32 * x;
+								lo = lo < 0 ? 0 : lo;
+								hi = hi > 32 ? 32 : hi;
+								if (lo < hi)
+									any |= S.nm[(i >> 5) + x] & (0xFFFFFFFFu >> lo) & ~(hi == 32 ? 0u : (0xFFFFFFFFu >> hi));
+							}
+							bad = any != 0;
+						}
+						int rv = is_win ? -2 : -3;
+						if (is_win && !bad) {
+							const int p = i - S.rstart[j];
+							const int nw = S.rlen[j] - k + 1;
+							const int gi = (int)(((u32)p * wrecip) >> 16);
+							int qr = (gi + 1) * w - 1;
+							qr = qr < nw - 1 ? qr : nw - 1;
+							const int q = S.rstart[j] + qr;
+							const int hidx = S.hbase[j] + gi;
+							const typename Mmer<MM>::type mf = tile_mmer<MM>(S.cw, q);
+							const u32 strand = mf < mmer_rc<MM>(mf) ? 1u : 0u;
+							rv = -16 - (int)((u32)q | (strand << 11) | ((u32)hidx << 12));
+							if (bx.has_img && !(k & 1)) { // see the minimizer path below: a necessary condition
+								const int qm = 2 * i + (k - MM) - q;
+								if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, q))
+									atomicOr(&S.redo, 1u << j);
+							}
+						}
+						reinterpret_cast<int*>(S.b)[i] = rv;
+					}
+				} else if (bx.has_img && !(k & 1)) {
+					// a reverse-complement palindrome carries its seed twice, mirrored about its centre: necessary
+					// condition for a palindromic window (the slow kernel decides exactly), only looked for when
+					// the index holds quirk images
+					for (int base = 0; base < n; base += 64) {
+						const int i = base + lane;
+						const u32 wm = i < n ? S.wmeta[i >> 5] : 0u;
+						const int j = (int)(wm >> 16);
+						if (i < n && (int)(wm & 0xFFFFu) - i >= k) {
+							const int p = i - S.rstart[j];
+							const int nw = S.rlen[j] - k + 1;
+							const int gi = (int)(((u32)p * wrecip) >> 16);
+							int qr = (gi + 1) * w - 1;
+							qr = qr < nw - 1 ? qr : nw - 1;
+							const int q = S.rstart[j] + qr;
+							const int qm = 2 * i + (k - MM) - q;
+							if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, q))
+								atomicOr(&S.redo, 1u << j);
+						}
+					}
+				}
+			}
 			// ---- T2 .. T4 once per pass of <= kSW words; the medium kernel's single read is one pass ---------
-			const int npass = (FULL || tw0 == tw) ? 1 : 2;
+			const int npass = DENSE ? 0 : ((FULL || tw0 == tw) ? 1 : 2);
 			for (int ps = 0; ps < npass; ++ps) {
 				// ---- T2 / T3: lane l owns the 8 positions 8l .. 8l+7 of the pass (16 words = 512 positions) -------
 				const int l0 = lane * 8;                      // index into the pass-local minimum arrays
@@ -1004,10 +1118,10 @@ map_reads_b_kernel(
 					ARKS_WAVE_SYNC();
 					for (int base = 0; base < n; base += 64) {
 						const int i = base + lane;
-						const u32 wm = S.wmeta[i >> 5];
+						const u32 wm = i < n ? S.wmeta[i >> 5] : 0u; // n is a multiple of 32, not of 64
 						const int j = (int)(wm >> 16);
 						const int rem = (int)(wm & 0xFFFFu) - i;
-						const bool is_win = rem >= k;
+						const bool is_win = i < n && rem >= k;
 						bool bad = false;
 						if (has_n && is_win) {
 							const int tn = i & 31, e = tn + k;
@@ -1061,8 +1175,19 @@ map_reads_b_kernel(
 			const int nh = nheads < kNH ? nheads : kNH;
 			for (int h = lane; h < nh; h += 64) {
 				const u32 q = ((u32)S.heads[h] >> 1) & 2047u;
-				const u32 cnt = probe_minimizer_table<MM>(bx, tile_canonical_mmer<MM>(S.cw, (int)q), hc[h]);
-				S.hn[h] = (unsigned char)cnt;
+				if (DENSE) {
+					// the seed's strand is decided here; a seed that holds an invalid base has no entries (every
+					// window of its group holds that base too: all NULL)
+					const typename Mmer<MM>::type mf = tile_mmer<MM>(S.cw, (int)q), mr = mmer_rc<MM>(mf);
+					u32 cnt = 0;
+					if (!(has_n && tile_span_has_n(S.nm, (int)q, MM)))
+						cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, hc[h]);
+					S.heads[h] = (unsigned short)(S.heads[h] | (mf < mr ? 1u : 0u));
+					S.hn[h] = (unsigned char)cnt;
+				} else {
+					const u32 cnt = probe_minimizer_table<MM>(bx, tile_canonical_mmer<MM>(S.cw, (int)q), hc[h]);
+					S.hn[h] = (unsigned char)cnt;
+				}
 			}
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(5);
@@ -1597,6 +1722,17 @@ launch_map_reads(
 	const u64 cap = (u64)(n_cu > 0 ? n_cu : 256) * 8ull;
 	const unsigned b = (unsigned)(want < cap ? want : cap);
 	const unsigned bs = (unsigned)(want < 256 ? want : 256); // slow path: the queue is short
+	static const bool dbg_sync = std::getenv("ARKS_DEBUG_SYNC") != nullptr;
+#define ARKS_DEBUG_STAGE(name)                                                                     \
+	do {                                                                                           \
+		if (dbg_sync) {                                                                            \
+			std::fprintf(stderr, "[arks] map stage %s launched (dense %d stats %d)\n", name, bx.dense, stats != nullptr); \
+			std::fflush(stderr);                                                                   \
+			hipError_t de_ = hipStreamSynchronize(st);                                             \
+			std::fprintf(stderr, "[arks] map stage %s: %s\n", name, hipGetErrorString(de_));       \
+			std::fflush(stderr);                                                                   \
+		}                                                                                          \
+	} while (0)
 #define ARKS_MAP_HASH(KWV, ST, RAWV)                                                               \
 	do {                                                                                           \
 		map_reads_kernel<KWV, ST, true, false, kMShort, RAWV><<<b, 256, 0, st>>>(                  \
@@ -1606,31 +1742,39 @@ launch_map_reads(
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, t, bx, out, stats, queue,     \
 		    queue_count);                                                                          \
 	} while (0)
-#define ARKS_MAP_B(KWV, ST, MMV, RAWV)                                                             \
+#define ARKS_MAP_B(KWV, ST, MMV, RAWV, DN)                                                         \
 	do {                                                                                           \
 		int per_cu = 0;                                                                            \
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                          \
-		        &per_cu, map_reads_b_kernel<KWV, ST, false, MMV, RAWV>, 64, 0) != hipSuccess ||    \
+		        &per_cu, map_reads_b_kernel<KWV, ST, false, MMV, RAWV, DN>, 64, 0) != hipSuccess ||\
 		    per_cu <= 0)                                                                           \
 			per_cu = 8;                                                                            \
 		const u64 res = (u64)(n_cu > 0 ? n_cu : 256) * (u64)per_cu;                                \
 		const u64 wantw = ((u64)n_reads + 3) / 4;                                                  \
 		const unsigned bb = (unsigned)(wantw < res ? wantw : res);                                 \
-		map_reads_b_kernel<KWV, ST, false, MMV, RAWV><<<bb, 64, 0, st>>>(                          \
+		map_reads_b_kernel<KWV, ST, false, MMV, RAWV, DN><<<bb, 64, 0, st>>>(                      \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue + n_reads, queue_count);                                                         \
-		map_reads_b_kernel<KWV, ST, true, MMV, RAWV><<<bb, 64, 0, st>>>(                           \
+		ARKS_DEBUG_STAGE("hot");                                                                   \
+		map_reads_b_kernel<KWV, ST, true, MMV, RAWV, DN><<<bb, 64, 0, st>>>(                       \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue + n_reads, queue_count);                                                         \
+		ARKS_DEBUG_STAGE("medium");                                                                \
 		map_reads_kernel<KWV, ST, false, true, MMV, RAWV><<<bs, 256, 0, st>>>(                     \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, t, bx, out, stats, queue,     \
 		    queue_count);                                                                          \
+		ARKS_DEBUG_STAGE("slow");                                                                  \
+	} while (0)
+#define ARKS_MAP_B_DN(KWV, ST, MMV, RAWV)                                                          \
+	do {                                                                                           \
+		if (bx.dense) ARKS_MAP_B(KWV, ST, MMV, RAWV, true);                                        \
+		else ARKS_MAP_B(KWV, ST, MMV, RAWV, false);                                                \
 	} while (0)
 #define ARKS_MAP_B_ST(KWV, MMV)                                                                    \
 	do {                                                                                           \
-		if (raw) ARKS_MAP_B(KWV, false, MMV, true);                                                \
-		else if (stats) ARKS_MAP_B(KWV, true, MMV, false);                                         \
-		else ARKS_MAP_B(KWV, false, MMV, false);                                                   \
+		if (raw) ARKS_MAP_B_DN(KWV, false, MMV, true);                                             \
+		else if (stats) ARKS_MAP_B_DN(KWV, true, MMV, false);                                      \
+		else ARKS_MAP_B_DN(KWV, false, MMV, false);                                                \
 	} while (0)
 #define ARKS_MAP_HASH_ST(KWV)                                                                      \
 	do {                                                                                           \
@@ -1650,6 +1794,7 @@ launch_map_reads(
 #undef ARKS_MAP_HASH_ST
 #undef ARKS_MAP_HASH
 #undef ARKS_MAP_B
+#undef ARKS_MAP_B_DN
 #undef ARKS_MAP_B_ST
 	if (user_stats)
 		fold_stats_kernel<<<1, 64, 0, st>>>(stats, user_stats);

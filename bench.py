@@ -399,7 +399,8 @@ def main():
                        "k": k, "j": j, "pairs_per_gpu": my_pairs, "launches_per_step": n_launch,
                        "windows_per_gpu": st["windows"], "windows_incl_gated_reads": wl.windows_all,
                        "index_keys": len(wl.index),
-                       "index_kind": "locality (text + minimizer table)" if wl.index.kind == 1 else "hash table",
+                       "index_kind": {0: "hash table", 1: "locality (text + minimizer table)",
+                                      2: "locality (text + seed table: every m-mer position)"}[wl.index.kind],
                        "index_bytes": wl.index.device_bytes,
                        "parallelism": f"index replica x{world}, reads sharded"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -409,7 +410,7 @@ def main():
                          "traffic_source": traffic["source"] if traffic else None,
                          "kernel_build_id": kernel_build_id(),
                          "alg_bytes_per_launch_GB": win_per_launch * b_alg / 1e9,
-                         "kernel": "map_reads_b_kernel" if wl.index.kind == 1 else "map_reads_kernel",
+                         "kernel": "map_reads_b_kernel" if wl.index.kind >= 1 else "map_reads_kernel",
                          "kernel_ms": kernel_ms, "launches_timed": len(launch_ms),
                          "alg_bytes_per_window": b_alg},
             "counters": st, "stored_pairs": stored,

@@ -139,8 +139,12 @@ int64_t arks_index_size(const arks_index* idx);
 /* device bytes held by the index */
 int64_t arks_index_device_bytes(const arks_index* idx);
 /* layout of the index: 0 = exact open-addressed hash table of packed keys (k < 20, or when the
- * environment says ARKS_INDEX_KIND=hash), 1 = locality index (packed contig-end text + minimizer
- * table + exact fallback table).  Results are identical, only the traffic differs. */
+ * environment says ARKS_INDEX_KIND=hash); 1 = locality index over MINIMIZERS (packed contig-end text +
+ * table of the minimizer positions + exact fallback table; ARKS_INDEX_KIND=minimizer); 2 = locality
+ * index over SEEDS (the same text and fallback, but the table holds every m-mer position of the text --
+ * 32 B per text position -- so that the read side needs no minimizers, only one fixed-position seed per
+ * k - m + 1 windows; the default whenever the table fits in half of the free device memory;
+ * ARKS_INDEX_KIND=seeds).  DESIGN.md.  Results are identical, only speed and memory differ. */
 int arks_index_kind(const arks_index* idx);
 /* Copies every (key, value) to host: h_keys = size * arks_key_bytes(k) bytes in the reference's
  * byte order (what ReadsProcessor::getStr returns), h_vals = size int32.  Order unspecified. */

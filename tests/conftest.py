@@ -75,3 +75,11 @@ def gpu(arks):
     assert torch.cuda.is_available(), "gpu-marked test on a machine without a GPU"
     assert arks.device_count() >= 1, "no gfx950 device visible to libarks_hip"
     return 0
+
+
+@pytest.fixture(params=["seeds", "minimizer"])
+def index_layout(request, monkeypatch):
+    """both layouts of the locality index: the seed index (every m-mer position in the table, fixed seeds
+    on the read side; arks_index_kind 2) and the minimizer index (kind 1); results must be identical"""
+    monkeypatch.setenv("ARKS_INDEX_KIND", request.param)
+    return request.param

@@ -128,7 +128,7 @@ def test_human_scale_draft(arks, gpu, oracle):
     contigs = synth.make_draft(3_000_000_000, seed=synth.SEED, dup_events=dup_events, touched=touched)
     ix = arks.ArksIndex.build(_ends_of(arks, contigs), k, device=gpu)
     st = ix.build_stats
-    assert ix.kind == 1
+    assert ix.kind == 2          # the seed index: 46 GB of table at this size, chosen because it fits
     assert st["recorded"] + st["collisions"] == st["total_kmers"] and len(ix) == st["recorded"]
     assert st["unique"] <= st["recorded"] and st["removed_dup"] <= st["collisions"]
     assert len(ix) > 1_400_000_000
@@ -247,7 +247,7 @@ def test_beyond_one_index_in_shards(arks, gpu, oracle):
         check(lib().arks_index_build_shard(C.byref(h), k, data.ctypes.data, offs.ctypes.data, lens.ctypes.data,
                                            len(lens), s, 2, gpu), "arks_index_build_shard")
         sh = arks.ArksIndex(h, k, gpu, None)
-        assert sh.kind == 1
+        assert sh.kind in (1, 2)
         v = arks.map_votes_packed(sh, reads, eval_mask=ev)
         votes = v.clone() if votes is None else arks.max_votes(votes, v)
         torch.cuda.synchronize()

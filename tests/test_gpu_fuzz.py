@@ -8,7 +8,7 @@ also went through 2..5 index shards (FUZZ_SHARDS=1): votes, maximum, j_index tes
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("index_layout")]
 
 COMP = str.maketrans("ACGTacgtNn", "TGCAtgcaNn")
 def rc(s):

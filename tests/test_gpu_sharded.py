@@ -11,7 +11,7 @@ import pytest
 
 from util import index_digest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("index_layout")]
 
 
 def _rc(s):
