@@ -1652,6 +1652,450 @@ map_reads_b_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3s: the hot kernel of the SEED index (BIndexView::dense): bestContig for a batch, one wave per tile.
+//
+// With every m-mer position of the text in the table a read needs no minimizers: its windows are cut into
+// groups of w = k - MM + 1 consecutive ones and the m-mer at the start of a group's last window -- which
+// lies inside every window of the group -- is the group's seed.  What is left of the minimizer kernel is
+// its back half, and that is reorganised here around twice the tile: up to 64 packed words (14 10x reads)
+// per tile, lanes = words for ONE diagonal at a time (the second diagonal of a read -- a duplicated
+// segment, a chance seed hit -- is rare: its pass over the same lanes only runs for a tile that has one),
+// the seeds' entry lists stay in registers (lanes = seeds from the probe to the election of the
+// diagonals), and everything a tile needs per read is written by the lane that holds the read's chunk
+// metadata.  Per tile: one round trip for the read words, one for the seed probes, one for the text along
+// the diagonals; 8 waves per SIMD.  Reads the hot path cannot finish (a third diagonal, a heavy seed, more
+// than two entries, a match that spans two contig ends) go to the medium queue (map_reads_b_kernel<FULL,
+// DENSE>), palindromes next to quirk images and reads beyond a medium tile to the slow one.
+//   S0 tile = the next reads of the chunk that fit 64 words / 16 reads / 64 seeds (one ballot);
+//   S1 words -> LDS; per-read metadata, per-word metadata and the seeds by the reads' own lanes;
+//   S2 lanes = seeds: canonical m-mer, table probe (<= 2 entries), proposals of diagonals;
+//   S3 election of <= 2 diagonals per read (LDS atomic minima keyed by seed index), flags;
+//   S4 lanes = staging slots: text / visited / ambiguous / owner words of diagonal A (then B);
+//   S5 lanes = words: read XOR text -> mismatch bit per base; valid windows, k clear mismatch bits,
+//      visited, ambiguous -> popcounts into per-read counters;
+//   S6 lane = read: the vote of Arcs.cpp:996-1013.
+// ------------------------------------------------------------------------------------------------
+constexpr int sTW = 64;               // tile capacity in packed words (= lanes of S5)
+constexpr int sTR = 16;               // reads per tile
+constexpr int sNH = 64;               // seeds per tile (= lanes of S2)
+constexpr int sChunk = 56;            // reads per grab of the work counter: four tiles of 10x reads
+constexpr int sSlots = sTW + sTR + 2; // staging slots: one more than its words per read
+
+struct SeedTileLds
+{
+	u64 cw[sTW + 4];
+	u32 nm[sTW + 4];
+	u32 wmeta[sTW + 4]; // per word: read of the tile << 16 | local end position of that read (0 = not evaluated)
+	// text words along ONE diagonal per read (read j: slots from (rstart[j] >> 5) + j), mismatch bits per base
+	u64 tcodes[sSlots];
+	u32 tvis[sSlots];
+	u32 tamb[sSlots];
+	u32 town[sSlots];
+	u32 mm32[sTW + 8];
+	unsigned short heads[sNH]; // seeds: [11:1] tile position, [15:12] read of the tile
+	unsigned char sread[sSlots + 2];
+	int rstart[sTR + 1];
+	int rlen[sTR];
+	u64 pdiag[sTR][2];  // the read's two diagonals: [39:0] D, [40] same strand, [41] valid
+	u32 tfirst[sTR][2]; // first text word staged for read j on diagonal d
+	u32 rcnt[sTR][2];   // matched unambiguous windows | ambiguous ones << 10 | (d = 0: valid windows) << 20
+	u32 rmin[sTR][2];   // smallest / largest contig end among the former (they differ iff more than one)
+	u32 rmax[sTR][2];
+	u32 redo;  // reads for the slow queue
+	u32 redo2; // reads for the medium queue
+	u64 wstats[8];
+};
+
+template <int KW, bool STATS, int MM, bool RAW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
+map_reads_s_kernel(
+    const u64* __restrict__ codes,
+    const u32* __restrict__ nmask,
+    const u64* __restrict__ word_off,
+    const u32* __restrict__ lens,
+    const uint8_t* __restrict__ eval, // may be NULL
+    long n_reads,
+    double j_index,
+    KeyGeom g,
+    BIndexView bx,
+    int* __restrict__ out_conreci,
+    u64* __restrict__ stats,
+    u32* __restrict__ queue,       // slow queue
+    u32* __restrict__ mqueue,      // medium queue
+    u32* __restrict__ queue_count) // [0] slow length, [2] medium length; work counters behind (kWorkCtrOffset)
+{
+	typedef typename Mmer<MM>::type mm_t;
+	__shared__ SeedTileLds S;
+	constexpr u64 kDiagMask = (1ull << 42) - 1ull; // [39:0] D, [40] same strand, [41] valid
+	const int lane_id = threadIdx.x;
+	const int k = g.k, w = bx.w;
+	const u32 wrecip = (65536u + (u32)w - 1u) / (u32)w; // x / w == (x * wrecip) >> 16 for x < 65536 / w
+	if (STATS && lane_id < 8)
+		S.wstats[lane_id] = 0;
+	u32* const work_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kWorkCtrOffset);
+	u32 ctr = blockIdx.x & (u32)(kCounters - 1), misses = 0;
+	bool first_grab = true;
+	for (;;) {
+		// ---- the next chunk: the first one is the wave's own (its block index), later ones come from the
+		//      interleaved counters (see map_reads_b_kernel) -------------------------------------------
+		long c0;
+		if (first_grab) {
+			c0 = (long)blockIdx.x * sChunk;
+			first_grab = false;
+			if (c0 >= n_reads)
+				break;
+		} else {
+			u32 cnt = 0;
+			if (lane_id == 0)
+				cnt = atomicAdd(work_ctr + ctr * kCounterStride, 1u);
+			cnt = (u32)__builtin_amdgcn_readfirstlane((int)cnt);
+			c0 = ((long)gridDim.x + (long)ctr + (long)cnt * kCounters) * sChunk;
+			if (c0 >= n_reads) {
+				ctr = (ctr + 1u) & (u32)(kCounters - 1);
+				if (++misses == (u32)kCounters)
+					break;
+				continue;
+			}
+			misses = 0;
+		}
+		const int nchunk = (int)((c0 + sChunk < n_reads ? c0 + sChunk : n_reads) - c0);
+		// lane l holds read c0 + l: first word, length (-1 = not evaluated), seeds; lane nchunk the end offset
+		u64 wo = 0;
+		int rl = 0;
+		if (lane_id <= nchunk)
+			wo = word_off[c0 + lane_id];
+		if (lane_id < nchunk) {
+			rl = (int)lens[c0 + lane_id];
+			if (eval && !eval[c0 + lane_id])
+				rl = -1;
+		}
+		const int nwin_l = rl - k + 1;
+		const int G = nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
+		int gsum = G; // inclusive prefix over the lanes of the chunk
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const int o = __shfl_up(gsum, d);
+			gsum += lane_id >= d ? o : 0;
+		}
+		const int gex = gsum - G; // seeds of the chunk's reads before this one
+		const u64 wo_next = __shfl_down(wo, 1);
+		// reads beyond kSW words (512 bases) do not enter a tile: the per-read counters hold 10-bit fields
+		const u64 longmask = __ballot(lane_id < nchunk && wo_next - wo > (u64)kSW);
+		int cur = 0;
+		while (cur < nchunk) {
+			int lane = lane_id;
+			asm volatile("" : "+v"(lane));
+			// ---- S0: tile = reads [cur, nxt) ---------------------------------------------------------
+			const u64 base_w = lane_value_u64(wo, cur);
+			const int gbase = __builtin_amdgcn_readlane(gex, cur);
+			const u64 lm = longmask & (~0ull << cur);
+			const int limit = lm ? __ffsll((long long)lm) - 1 : 64; // the first long read from cur on
+			const u64 fit = __ballot(
+			    lane > cur && lane <= nchunk && lane <= limit && wo - base_w <= (u64)sTW && lane - cur <= sTR &&
+			    gex - gbase <= sNH);
+			if (fit == 0) { // a single read beyond the tile (or with more seeds than lanes): general kernels
+				if (lane == cur) {
+					if (rl < 0)
+						put_none<RAW>(out_conreci, c0 + cur);
+					else if (wo_next - wo <= (u64)kSW)
+						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)(c0 + cur);
+					else
+						queue[atomicAdd(queue_count, 1u)] = (u32)(c0 + cur);
+				}
+				cur++;
+				continue;
+			}
+			const int nxt = 63 - __clzll((long long)fit);
+			const int nr = nxt - cur;
+			const int tw = (int)(lane_value_u64(wo, nxt) - base_w);
+			const int nh = __builtin_amdgcn_readlane(gex, nxt) - gbase;
+			// ---- S1: words, metadata, seeds ----------------------------------------------------------
+			{
+				u64 c_in = 0, c_pad = 0;
+				u32 m_in = 0, m_pad = 0;
+				if (lane < tw) {
+					c_in = codes[base_w + (u64)lane];
+					m_in = nmask[base_w + (u64)lane];
+				}
+				if (lane < 4) { // the windows of the last words read past the tile
+					c_pad = codes[base_w + (u64)(tw + lane)];
+					m_pad = nmask[base_w + (u64)(tw + lane)];
+				}
+				if (lane >= cur && lane < nxt) {
+					const int j = lane - cur;
+					const int w0 = (int)(wo - base_w), w1 = (int)(wo_next - base_w);
+					const int rs = w0 * 32;
+					const int rend = rl > 0 ? rs + rl : 0;
+					S.rstart[j] = rs;
+					S.rlen[j] = rl;
+					if (lane == nxt - 1)
+						S.rstart[j + 1] = w1 * 32;
+					for (int x = w0; x < w1; ++x)
+						S.wmeta[x] = ((u32)j << 16) | (u32)rend;
+					for (int x = w0; x <= w1; ++x) // one staging slot more than the read has words
+						S.sread[x + j] = (unsigned char)j;
+					const int hb = gex - gbase;
+					for (int gi = 0; gi < G; ++gi) {
+						int q = (gi + 1) * w - 1;
+						q = q < nwin_l - 1 ? q : nwin_l - 1;
+						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)j << 12));
+					}
+					S.pdiag[j][0] = ~0ull;
+					S.pdiag[j][1] = ~0ull;
+					S.rcnt[j][0] = 0u, S.rcnt[j][1] = 0u;
+					S.rmin[j][0] = 0xFFFFFFFFu, S.rmin[j][1] = 0xFFFFFFFFu;
+					S.rmax[j][0] = 0u, S.rmax[j][1] = 0u;
+				}
+				if (lane == 0) {
+					S.redo = 0;
+					S.redo2 = 0;
+				}
+				asm volatile("" : "+v"(c_in), "+v"(m_in), "+v"(c_pad), "+v"(m_pad)); // all four loads in flight
+				if (lane < tw) {
+					S.cw[lane] = c_in;
+					S.nm[lane] = m_in;
+				}
+				if (lane < 4) {
+					S.cw[tw + lane] = c_pad;
+					S.nm[tw + lane] = m_pad;
+				}
+			}
+			ARKS_WAVE_SYNC();
+			const bool has_n = __ballot(lane < tw && S.nm[lane] != 0) != 0;
+			if (bx.has_img && !(k & 1)) {
+				// a reverse-complement palindrome carries its seed twice, mirrored about its centre: necessary
+				// condition for a palindromic window (the slow kernel decides exactly); only looked for when the
+				// index holds quirk images
+				const int n = tw * 32;
+				for (int base = 0; base < n; base += 64) {
+					const int i = base + lane;
+					const u32 wm = S.wmeta[i >> 5];
+					const int j = (int)(wm >> 16);
+					if ((int)(wm & 0xFFFFu) - i >= k) {
+						const int p = i - S.rstart[j];
+						const int nw = S.rlen[j] - k + 1;
+						const int gi = (int)(((u32)p * wrecip) >> 16);
+						int qr = (gi + 1) * w - 1;
+						qr = qr < nw - 1 ? qr : nw - 1;
+						const int q = S.rstart[j] + qr;
+						const int qm = 2 * i + (k - MM) - q;
+						if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, q))
+							atomicOr(&S.redo, 1u << j);
+					}
+				}
+			}
+			// ---- S2: lanes = seeds: probe, proposals (0 = none) of up to two diagonals -------------------
+			int jh = 0;
+			u64 dk0 = 0, dk1 = 0;
+			bool off = false;
+			if (lane < nh) {
+				const u32 hv = S.heads[lane];
+				const int q = (int)((hv >> 1) & 2047u);
+				jh = (int)(hv >> 12);
+				const mm_t mf = tile_mmer<MM>(S.cw, q), mr = mmer_rc<MM>(mf);
+				u64 ent[2];
+				u32 cnt = 0;
+				// a seed that holds an invalid base has no entries: every window of its group holds that base too
+				if (!(has_n && tile_span_has_n(S.nm, q, MM)))
+					cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, ent);
+				off = cnt == kHnHeavy || cnt == kHnOverflow;
+				if (cnt >= 1 && cnt <= 2) {
+					const int o = q - S.rstart[jh]; // offset of the seed in the read
+					const u32 rstrand = mf < mr ? 1u : 0u;
+					// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
+					const bool s0 = ((u32)(ent[0] >> 62) & 1u) == rstrand;
+					dk0 = (s0 ? (u64)(u32)ent[0] - (u64)o : (u64)(u32)ent[0] + (u64)(MM - 1 + o)) | ((u64)s0 << 40) |
+					      (1ull << 41);
+					if (cnt == 2) {
+						const bool s1 = ((u32)(ent[1] >> 62) & 1u) == rstrand;
+						dk1 = (s1 ? (u64)(u32)ent[1] - (u64)o : (u64)(u32)ent[1] + (u64)(MM - 1 + o)) |
+						      ((u64)s1 << 40) | (1ull << 41);
+					}
+				}
+			}
+			// ---- S3: A = entry 0 of the read's first seed that has entries, B = the first entry (in seed order)
+			//      on another diagonal; a seed that proposes a third one sends its read to the medium queue ------
+			if (dk0)
+				atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][0]),
+				          (unsigned long long)(((u64)lane << 42) | dk0));
+			ARKS_WAVE_SYNC();
+			if (dk0) {
+				const u64 dA = S.pdiag[jh][0] & kDiagMask;
+				if (dk0 != dA)
+					atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][1]),
+					          (unsigned long long)(((u64)lane << 43) | dk0));
+				else if (dk1 && dk1 != dA)
+					atomicMin(reinterpret_cast<unsigned long long*>(&S.pdiag[jh][1]),
+					          (unsigned long long)(((u64)lane << 43) | (1ull << 42) | dk1));
+			}
+			ARKS_WAVE_SYNC();
+			if (dk0) {
+				const u64 dA = S.pdiag[jh][0] & kDiagMask;
+				const u64 rb = S.pdiag[jh][1];
+				const u64 dB = rb == ~0ull ? 0ull : (rb & kDiagMask);
+				off = off || (dk0 != dA && dk0 != dB) || (dk1 && dk1 != dA && dk1 != dB);
+			}
+			if (off)
+				atomicOr(&S.redo2, 1u << jh);
+			ARKS_WAVE_SYNC();
+			bool has_b = false;
+			if (lane < nr) {
+				// strip the seed index; first text word of the span [lo, lo + L) the read covers
+#pragma unroll
+				for (int d = 0; d < 2; ++d) {
+					const u64 raw = S.pdiag[lane][d];
+					const u64 pdv = raw == ~0ull ? 0ull : (raw & kDiagMask);
+					S.pdiag[lane][d] = pdv;
+					const u64 Dv = pdv & 0xFFFFFFFFFFull;
+					const u64 lo = ((pdv >> 40) & 1ull) ? Dv : Dv - (u64)(S.rlen[lane] - 1);
+					S.tfirst[lane][d] = (u32)(lo >> 5);
+					has_b = d == 1 && pdv != 0;
+				}
+			}
+			const bool any_b = __ballot(has_b) != 0;
+			ARKS_WAVE_SYNC();
+			// ---- S4 / S5 per diagonal: A for every tile, B only for a tile that has one ---------------------
+			u32 ok_a = 0; // the word's windows matched on diagonal A (a window matched on both counts once, on A)
+			int jw = 0;
+			u32 valid = 0;
+			if (lane < tw) {
+				const u32 wm = S.wmeta[lane];
+				jw = (int)(wm >> 16);
+				// windows of the word that exist and hold no invalid base
+				valid = word_valid_windows(S.nm, lane, S.rlen[jw] - k + 1 - (lane * 32 - S.rstart[jw]), k, has_n);
+			}
+			for (int d = 0; d < (any_b ? 2 : 1); ++d) {
+				// S4: lanes = staging slots (one round trip: text, visited, ambiguous, owner words)
+				const int ns = tw + nr;
+				for (int sl = lane; sl < ns; sl += 64) {
+					const int j = S.sread[sl];
+					if (S.pdiag[j][d] >> 41) {
+						const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
+						S.tcodes[sl] = bx.codes[tw_idx];
+						S.tvis[sl] = bx.visited[tw_idx];
+						S.tamb[sl] = bx.ambig[tw_idx];
+						S.town[sl] = bx.word_owner[tw_idx];
+					}
+				}
+				if (lane < 8) // the spans of the last words read past the tile: no mismatch there
+					S.mm32[tw + lane] = 0u;
+				ARKS_WAVE_SYNC();
+				// S5a: lanes = words: XOR with the 32 text bases the word faces -> one mismatch bit per base
+				u64 pdv = 0;
+				if (lane < tw) {
+					pdv = S.pdiag[jw][d];
+					S.mm32[lane] = (pdv >> 41) ? word_mismatch_bits(S.cw[lane], pdv, S.tcodes, lane * 32 - S.rstart[jw],
+					                                                (S.rstart[jw] >> 5) + jw, S.tfirst[jw][d])
+					                           : 0u;
+				}
+				ARKS_WAVE_SYNC();
+				// S5b: lanes = words, one bit per window: k clear mismatch bits, visited, ambiguous
+				u32 ok = 0, amb = 0, own = 0;
+				if (lane < tw && (pdv >> 41) && valid)
+					word_match(pdv, S.mm32, S.tvis, S.tamb, S.town, lane, lane * 32 - S.rstart[jw], (S.rstart[jw] >> 5) + jw,
+					           S.tfirst[jw][d], k, valid, ok, amb, own);
+				if (d) {
+					ok &= ~ok_a;
+					amb &= ok;
+				} else
+					ok_a = ok;
+				const u32 recm = ok & ~amb;
+				const u32 pack = (u32)__popc(recm) | ((u32)__popc(amb) << 10) | (d ? 0u : ((u32)__popc(valid) << 20));
+				if (pack)
+					atomicAdd(&S.rcnt[jw][d], pack);
+				if (recm) {
+					atomicMin(&S.rmin[jw][d], own == 0xFFFFFFFFu ? 1u : own); // mixed word: min != max
+					atomicMax(&S.rmax[jw][d], own);
+				}
+				ARKS_WAVE_SYNC(); // the staging storage is rewritten by the next diagonal
+			}
+			// ---- S6: lane = read: at most two distinct positive values (one per diagonal): the vote of
+			//      Arcs.cpp:998-1004 is a compare ------------------------------------------------------------
+			const u32 redo_mask = S.redo, redo2_mask = S.redo2;
+			u32 st_a = 0, st_b = 0, st_c = 0;
+			if (lane < nr) {
+				const int j = lane;
+				const long r = c0 + cur + j;
+				const int L = S.rlen[j];
+				if (L < 0) {
+					put_none<RAW>(out_conreci, r);
+				} else if ((redo_mask >> j) & 1u) {
+					queue[atomicAdd(queue_count, 1u)] = (u32)r;
+				} else {
+					bool medium = (redo2_mask >> j) & 1u;
+					const u32 ca = S.rcnt[j][0], cb = S.rcnt[j][1];
+					const int rec_a = (int)(ca & 1023u), amb_a = (int)((ca >> 10) & 1023u);
+					const int rec_b = (int)(cb & 1023u), amb_b = (int)((cb >> 10) & 1023u);
+					const int nvalid = (int)(ca >> 20);
+					const u32 own_a = rec_a ? S.rmin[j][0] : 0u, own_b = rec_b ? S.rmin[j][1] : 0u;
+					// matches on one diagonal that belong to different contig ends: general path
+					medium = medium || (rec_a && S.rmax[j][0] != own_a) || (rec_b && S.rmax[j][1] != own_b);
+					if (medium) {
+						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)r;
+					} else {
+						int best = 0, best_cnt = 0;
+						if (rec_a > 0 && rec_b > 0 && own_a == own_b) {
+							best = (int)own_a;
+							best_cnt = rec_a + rec_b;
+						} else if (rec_a > rec_b || (rec_a == rec_b && own_a < own_b)) {
+							best = (int)own_a; // strict `>` of the reference walk: the smaller value keeps a tie
+							best_cnt = rec_a;
+						} else {
+							best = (int)own_b;
+							best_cnt = rec_b;
+						}
+						const int nwin = L - k + 1;
+						const int total = nwin > 0 ? nwin : 0;
+						const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
+						const bool pass = maxj > j_index;
+						put_result<RAW>(out_conreci, r, best, best_cnt, pass);
+						if (STATS) { // <= 16 reads: three words of 16-bit (8-bit) fields
+							st_a = (u32)nvalid | ((u32)total << 16);
+							st_b = (u32)(rec_a + amb_a + rec_b + amb_b) | ((u32)(rec_a + rec_b) << 16);
+							st_c = (u32)(amb_a + amb_b) | (pass ? 1u << 16 : 1u << 24);
+						}
+					}
+				}
+			}
+			if (STATS) {
+#define ARKS_ROW_ADD(v, ctrl) v += (u32)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, true)
+				ARKS_ROW_ADD(st_a, 0x111); ARKS_ROW_ADD(st_b, 0x111); ARKS_ROW_ADD(st_c, 0x111); // row_shr:1
+				ARKS_ROW_ADD(st_a, 0x112); ARKS_ROW_ADD(st_b, 0x112); ARKS_ROW_ADD(st_c, 0x112); // row_shr:2
+				ARKS_ROW_ADD(st_a, 0x114); ARKS_ROW_ADD(st_b, 0x114); ARKS_ROW_ADD(st_c, 0x114); // row_shr:4
+				ARKS_ROW_ADD(st_a, 0x118); ARKS_ROW_ADD(st_b, 0x118); ARKS_ROW_ADD(st_c, 0x118); // row_shr:8
+#undef ARKS_ROW_ADD
+				if (lane == 15) {
+					S.wstats[0] += st_a & 0xFFFFu;       // valid windows
+					S.wstats[7] += st_a >> 16;           // all windows (bad = all - valid)
+					S.wstats[2] += st_b & 0xFFFFu;       // found
+					S.wstats[3] += st_b >> 16;           // recorded
+					S.wstats[4] += st_c & 0xFFFFu;       // duplicate (value 0)
+					S.wstats[5] += (st_c >> 16) & 0xFFu; // reads passing
+					S.wstats[6] += st_c >> 24;           // reads failing
+				}
+			}
+			ARKS_WAVE_SYNC();
+			cur = nxt;
+		}
+	}
+	if (STATS) {
+		ARKS_WAVE_SYNC();
+		if (lane_id == 0) {
+			u64* row = stats + kStatRow * (blockIdx.x & (kStatRows - 1));
+			const u64 valid = S.wstats[0], all = S.wstats[7];
+			if (valid) atomicAdd(row + 0, valid);
+			if (all - valid) atomicAdd(row + 1, all - valid);
+			if (S.wstats[2]) atomicAdd(row + 2, S.wstats[2]);
+			if (S.wstats[3]) atomicAdd(row + 3, S.wstats[3]);
+			if (S.wstats[4]) atomicAdd(row + 4, S.wstats[4]);
+			if (S.wstats[5]) atomicAdd(row + 5, S.wstats[5]);
+			if (S.wstats[6]) atomicAdd(row + 6, S.wstats[6]);
+			if (all) atomicAdd(row + 7, all);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4: pair gate and pair rule of chromiumRead.
 // ------------------------------------------------------------------------------------------------
 __global__ void
@@ -1746,15 +2190,22 @@ launch_map_reads(
 	do {                                                                                           \
 		int per_cu = 0;                                                                            \
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(                                          \
-		        &per_cu, map_reads_b_kernel<KWV, ST, false, MMV, RAWV, DN>, 64, 0) != hipSuccess ||\
+		        &per_cu, map_reads_b_kernel<KWV, ST, false, MMV, RAWV, false>, 64, 0) != hipSuccess ||\
 		    per_cu <= 0)                                                                           \
 			per_cu = 8;                                                                            \
 		const u64 res = (u64)(n_cu > 0 ? n_cu : 256) * (u64)per_cu;                                \
 		const u64 wantw = ((u64)n_reads + 3) / 4;                                                  \
 		const unsigned bb = (unsigned)(wantw < res ? wantw : res);                                 \
-		map_reads_b_kernel<KWV, ST, false, MMV, RAWV, DN><<<bb, 64, 0, st>>>(                      \
-		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
-		    queue + n_reads, queue_count);                                                         \
+		if (DN) {                                                                                  \
+			const u64 wants = ((u64)n_reads + sChunk - 1) / sChunk;                                \
+			const u64 ress = (u64)(n_cu > 0 ? n_cu : 256) * 32ull; /* 5 KB of LDS, < 64 VGPRs: 8 waves per SIMD */ \
+			map_reads_s_kernel<KWV, ST, MMV, RAWV><<<(unsigned)(wants < ress ? wants : ress), 64, 0, st>>>( \
+			    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,    \
+			    queue + n_reads, queue_count);                                                     \
+		} else                                                                                     \
+			map_reads_b_kernel<KWV, ST, false, MMV, RAWV, false><<<bb, 64, 0, st>>>(               \
+			    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,    \
+			    queue + n_reads, queue_count);                                                     \
 		ARKS_DEBUG_STAGE("hot");                                                                   \
 		map_reads_b_kernel<KWV, ST, true, MMV, RAWV, DN><<<bb, 64, 0, st>>>(                       \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
