@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "lib", "libarks_hip.so")
+# ARKS_HIP_LIB: another build of the same library (A/B runs of kernel variants: profiles/tools/ab.py)
+_PATH = os.environ.get("ARKS_HIP_LIB") or os.path.join(_HERE, "lib", "libarks_hip.so")
 
 
 class ArksError(RuntimeError):
@@ -69,6 +70,7 @@ SYMBOLS = {
     "arks_imap_export": (_I, [_VP, _VP]),
     "arks_imap_set_pair_base": (_I, [_VP, C.c_uint64]),
     "arks_imap_export_ordered": (_I, [_VP, _VP, _VP]),
+    "arks_debug_queue_counts": (_I, [_VP, _VP]),
     "arks_pair_gate_device": (_I, [_VP, _VP, _I64, _VP, _I, _VP]),
     "arks_pairs_device": (_I, [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _I, _VP]),
 }

@@ -531,6 +531,20 @@ bdilate_kernel(const u32* __restrict__ in, u64 total_words, int w, u32* __restri
 	out[word] = acc;
 }
 
+// text records of the seed index: what the hot kernel stages per text word, side by side
+__global__ void
+btextrec_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ visited, const u32* __restrict__ ambig,
+    const u32* __restrict__ word_owner, u64 alloc_words, u64* __restrict__ trec)
+{
+	const u64 word = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (word >= alloc_words)
+		return;
+	trec[3 * word + 0] = codes[word];
+	trec[3 * word + 1] = (u64)visited[word] | ((u64)ambig[word] << 32);
+	trec[3 * word + 2] = (u64)word_owner[word];
+}
+
 // bit of window pos = some position of [pos, pos + w) is set in `bits`
 __device__ __forceinline__ bool
 any_bit_in_span(const u32* __restrict__ bits, u64 pos, int w)
@@ -1035,6 +1049,18 @@ launch_bfallback(
 		ARKS_KM_DISPATCH(kw, mm, ARKS_FB_F);
 #undef ARKS_FB_T
 #undef ARKS_FB_F
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_btextrec(
+    const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner, u64 alloc_words, u64* trec,
+    hipStream_t st)
+{
+	if (alloc_words == 0)
+		return hipSuccess;
+	btextrec_kernel<<<blocks_for(alloc_words, 256), 256, 0, st>>>(codes, visited, ambig, word_owner, alloc_words, trec);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

@@ -141,6 +141,7 @@ struct arks_index
 	u32* ambig = nullptr;
 	u32* word_owner = nullptr;
 	u64* mtab = nullptr;
+	u64* trec = nullptr; // seed index: text records (BIndexView::trec)
 	u64 text_words = 0;  // words of text incl. front padding (excl. back padding)
 	u64 alloc_words = 0;
 	int64_t n_keys = 0;
@@ -818,6 +819,15 @@ index_build_impl(
 		idx->bx.w = w;
 		idx->bx.enabled = 1;
 		idx->bx.dense = dense ? 1 : 0;
+		if (dense) {
+			void* p = nullptr;
+			HIP_TRY(hipMalloc(&p, 3 * sizeof(u64) * alloc_words));
+			idx->trec = static_cast<u64*>(p);
+			// (word_owner is 0 in the padding, visited / ambig too: a diagonal that runs off the text matches nothing)
+			HIP_TRY(launch_btextrec(idx->codes, idx->visited, idx->ambig, idx->word_owner, alloc_words, idx->trec, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			idx->bx.trec = idx->trec;
+		}
 	}
 	{
 		void* p = nullptr;
@@ -891,6 +901,8 @@ arks_index_free(arks_index* idx)
 		(void)hipFree(idx->word_owner);
 	if (idx->mtab)
 		(void)hipFree(idx->mtab);
+	if (idx->trec)
+		(void)hipFree(idx->trec);
 	if (idx->queue)
 		(void)hipFree(idx->queue);
 	if (idx->queue_count)
@@ -918,7 +930,8 @@ arks_index_device_bytes(const arks_index* idx)
 		return 0;
 	int64_t b = (int64_t)(idx->table.cap * kSlotWords * sizeof(u64)) + idx->queue_cap * (int64_t)sizeof(u32);
 	if (idx->kind >= 1)
-		b += (int64_t)(idx->alloc_words * (sizeof(u64) + 3 * sizeof(u32))) + (int64_t)(idx->bx.mtab_cap * sizeof(u64));
+		b += (int64_t)(idx->alloc_words * (sizeof(u64) + 3 * sizeof(u32))) + (int64_t)(idx->bx.mtab_cap * sizeof(u64)) +
+		     (idx->trec ? (int64_t)(idx->alloc_words * 3 * sizeof(u64)) : 0);
 	return b;
 }
 

@@ -46,6 +46,9 @@ hipError_t launch_bfallback(
     int kw, int mm, bool insert, const u64* codes, const u32* visited, const u32* ambig, const u32* is_pal,
     const u32* is_img, const u32* heavy_min, const u32* word_owner, u64 total_words, const KeyGeom& g,
     int w, bool dense, TableView fb, u64* counter, hipStream_t st);
+hipError_t launch_btextrec(
+    const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner, u64 alloc_words, u64* trec,
+    hipStream_t st);
 hipError_t launch_bexport(
     int kw, const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner,
     u64 total_words, const KeyGeom& g, u64* out_keys, int* out_vals, u64* counter, hipStream_t st);

@@ -534,8 +534,11 @@ probe_minimizer_table(const BIndexView& bx, typename Mmer<MM>::type cm, u64* ent
 				end = true;
 				continue;
 			}
-			if (cnt < 2)
-				entries[cnt] = e;
+			// (no dynamic index: `entries` may be a pair of registers)
+			if (cnt == 0)
+				entries[0] = e;
+			if (cnt == 1)
+				entries[1] = e;
 			cnt = cnt < 2 ? cnt + 1 : kHnOverflow;
 			if (cnt == kHnOverflow)
 				end = true;
@@ -1706,8 +1709,11 @@ struct SeedTileLds
 	u64 wstats[8];
 };
 
+#ifndef ARKS_SEED_WAVES
+#define ARKS_SEED_WAVES 8
+#endif
 template <int KW, bool STATS, int MM, bool RAW>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ARKS_SEED_WAVES)))
 map_reads_s_kernel(
     const u64* __restrict__ codes,
     const u32* __restrict__ nmask,
@@ -1971,10 +1977,12 @@ map_reads_s_kernel(
 					const int j = S.sread[sl];
 					if (S.pdiag[j][d] >> 41) {
 						const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
-						S.tcodes[sl] = bx.codes[tw_idx];
-						S.tvis[sl] = bx.visited[tw_idx];
-						S.tamb[sl] = bx.ambig[tw_idx];
-						S.town[sl] = bx.word_owner[tw_idx];
+						const u64* rec = bx.trec + 3 * tw_idx; // codes | visited, ambig | owner: one 24-byte record
+						const u64 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+						S.tcodes[sl] = r0;
+						S.tvis[sl] = (u32)r1;
+						S.tamb[sl] = (u32)(r1 >> 32);
+						S.town[sl] = (u32)r2;
 					}
 				}
 				if (lane < 8) // the spans of the last words read past the tile: no mismatch there
@@ -2198,7 +2206,7 @@ launch_map_reads(
 		const unsigned bb = (unsigned)(wantw < res ? wantw : res);                                 \
 		if (DN) {                                                                                  \
 			const u64 wants = ((u64)n_reads + sChunk - 1) / sChunk;                                \
-			const u64 ress = (u64)(n_cu > 0 ? n_cu : 256) * 32ull; /* 5 KB of LDS, < 64 VGPRs: 8 waves per SIMD */ \
+			const u64 ress = (u64)(n_cu > 0 ? n_cu : 256) * 4ull * ARKS_SEED_WAVES;                \
 			map_reads_s_kernel<KWV, ST, MMV, RAWV><<<(unsigned)(wants < ress ? wants : ress), 64, 0, st>>>( \
 			    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,    \
 			    queue + n_reads, queue_count);                                                     \

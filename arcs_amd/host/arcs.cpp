@@ -388,6 +388,11 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 			len.push_back((uint32_t)cut);
 			bases.append(rd.seq, rd.seq.length() - (size_t)cut, (size_t)cut);
 			valid++;
+			// mapKmers' warning for an end shorter than k (Arcs.cpp:877-882: unconditional, with the
+			// conreci, between the progress lines); with a k list it is printed per k further down
+			if (params.k_list.size() == 1 && cut < params.k_list[0])
+				for (size_t c = contigRecord.size() - 2; c < contigRecord.size(); ++c)
+					appendf(log, "Warning: ends of contig is shorter than k-value for contigID (no k-mers added): %zu\n", c);
 		} else
 			skipped++;
 		if (params.verbose && total % 1000 == 0)
@@ -425,8 +430,10 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 		if (params.verbose) {
 			if (params.k_list.size() > 1)
 				appendf(log, "k = %d:\n", k);
-			for (uint64_t i = 0; i < st.short_ends; ++i) // Arcs.cpp:877-882 prints one line per short end
-				log += "Warning: ends of contig is shorter than k-value (no k-mers added)\n";
+			if (params.k_list.size() > 1)
+				for (size_t e = 0; e < len.size(); ++e) // Arcs.cpp:877-882 prints one line per short end
+					if ((int)len[e] < k)
+						appendf(log, "Warning: ends of contig is shorter than k-value for contigID (no k-mers added): %zu\n", e + 1);
 			appendf(log, "%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n%s %u\n",
 			        "Total number of contigs in draft genome: ", (unsigned)total, "Total valid contigs: ", (unsigned)valid,
 			        "Total skipped contigs: ", (unsigned)skipped, "Total number of Kmers: ", (unsigned)st.total_kmers,
@@ -735,6 +742,12 @@ read_chroms(
 			       "%u\nSkipped reads pairs without a good contig: %u\n",
 			       (unsigned)stored[slot], (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
 			       (unsigned)(mc.gated - stored[slot]));
+			if (params.index_shards > 1)
+				// a key shared by ends of two shards reads 0 in both: the per-window counters of the shards
+				// do not add up to the reference's, so they are not collected (include/arks_hip.h)
+				appendf(out, "(index in %d shards: the k-mer counters of the read stage are not collected)\n",
+				        params.index_shards);
+			else
 			appendf(out, "Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
 			       "%u\nNumber of kmers recorded in Ktrack: %u\nNumber of kmers found in ContigKmap but "
 			       "duplicate: %u\nNumber of reads passing jaccard threshold: %u\nNumber of reads failing "

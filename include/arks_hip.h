@@ -306,6 +306,13 @@ int arks_pairs_device(
     int device,
     void* stream);
 
+/* ---- debugging aid --------------------------------------------------------------------------- */
+
+/* Lengths of the work queues after the last map call on `idx` (waits for the device): out4[0] = reads
+ * that took the slow kernel, out4[2] = reads that took the medium kernel ([1], [3]: their work
+ * counters).  For tests and profiling; results never depend on it. */
+int arks_debug_queue_counts(const arks_index* idx, unsigned* out4);
+
 #ifdef __cplusplus
 }
 #endif
