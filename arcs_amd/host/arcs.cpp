@@ -20,6 +20,8 @@
 
 #include <getopt.h>
 #include <hip/hip_runtime_api.h>
+#include <signal.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -55,6 +57,7 @@ struct Params
 	long batch_pairs = 262144; // --batch-pairs (this build only): read pairs per GPU batch
 	int index_shards = 1;      // --index-shards (this build only): the contig k-mer index in N parts
 	int device = 0;             // --device (this build only)
+	int ranks = 1;              // --ranks (this build only): one process per GPU, read files dealt to the ranks
 };
 
 Params params;
@@ -75,7 +78,8 @@ enum
 	OPT_ARKS_METHOD,
 	OPT_BATCH_PAIRS,
 	OPT_DEVICE,
-	OPT_INDEX_SHARDS
+	OPT_INDEX_SHARDS,
+	OPT_RANKS
 };
 
 const char shortopts[] = "f:a:B:s:c:Dl:z:b:g:m:d:e:r:vt:u:j:k:P";
@@ -116,6 +120,7 @@ const struct option longopts[] = {
 	{ "batch-pairs", required_argument, NULL, OPT_BATCH_PAIRS },
 	{ "device", required_argument, NULL, OPT_DEVICE },
 	{ "index-shards", required_argument, NULL, OPT_INDEX_SHARDS },
+	{ "ranks", required_argument, NULL, OPT_RANKS },
 	{ NULL, 0, NULL, 0 }
 };
 
@@ -154,6 +159,8 @@ const char USAGE[] =
             "       --samples_tsv=FILE  write intra-contig distance/barcode samples to FILE\n"
             "       --batch-pairs=N   read pairs per GPU batch [262144]\n"
             "       --index-shards=N  build and map the contig k-mer index in N parts (very large drafts) [1]\n"
+            "       --ranks=N         N processes, one per GPU (device, device + 1, ...): the read files are dealt to\n"
+            "                         them, rank 0 merges the results; outputs as with one process [1]\n"
             "       --device=N        GPU ordinal [0]\n";
 
 void
@@ -474,11 +481,14 @@ struct Mapper
 	arks_map_stats* d_stats = nullptr; // [n_k][n_files]
 	size_t n_files;
 
-	Mapper(const std::vector<arks_index*>& is, int64_t imap_capacity, size_t nfiles)
+	std::vector<size_t> global_file; // position of this rank's files in the command line (pair numbering)
+
+	Mapper(const std::vector<arks_index*>& is, int64_t imap_capacity, size_t nfiles, const std::vector<size_t>& mine)
 	  : idxs(is)
 	  , n_shards((size_t)std::max(1, params.index_shards))
 	  , n_k(is.size() / (size_t)std::max(1, params.index_shards))
 	  , n_files(nfiles)
+	  , global_file(mine)
 	{
 		for (size_t ki = 0; ki < n_k; ++ki) {
 			arks_imap* im = nullptr;
@@ -589,7 +599,7 @@ struct Mapper
 			if (rc == ARKS_OK) {
 				// pairs are numbered in input order (file, batch, pair): the order in which a single-threaded
 				// chromiumRead creates the IndexMap's barcodes (Arcs.cpp:1282-1285)
-				arks_imap_set_pair_base(imaps[ki], ((uint64_t)pb->file << 48) | ((uint64_t)pb->seq << 24));
+				arks_imap_set_pair_base(imaps[ki], ((uint64_t)global_file[(size_t)pb->file] << 48) | ((uint64_t)pb->seq << 24));
 				rc = arks_pairs_device(s.d_conreci.p, s.d_ok.p, s.d_bid.p, np, nullptr, imaps[ki], d_stored + slot,
 				                       params.device, s.stream);
 			}
@@ -609,64 +619,61 @@ struct Mapper
 	}
 };
 
-// what the barcode pre-pass (readBarcodes, Arcs.cpp:481-547) prints, rebuilt from the per-file
-// summaries of the fused pass; `added` is its global running count of tagged reads
-void
-prepass_log(const std::vector<std::string>& files, const std::vector<PrepassInfo>& pre, std::string& out, std::string& err)
+// ---- the read stage in two parts, so that it can run as one process per GPU ---------------------------
+// map_files: what ONE rank does -- its share of the read files through the ingest pipeline and its GPU.
+// merge_results: what rank 0 does with the results of all ranks -- the stage's log in file order, the
+// barcode multiplicities of the fused mode, and the IndexMap of every k.  A single process is one rank.
+struct FileResult
 {
-	const uint64_t step = 100000000;
-	uint64_t added = 0;
-	for (size_t f = 0; f < files.size(); ++f) {
-		if (params.verbose)
-			out += "Reading chrom " + files[f] + "\n";
-		err += "File " + files[f] + " opened.\n";
-		if (params.verbose) {
-			// the progress line appears at every record with a comment while added % step == 0
-			const PrepassInfo& pi = pre[f];
-			if (added % step == 0)
-				for (uint64_t i = 0; i < pi.lead; ++i)
-					out += std::to_string(added) + " read with valid barcode\n";
-			size_t e = 0;
-			for (uint64_t x = step - added % step; x <= pi.total; x += step) {
-				uint64_t count = 1;
-				while (e < pi.untagged_at.size() && pi.untagged_at[e] < x)
-					e++;
-				while (e < pi.untagged_at.size() && pi.untagged_at[e] == x)
-					e++, count++;
-				for (uint64_t i = 0; i < count; ++i)
-					out += std::to_string(added + x) + " read with valid barcode\n";
-			}
-		}
-		added += pre[f].total;
-	}
-}
+	bool have = false;
+	FileCounters fc;
+	std::map<int64_t, std::string> messages; // by batch number within the file
+	std::vector<uint64_t> stored;            // per k
+	std::vector<arks_map_stats> st;          // per k
+	// fused mode: what readBarcodes would have seen in this file (PrepassInfo, counts by barcode NAME id)
+	bool zero_len = false;
+	uint64_t pre_total = 0, pre_lead = 0;
+	std::vector<uint64_t> untagged_at;
+	std::vector<std::pair<uint32_t, uint32_t>> pre_counts; // (id into RankResult::names, reads)
+};
 
-// fused == true: no multiplicity file; `mult` is an OUTPUT (reads per barcode, as readBarcodes would
-// have counted them) and *redo is set when the input needs the exact two-pass flow instead
-void
-read_chroms(
-    const std::vector<std::string>& files, const std::vector<arks_index*>& idxs, std::vector<IndexMap>& imaps,
-    std::unordered_map<std::string, int>& mult, const std::vector<CI>& contigRecord, bool fused, std::string& out,
-    std::string& err, std::string* pre_out, std::string* pre_err, bool* redo)
+struct RankResult
+{
+	bool redo = false;
+	std::vector<FileResult> files;  // one per input file; only this rank's are filled
+	std::vector<std::string> names; // barcode id -> text, the ids of the triples and of pre_counts
+	// per k: (barcode id, conreci, count) x n, and the sequence number of each entry's first stored pair
+	std::vector<std::vector<uint32_t>> triples;
+	std::vector<std::vector<uint64_t>> first;
+};
+
+// fused == true: no multiplicity file; the reads per barcode come back in the result (pre_counts) and
+// `redo` is set when the input needs the exact two-pass flow instead
+RankResult
+map_files(
+    const std::vector<std::string>& files, const std::vector<size_t>& mine, const std::vector<arks_index*>& idxs,
+    const std::unordered_map<std::string, int>& mult, bool fused, std::string* open_error)
 {
 	const size_t nf = files.size();
+	RankResult res;
+	res.files.resize(nf);
+	const size_t nk = idxs.size() / (size_t)std::max(1, params.index_shards);
+	res.triples.resize(nk);
+	res.first.resize(nk);
 	std::vector<std::unique_ptr<SeqReader>> readers;
-	for (const auto& file : files) {
+	for (const size_t f : mine) {
 		// inflate threads for bgzip'ed files: what is left of -t per file (bgzf.hpp)
-		readers.emplace_back(new SeqReader(file.c_str(), std::max(1u, params.threads / (unsigned)std::max<size_t>(files.size(), 1))));
+		readers.emplace_back(new SeqReader(files[f].c_str(), std::max(1u, params.threads / (unsigned)std::max<size_t>(mine.size(), 1))));
 		if (!readers.back()->ok()) {
-			std::cout << out;
-			if (params.verbose)
-				std::cout << "Reading chrom " << file << std::endl;
-			std::cerr << "File " << file << " cannot be opened." << std::endl;
-			exit(1);
+			*open_error = files[f];
+			return res;
 		}
 	}
 	std::unique_ptr<BarcodeDict> dict(fused ? nullptr : new BarcodeDict(mult));
 	// distinct (barcode, contig end) pairs: a few per barcode; a starting size only, the accumulator grows
 	const int64_t imap_cap = fused ? (int64_t)1 << 20 : std::max<int64_t>(1 << 16, (int64_t)mult.size() * 4);
-	const size_t nk = idxs.size() / (size_t)std::max(1, params.index_shards);
-	Mapper mapper(idxs, imap_cap, std::max<size_t>(nf, 1));
+	const size_t nm = std::max<size_t>(mine.size(), 1);
+	Mapper mapper(idxs, imap_cap, nm, mine);
 	HostAllocator pinned;
 	pinned.alloc = [](size_t n) {
 		void* p = nullptr;
@@ -677,15 +684,14 @@ read_chroms(
 	for (auto& r : readers)
 		rdp.push_back(r.get());
 	IngestPipeline pipe(rdp, dict.get(), params.batch_pairs, params.verbose != 0, params.threads, pinned);
-	std::vector<FileCounters> fc(nf);
-	std::vector<std::map<int64_t, std::string>> messages(nf);
 	const int prc = pipe.run([&](PackedBatch* pb) {
-		FileCounters& f = fc[(size_t)pb->file];
+		FileResult& fr = res.files[mine[(size_t)pb->file]];
+		FileCounters& f = fr.fc;
 		f.skipped_unpaired += pb->fc.skipped_unpaired, f.emptybarcode += pb->fc.emptybarcode,
 		    f.invalidbarcode += pb->fc.invalidbarcode, f.gated += pb->fc.gated,
 		    f.skipped_invalid += pb->fc.skipped_invalid;
 		if (!pb->messages.empty())
-			messages[(size_t)pb->file][pb->seq].swap(pb->messages);
+			fr.messages[pb->seq].swap(pb->messages);
 		pb->messages.clear();
 		return mapper.submit(pb, pipe);
 	}, [&] { mapper.drain(pipe); }); // the in-flight batches are retired before their pinned buffers go
@@ -698,62 +704,301 @@ read_chroms(
 	if (fused) {
 		for (const PrepassInfo& pi : pipe.prepass())
 			if (pi.zero_len || pi.untagged_at.size() > (1u << 22)) {
-				*redo = true; // rare input shapes: let the caller run the literal two passes
+				res.redo = true; // rare input shapes: let the caller run the literal two passes
 				for (arks_imap* im : mapper.imaps)
 					arks_imap_free(im);
-				return;
+				return res;
 			}
 		DynamicDict& dyn = pipe.dynamic();
-		for (const PrepassInfo& pi : pipe.prepass())
+		res.names.reserve(dyn.size());
+		for (size_t id = 0; id < dyn.size(); ++id)
+			res.names.push_back(dyn.name((uint32_t)id));
+		for (size_t i = 0; i < mine.size(); ++i) {
+			const PrepassInfo& pi = pipe.prepass()[i];
+			FileResult& fr = res.files[mine[i]];
+			fr.pre_total = pi.total, fr.pre_lead = pi.lead, fr.untagged_at = pi.untagged_at;
 			for (size_t id = 0; id < pi.counts.size(); ++id)
 				if (pi.counts[id])
-					mult[dyn.name((uint32_t)id)] += (int)pi.counts[id];
-		prepass_log(files, pipe.prepass(), *pre_out, *pre_err);
+					fr.pre_counts.emplace_back((uint32_t)id, pi.counts[id]);
+		}
+	} else {
+		res.names.reserve(dict->name.size());
+		for (const std::string* s : dict->name)
+			res.names.push_back(*s);
+	}
+	std::vector<uint64_t> stored(nk * nm);
+	std::vector<arks_map_stats> st(nk * nm);
+	(void)hipMemcpy(stored.data(), mapper.d_stored, nk * nm * sizeof(uint64_t), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(st.data(), mapper.d_stats, nk * nm * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
+	for (size_t i = 0; i < mine.size(); ++i) {
+		FileResult& fr = res.files[mine[i]];
+		fr.have = true;
+		for (size_t ki = 0; ki < nk; ++ki) {
+			fr.stored.push_back(stored[ki * nm + i]);
+			fr.st.push_back(st[ki * nm + i]);
+		}
+	}
+	for (size_t ki = 0; ki < nk; ++ki) {
+		const int64_t n = arks_imap_size(mapper.imaps[ki]);
+		if (n < 0)
+			die_arks((int)-n, "reading the IndexMap accumulator");
+		res.triples[ki].resize((size_t)n * 3 + 3);
+		res.first[ki].resize((size_t)n + 1);
+		const int rc = arks_imap_export_ordered(mapper.imaps[ki], res.triples[ki].data(), res.first[ki].data());
+		if (rc != ARKS_OK)
+			die_arks(rc, "exporting the IndexMap");
+		res.triples[ki].resize((size_t)n * 3);
+		res.first[ki].resize((size_t)n);
+		arks_imap_free(mapper.imaps[ki]);
+	}
+	return res;
+}
+
+// rank results <-> a byte stream (the pipe between a worker rank and rank 0)
+struct ByteSink
+{
+	int fd;
+	std::vector<char> buf;
+	void put(const void* p, size_t n)
+	{
+		buf.insert(buf.end(), (const char*)p, (const char*)p + n);
+		if (buf.size() > (1u << 20))
+			flush();
+	}
+	template <typename T> void pod(const T& v) { put(&v, sizeof v); }
+	void str(const std::string& s)
+	{
+		pod<uint64_t>(s.size());
+		put(s.data(), s.size());
+	}
+	template <typename T> void vec(const std::vector<T>& v)
+	{
+		pod<uint64_t>(v.size());
+		if (!v.empty())
+			put(v.data(), v.size() * sizeof(T));
+	}
+	void flush()
+	{
+		size_t done = 0;
+		while (done < buf.size()) {
+			const ssize_t w = ::write(fd, buf.data() + done, buf.size() - done);
+			if (w <= 0) {
+				std::cerr << PROGRAM ": cannot send a rank's results\n";
+				_exit(EXIT_FAILURE);
+			}
+			done += (size_t)w;
+		}
+		buf.clear();
+	}
+};
+
+struct ByteSource
+{
+	int fd;
+	bool ok = true;
+	void get(void* p, size_t n)
+	{
+		size_t done = 0;
+		while (ok && done < n) {
+			const ssize_t r = ::read(fd, (char*)p + done, n - done);
+			if (r <= 0)
+				ok = false;
+			else
+				done += (size_t)r;
+		}
+	}
+	template <typename T> T pod()
+	{
+		T v{};
+		get(&v, sizeof v);
+		return v;
+	}
+	std::string str()
+	{
+		std::string s((size_t)pod<uint64_t>(), '\0');
+		if (ok && !s.empty())
+			get(&s[0], s.size());
+		return s;
+	}
+	template <typename T> void vec(std::vector<T>& v)
+	{
+		const uint64_t n = pod<uint64_t>();
+		if (!ok)
+			return;
+		v.resize((size_t)n);
+		if (n)
+			get(v.data(), (size_t)n * sizeof(T));
+	}
+};
+
+void
+send_result(int fd, const RankResult& r)
+{
+	ByteSink o{ fd, {} };
+	o.pod<uint8_t>(r.redo);
+	o.pod<uint64_t>(r.files.size());
+	for (const FileResult& f : r.files) {
+		o.pod<uint8_t>(f.have);
+		if (!f.have)
+			continue;
+		o.pod(f.fc);
+		o.pod<uint64_t>(f.messages.size());
+		for (const auto& kv : f.messages) {
+			o.pod<int64_t>(kv.first);
+			o.str(kv.second);
+		}
+		o.vec(f.stored);
+		o.vec(f.st);
+		o.pod<uint8_t>(f.zero_len);
+		o.pod(f.pre_total);
+		o.pod(f.pre_lead);
+		o.vec(f.untagged_at);
+		o.vec(f.pre_counts);
+	}
+	o.pod<uint64_t>(r.names.size());
+	for (const std::string& s : r.names)
+		o.str(s);
+	o.pod<uint64_t>(r.triples.size());
+	for (size_t k = 0; k < r.triples.size(); ++k) {
+		o.vec(r.triples[k]);
+		o.vec(r.first[k]);
+	}
+	o.flush();
+}
+
+bool
+receive_result(int fd, RankResult& r)
+{
+	ByteSource in{ fd };
+	r.redo = in.pod<uint8_t>() != 0;
+	r.files.resize((size_t)in.pod<uint64_t>());
+	for (FileResult& f : r.files) {
+		f.have = in.pod<uint8_t>() != 0;
+		if (!f.have || !in.ok)
+			continue;
+		f.fc = in.pod<FileCounters>();
+		const uint64_t nm = in.pod<uint64_t>();
+		for (uint64_t i = 0; i < nm && in.ok; ++i) {
+			const int64_t seq = in.pod<int64_t>();
+			f.messages[seq] = in.str();
+		}
+		in.vec(f.stored);
+		in.vec(f.st);
+		f.zero_len = in.pod<uint8_t>() != 0;
+		f.pre_total = in.pod<uint64_t>();
+		f.pre_lead = in.pod<uint64_t>();
+		in.vec(f.untagged_at);
+		in.vec(f.pre_counts);
+	}
+	r.names.resize((size_t)in.pod<uint64_t>());
+	for (std::string& s : r.names)
+		s = in.str();
+	const size_t nk = (size_t)in.pod<uint64_t>();
+	r.triples.resize(nk);
+	r.first.resize(nk);
+	for (size_t k = 0; k < nk && in.ok; ++k) {
+		in.vec(r.triples[k]);
+		in.vec(r.first[k]);
+	}
+	return in.ok;
+}
+
+// what the barcode pre-pass (readBarcodes, Arcs.cpp:481-547) prints, rebuilt from the per-file
+// summaries of the fused pass; `added` is its global running count of tagged reads
+void
+prepass_log(const std::vector<std::string>& files, const std::vector<const FileResult*>& pre, std::string& out, std::string& err)
+{
+	const uint64_t step = 100000000;
+	uint64_t added = 0;
+	for (size_t f = 0; f < files.size(); ++f) {
+		if (params.verbose)
+			out += "Reading chrom " + files[f] + "\n";
+		err += "File " + files[f] + " opened.\n";
+		if (params.verbose) {
+			// the progress line appears at every record with a comment while added % step == 0
+			const FileResult& pi = *pre[f];
+			if (added % step == 0)
+				for (uint64_t i = 0; i < pi.pre_lead; ++i)
+					out += std::to_string(added) + " read with valid barcode\n";
+			size_t e = 0;
+			for (uint64_t x = step - added % step; x <= pi.pre_total; x += step) {
+				uint64_t count = 1;
+				while (e < pi.untagged_at.size() && pi.untagged_at[e] < x)
+					e++;
+				while (e < pi.untagged_at.size() && pi.untagged_at[e] == x)
+					e++, count++;
+				for (uint64_t i = 0; i < count; ++i)
+					out += std::to_string(added + x) + " read with valid barcode\n";
+			}
+		}
+		added += pre[f]->pre_total;
+	}
+}
+
+// results of all ranks (every file filled by exactly one) -> the log of the stage, the multiplicities
+// of the fused mode, the IndexMap of every k
+void
+merge_results(
+    const std::vector<std::string>& files, const std::vector<RankResult>& ranks, std::vector<IndexMap>& imaps,
+    std::unordered_map<std::string, int>& mult, const std::vector<CI>& contigRecord, bool fused, std::string& out,
+    std::string& err, std::string* pre_out, std::string* pre_err)
+{
+	const size_t nf = files.size();
+	const size_t nk = ranks.empty() ? 0 : ranks[0].triples.size();
+	std::vector<const FileResult*> fr(nf, nullptr);
+	std::vector<const RankResult*> owner(nf, nullptr);
+	for (const RankResult& r : ranks)
+		for (size_t f = 0; f < nf && f < r.files.size(); ++f)
+			if (r.files[f].have) {
+				fr[f] = &r.files[f];
+				owner[f] = &r;
+			}
+	if (fused) {
+		// reads per barcode as readBarcodes would have counted them, file by file
+		for (size_t f = 0; f < nf; ++f)
+			for (const auto& ic : fr[f]->pre_counts)
+				mult[owner[f]->names[ic.first]] += (int)ic.second;
+		prepass_log(files, fr, *pre_out, *pre_err);
 		if (params.verbose)
 			*pre_out += "Saw " + std::to_string(mult.size()) + " distinct barcode.\n";
 	}
 	// the log of the stage, file by file as the reference prints it (Arcs.cpp:1158-1166, 1209-1215,
 	// 1321-1349); its s_* k-mer counters are process-wide, i.e. cumulative over the files
-	const size_t nfs = std::max<size_t>(nf, 1);
-	std::vector<uint64_t> stored(nk * nfs);
-	std::vector<arks_map_stats> st(nk * nfs);
-	(void)hipMemcpy(stored.data(), mapper.d_stored, nk * nfs * sizeof(uint64_t), hipMemcpyDeviceToHost);
-	(void)hipMemcpy(st.data(), mapper.d_stats, nk * nfs * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
 	std::vector<arks_map_stats> cum(nk);
 	std::memset(cum.data(), 0, nk * sizeof(arks_map_stats));
 	for (size_t f = 0; f < nf; ++f) {
 		if (params.verbose)
 			out += "Reading chrom " + files[f] + "\n";
 		err += "File " + files[f] + " opened.\n";
-		for (const auto& kv : messages[f])
+		for (const auto& kv : fr[f]->messages)
 			out += kv.second;
 		for (size_t ki = 0; ki < nk; ++ki) {
-			const size_t slot = ki * nfs + f;
+			const arks_map_stats& s = fr[f]->st[ki];
 			arks_map_stats& c = cum[ki];
-			c.total_valid += st[slot].total_valid, c.bad += st[slot].bad, c.found += st[slot].found,
-			    c.recorded += st[slot].recorded, c.dups += st[slot].dups, c.reads_pass += st[slot].reads_pass,
-			    c.reads_fail += st[slot].reads_fail, c.windows += st[slot].windows;
+			c.total_valid += s.total_valid, c.bad += s.bad, c.found += s.found, c.recorded += s.recorded,
+			    c.dups += s.dups, c.reads_pass += s.reads_pass, c.reads_fail += s.reads_fail, c.windows += s.windows;
 			if (!params.verbose)
 				continue;
-			const FileCounters& mc = fc[f];
+			const FileCounters& mc = fr[f]->fc;
+			const uint64_t stored = fr[f]->stored[ki];
 			if (nk > 1)
 				appendf(out, "k = %d:\n", params.k_list[ki]);
 			appendf(out, "Stored read pairs: %u\nSkipped invalid read pairs: %u\nSkipped unpaired reads: "
 			       "%u\nSkipped reads pairs without a good contig: %u\n",
-			       (unsigned)stored[slot], (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
-			       (unsigned)(mc.gated - stored[slot]));
+			       (unsigned)stored, (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
+			       (unsigned)(mc.gated - stored));
 			if (params.index_shards > 1)
 				// a key shared by ends of two shards reads 0 in both: the per-window counters of the shards
 				// do not add up to the reference's, so they are not collected (include/arks_hip.h)
 				appendf(out, "(index in %d shards: the k-mer counters of the read stage are not collected)\n",
 				        params.index_shards);
 			else
-			appendf(out, "Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
-			       "%u\nNumber of kmers recorded in Ktrack: %u\nNumber of kmers found in ContigKmap but "
-			       "duplicate: %u\nNumber of reads passing jaccard threshold: %u\nNumber of reads failing "
-			       "jaccard threshold: %u\n",
-			       (unsigned)c.total_valid, (unsigned)c.bad, (unsigned)c.found, (unsigned)c.recorded,
-			       (unsigned)c.dups, (unsigned)c.reads_pass, (unsigned)c.reads_fail);
+				appendf(out, "Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
+				       "%u\nNumber of kmers recorded in Ktrack: %u\nNumber of kmers found in ContigKmap but "
+				       "duplicate: %u\nNumber of reads passing jaccard threshold: %u\nNumber of reads failing "
+				       "jaccard threshold: %u\n",
+				       (unsigned)c.total_valid, (unsigned)c.bad, (unsigned)c.found, (unsigned)c.recorded,
+				       (unsigned)c.dups, (unsigned)c.reads_pass, (unsigned)c.reads_fail);
 			if (mc.emptybarcode > 0)
 				appendf(out, "WARNING:: Your chromium read file has %d readpairs that have an empty barcode.",
 				       (int)mc.emptybarcode);
@@ -763,38 +1008,107 @@ read_chroms(
 				       (int)mc.invalidbarcode);
 		}
 	}
-	// the reference completes the IndexMap after every file (Arcs.cpp:1304-1319); the accumulator is
-	// additive, so the rebuild below after the last file gives the same map
+	// The reference completes the IndexMap after every file (Arcs.cpp:1304-1319); the accumulators are
+	// additive, so the rebuild below after the last file gives the same map.  Barcodes enter the unordered
+	// IndexMap in the order of their first stored pair (pairs are numbered file, batch, pair), as in a
+	// single-threaded reference run: the container's iteration order -- which -D's tie handling sees,
+	// Arcs/DistanceEst.h:230-262 -- is then the reference's for the same libstdc++.
 	imaps.assign(nk, IndexMap());
 	for (size_t ki = 0; ki < nk; ++ki) {
-		const int64_t n = arks_imap_size(mapper.imaps[ki]);
-		if (n < 0)
-			die_arks((int)-n, "reading the IndexMap accumulator");
-		std::vector<uint32_t> triples((size_t)n * 3 + 3);
-		std::vector<uint64_t> first((size_t)n + 1);
-		const int rc = arks_imap_export_ordered(mapper.imaps[ki], triples.data(), first.data());
-		if (rc != ARKS_OK)
-			die_arks(rc, "exporting the IndexMap");
-		IndexMap& imap = imaps[ki];
-		// Barcodes enter the unordered IndexMap in the order of their first stored pair, as in a
-		// single-threaded reference run: the container's iteration order (which -D's tie handling sees,
-		// Arcs/DistanceEst.h:230-262) is then the reference's for the same libstdc++.  The triples are
-		// sorted by barcode id: one group per barcode.
-		std::vector<std::pair<uint64_t, int64_t>> groups; // (first stored pair of the barcode, first triple)
-		for (int64_t i = 0; i < n; ++i) {
-			if (i == 0 || triples[3 * i] != triples[3 * (i - 1)])
-				groups.emplace_back(first[(size_t)i], i);
-			else
-				groups.back().first = std::min(groups.back().first, first[(size_t)i]);
+		struct Entry
+		{
+			const std::string* barcode;
+			uint32_t conreci, count;
+			uint64_t first;
+		};
+		std::vector<Entry> ent;
+		for (const RankResult& r : ranks) {
+			const std::vector<uint32_t>& t = r.triples[ki];
+			for (size_t i = 0; 3 * i < t.size(); ++i)
+				ent.push_back(Entry{ &r.names[t[3 * i]], t[3 * i + 1], t[3 * i + 2], r.first[ki][i] });
 		}
-		std::sort(groups.begin(), groups.end());
-		for (const auto& g : groups)
-			for (int64_t i = g.second; i < n && triples[3 * i] == triples[3 * g.second]; ++i)
-				imap[fused ? pipe.dynamic().name(triples[3 * i]) : *dict->name[triples[3 * i]]]
-				    [contigRecord[triples[3 * i + 1]]] += (int)triples[3 * i + 2];
+		// first stored pair of every barcode over all ranks
+		std::unordered_map<std::string_view, uint64_t> first_of;
+		first_of.reserve(ent.size());
+		for (const Entry& e : ent) {
+			auto it = first_of.emplace(std::string_view(*e.barcode), e.first).first;
+			it->second = std::min(it->second, e.first);
+		}
+		std::vector<std::pair<uint64_t, std::string_view>> order;
+		order.reserve(first_of.size());
+		for (const auto& kv : first_of)
+			order.emplace_back(kv.second, kv.first);
+		std::sort(order.begin(), order.end());
+		IndexMap& imap = imaps[ki];
+		for (const auto& o : order)
+			imap[std::string(o.second)]; // creation order
+		for (const Entry& e : ent)
+			imap[*e.barcode][contigRecord[e.conreci]] += (int)e.count;
 		add_opposite_ends(imap);
-		arks_imap_free(mapper.imaps[ki]);
 	}
+}
+
+// The read stage of this process and, with --ranks N, of its N - 1 worker processes (g_workers: forked
+// before the first HIP call, one GPU each, they ran the stages up to here on their own and now map the
+// files dealt to them -- file f goes to rank f mod N -- and send their results through their pipes).
+struct Worker
+{
+	pid_t pid;
+	int fd;
+};
+std::vector<Worker> g_workers;
+int g_rank = 0, g_world = 1, g_result_fd = -1;
+
+void
+read_stage(
+    const std::vector<std::string>& files, const std::vector<arks_index*>& idxs, std::vector<IndexMap>& imaps,
+    std::unordered_map<std::string, int>& mult, const std::vector<CI>& contigRecord, bool fused, std::string& out,
+    std::string& err, std::string& pre_out, std::string& pre_err, bool& redo)
+{
+	// after a fall-back to two passes the workers are gone: rank 0 maps every file
+	const int world = g_workers.empty() && g_rank == 0 ? 1 : g_world;
+	std::vector<size_t> mine;
+	for (size_t f = 0; f < files.size(); ++f)
+		if ((int)(f % (size_t)world) == g_rank)
+			mine.push_back(f);
+	std::string open_error;
+	std::vector<RankResult> ranks(1);
+	ranks[0] = map_files(files, mine, idxs, mult, fused, &open_error);
+	if (!open_error.empty()) {
+		// the reference stops at the first file it cannot open, after the log of the files before it
+		// (Arcs.cpp:1158-1163); the workers' share is dropped
+		for (const Worker& wk : g_workers)
+			(void)::kill(wk.pid, SIGTERM);
+		std::cout << out;
+		if (params.verbose)
+			std::cout << "Reading chrom " << open_error << std::endl;
+		std::cerr << "File " << open_error << " cannot be opened." << std::endl;
+		exit(1);
+	}
+	if (g_rank != 0) { // a worker: hand the results to rank 0 and leave
+		send_result(g_result_fd, ranks[0]);
+		::close(g_result_fd);
+		std::fflush(nullptr);
+		_exit(EXIT_SUCCESS);
+	}
+	for (const Worker& wk : g_workers) {
+		ranks.emplace_back();
+		const bool ok = receive_result(wk.fd, ranks.back());
+		::close(wk.fd);
+		int status = 0;
+		(void)::waitpid(wk.pid, &status, 0);
+		if (!ok || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+			std::cerr << PROGRAM ": a worker rank failed (pid " << wk.pid << ")\n";
+			exit(EXIT_FAILURE);
+		}
+	}
+	g_workers.clear();
+	redo = false;
+	for (const RankResult& r : ranks)
+		redo = redo || r.redo;
+	if (redo)
+		return;
+	merge_results(files, ranks, imaps, mult, contigRecord, fused, out, err, &pre_out, &pre_err);
 }
 
 // file names of one k: with a single -k exactly the reference's (Arcs.cpp:2144-2157); with a list
@@ -850,6 +1164,51 @@ run_arks(const std::vector<std::string>& filenames)
 		std::cout << ' ' << f << '\n';
 	std::cout.flush();
 
+	// --ranks N: N - 1 worker processes, forked here -- before the first HIP call of this process -- each
+	// with a GPU of its own (device + rank, modulo the devices there are, so that a test can run several
+	// ranks on one GPU).  A worker runs the same stages silently up to the read stage, maps the files dealt
+	// to it and sends its results to this process (read_stage); everything after that is rank 0's.
+	if (params.ranks > 1 && filenames.size() > 1) {
+		g_world = (int)std::min<size_t>((size_t)params.ranks, filenames.size());
+		std::fflush(nullptr);
+		for (int r = 1; r < g_world; ++r) {
+			int fds[2];
+			if (::pipe(fds) != 0) {
+				std::cerr << PROGRAM ": cannot create a pipe\n";
+				exit(EXIT_FAILURE);
+			}
+			const pid_t pid = ::fork();
+			if (pid < 0) {
+				std::cerr << PROGRAM ": cannot fork a worker rank\n";
+				exit(EXIT_FAILURE);
+			}
+			if (pid == 0) {
+				::close(fds[0]);
+				for (const Worker& wk : g_workers)
+					::close(wk.fd);
+				g_workers.clear();
+				g_rank = r;
+				g_result_fd = fds[1];
+				if (!std::freopen("/dev/null", "w", stdout))
+					_exit(EXIT_FAILURE);
+				break;
+			}
+			::close(fds[1]);
+			g_workers.push_back(Worker{ pid, fds[0] });
+		}
+	}
+	if (arks_device_count() < 1) {
+		std::cerr << PROGRAM ": error: no gfx950 (MI355X) device is visible; this build has no CPU path.\n";
+		exit(EXIT_FAILURE);
+	}
+	{
+		int ndev = 0;
+		if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+			params.device = (params.device + g_rank) % ndev;
+			(void)hipSetDevice(params.device);
+		}
+	}
+
 	std::vector<IndexMap> imaps;
 	std::unordered_map<std::string, int> mult;
 	ContigToLength contigToLength;
@@ -893,15 +1252,18 @@ run_arks(const std::vector<std::string>& filenames)
 	{
 		std::string out, err, pre_out, pre_err;
 		bool redo = false;
-		read_chroms(filenames, idxs, imaps, mult, contigRecord, fused, out, err, &pre_out, &pre_err, &redo);
+		read_stage(filenames, idxs, imaps, mult, contigRecord, fused, out, err, pre_out, pre_err, redo);
 		if (fused && redo) {
+			// (a rank met an input the fused pass cannot reproduce: the literal two passes, in this process)
 			mult.clear();
 			imaps.clear();
 			out.clear();
 			err.clear();
+			pre_out.clear();
+			pre_err.clear();
 			read_barcodes(filenames, mult);
 			std::cout << mid << std::flush;
-			read_chroms(filenames, idxs, imaps, mult, contigRecord, false, out, err, nullptr, nullptr, nullptr);
+			read_stage(filenames, idxs, imaps, mult, contigRecord, false, out, err, pre_out, pre_err, redo);
 		} else if (fused) {
 			std::cout << pre_out;
 			std::cerr << pre_err;
@@ -1042,6 +1404,7 @@ main(int argc, char** argv)
 			break;
 		case OPT_DEVICE: arg >> params.device; break;
 		case OPT_INDEX_SHARDS: arg >> params.index_shards; break;
+		case OPT_RANKS: arg >> params.ranks; break;
 		case 'm': {
 			std::string first, second;
 			std::getline(arg, first, '-');
@@ -1139,10 +1502,7 @@ main(int argc, char** argv)
 		std::cerr << "Try " << PROGRAM << " --help for more information.\n";
 		exit(EXIT_FAILURE);
 	}
-	if (arks_device_count() < 1) {
-		std::cerr << PROGRAM ": error: no gfx950 (MI355X) device is visible; this build has no CPU path.\n";
-		exit(EXIT_FAILURE);
-	}
+	// (the device check is the first HIP call: it waits until the worker ranks, if any, are forked -- run_arks)
 	printf("%s\n", "Finished reading user inputs...entering runArcs()...");
 	run_arks(filenames);
 	return 0;

@@ -177,6 +177,30 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
     # messages keep file order
     assert out2.index(f"Reading chrom {paths[0]}") < out2.index(f"Reading chrom {paths[1]}") < \
         out2.index(f"Reading chrom {paths[2]}")
+    # ---- one process per GPU (--ranks N; here the ranks share the one GPU): the files are dealt to the
+    #      ranks, rank 0 merges their results -- same log (but for pid and time stamps), same files ---------
+    import re as _re
+
+    def _norm(text, basename, countsname):
+        keep = []
+        for ln in text.split("\n"):
+            if ln.startswith(" pid ") or "Cumulative memory usage" in ln or _re.search(r"\d\d:\d\d:\d\d \d{4}$", ln):
+                continue
+            keep.append(ln.replace("/" + countsname, "/COUNTS").replace("/" + basename, "/BASE"))
+        return "\n".join(keep)
+
+    for n_ranks in (2, 3):
+        argsr = list(args2)
+        tag = f"ranks{n_ranks}"
+        argsr[argsr.index("-b") + 1] = str(tmp_path / tag)
+        argsr[argsr.index("--barcode-counts") + 1] = str(tmp_path / (tag + "_counts"))
+        resr = subprocess.run(argsr + ["--ranks", str(n_ranks)] + [str(x) for x in paths], capture_output=True,
+                              text=True, timeout=300)
+        assert resr.returncode == 0, resr.stderr[-2000:]
+        for suffix in ("_original.gv", "_pair.tsv", "_main.tsv", ".dist.gv"):
+            assert open(str(tmp_path / tag) + suffix).read() == open(str(tmp_path / "multi") + suffix).read(), suffix
+        assert open(str(tmp_path / (tag + "_counts.tsv"))).read() == open(str(tmp_path / "counts2.tsv")).read()
+        assert _norm(resr.stdout, tag, tag + "_counts") == _norm(res2.stdout, "multi", "counts2")
     # ---- the contig k-mer index in three parts (--index-shards): per batch the votes of every part,
     #      their maximum, then the j_index test -- same files, same stored pairs ----------------------
     args4 = list(args)
