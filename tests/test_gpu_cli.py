@@ -280,7 +280,7 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
         assert "invalid barcode" not in outs[0][0] or "barcodes not in the barcode multiplicity file" in outs[0][0]
 
 
-def test_arcs_cli_k_list_single_pass(arks, gpu, tmp_path):
+def test_arcs_cli_k_list_single_pass(arks, gpu, oracle, tmp_path):
     """-k 40,60,80: one pass over the reads against three resident indexes; every output set equals the
     one of a single-k run (arks-long style input: pseudo-linked pairs with a multiplicity file)"""
     from arcs_amd import build as b, synth
@@ -325,9 +325,28 @@ def test_arcs_cli_k_list_single_pass(arks, gpu, tmp_path):
         line = [ln for ln in r1.stdout.split("\n") if ln.startswith("Total valid kmers:")][0]
         assert line in block.split("k = ")[1]
     assert len(differ) > 1, "the three k should not all give the same evidence"
+    # every k of the single pass against the CPU oracle + tests/graph_ref.py (not against another CLI run)
+    from util import expected_cli_outputs
+    recs = [(f"r{p}/1", f"BX:Z:{int(bid[p]) + 1}", reads[2 * p], f"r{p}/2", f"BX:Z:{int(bid[p]) + 1}", reads[2 * p + 1])
+            for p in range(n_pairs)]
+    P = {"min_reads": 3, "min_links": 0, "min_mult": 8, "max_mult": 10000, "max_degree": 0, "error_percent": 0.05,
+         "gap": 100}
+    names = [str(i + 1) for i in range(len(cs))]
+    n_edges = 0
+    for k in (40, 60, 80):
+        want = expected_cli_outputs(oracle, G, names, cs, recs, mult, k, 0.5, P)
+        base = str(tmp_path / f"multi_k{k}")
+        assert open(base + "_original.gv").read() == want["original.gv"], k
+        assert open(base + "_pair.tsv").read() == want["pair.tsv"], k
+        assert open(base + "_main.tsv").read() == want["main.tsv"], k
+        block = r.stdout[r.stdout.index(f"k = {k}:\nStored read pairs"):].split("k = ")[1]
+        assert f"Stored read pairs: {int((want['pair'] != 0).sum())}\n" in block
+        assert f"Number of kmers found in ContigKmap: {want['stats']['found']}\n" in block
+        n_edges += len(want["edges"])
+    assert n_edges > 0
 
 
-def test_arks_long_pipe(arks, gpu, tmp_path):
+def test_arks_long_pipe(arks, gpu, oracle, tmp_path):
     """the arks-long flow of bin/arcs-make:299-313: long reads -> long-to-linked-pe (pseudo-linked pairs,
     BX = read number) piped into `arcs --arks ... -u multiplicities /dev/stdin`; same outputs as reading
     the materialised pairs from a file, for a k list in one pass"""
@@ -341,6 +360,7 @@ def test_arks_long_pipe(arks, gpu, tmp_path):
     fa = tmp_path / "draft.fa"
     fa.write_text("".join(f">{i + 1}\n{s_}\n" for i, s_ in enumerate(cs)))
     comp = str.maketrans("ACGT", "TGCA")
+    long_reads = []
     with gzip.open(tmp_path / "long.fa.gz", "wt") as f:
         for i in range(400):
             n = int(rng.integers(3000, 30000))
@@ -351,6 +371,7 @@ def test_arks_long_pipe(arks, gpu, tmp_path):
             r = "".join(r)
             if i % 2:
                 r = r[::-1].translate(comp)
+            long_reads.append(r)
             f.write(f">long{i}\n{r}\n")
     mult = tmp_path / "bx.tsv"
     subprocess.run([feeder, "-l", "250", "-m", "2000", "--bx-only", "-b", str(mult), str(tmp_path / "long.fa.gz")], check=True)
@@ -372,3 +393,98 @@ def test_arks_long_pipe(arks, gpu, tmp_path):
             assert a == open(str(tmp_path / f"filed_k{k}") + suffix).read(), (k, suffix)
         n_edges += open(str(tmp_path / f"piped_k{k}") + "_original.gv").read().count("--")
     assert n_edges > 0, "long reads spanning contigs should link some ends"
+    # the pseudo-linked pairs by the rules of src/long-to-linked-pe.cpp:224-287 (restated in
+    # tests/test_host_longreads.py::expected), then chromiumRead's flow through the CPU oracle and the
+    # graph stage through tests/graph_ref.py: what the pipe must have produced, independent of any CLI run
+    from test_host_longreads import expected as expected_pairs
+    from util import expected_cli_outputs
+    want_text, want_bx = expected_pairs([(f"long{i}", s_, "") for i, s_ in enumerate(long_reads)], 250, 2000, False)
+    assert pairs.decode() == want_text and mult.read_text() == want_bx
+    lines = want_text.split("\n")
+    recs = []
+    for i in range(0, len(lines) - 1, 8):
+        n1, c1 = lines[i][1:].split(" ", 1)
+        n2, c2 = lines[i + 4][1:].split(" ", 1)
+        recs.append((n1, c1, lines[i + 1], n2, c2, lines[i + 5]))
+    multd = {ln.split("\t")[0]: int(ln.split("\t")[1]) for ln in want_bx.split("\n") if ln}
+    P = {"min_reads": 4, "min_links": 0, "min_mult": 8, "max_mult": 10000, "max_degree": 0, "error_percent": 0.05,
+         "gap": 100}
+    names = [str(i + 1) for i in range(len(cs))]
+    for k in (20, 40):
+        want = expected_cli_outputs(oracle, G, names, cs, recs, multd, k, 0.05, P)
+        assert open(str(tmp_path / f"piped_k{k}") + "_original.gv").read() == want["original.gv"], k
+        assert open(str(tmp_path / f"piped_k{k}") + "_main.tsv").read() == want["main.tsv"], k
+
+
+def test_arks_long_multi_k_at_scale(arks, gpu, oracle, tmp_path):
+    """BASELINE configs[4]'s shape on one GPU, cut to a test's size: a 100 Mbp draft, ONT-like long reads cut
+    into 250-bp pseudo-linked pairs by long-to-linked-pe (bin/arcs-make:299-313), `arcs --arks -k 40,60,80
+    -j 0.05` in one pass over the pipe; every k's outputs against the CPU oracle + tests/graph_ref.py."""
+    from arcs_amd import build as b, synth
+    from test_host_longreads import expected as expected_pairs
+    from util import expected_cli_outputs
+    exe = b.build_host()
+    feeder = os.path.join(os.path.dirname(exe), "long-to-linked-pe")
+    rng = np.random.Generator(np.random.PCG64(55))
+    contigs = synth.make_draft(100_000_000, seed=95)
+    cs = synth.contigs_to_strings(contigs)
+    names = [f"s{i + 1}" for i in range(len(cs))]
+    fa = tmp_path / "draft.fa"
+    with open(fa, "w") as f:
+        for n, s_ in zip(names, cs):
+            f.write(f">{n}\n{s_}\n")
+    genome = np.concatenate(contigs)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a_, b_ in zip(b"ACGTN", b"TGCAN"):
+        comp[a_] = b_
+    long_reads = []
+    with open(tmp_path / "long.fa", "w") as f:
+        bounds = np.cumsum([len(c) for c in contigs])[:-1]
+        hot = bounds[rng.choice(len(bounds), size=60, replace=False)]   # joins that several reads span
+        for i in range(1500):
+            n = int(rng.integers(5000, 40000))
+            if i % 2:
+                p0 = int(hot[int(rng.integers(len(hot)))]) - int(rng.integers(2000, n - 2000))
+                p0 = min(max(p0, 0), len(genome) - n)
+            else:
+                p0 = int(rng.integers(0, len(genome) - n))
+            r = genome[p0:p0 + n].copy()
+            q = rng.integers(0, n, size=n // 50)                 # 2 % substitutions: ONT-like
+            r[q] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(q))]
+            if i % 4 >= 2:
+                r = comp[r[::-1]]
+            long_reads.append(r.tobytes().decode())
+            f.write(f">ont{i}\n{long_reads[-1]}\n")
+    mult = tmp_path / "bx.tsv"
+    subprocess.run([feeder, "-l", "250", "-m", "2000", "--bx-only", "-b", str(mult), str(tmp_path / "long.fa")], check=True)
+    pairs = subprocess.run([feeder, "-l", "250", "-m", "2000", "-t", "4", str(tmp_path / "long.fa")],
+                           capture_output=True, check=True).stdout
+    res = subprocess.run([exe, "--arks", "-v", "-f", str(fa), "-c", "4", "-m", "8-10000", "-e", "30000", "-z", "500",
+                          "-j", "0.05", "-k", "40,60,80", "-t", "8", "-u", str(mult), "-b", str(tmp_path / "out"),
+                          "/dev/stdin"], input=pairs, capture_output=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    want_text, want_bx = expected_pairs([(f"ont{i}", s_, "") for i, s_ in enumerate(long_reads)], 250, 2000, False)
+    assert pairs.decode() == want_text and mult.read_text() == want_bx
+    lines = want_text.split("\n")
+    recs = []
+    for i in range(0, len(lines) - 1, 8):
+        n1, c1 = lines[i][1:].split(" ", 1)
+        n2, c2 = lines[i + 4][1:].split(" ", 1)
+        recs.append((n1, c1, lines[i + 1], n2, c2, lines[i + 5]))
+    assert len(recs) > 50_000
+    multd = {ln.split("\t")[0]: int(ln.split("\t")[1]) for ln in want_bx.split("\n") if ln}
+    P = {"min_reads": 4, "min_links": 0, "min_mult": 8, "max_mult": 10000, "max_degree": 0, "error_percent": 0.05,
+         "gap": 100}
+    out = res.stdout.decode()
+    n_edges = 0
+    for k in (40, 60, 80):
+        want = expected_cli_outputs(oracle, G, names, cs, recs, multd, k, 0.05, P, threads=min(64, os.cpu_count() or 1))
+        base = str(tmp_path / f"out_k{k}")
+        assert open(base + "_original.gv").read() == want["original.gv"], k
+        assert open(base + "_main.tsv").read() == want["main.tsv"], k
+        block = out[out.index(f"k = {k}:\nStored read pairs"):].split("k = ")[1]
+        assert f"Stored read pairs: {int((want['pair'] != 0).sum())}\n" in block
+        assert f"Number of kmers found in ContigKmap: {want['stats']['found']}\n" in block
+        assert f"Number of reads passing jaccard threshold: {want['stats']['reads_pass']}\n" in block
+        n_edges += len(want["edges"])
+    assert n_edges > 20, "long reads spanning contigs should link many ends"
