@@ -5,6 +5,7 @@ This package only loads it and offers thin host-side helpers for tests, bench.py
 multi-GPU driver; there is no CPU fallback -- on a machine without the built library or without a
 gfx950 device every compute call raises.
 """
+from . import api  # noqa: F401
 from ._lib import ArksError, lib, lib_path  # noqa: F401
 from .api import (ArksIndex, ImapAccumulator, PackedReads, PairStep, contig_ends, device_count,  # noqa: F401
                   end_cutoff, key_bytes, map_pairs_packed, map_reads_packed, map_votes_packed, max_votes,

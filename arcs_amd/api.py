@@ -114,6 +114,23 @@ class ArksIndex:
         check(rc, "arks_index_build_shard")
         return cls(h, k, device, None)
 
+    @classmethod
+    def build_seed_shard(cls, ends, k, rank, n_ranks, device=0):
+        """arks_index_build_seed_shard: text, bitmaps and fallback table whole, the seed table's entries that
+        rank `rank` of `n_ranks` owns (by a hash prefix of the m-mer), a replicated minimizer table for the
+        general kernels; every rank is given the same list"""
+        data, offsets, lens = _concat(ends)
+        data = np.concatenate([data, np.zeros(1, np.uint8)])
+        h = C.c_void_p()
+        rc = lib().arks_index_build_seed_shard(C.byref(h), k, data.ctypes.data, offsets.ctypes.data,
+                                               lens.ctypes.data, len(lens), rank, n_ranks, device)
+        check(rc, "arks_index_build_seed_shard")
+        return cls(h, k, device, None)
+
+    @property
+    def seed_ranks(self):
+        return lib().arks_index_seed_ranks(self._h)
+
     def close(self):
         if self._h:
             lib().arks_index_free(self._h)
@@ -263,6 +280,56 @@ def map_reads_packed(index, reads, j_index, eval_mask=None, stats=None, out=None
         reads.lens.data_ptr(), eval_mask.data_ptr() if eval_mask is not None else None, n,
         float(j_index), out.data_ptr(), stats.data_ptr() if stats is not None else None,
         _stream_ptr(reads.device)), "arks_map_reads_device")
+    return out[:n]
+
+
+def seed_counts(index, reads, eval_mask=None):
+    """arks_seed_counts_device: int32[n_reads], the seeds each read asks of the seed table"""
+    torch = _torch()
+    n = reads.n_reads
+    out = torch.empty(max(n, 1), dtype=torch.int32, device=reads.codes.device)
+    check(lib().arks_seed_counts_device(index.handle, reads.lens.data_ptr(),
+                                        eval_mask.data_ptr() if eval_mask is not None else None, n,
+                                        out.data_ptr(), _stream_ptr(reads.device)), "arks_seed_counts_device")
+    return out[:n]
+
+
+def seeds_fill(index, reads, seed_off, eval_mask=None):
+    """arks_seeds_fill_device: (int64[n_seeds] canonical m-mers, int32[n_seeds] owner ranks), read-major;
+    seed_off = int64[n_reads + 1], the exclusive prefix sum of seed_counts"""
+    torch = _torch()
+    n_seeds = int(seed_off[-1].item())
+    dev = reads.codes.device
+    mmer = torch.empty(max(n_seeds, 1), dtype=torch.int64, device=dev)
+    owner = torch.empty(max(n_seeds, 1), dtype=torch.int32, device=dev)
+    check(lib().arks_seeds_fill_device(
+        index.handle, reads.codes.data_ptr(), reads.nmask.data_ptr(), reads.word_off.data_ptr(),
+        reads.lens.data_ptr(), eval_mask.data_ptr() if eval_mask is not None else None, reads.n_reads,
+        seed_off.data_ptr(), mmer.data_ptr(), owner.data_ptr(), _stream_ptr(reads.device)), "arks_seeds_fill_device")
+    return mmer[:n_seeds], owner[:n_seeds]
+
+
+def seeds_probe(index, mmer):
+    """arks_seeds_probe_device (owner side): int64[2 n], the answers to the asked m-mers"""
+    torch = _torch()
+    n = int(mmer.numel())
+    ans = torch.empty(max(2 * n, 2), dtype=torch.int64, device=mmer.device)
+    check(lib().arks_seeds_probe_device(index.handle, mmer.data_ptr(), n, ans.data_ptr(),
+                                        _stream_ptr(index.device)), "arks_seeds_probe_device")
+    return ans[:2 * n]
+
+
+def map_reads_seeded(index, reads, j_index, seed_off, answers, eval_mask=None, stats=None, out=None):
+    """arks_map_reads_seeded_device: bestContig of every read with the seed probes answered beforehand"""
+    torch = _torch()
+    n = reads.n_reads
+    if out is None:
+        out = torch.empty(max(n, 1), dtype=torch.int32, device=reads.codes.device)
+    check(lib().arks_map_reads_seeded_device(
+        index.handle, reads.codes.data_ptr(), reads.nmask.data_ptr(), reads.word_off.data_ptr(),
+        reads.lens.data_ptr(), eval_mask.data_ptr() if eval_mask is not None else None, n,
+        seed_off.data_ptr(), answers.data_ptr(), float(j_index), out.data_ptr(),
+        stats.data_ptr() if stats is not None else None, _stream_ptr(reads.device)), "arks_map_reads_seeded_device")
     return out[:n]
 
 

@@ -545,6 +545,29 @@ btextrec_kernel(
 	trec[3 * word + 2] = (u64)word_owner[word];
 }
 
+// registered m-mer positions per owner rank of a sharded seed table
+template <int MM>
+__global__ void
+bowners_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ is_min, u64 total_words, u32 n_own, u64* __restrict__ per_owner)
+{
+	typedef typename Mmer<MM>::type mm_t;
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 word = pos >> 5;
+	const bool reg = word < total_words && ((is_min[word] >> (31 - (u32)(pos & 31))) & 1u);
+	u32 own = 0xFFFFFFFFu;
+	if (reg) {
+		const mm_t mf = mmer_fw<MM>(codes, pos);
+		const mm_t mr = mmer_rc<MM>(mf);
+		own = seed_owner<MM>(mf < mr ? mf : mr, n_own);
+	}
+	for (u32 o = 0; o < n_own; ++o) { // few owners: one ballot each
+		const u64 b = __ballot(own == o);
+		if ((threadIdx.x & 63) == 0 && b)
+			atomicAdd(per_owner + o, (u64)__popcll(b));
+	}
+}
+
 // bit of window pos = some position of [pos, pos + w) is set in `bits`
 __device__ __forceinline__ bool
 any_bit_in_span(const u32* __restrict__ bits, u64 pos, int w)
@@ -596,7 +619,7 @@ template <int MM>
 __global__ void
 bcount_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ is_min, u64 total_words,
-    u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap)
+    u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u32 own, u32 n_own)
 {
 	typedef typename Mmer<MM>::type mm_t;
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -605,7 +628,10 @@ bcount_kernel(
 		return;
 	const mm_t mf = mmer_fw<MM>(codes, pos);
 	const mm_t mr = mmer_rc<MM>(mf);
-	atomicAdd(ctab_slot<MM>(ckeys, ccnts, ccap, mf < mr ? mf : mr, true), 1u);
+	const mm_t cm = mf < mr ? mf : mr;
+	if (n_own > 1 && seed_owner<MM>(cm, n_own) != own) // a sharded seed table: one owner's m-mers per pass
+		return;
+	atomicAdd(ctab_slot<MM>(ckeys, ccnts, ccap, cm, true), 1u);
 }
 
 // m-mer at offset o of a key (rare paths only)
@@ -627,7 +653,7 @@ template <int KW, int MM, int PHASE>
 __global__ void
 bforce_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ is_pal, u64 total_words, KeyGeom g, int w, int dense,
-    u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap)
+    u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap, u32 own, u32 n_own)
 {
 	typedef typename Mmer<MM>::type mm_t;
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -648,6 +674,8 @@ bforce_kernel(
 		const mm_t mf = key_mmer<KW, MM>(x, o), mr = mmer_rc<MM>(mf);
 		const mm_t cm = mf < mr ? mf : mr;
 		if (!dense && mmer_order<MM>(cm) != min_h) // seed index: a query may come through any m-mer of X'
+			continue;
+		if (n_own > 1 && seed_owner<MM>(cm, n_own) != own)
 			continue;
 		u32* cnt = ctab_slot<MM>(ckeys, ccnts, ccap, cm, true);
 		if (PHASE == 0)
@@ -672,7 +700,7 @@ __global__ void
 bfill_mtab_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ is_min, u64 total_words,
     u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap,
-    u32* __restrict__ heavy_min)
+    u32* __restrict__ heavy_min, u32 own, u32 n_own, int fill)
 {
 	typedef typename Mmer<MM>::type mm_t;
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -682,16 +710,21 @@ bfill_mtab_kernel(
 	const mm_t mf = mmer_fw<MM>(codes, pos);
 	const mm_t mr = mmer_rc<MM>(mf);
 	const mm_t cm = mf < mr ? mf : mr;
+	if (n_own > 1 && seed_owner<MM>(cm, n_own) != own)
+		return;
 	u32* cnt = ctab_slot<MM>(ckeys, ccnts, ccap, cm, false);
 	const u32 c = *cnt;
 	u64 e;
 	if ((c & kCntForced) || (c & kCntMask) > (u32)kHeavy) {
 		atomicOr(heavy_min + word, 1u << (31 - (u32)(pos & 31)));
-		if (atomicOr(cnt, kCntMarker) & kCntMarker)
+		if (!fill || (atomicOr(cnt, kCntMarker) & kCntMarker))
 			return;
 		e = mtab_entry(mmer_fp<MM>(cm), 0, kHeavyPos);
-	} else
+	} else {
+		if (!fill) // another rank's shard: only the heavy bits are wanted (the fallback table is the same everywhere)
+			return;
 		e = mtab_entry(mmer_fp<MM>(cm), mf < mr ? 1u : 0u, (u32)pos);
+	}
 	u64 s = mtab_home<MM>(cm, mcap);
 	for (;;) {
 		u64 expect = 0;
@@ -977,15 +1010,17 @@ launch_bmark(
 }
 
 hipError_t
-launch_bcount(int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, hipStream_t st)
+launch_bcount(
+    int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, u32 own, u32 n_own,
+    hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
 	if (mm == kMShort)
-		bcount_kernel<kMShort><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap);
+		bcount_kernel<kMShort><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap, own, n_own);
 	else
-		bcount_kernel<kMLong><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap);
+		bcount_kernel<kMLong><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap, own, n_own);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }
@@ -993,15 +1028,15 @@ launch_bcount(int mm, const u64* codes, const u32* is_min, u64 total_words, u64*
 hipError_t
 launch_bforce(
     int kw, int mm, int phase, const u64* codes, const u32* is_pal, u64 total_words, const KeyGeom& g, int w,
-    bool dense, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st)
+    bool dense, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, u32 own, u32 n_own, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
 #define ARKS_CALL0(KWV, MMV)                                                                       \
-	bforce_kernel<KWV, MMV, 0><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, dense ? 1 : 0, ckeys, ccnts, ccap, mtab, mcap)
+	bforce_kernel<KWV, MMV, 0><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, dense ? 1 : 0, ckeys, ccnts, ccap, mtab, mcap, own, n_own)
 #define ARKS_CALL1(KWV, MMV)                                                                       \
-	bforce_kernel<KWV, MMV, 1><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, dense ? 1 : 0, ckeys, ccnts, ccap, mtab, mcap)
+	bforce_kernel<KWV, MMV, 1><<<b, 256, 0, st>>>(codes, is_pal, total_words, g, w, dense ? 1 : 0, ckeys, ccnts, ccap, mtab, mcap, own, n_own)
 	if (phase == 0)
 		ARKS_KM_DISPATCH(kw, mm, ARKS_CALL0);
 	else
@@ -1015,15 +1050,17 @@ launch_bforce(
 hipError_t
 launch_bfill_mtab(
     int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab,
-    u64 mcap, u32* heavy_min, hipStream_t st)
+    u64 mcap, u32* heavy_min, u32 own, u32 n_own, bool fill, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
 	if (mm == kMShort)
-		bfill_mtab_kernel<kMShort><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min);
+		bfill_mtab_kernel<kMShort><<<b, 256, 0, st>>>(
+		    codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min, own, n_own, fill ? 1 : 0);
 	else
-		bfill_mtab_kernel<kMLong><<<b, 256, 0, st>>>(codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min);
+		bfill_mtab_kernel<kMLong><<<b, 256, 0, st>>>(
+		    codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min, own, n_own, fill ? 1 : 0);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }
@@ -1049,6 +1086,30 @@ launch_bfallback(
 		ARKS_KM_DISPATCH(kw, mm, ARKS_FB_F);
 #undef ARKS_FB_T
 #undef ARKS_FB_F
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_bdilate(const u32* visited, u64 total_words, int w, u32* is_min, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	bdilate_kernel<<<blocks_for(total_words, 256), 256, 0, st>>>(visited, total_words, w, is_min);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_bowners(int mm, const u64* codes, const u32* is_min, u64 total_words, u32 n_own, u64* per_owner, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+	if (mm == kMShort)
+		bowners_kernel<kMShort><<<b, 256, 0, st>>>(codes, is_min, total_words, n_own, per_owner);
+	else
+		bowners_kernel<kMLong><<<b, 256, 0, st>>>(codes, is_min, total_words, n_own, per_owner);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

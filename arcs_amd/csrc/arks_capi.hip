@@ -142,6 +142,12 @@ struct arks_index
 	u32* word_owner = nullptr;
 	u64* mtab = nullptr;
 	u64* trec = nullptr; // seed index: text records (BIndexView::trec)
+	// seed table sharded over ranks (arks_index_build_seed_shard): `mtab` holds the seeds this rank owns, the
+	// hot kernel gets its probes answered by their owners; the general kernels (medium, slow) work from a
+	// replicated minimizer table (bxg), ~20x smaller than the whole seed table
+	int seed_rank = 0, seed_ranks = 1;
+	u64* mtab_gen = nullptr;
+	BIndexView bxg{};
 	u64 text_words = 0;  // words of text incl. front padding (excl. back padding)
 	u64 alloc_words = 0;
 	int64_t n_keys = 0;
@@ -538,10 +544,12 @@ index_build_impl(
     int shard,
     int n_shards,
     int device,
-    arks_build_stats* stats)
+    arks_build_stats* stats,
+    int seed_rank = 0,
+    int seed_ranks = 1)
 {
 	if (!out || n_ends < 0 || (n_ends > 0 && (!h_bases || !h_offsets || !h_all_lens)) || n_shards < 1 ||
-	    shard < 0 || shard >= n_shards)
+	    shard < 0 || shard >= n_shards || seed_ranks < 1 || seed_rank < 0 || seed_rank >= seed_ranks)
 		return ARKS_ERR_BAD_ARG;
 	*out = nullptr;
 	// a shard sees the other shards' ends as empty strings: same conreci numbering, none of their k-mers
@@ -721,8 +729,10 @@ index_build_impl(
 	} else {
 		// (decided here, with the exact table of the build -- 64 B per visited window -- still allocated: what
 		// is free now is a lower bound of what the index may use)
-		dense = want_seeds(visited_total + (u64)w * (u64)n_ends, device);
+		dense = seed_ranks > 1 || want_seeds(visited_total + (u64)w * (u64)n_ends, device);
 		idx->kind = dense ? 2 : 1;
+		idx->seed_rank = seed_rank;
+		idx->seed_ranks = seed_ranks;
 		{
 			void* p = nullptr;
 			HIP_TRY(hipMalloc(&p, bm_bytes));
@@ -742,7 +752,7 @@ index_build_impl(
 		HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
 		HIP_TRY(hipMemcpyAsync(idx->word_owner, d_wown.p, bm_bytes, hipMemcpyDeviceToDevice, st));
 		HIP_TRY(launch_bmark(
-		    idx->kw, mm, idx->codes, idx->visited, text_words, idx->geom, full, w, dense, idx->ambig,
+		    idx->kw, mm, idx->codes, idx->visited, text_words, idx->geom, full, w, dense && seed_ranks == 1, idx->ambig,
 		    d_ismin.as<u32>(), d_ispal.as<u32>(), d_isimg.as<u32>(), st));
 	ARKS_TRACE_STEP("launch_bmark");
 		HIP_TRY(launch_popcount(d_ismin.as<u32>(), text_words, d_counters.as<u64>() + 0, st));
@@ -758,32 +768,82 @@ index_build_impl(
 		// the full table is no longer needed: every position now carries its value bits
 		(void)hipFree(d_full.p);
 		d_full.p = nullptr;
-		ccap = 2 * (n_min + 4 * n_pal) + 64;
-		mcap = ((u64)(dense ? ARKS_SEED_LOAD_INV : ARKS_MTAB_LOAD_INV) * (n_min + 4 * n_pal) + 64 + 3) & ~3ull; // whole groups of 4 (mtab_home)
-		HIP_TRY(d_ckeys.alloc(sizeof(u64) * ccap));
-		HIP_TRY(d_ccnts.alloc(sizeof(u32) * ccap));
-		{
-			void* p = nullptr;
-			HIP_TRY(hipMalloc(&p, sizeof(u64) * mcap));
-			idx->mtab = static_cast<u64*>(p);
+		// One table = count the occurrences of every registered m-mer (heavy ones get one marker instead
+		// of their positions), decree the m-mers of the quirk images heavy, fill.  With the seed table
+		// sharded over ranks the counting runs once per owner -- every rank needs the heavy bits of ALL
+		// seeds, because the fallback table (the same on every rank) holds the windows under heavy seeds --
+		// but only this rank's seeds are filled in.
+		auto build_table = [&](bool dense_t, int own_n, int own_r, u64 n_pos_total, const u64* pos_per_owner,
+		                       u64** out_tab, u64* out_cap) -> int {
+			int rc = ARKS_OK;
+			const u64 pal_extra = (u64)(dense_t ? w : 4) * n_pal;
+			for (int p_own = 0; p_own < own_n; ++p_own) {
+				const u64 npos = own_n > 1 ? pos_per_owner[p_own] : n_pos_total;
+				const bool mine = own_n == 1 || p_own == own_r;
+				const u64 ccap_t = 2 * (npos + pal_extra) + 64;
+				HIP_TRY(d_ckeys.alloc(sizeof(u64) * ccap_t));
+				HIP_TRY(d_ccnts.alloc(sizeof(u32) * ccap_t));
+				HIP_TRY(hipMemsetAsync(d_ckeys.p, 0, sizeof(u64) * ccap_t, st));
+				HIP_TRY(hipMemsetAsync(d_ccnts.p, 0, sizeof(u32) * ccap_t, st));
+				u64 mcap_t = 0;
+				if (mine) {
+					mcap_t = ((u64)(dense_t ? ARKS_SEED_LOAD_INV : ARKS_MTAB_LOAD_INV) * (npos + pal_extra) + 64 + 3) & ~3ull; // whole groups of 4 (mtab_home)
+					void* p = nullptr;
+					HIP_TRY(hipMalloc(&p, sizeof(u64) * mcap_t));
+					*out_tab = static_cast<u64*>(p);
+					*out_cap = mcap_t;
+					HIP_TRY(hipMemsetAsync(*out_tab, 0, sizeof(u64) * mcap_t, st));
+				}
+				HIP_TRY(launch_bcount(mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t,
+				                      (u32)p_own, (u32)own_n, st));
+				HIP_TRY(launch_bforce(idx->kw, mm, 0, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense_t,
+				                      d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t, nullptr, 0, (u32)p_own, (u32)own_n, st));
+				HIP_TRY(launch_bfill_mtab(mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(),
+				                          ccap_t, mine ? *out_tab : nullptr, mcap_t, d_heavy.as<u32>(), (u32)p_own, (u32)own_n,
+				                          mine, st));
+				if (mine)
+					HIP_TRY(launch_bforce(idx->kw, mm, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense_t,
+					                      d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t, *out_tab, mcap_t, (u32)p_own, (u32)own_n, st));
+				HIP_TRY(hipStreamSynchronize(st));
+			}
+		done:
+			return rc;
+		};
+		if (seed_ranks > 1) {
+			// the general kernels' minimizer table first (is_min = minimizer positions at this point) ...
+			u64 gcap = 0;
+			rc = build_table(false, 1, 0, n_min, nullptr, &idx->mtab_gen, &gcap);
+			if (rc != ARKS_OK)
+				goto done;
+			idx->bxg.mtab = idx->mtab_gen;
+			idx->bxg.mtab_cap = gcap;
+			ARKS_TRACE_STEP("general (minimizer) table");
+			// ... then every m-mer position, and how many of them each rank owns
+			HIP_TRY(hipMemsetAsync(d_heavy.p, 0, bm_bytes, st));
+			HIP_TRY(launch_bdilate(idx->visited, text_words, w, d_ismin.as<u32>(), st));
+			HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
+			HIP_TRY(launch_popcount(d_ismin.as<u32>(), text_words, d_counters.as<u64>() + 0, st));
+			HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			n_min = counters[0];
+			std::vector<u64> per_owner((size_t)seed_ranks, 0);
+			{
+				DevBuf d_po;
+				HIP_TRY(d_po.alloc(sizeof(u64) * (size_t)seed_ranks));
+				HIP_TRY(hipMemsetAsync(d_po.p, 0, sizeof(u64) * (size_t)seed_ranks, st));
+				HIP_TRY(launch_bowners(mm, idx->codes, d_ismin.as<u32>(), text_words, (u32)seed_ranks, d_po.as<u64>(), st));
+				HIP_TRY(hipMemcpyAsync(per_owner.data(), d_po.p, sizeof(u64) * (size_t)seed_ranks, hipMemcpyDeviceToHost, st));
+				HIP_TRY(hipStreamSynchronize(st));
+			}
+			rc = build_table(true, seed_ranks, seed_rank, n_min, per_owner.data(), &idx->mtab, &mcap);
+			if (rc != ARKS_OK)
+				goto done;
+		} else {
+			rc = build_table(dense, 1, 0, n_min, nullptr, &idx->mtab, &mcap);
+			if (rc != ARKS_OK)
+				goto done;
 		}
-		HIP_TRY(hipMemsetAsync(d_ckeys.p, 0, sizeof(u64) * ccap, st));
-		HIP_TRY(hipMemsetAsync(d_ccnts.p, 0, sizeof(u32) * ccap, st));
-		HIP_TRY(hipMemsetAsync(idx->mtab, 0, sizeof(u64) * mcap, st));
-		HIP_TRY(launch_bcount(mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap, st));
-	ARKS_TRACE_STEP("launch_bcount");
-		HIP_TRY(launch_bforce(
-		    idx->kw, mm, 0, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense, d_ckeys.as<u64>(),
-		    d_ccnts.as<u32>(), ccap, idx->mtab, mcap, st));
-	ARKS_TRACE_STEP("launch_bforce");
-		HIP_TRY(launch_bfill_mtab(
-		    mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap,
-		    idx->mtab, mcap, d_heavy.as<u32>(), st));
-	ARKS_TRACE_STEP("launch_bfill_mtab");
-		HIP_TRY(launch_bforce(
-		    idx->kw, mm, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense, d_ckeys.as<u64>(),
-		    d_ccnts.as<u32>(), ccap, idx->mtab, mcap, st));
-	ARKS_TRACE_STEP("launch_bforce");
+		ARKS_TRACE_STEP("table");
 		HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
 		HIP_TRY(launch_bfallback(
 		    idx->kw, mm, false, idx->codes, idx->visited, idx->ambig, d_ispal.as<u32>(), d_isimg.as<u32>(),
@@ -819,6 +879,15 @@ index_build_impl(
 		idx->bx.w = w;
 		idx->bx.enabled = 1;
 		idx->bx.dense = dense ? 1 : 0;
+		if (seed_ranks > 1) { // the general kernels' view: same text and fallback, the replicated minimizer table
+			u64* gen_tab = idx->mtab_gen;
+			const u64 gen_cap = idx->bxg.mtab_cap;
+			idx->bxg = idx->bx;
+			idx->bxg.mtab = gen_tab;
+			idx->bxg.mtab_cap = gen_cap;
+			idx->bxg.dense = 0;
+		} else
+			idx->bxg = idx->bx;
 		if (dense) {
 			void* p = nullptr;
 			HIP_TRY(hipMalloc(&p, 3 * sizeof(u64) * alloc_words));
@@ -884,6 +953,35 @@ arks_index_build_shard(
 }
 
 int
+arks_index_build_seed_shard(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int rank,
+    int n_ranks,
+    int device)
+{
+	if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+		return ARKS_ERR_BAD_ARG;
+	const int rc = index_build_impl(out, k, h_bases, h_offsets, h_lens, n_ends, 0, 1, device, nullptr, rank, n_ranks);
+	if (rc == ARKS_OK && n_ranks > 1 && (*out)->kind != 2) { // k < 20: no seed table to shard
+		arks_index_free(*out);
+		*out = nullptr;
+		return ARKS_ERR_K_UNSUPPORTED;
+	}
+	return rc;
+}
+
+int
+arks_index_seed_ranks(const arks_index* idx)
+{
+	return idx ? idx->seed_ranks : 0;
+}
+
+int
 arks_index_free(arks_index* idx)
 {
 	if (!idx)
@@ -903,6 +1001,8 @@ arks_index_free(arks_index* idx)
 		(void)hipFree(idx->mtab);
 	if (idx->trec)
 		(void)hipFree(idx->trec);
+	if (idx->mtab_gen)
+		(void)hipFree(idx->mtab_gen);
 	if (idx->queue)
 		(void)hipFree(idx->queue);
 	if (idx->queue_count)
@@ -931,7 +1031,8 @@ arks_index_device_bytes(const arks_index* idx)
 	int64_t b = (int64_t)(idx->table.cap * kSlotWords * sizeof(u64)) + idx->queue_cap * (int64_t)sizeof(u32);
 	if (idx->kind >= 1)
 		b += (int64_t)(idx->alloc_words * (sizeof(u64) + 3 * sizeof(u32))) + (int64_t)(idx->bx.mtab_cap * sizeof(u64)) +
-		     (idx->trec ? (int64_t)(idx->alloc_words * 3 * sizeof(u64)) : 0);
+		     (idx->trec ? (int64_t)(idx->alloc_words * 3 * sizeof(u64)) : 0) +
+		     (idx->mtab_gen ? (int64_t)(idx->bxg.mtab_cap * sizeof(u64)) : 0);
 	return b;
 }
 
@@ -1060,6 +1161,8 @@ arks_map_reads_device(
 		return ARKS_OK;
 	if (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_out_conreci)
 		return ARKS_ERR_BAD_ARG;
+	if (idx->seed_ranks > 1)
+		return ARKS_ERR_BAD_ARG; // this rank holds a shard of the seed table: arks_map_reads_seeded_device
 	DeviceGuard guard(idx->device);
 	int rc = ensure_queue(idx, n_reads);
 	if (rc != ARKS_OK)
@@ -1098,6 +1201,102 @@ arks_map_votes_device(
 	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, 0.0,
 	    idx->geom, idx->table, idx->bx, reinterpret_cast<int*>(d_out_votes), nullptr, idx->queue,
 	    idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream), true));
+done:
+	return rc;
+}
+
+int
+arks_seed_counts_device(
+    const arks_index* idx, const uint32_t* d_lens, const uint8_t* d_eval, int64_t n_reads, int32_t* d_counts, void* stream)
+{
+	if (!idx || n_reads < 0 || idx->kind != 2)
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads == 0)
+		return ARKS_OK;
+	if (!d_lens || !d_counts)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(idx->device);
+	int rc = ARKS_OK;
+	HIP_TRY(launch_seed_counts(d_lens, d_eval, (long)n_reads, idx->k, idx->bx.w, d_counts, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+int
+arks_seeds_fill_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    const int64_t* d_seed_off,
+    uint64_t* d_seed_mmer,
+    int32_t* d_seed_owner,
+    void* stream)
+{
+	if (!idx || n_reads < 0 || idx->kind != 2)
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads == 0)
+		return ARKS_OK;
+	if (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_seed_off || !d_seed_mmer || !d_seed_owner)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(idx->device);
+	int rc = ARKS_OK;
+	HIP_TRY(launch_seeds_fill(
+	    idx->bx.m, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, idx->k, idx->bx.w,
+	    (u32)idx->seed_ranks, (const long*)d_seed_off, (u64*)d_seed_mmer, d_seed_owner, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+int
+arks_seeds_probe_device(const arks_index* idx, const uint64_t* d_mmer, int64_t n, uint64_t* d_answers, void* stream)
+{
+	if (!idx || n < 0 || idx->kind != 2)
+		return ARKS_ERR_BAD_ARG;
+	if (n == 0)
+		return ARKS_OK;
+	if (!d_mmer || !d_answers)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(idx->device);
+	int rc = ARKS_OK;
+	HIP_TRY(launch_seeds_probe(idx->bx.m, idx->bx, (const u64*)d_mmer, (long)n, (u64*)d_answers, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+int
+arks_map_reads_seeded_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    const int64_t* d_seed_off,
+    const uint64_t* d_answers,
+    double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream)
+{
+	if (!idx || n_reads < 0 || n_reads > 0xFFFFFFFFll || idx->kind != 2)
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads == 0)
+		return ARKS_OK;
+	if (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_out_conreci || !d_seed_off || !d_answers)
+		return ARKS_ERR_BAD_ARG;
+	DeviceGuard guard(idx->device);
+	int rc = ensure_queue(idx, n_reads);
+	if (rc != ARKS_OK)
+		return rc;
+	HIP_TRY(launch_map_reads_seeded(
+	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, j_index, idx->geom,
+	    idx->bx, idx->bxg, (const long*)d_seed_off, (const u64*)d_answers, d_out_conreci, reinterpret_cast<u64*>(d_stats),
+	    idx->queue, idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream)));
 done:
 	return rc;
 }

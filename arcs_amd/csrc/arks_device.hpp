@@ -481,6 +481,18 @@ mtab_home(typename Mmer<MM>::type cm, u64 cap)
 	return mulhi64(h * 0xD6E8FEB86659FD93ull, cap) & ~3ull;
 }
 
+// Seed table sharded over the ranks of a node (BASELINE configs[3]): the rank that owns the canonical m-mer
+// cm -- by the top bits of a hash that is independent of the slot hash above, so that a shard's entries
+// still spread over all of its slots
+template <int MM>
+__device__ __forceinline__ u32
+seed_owner(typename Mmer<MM>::type cm, u32 n_owners)
+{
+	u64 h = ((u64)cm ^ 0x5851F42D4C957F2Dull) * 0xC2B2AE3D27D4EB4Full;
+	h ^= h >> 32;
+	return (u32)mulhi64(h * 0x9FB21C651E98DF25ull, (u64)n_owners);
+}
+
 __device__ __forceinline__ u32
 bit_at(const u32* __restrict__ bits, u64 pos)
 {

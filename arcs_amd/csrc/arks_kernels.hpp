@@ -30,22 +30,35 @@ hipError_t launch_map_reads(
     const uint8_t* eval, long n_reads, double j_index, const KeyGeom& g, TableView t,
     const BIndexView& bx, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu,
     hipStream_t st, bool raw = false); // raw: out is u64[n_reads], the votes of put_result<true>
+hipError_t launch_seed_counts(const u32* lens, const uint8_t* eval, long n_reads, int k, int w, int* out, hipStream_t st);
+hipError_t launch_seeds_fill(
+    int mm, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval, long n_reads,
+    int k, int w, u32 n_owners, const long* seed_off, u64* out_cm, int* out_owner, hipStream_t st);
+hipError_t launch_seeds_probe(int mm, const BIndexView& bx, const u64* cm, long n, u64* ans, hipStream_t st);
+hipError_t launch_map_reads_seeded(
+    int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval,
+    long n_reads, double j_index, const KeyGeom& g, const BIndexView& bx, const BIndexView& bxg, const long* seed_off,
+    const u64* ans, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st);
 hipError_t launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner, hipStream_t st);
 hipError_t launch_bmark(
     int kw, int mm, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,
     int w, bool dense, u32* ambig, u32* is_min, u32* is_pal, u32* is_img, hipStream_t st);
 hipError_t launch_bcount(
-    int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, hipStream_t st);
+    int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, u32 own, u32 n_own,
+    hipStream_t st);
 hipError_t launch_bforce(
     int kw, int mm, int phase, const u64* codes, const u32* is_pal, u64 total_words, const KeyGeom& g, int w,
-    bool dense, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, hipStream_t st);
+    bool dense, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, u32 own, u32 n_own, hipStream_t st);
 hipError_t launch_bfill_mtab(
     int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab,
-    u64 mcap, u32* heavy_min, hipStream_t st);
+    u64 mcap, u32* heavy_min, u32 own, u32 n_own, bool fill, hipStream_t st);
 hipError_t launch_bfallback(
     int kw, int mm, bool insert, const u64* codes, const u32* visited, const u32* ambig, const u32* is_pal,
     const u32* is_img, const u32* heavy_min, const u32* word_owner, u64 total_words, const KeyGeom& g,
     int w, bool dense, TableView fb, u64* counter, hipStream_t st);
+hipError_t launch_bdilate(const u32* visited, u64 total_words, int w, u32* is_min, hipStream_t st);
+hipError_t launch_bowners(
+    int mm, const u64* codes, const u32* is_min, u64 total_words, u32 n_own, u64* per_owner, hipStream_t st);
 hipError_t launch_btextrec(
     const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner, u64 alloc_words, u64* trec,
     hipStream_t st);

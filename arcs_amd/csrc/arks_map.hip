@@ -1678,6 +1678,19 @@ map_reads_b_kernel(
 //      visited, ambiguous -> popcounts into per-read counters;
 //   S6 lane = read: the vote of Arcs.cpp:996-1013.
 // ------------------------------------------------------------------------------------------------
+// A seed's answer from its owner (sharded seed table): a0 = first entry or 0, a1 = second or 0; entries have
+// bit 63 set, so 1 = "more than two entries" and 2 = "heavy seed" cannot be entries
+constexpr u64 kAnsOverflow = 1ull, kAnsHeavy = 2ull;
+__device__ __forceinline__ u32
+seed_answer_count(u64 a0, u64 a1)
+{
+	if (a0 == kAnsOverflow)
+		return kHnOverflow;
+	if (a0 == kAnsHeavy)
+		return kHnHeavy;
+	return a0 == 0 ? 0u : (a1 == 0 ? 1u : 2u);
+}
+
 constexpr int sTW = 64;               // tile capacity in packed words (= lanes of S5)
 constexpr int sTR = 16;               // reads per tile
 constexpr int sNH = 64;               // seeds per tile (= lanes of S2)
@@ -1712,7 +1725,11 @@ struct SeedTileLds
 #ifndef ARKS_SEED_WAVES
 #define ARKS_SEED_WAVES 8
 #endif
-template <int KW, bool STATS, int MM, bool RAW>
+// REMOTE = true: the seed table is sharded over the ranks of a node (arks_index_build_seed_shard): the probes
+//                of S2 were answered by the seeds' owners before the launch (arks_seeds_fill_device -> all-to-all
+//                -> arks_seeds_probe_device -> all-to-all); seed_off[r] = index of read r's first seed,
+//                ans[2 s], ans[2 s + 1] = the answer to seed s (seed_answer).
+template <int KW, bool STATS, int MM, bool RAW, bool REMOTE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ARKS_SEED_WAVES)))
 map_reads_s_kernel(
     const u64* __restrict__ codes,
@@ -1728,7 +1745,9 @@ map_reads_s_kernel(
     u64* __restrict__ stats,
     u32* __restrict__ queue,       // slow queue
     u32* __restrict__ mqueue,      // medium queue
-    u32* __restrict__ queue_count) // [0] slow length, [2] medium length; work counters behind (kWorkCtrOffset)
+    u32* __restrict__ queue_count, // [0] slow length, [2] medium length; work counters behind (kWorkCtrOffset)
+    const long* __restrict__ seed_off = nullptr, // REMOTE only
+    const u64* __restrict__ ans = nullptr)       // REMOTE only
 {
 	typedef typename Mmer<MM>::type mm_t;
 	__shared__ SeedTileLds S;
@@ -1775,6 +1794,7 @@ map_reads_s_kernel(
 			if (eval && !eval[c0 + lane_id])
 				rl = -1;
 		}
+		const long soff0 = REMOTE ? seed_off[c0] : 0; // index of the chunk's first seed in `ans`
 		const int nwin_l = rl - k + 1;
 		const int G = nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
 		int gsum = G; // inclusive prefix over the lanes of the chunk
@@ -1902,8 +1922,14 @@ map_reads_s_kernel(
 				u64 ent[2];
 				u32 cnt = 0;
 				// a seed that holds an invalid base has no entries: every window of its group holds that base too
-				if (!(has_n && tile_span_has_n(S.nm, q, MM)))
-					cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, ent);
+				if (!(has_n && tile_span_has_n(S.nm, q, MM))) {
+					if (REMOTE) {
+						const u64* a = ans + 2 * (soff0 + (long)(gbase + lane));
+						ent[0] = a[0], ent[1] = a[1];
+						cnt = seed_answer_count(ent[0], ent[1]);
+					} else
+						cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, ent);
+				}
 				off = cnt == kHnHeavy || cnt == kHnOverflow;
 				if (cnt >= 1 && cnt <= 2) {
 					const int o = q - S.rstart[jh]; // offset of the seed in the read
@@ -2103,6 +2129,80 @@ map_reads_s_kernel(
 	}
 }
 
+// ---- the sharded seed table: what a read asks, and what an owner answers -------------------------------
+// seeds of read r (the G of map_reads_s_kernel): ceil(windows / w), 0 for a read that is not evaluated
+__global__ void
+seed_counts_kernel(
+    const u32* __restrict__ lens, const uint8_t* __restrict__ eval, long n_reads, int k, int w, int* __restrict__ out)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads)
+		return;
+	const int nwin = (eval && !eval[r]) ? 0 : (int)lens[r] - k + 1;
+	out[r] = nwin > 0 ? (nwin + w - 1) / w : 0;
+}
+
+// canonical m-mer and owner rank of every seed, read-major (seed_off = exclusive prefix of the counts);
+// ~0 = the seed holds an invalid base (no entries anywhere; owner 0)
+template <int MM>
+__global__ void
+seeds_fill_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ nmask, const u64* __restrict__ word_off,
+    const u32* __restrict__ lens, const uint8_t* __restrict__ eval, long n_reads, int k, int w, u32 n_owners,
+    const long* __restrict__ seed_off, u64* __restrict__ out_cm, int* __restrict__ out_owner)
+{
+	typedef typename Mmer<MM>::type mm_t;
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads)
+		return;
+	const int nwin = (eval && !eval[r]) ? 0 : (int)lens[r] - k + 1;
+	const int G = nwin > 0 ? (nwin + w - 1) / w : 0;
+	const u64 wb = word_off[r];
+	const long s0 = seed_off[r];
+	for (int gi = 0; gi < G; ++gi) {
+		int q = (gi + 1) * w - 1;
+		q = q < nwin - 1 ? q : nwin - 1;
+		const u64 pos = wb * 32ull + (u64)q;
+		const u32* nm = nmask + (pos >> 5);
+		const u64 two = ((u64)nm[0] << 32) | (u64)nm[1];
+		u64 cm = ~0ull;
+		u32 own = 0;
+		if (((two << (pos & 31)) >> (64 - MM)) == 0) {
+			const mm_t mf = mmer_fw<MM>(codes, pos), mr = mmer_rc<MM>(mf);
+			cm = (u64)(mf < mr ? mf : mr);
+			own = seed_owner<MM>((mm_t)cm, n_owners);
+		}
+		out_cm[s0 + gi] = cm;
+		out_owner[s0 + gi] = (int)own;
+	}
+}
+
+// owner side: the entries of every asked m-mer in this rank's shard of the seed table
+template <int MM>
+__global__ void
+seeds_probe_kernel(BIndexView bx, const u64* __restrict__ cm, long n, u64* __restrict__ ans)
+{
+	typedef typename Mmer<MM>::type mm_t;
+	const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	u64 ent[2] = { 0, 0 };
+	u64 a0 = 0, a1 = 0;
+	if (cm[i] != ~0ull) {
+		const u32 cnt = probe_minimizer_table<MM>(bx, (mm_t)cm[i], ent);
+		if (cnt == kHnOverflow)
+			a0 = kAnsOverflow;
+		else if (cnt == kHnHeavy)
+			a0 = kAnsHeavy;
+		else {
+			a0 = cnt >= 1 ? ent[0] : 0;
+			a1 = cnt >= 2 ? ent[1] : 0;
+		}
+	}
+	ans[2 * i] = a0;
+	ans[2 * i + 1] = a1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: pair gate and pair rule of chromiumRead.
 // ------------------------------------------------------------------------------------------------
@@ -2292,6 +2392,99 @@ max_votes_kernel(u64* __restrict__ acc, const u64* __restrict__ in, long n)
 		if (b > a)
 			acc[r] = b;
 	}
+}
+
+hipError_t
+launch_seed_counts(const u32* lens, const uint8_t* eval, long n_reads, int k, int w, int* out, hipStream_t st)
+{
+	if (n_reads <= 0)
+		return hipSuccess;
+	seed_counts_kernel<<<blocks_for((u64)n_reads, 256), 256, 0, st>>>(lens, eval, n_reads, k, w, out);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_seeds_fill(
+    int mm, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval, long n_reads,
+    int k, int w, u32 n_owners, const long* seed_off, u64* out_cm, int* out_owner, hipStream_t st)
+{
+	if (n_reads <= 0)
+		return hipSuccess;
+	const unsigned b = blocks_for((u64)n_reads, 256);
+	if (mm == kMShort)
+		seeds_fill_kernel<kMShort><<<b, 256, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, seed_off, out_cm, out_owner);
+	else
+		seeds_fill_kernel<kMLong><<<b, 256, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, seed_off, out_cm, out_owner);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
+launch_seeds_probe(int mm, const BIndexView& bx, const u64* cm, long n, u64* ans, hipStream_t st)
+{
+	if (n <= 0)
+		return hipSuccess;
+	const unsigned b = blocks_for((u64)n, 256);
+	if (mm == kMShort)
+		seeds_probe_kernel<kMShort><<<b, 256, 0, st>>>(bx, cm, n, ans);
+	else
+		seeds_probe_kernel<kMLong><<<b, 256, 0, st>>>(bx, cm, n, ans);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+// bestContig for a batch whose seed probes were answered beforehand (sharded seed table): the hot kernel with
+// REMOTE answers, then the general kernels over the replicated minimizer table (bxg)
+hipError_t
+launch_map_reads_seeded(
+    int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval,
+    long n_reads, double j_index, const KeyGeom& g, const BIndexView& bx, const BIndexView& bxg, const long* seed_off,
+    const u64* ans, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st)
+{
+	if (n_reads <= 0)
+		return hipSuccess;
+	u64* const user_stats = stats;
+	if (stats)
+		stats = reinterpret_cast<u64*>(reinterpret_cast<char*>(queue_count) + 64);
+	hipError_t e = hipMemsetAsync(queue_count, 0, kMapScratchBytes, st);
+	if (e != hipSuccess)
+		return e;
+	const u64 cus = (u64)(n_cu > 0 ? n_cu : 256);
+	const u64 wants = ((u64)n_reads + sChunk - 1) / sChunk, ress = cus * 4ull * ARKS_SEED_WAVES;
+	const unsigned bh = (unsigned)(wants < ress ? wants : ress);
+	const u64 wantw = ((u64)n_reads + 3) / 4;
+	const unsigned bb = (unsigned)(wantw < cus * 16 ? wantw : cus * 16);
+	const u64 want = ((u64)n_reads + 3) / 4;
+	const unsigned bs = (unsigned)(want < 256 ? want : 256);
+	const TableView none{ nullptr, 0 };
+#define ARKS_SEEDED(KWV, ST, MMV)                                                                  \
+	do {                                                                                           \
+		map_reads_s_kernel<KWV, ST, MMV, false, true><<<bh, 64, 0, st>>>(                          \
+		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
+		    queue + n_reads, queue_count, seed_off, ans);                                          \
+		map_reads_b_kernel<KWV, ST, true, MMV, false, false><<<bb, 64, 0, st>>>(                   \
+		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bxg, out, stats, queue,       \
+		    queue + n_reads, queue_count);                                                         \
+		map_reads_kernel<KWV, ST, false, true, MMV, false><<<bs, 256, 0, st>>>(                    \
+		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, none, bxg, out, stats, queue, \
+		    queue_count);                                                                          \
+	} while (0)
+#define ARKS_SEEDED_ST(KWV, MMV)                                                                   \
+	do {                                                                                           \
+		if (stats) ARKS_SEEDED(KWV, true, MMV);                                                    \
+		else ARKS_SEEDED(KWV, false, MMV);                                                         \
+	} while (0)
+	if (kw == 2 && bx.m == kMShort) ARKS_SEEDED_ST(2, kMShort);
+	else if (kw == 2) ARKS_SEEDED_ST(2, kMLong);
+	else if (bx.m == kMShort) ARKS_SEEDED_ST(3, kMShort);
+	else ARKS_SEEDED_ST(3, kMLong);
+#undef ARKS_SEEDED
+#undef ARKS_SEEDED_ST
+	if (user_stats)
+		fold_stats_kernel<<<1, 64, 0, st>>>(stats, user_stats);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
 }
 
 hipError_t

@@ -130,3 +130,69 @@ class ShardedPairStep:
             reduce_votes(self.votes, self.group)
         api.resolve_votes(self.votes, self.reads, self.index.k, self.j, out=self.conreci)
         self.pair = api.pairs_rule(self.conreci, self.reads, self.pair_ok, self.barcode_id, self.imap, stored)
+
+
+# ---- sharded seed table (BASELINE configs[3]) ------------------------------------------------------------
+
+def _all_to_all(out, inp, out_splits, in_splits, group=None):
+    """all_to_all_single; with gloo and device tensors (ranks sharing one GPU in the tests) through host memory"""
+    import torch.distributed as dist
+    if inp.is_cuda and dist.get_backend(group) != "nccl":
+        h_out = out.cpu()
+        dist.all_to_all_single(h_out, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+    return out
+
+
+def exchange_seeds(index, mmer, owner, group=None):
+    """The north star's all-to-all: every seed (an 8-byte canonical m-mer) goes to the rank that owns it, the
+    owner looks it up in its shard of the seed table, the 16-byte answers come back in the seeds' order.
+    Returns int64[2 n_seeds]."""
+    import torch
+    import torch.distributed as dist
+    from . import api
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return api.seeds_probe(index, mmer.contiguous())               # one rank owns every seed
+    world = dist.get_world_size(group)
+    dev = mmer.device
+    n = int(mmer.numel())
+    order = torch.argsort(owner.to(torch.int64), stable=True)          # seeds grouped by owner
+    send = mmer[order].contiguous()
+    send_counts = torch.bincount(owner.to(torch.int64), minlength=world).to(torch.int64)
+    recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
+    _all_to_all(recv_counts, send_counts, None, None, group)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    asked = torch.empty(max(sum(rc), 1), dtype=torch.int64, device=dev)[:sum(rc)]
+    _all_to_all(asked, send, rc, sc, group)
+    answers = api.seeds_probe(index, asked)                            # the owner's part
+    back = torch.empty(max(2 * n, 2), dtype=torch.int64, device=dev)[:2 * n]
+    _all_to_all(back, answers.contiguous(), [2 * x for x in sc], [2 * x for x in rc], group)
+    out = torch.empty_like(back)
+    out.view(-1, 2)[order] = back.view(-1, 2)                          # back to the seeds' own order
+    return out
+
+
+def map_reads_seed_sharded(index, reads, j_index, eval_mask=None, stats=None, group=None):
+    """bestContig of this rank's reads against a seed table sharded over the ranks of `group`
+    (ArksIndex.build_seed_shard on every rank).  Every rank must call it in step (the exchange is collective),
+    each with its own reads; ranks may hold different numbers of reads, also none."""
+    import torch
+    from . import api
+    counts = api.seed_counts(index, reads, eval_mask)
+    seed_off = torch.zeros(reads.n_reads + 1, dtype=torch.int64, device=reads.codes.device)
+    seed_off[1:] = torch.cumsum(counts.to(torch.int64), 0)
+    mmer, owner = api.seeds_fill(index, reads, seed_off, eval_mask)
+    answers = exchange_seeds(index, mmer, owner, group)
+    return api.map_reads_seeded(index, reads, j_index, seed_off, answers, eval_mask=eval_mask, stats=stats)
+
+
+def map_pairs_seed_sharded(index, reads, j_index, pair_ok=None, barcode_id=None, imap=None, stored=None,
+                           stats=None, group=None):
+    """chromiumRead's per-pair flow (Arcs.cpp:1264-1292) for this rank's read pairs, seed table sharded"""
+    from . import api
+    ev = api.pair_gate(reads, pair_ok)
+    conreci = map_reads_seed_sharded(index, reads, j_index, eval_mask=ev, stats=stats, group=group)
+    pair = api.pairs_rule(conreci, reads, pair_ok, barcode_id, imap, stored)
+    return conreci, pair

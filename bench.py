@@ -319,9 +319,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] line and the end-to-end figure")
     ap.add_argument("--sharded-index", action="store_true",
-                    help="BASELINE configs[3]: rank r holds shard r of the index, every rank maps the SAME "
-                         "batch, one all-reduce(MAX) of the per-read votes per step (default: index replicas, "
-                         "reads sharded, no data-path collective)")
+                    help="BASELINE configs[3]: the index's seed table sharded over the ranks by a hash prefix of the "
+                         "m-mer, the --pairs read pairs split over the ranks, every seed routed to its owner and "
+                         "answered there (all-to-all); default: index replicas, reads sharded, no data-path collective")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -441,11 +441,14 @@ def main():
 
 
 def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
-    """BASELINE configs[3] (kept from round 1): see DESIGN.md 6"""
+    """BASELINE configs[3]: the seed table of the index sharded over the ranks by a hash prefix of the m-mer
+    (arks_index_build_seed_shard), the --pairs read pairs split over the ranks (strong scaling), every seed
+    routed to its owner and answered there (all_to_all_single over RCCL), DESIGN.md 6.  One step = gate ->
+    seeds -> exchange -> map -> pair rule over this rank's reads, in launches of --chunk pairs."""
     import torch.distributed as dist
-    from arcs_amd.dist import ShardedPairStep
+    from arcs_amd import dist as adist
     k, j = args.k, args.j
-    pairs = min(args.pairs, args.chunk)
+    lo, hi = adist.shard_pairs(args.pairs, rank, world)
     contigs = synth.make_draft(int(args.draft_mbp * 1e6), seed=synth.SEED)
     ends = []
     for c in contigs:
@@ -453,41 +456,72 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
         if cut is not None:
             ends.append(c[:cut].tobytes())
             ends.append(c[len(c) - cut:].tobytes())
-    index = arcs_amd.ArksIndex.build_shard(ends, k, rank, world, device=local)
+    t0 = time.time()
+    index = arcs_amd.ArksIndex.build_seed_shard(ends, k, rank, world, device=local)
     del ends
-    batch = synth.make_read_pairs(contigs, pairs, seed=synth.SEED + 1, device=dev)
-    reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
-    windows = reads.windows(k)
-    bases = int(batch["lens"].to(torch.int64).sum().item())
-    imap = arcs_amd.ImapAccumulator(max(1 << 16, 8 * (int(batch["barcode_id"].max().item()) + 1)), device=local)
-    step = ShardedPairStep(index, reads, j, pair_ok=batch["pair_ok"], barcode_id=batch["barcode_id"], imap=imap)
+    log(f"seed shard {rank}/{world}: {index.device_bytes / 2**30:.2f} GiB, built in {time.time() - t0:.1f}s")
+    genome = torch.from_numpy(np.concatenate(contigs)).to(dev)
+    del contigs
+    chunks, windows, bases, done = [], 0, 0, 0
+    while done < hi - lo:
+        n = min(args.chunk, hi - lo - done)
+        batch = synth.make_read_pairs(genome, n, seed=synth.SEED + 1 + 1000 * rank + done // args.chunk, device=dev)
+        reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
+        bid = (batch["barcode_id"] + (lo + done) // 80).to(torch.int32)
+        chunks.append((reads, batch["pair_ok"], bid))
+        bases += int(batch["lens"].to(torch.int64).sum().item())
+        done += n
+        del batch
+    # every rank runs the same number of exchanges per step: ranks with fewer launches add empty ones
+    n_launch = torch.tensor([len(chunks)], dtype=torch.int64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(n_launch, op=dist.ReduceOp.MAX)
+    empty = arcs_amd.PackedReads.from_arrays_device(
+        torch.zeros(0, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
+        torch.zeros(0, dtype=torch.int32, device=dev), device=local)
+    imap = arcs_amd.ImapAccumulator(1 << 20, device=local)
+    stats = torch.zeros(8, dtype=torch.int64, device=dev)
+
+    def step(st=None):
+        for i in range(int(n_launch.item())):
+            if i < len(chunks):
+                reads, ok, bid = chunks[i]
+                adist.map_pairs_seed_sharded(index, reads, j, pair_ok=ok, barcode_id=bid, imap=imap, stats=st)
+            else:
+                adist.map_reads_seed_sharded(index, empty, j)
+
     for _ in range(args.warmup):
-        step.run()
+        step()
+    step(stats)
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step.run(map_events=ev[s])
+        step()
     barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+    win = torch.tensor([float(stats[7].item())], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+        dist.all_reduce(win, op=dist.ReduceOp.SUM)
+    elapsed, windows = float(el.item()), float(win.item())
     if rank == 0:
-        map_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        b_alg = alg_bytes_per_window(k, bases, windows)
-        achieved = windows * b_alg / (map_ms * 1e-3) / 1e9
+        b_alg = alg_bytes_per_window(k, 279, 161)
+        ms = 1e3 * elapsed / args.steps
+        achieved = windows * b_alg / (ms * 1e-3) / 1e9 / world       # per GPU
         print(json.dumps({
             "metric": METRIC, "value": windows * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.draft_mbp:g} Mbp draft + {pairs} linked-read pairs (R1 128 / R2 151 bp), "
-                                   f"k={k} j={j}", "k": k, "j": j, "index_keys_this_shard": len(index),
-                       "parallelism": f"index sharded x{world} (contigs dealt to the lightest shard), reads replicated, "
-                                      "all-reduce(MAX) of votes"},
+            "config": {"workload": f"synthetic {args.draft_mbp:g} Mbp draft + {args.pairs} linked-read pairs in total "
+                                   f"(R1 128 / R2 151 bp), k={k} j={j}, seed table sharded over {world} rank(s)"
+                                   + (" [BASELINE configs[3]]" if args.draft_mbp == 3000 and args.pairs == 500_000_000 else ""),
+                       "k": k, "j": j, "windows": windows, "shard_bytes": index.device_bytes,
+                       "parallelism": f"seed table hash-sharded x{world}, reads dealt to ranks, seeds routed to their "
+                                      "owners and back (all_to_all_single)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "map_reads_b_kernel",
-                         "kernel_ms": map_ms, "alg_bytes_per_window": b_alg}}), flush=True)
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "whole step (seeds, exchange, probe, map_reads_s_kernel, pair rule)",
+                         "alg_bytes_per_window": b_alg}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

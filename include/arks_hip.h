@@ -132,6 +132,32 @@ int arks_index_build_shard(
     int n_shards,
     int device);
 
+/* The north star's sharded configuration (BASELINE configs[3]): the SEED TABLE of the seed index -- 32 B per
+ * text position, 43 GB for a 3 Gbp draft, everything else of the index is ~2 GB -- split over the ranks
+ * of a node by a hash prefix of the canonical m-mer.  Every rank passes the same end list and gets: the
+ * packed text, its bitmaps and the exact fallback table (replicated: identical on every rank), the seeds
+ * it OWNS, and a replicated minimizer table for the general kernels (the few reads the hot kernel does not
+ * finish).  A read is mapped on ONE rank (its home, reads are dealt to ranks); per batch the home
+ *   1. lists its reads' seeds        arks_seed_counts_device, a prefix sum, arks_seeds_fill_device
+ *   2. routes each seed (8 B) to its owner -- the all-to-all of the north star (RCCL over xGMI)
+ *   3. the owner answers             arks_seeds_probe_device (16 B per seed)
+ *   4. the answers travel back       the reverse all-to-all
+ *   5. the home finishes             arks_map_reads_seeded_device (== arks_map_reads_device's results)
+ * ~60 B per read on the wire instead of the 2.6 KB of keys that routing every k-mer would cost; the table,
+ * the probes and the reads all divide by the number of ranks.  n_ranks == 1 is arks_index_build. */
+int arks_index_build_seed_shard(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int rank,
+    int n_ranks,
+    int device);
+/* number of ranks the index's seed table is sharded over (1 = whole) */
+int arks_index_seed_ranks(const arks_index* idx);
+
 int arks_index_free(arks_index* idx);
 int arks_index_k(const arks_index* idx);
 /* number of distinct keys (== kmap.size()) */
@@ -226,6 +252,46 @@ int arks_map_votes_device(
     const uint8_t* d_eval,
     int64_t n_reads,
     uint64_t* d_out_votes,
+    void* stream);
+
+/* ---- read mapping over a sharded seed table (arks_index_build_seed_shard) ------------------------------- */
+
+/* d_counts[r] = seeds of read r: ceil(windows / (k - m + 1)), 0 when d_eval[r] == 0 */
+int arks_seed_counts_device(
+    const arks_index* idx, const uint32_t* d_lens, const uint8_t* d_eval, int64_t n_reads, int32_t* d_counts, void* stream);
+/* d_seed_off = exclusive prefix sum of the counts (n_reads + 1 entries).  Seed s of the batch (read-major):
+ * d_seed_mmer[s] = its canonical m-mer right-aligned (~0: it holds an invalid base, nobody has it),
+ * d_seed_owner[s] = the rank whose shard holds it. */
+int arks_seeds_fill_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    const int64_t* d_seed_off,
+    uint64_t* d_seed_mmer,
+    int32_t* d_seed_owner,
+    void* stream);
+/* Owner side: d_answers[2 i], [2 i + 1] = the (up to two) entries of d_mmer[i] in this rank's shard; 0 = none,
+ * [2 i] == 1: more than two, [2 i] == 2: a heavy seed (the home consults the fallback table). */
+int arks_seeds_probe_device(const arks_index* idx, const uint64_t* d_mmer, int64_t n, uint64_t* d_answers, void* stream);
+/* arks_map_reads_device with the seed probes answered beforehand: d_answers[2 s] for the seeds in the
+ * order of arks_seeds_fill_device.  Same results, same counters. */
+int arks_map_reads_seeded_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    const int64_t* d_seed_off,
+    const uint64_t* d_answers,
+    double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
     void* stream);
 
 /* d_acc[r] = max(d_acc[r], d_in[r]) (unsigned): folds another shard's votes in, for a driver that

@@ -162,3 +162,34 @@ def test_two_rank_sharded_index_votes(tmp_path, oracle):
         assert got == want, j
     assert len({c for c in want if c}) > 5
     assert want[-2] == 1 and want[-1] == 3
+
+
+def _seed_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from arcs_amd import api, dist as adist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # an owner's answer is a function of (owner, m-mer): the test can tell who answered what
+    api.seeds_probe = lambda index, asked: torch.stack([asked * 3 + index, asked ^ 0x5A5A], 1).reshape(-1)
+    g = torch.Generator().manual_seed(100 + rank)
+    for n in ((0, 7, 1000)[rank % 3], 513, 0 if rank == 1 else 64):         # uneven, also empty, batches
+        mmer = torch.randint(0, 1 << 40, (n,), generator=g, dtype=torch.int64)
+        owner = (mmer % world).to(torch.int32)                               # any deterministic ownership
+        ans = adist.exchange_seeds(rank, mmer, owner)                        # `index` only reaches the fake probe
+        want = torch.stack([mmer * 3 + owner.to(torch.int64), mmer ^ 0x5A5A], 1).reshape(-1)
+        assert torch.equal(ans, want), (rank, n)
+    open(os.path.join(out_dir, f"ok{rank}"), "w").close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_seed_exchange_routes_to_owners_and_back(tmp_path, world):
+    """the all-to-all of the sharded seed table (arcs_amd.dist.exchange_seeds) on CPU tensors: every seed is
+    answered by its owner and the answers come back in the asking rank's own seed order, for batches of
+    different sizes per rank, an empty batch on one rank included"""
+    import torch.multiprocessing as mp
+    mp.spawn(_seed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), f"ok{r}")) for r in range(world))
