@@ -16,6 +16,8 @@
 #define ARKS_SEED_LOAD_INV 4
 #endif
 
+#include <immintrin.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -337,6 +339,42 @@ pack8_bmi2(const unsigned char* p, uint32_t* codes16, uint32_t* bad8, uint32_t* 
 	*n8 = (uint32_t)__builtin_ia32_pext_di(isn, k80);
 }
 
+// 32 bases -> one code word, one N-mask word, the invalid / N byte masks (bit j = base j): AVX2
+__attribute__((target("avx2"))) static inline void
+pack32_avx2(const unsigned char* p, uint64_t* codes, uint32_t* bad, uint32_t* isn)
+{
+	const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+	const __m256i u = _mm256_and_si256(x, _mm256_set1_epi8((char)0xDF)); // upper case
+	const __m256i va = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('A')), vc = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('C'));
+	const __m256i vg = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('G')), vt = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('T'));
+	const __m256i valid = _mm256_or_si256(_mm256_or_si256(va, vc), _mm256_or_si256(vg, vt));
+	const __m256i vn = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('N'));
+	// A C G T -> 0 1 2 3: ((c >> 1) ^ (c >> 2)) & 3 (16-bit shifts: the bits that cross bytes are masked off)
+	__m256i two = _mm256_xor_si256(_mm256_srli_epi16(x, 1), _mm256_srli_epi16(x, 2));
+	two = _mm256_and_si256(_mm256_and_si256(two, _mm256_set1_epi8(3)), valid);
+	// four codes per byte, first base in the top bits: (b0 * 4 + b1) per 16-bit lane, then (.. * 16 + ..) per 32-bit lane
+	const __m256i p16 = _mm256_maddubs_epi16(two, _mm256_set1_epi16(0x0104));
+	const __m256i p32 = _mm256_madd_epi16(p16, _mm256_set1_epi32(0x00010010));
+	// the low byte of the eight 32-bit lanes, lane 0 (bases 0..3) most significant
+	const __m256i sh = _mm256_shuffle_epi8(
+	    p32, _mm256_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 12, 8, 4, 0, -1, -1, -1, -1, -1, -1,
+	                          -1, -1, -1, -1, -1, -1));
+	const uint32_t lo = (uint32_t)_mm256_extract_epi32(sh, 0); // bases 0..15: byte 3 = bases 0..3
+	const uint32_t hi = (uint32_t)_mm256_extract_epi32(sh, 4); // bases 16..31
+	*codes = ((uint64_t)lo << 32) | hi;
+	*bad = ~(uint32_t)_mm256_movemask_epi8(valid);
+	*isn = (uint32_t)_mm256_movemask_epi8(vn);
+}
+
+static inline uint32_t
+bitrev32(uint32_t v)
+{
+	v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+	v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+	v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+	return __builtin_bswap32(v);
+}
+
 int
 arks_pack_reads_host(
     const char* h_ascii,
@@ -366,6 +404,7 @@ arks_pack_reads_host(
 		ready = true;
 	}
 	const bool fast = __builtin_cpu_supports("bmi2");
+	const bool wide = __builtin_cpu_supports("avx2");
 	for (int64_t r = 0; r < n_reads; ++r) {
 		const unsigned char* s = reinterpret_cast<const unsigned char*>(h_ascii) + h_offsets[r];
 		const uint32_t len = h_lens[r];
@@ -378,6 +417,15 @@ arks_pack_reads_host(
 			uint32_t m = 0;
 			const uint32_t n = std::min<uint32_t>(32, len - (uint32_t)(w * 32));
 			uint32_t i = 0;
+			if (wide && n == 32) { // a whole word at once
+				uint32_t bad, isn;
+				pack32_avx2(s + w * 32, &c, &bad, &isn);
+				cw[w] = c;
+				mw[w] = bitrev32(bad); // bit 31 = the word's first base
+				nn += (uint32_t)__builtin_popcount(isn);
+				other |= bad & ~isn;
+				continue;
+			}
 			if (fast)
 				for (; i + 8 <= n; i += 8) {
 					uint32_t codes16, bad8, n8;

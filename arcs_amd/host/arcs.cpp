@@ -621,8 +621,10 @@ map_files(
 	res.first.resize(nk);
 	std::vector<std::unique_ptr<SeqReader>> readers;
 	for (const size_t f : mine) {
-		// inflate threads for bgzip'ed files: what is left of -t per file (bgzf.hpp)
-		readers.emplace_back(new SeqReader(files[f].c_str(), std::max(1u, params.threads / (unsigned)std::max<size_t>(mine.size(), 1))));
+		// inflate threads for bgzip'ed files (bgzf.hpp): -t over the files that are read at the same time (a
+		// quarter of the threads are producers, one file each; the inflaters of a file only run while it is read)
+		const unsigned concurrent = (unsigned)std::min<size_t>(std::max<size_t>(mine.size(), 1), std::max(1u, params.threads / 4));
+		readers.emplace_back(new SeqReader(files[f].c_str(), std::max(1u, params.threads / concurrent)));
 		if (!readers.back()->ok()) {
 			*open_error = files[f];
 			return res;

@@ -20,11 +20,14 @@
 #include "arks_hip.h"
 #include "seqio.hpp"
 
+#include <immintrin.h>
+
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -208,6 +211,7 @@ struct PrepassInfo
 	uint64_t lead = 0;     // records with a comment but no tag before the first tagged one
 	std::vector<uint64_t> untagged_at; // running tagged count at every later such record
 	std::vector<uint32_t> counts;      // reads per barcode id
+	std::vector<std::pair<uint32_t, uint32_t>> sparse_counts; // the same as (id, reads) pairs (a batch's share)
 
 	void record(int l, const std::string& comment, DynamicDict& dict, std::unordered_map<std::string_view, uint32_t>& cache)
 	{
@@ -241,9 +245,70 @@ struct PrepassInfo
 	}
 };
 
+// what a later stretch of the same file saw (`part`, counted from zero) appended to `whole`
+inline void
+prepass_merge(PrepassInfo& whole, const PrepassInfo& part)
+{
+	if (!whole.active)
+		return; // the pre-pass had stopped before
+	for (uint64_t i = 0; i < part.lead; ++i) {
+		if (whole.total == 0)
+			whole.lead++;
+		else
+			whole.untagged_at.push_back(whole.total);
+	}
+	for (const uint64_t u : part.untagged_at)
+		whole.untagged_at.push_back(whole.total + u);
+	if (part.counts.size() > whole.counts.size())
+		whole.counts.resize(part.counts.size(), 0);
+	for (size_t i = 0; i < part.counts.size(); ++i)
+		whole.counts[i] += part.counts[i];
+	for (const auto& ic : part.sparse_counts) {
+		if (ic.first >= whole.counts.size())
+			whole.counts.resize((size_t)ic.first + 1 + whole.counts.size() / 2, 0);
+		whole.counts[ic.first] += ic.second;
+	}
+	whole.total += part.total;
+	whole.active = part.active;
+	whole.zero_len = whole.zero_len || part.zero_len;
+}
+
 struct FileCounters
 {
 	uint64_t skipped_unpaired = 0, emptybarcode = 0, invalidbarcode = 0, gated = 0, skipped_invalid = 0;
+};
+
+// a growing byte buffer that does not clear what it hands out (a std::vector would zero 160 MB per batch)
+struct TextBuf
+{
+	std::unique_ptr<char[]> p;
+	size_t n = 0, cap = 0;
+	const char* view = nullptr; // not owned: a stretch of a mapped file (then p is unused)
+	char* data() { return view ? const_cast<char*>(view) : p.get(); }
+	const char* data() const { return view ? view : p.get(); }
+	size_t size() const { return n; }
+	void clear()
+	{
+		n = 0;
+		view = nullptr;
+	}
+	void reserve(size_t want)
+	{
+		if (want <= cap)
+			return;
+		const size_t c = std::max(want, cap + cap / 2);
+		std::unique_ptr<char[]> q(new char[c]);
+		if (n)
+			std::memcpy(q.get(), p.get(), n);
+		p.swap(q);
+		cap = c;
+	}
+	void append(const char* src, size_t len)
+	{
+		reserve(n + len + 1);
+		std::memcpy(p.get() + n, src, len);
+		n += len;
+	}
 };
 
 struct RawBatch
@@ -258,7 +323,16 @@ struct RawBatch
 	FileCounters fc;      // this batch's share
 	std::string messages; // stdout text produced while parsing it
 	bool last = false;    // last batch of its file
+	// the split form (fast path): whole lines of 4-line FASTQ records, not parsed yet -- `text` holds
+	// 8 * n_text_pairs lines, line[i] = offset of line i (one more entry: the end); the worker that
+	// takes the batch parses it (parse_text_batch), `off` then points into `text`, `bases` stays empty
+	bool is_text = false;
+	TextBuf text;
+	std::vector<uint32_t> line;
+	int64_t n_text_pairs = 0;
+	uint64_t first_pair = 0; // index of the batch's first pair in its file (progress messages)
 	size_t pairs() const { return pair_ok.size(); }
+	const char* base_ptr() const { return is_text ? text.data() : bases.data(); }
 };
 
 // host buffers of one packed batch; `alloc`/`release` let the front end use pinned memory
@@ -351,8 +425,9 @@ pack_batch(RawBatch& rb, PackedBatch& pb, const HostAllocator& a)
 	pb.words = words;
 	std::memset(pb.codes, 0, words * sizeof(uint64_t));
 	std::memset(pb.nmask, 0, words * sizeof(uint32_t));
-	rb.bases.push_back('\0');
-	const int rc = arks_pack_reads_host(rb.bases.data(), rb.off.data(), rb.len.data(), pb.woff, n, pb.codes, pb.nmask,
+	if (!rb.is_text)
+		rb.bases.push_back('\0'); // (a text batch ends with a newline)
+	const int rc = arks_pack_reads_host(rb.base_ptr(), rb.off.data(), rb.len.data(), pb.woff, n, pb.codes, pb.nmask,
 	                                    pb.cls);
 	if (rc != ARKS_OK)
 		return rc;
@@ -375,18 +450,21 @@ inline void
 produce_file(
     SeqReader& rd, int file_idx, const BarcodeDict* dict, DynamicDict* dyn, PrepassInfo* pre, long batch_pairs,
     bool verbose, const std::function<void(RawBatch&&)>& emit,
-    const std::function<bool(RawBatch&)>& recycled = nullptr) // hands back a used batch (its buffers are warm)
+    const std::function<bool(RawBatch&)>& recycled = nullptr, // hands back a used batch (its buffers are warm)
+    int64_t first_seq = 0, uint64_t pairs_before = 0)        // a file whose head went through split_file
 {
 	std::unordered_map<std::string_view, uint32_t> cache; // fused mode: this producer's view of the dictionary
 	rd.keep_qual = false; // the mapping needs no base qualities: measure them, do not copy them
 	RawBatch b;
-	int64_t seq = 0;
+	int64_t seq = first_seq;
 	auto reset = [&](RawBatch& x) {
 		// a recycled batch keeps its capacity: a fresh 80 MB of bases costs an mmap and 20 k page faults
 		if (recycled && recycled(x)) {
 			x.bases.clear(), x.off.clear(), x.len.clear(), x.pair_ok.clear(), x.barcode_id.clear(), x.messages.clear();
 			x.fc = FileCounters();
 			x.last = false;
+			x.is_text = false;
+			x.text.clear(), x.line.clear();
 		} else
 			x = RawBatch();
 		x.file = file_idx;
@@ -398,7 +476,7 @@ produce_file(
 		x.barcode_id.reserve((size_t)batch_pairs);
 	};
 	reset(b);
-	size_t count = 0;
+	size_t count = 2 * (size_t)pairs_before;
 	bool stop = false;
 	std::string n1, n2, c1, c2, s1, s2;
 	while (!stop) {
@@ -472,6 +550,351 @@ produce_file(
 	emit(std::move(b));
 }
 
+// ---- the fast path: 4-line FASTQ split by lines, parsed by the worker threads ----------------------------
+// One record parser per file is what bounds the stage (~4 M pairs/s).  Nearly every read file is plain
+// 4-line FASTQ, and for such text record boundaries are line boundaries: the producer of a file only finds the
+// line starts of its (inflated) text, checks that each group of four lines IS a record as kseq would read it
+// -- '@' header, one sequence line that does not start with '@', '+' or '>', a '+' line, one quality line of
+// the sequence's length -- and hands out whole batches of lines; the workers do the parsing proper (names,
+// stripReadNum, BX:Z:, multiplicity gate) and the packing.  The first group that is anything else (multi-line
+// records, FASTA, a short quality line, an empty read, the unfinished lines at the end of the file) ends the
+// fast path of that file: the text from there on goes back to the reader and the kseq-compatible loop
+// (produce_file) takes over, so the semantics are kseq's for every input.
+
+// positions of the first `max` newlines of p[0, n): AVX-512 where the CPU has it
+__attribute__((target("avx512bw,bmi,bmi2"))) inline size_t
+newline_positions_avx512(const char* p, size_t n, uint32_t base, uint32_t* out, size_t max, size_t* scanned)
+{
+	size_t cnt = 0, i = 0;
+	const __m512i nl = _mm512_set1_epi8('\n');
+	for (; i + 64 <= n && cnt + 64 <= max; i += 64) {
+		unsigned long long m = _mm512_cmpeq_epi8_mask(_mm512_loadu_si512((const void*)(p + i)), nl);
+		while (m) {
+			out[cnt++] = base + (uint32_t)i + (uint32_t)_tzcnt_u64(m);
+			m &= m - 1;
+		}
+	}
+	for (; i < n && cnt < max; ++i)
+		if (p[i] == '\n')
+			out[cnt++] = base + (uint32_t)i;
+	*scanned = i;
+	return cnt;
+}
+
+inline size_t
+newline_positions(const char* p, size_t n, uint32_t base, uint32_t* out, size_t max, size_t* scanned)
+{
+	static const bool wide = __builtin_cpu_supports("avx512bw") && !std::getenv("ARKS_NO_AVX512");
+	if (wide)
+		return newline_positions_avx512(p, n, base, out, max, scanned);
+	size_t cnt = 0, i = 0;
+	while (i < n && cnt < max) {
+		const void* q = std::memchr(p + i, '\n', n - i);
+		if (!q) {
+			i = n;
+			break;
+		}
+		i = (size_t)((const char*)q - p);
+		out[cnt++] = base + (uint32_t)i;
+		++i;
+	}
+	*scanned = i;
+	return cnt;
+}
+
+// Is the line [b, e) -- e = position of its newline -- a length kseq would report for it?  (the reader drops a
+// trailing carriage return of a line longer than one character)
+inline uint32_t
+kseq_line_len(const char* t, uint32_t b, uint32_t e)
+{
+	uint32_t n = e - b;
+	if (n > 1 && t[e - 1] == '\r')
+		n--;
+	return n;
+}
+
+// the four lines from line index i on are one FASTQ record in kseq's reading (see above)
+inline bool
+regular_record(const char* t, const uint32_t* start, size_t i)
+{
+	const uint32_t h = start[i], s = start[i + 1], p = start[i + 2], q = start[i + 3], e = start[i + 4];
+	if (t[h] != '@' || t[p] != '+')
+		return false;
+	const uint32_t sl = kseq_line_len(t, s, p - 1), ql = kseq_line_len(t, q, e - 1);
+	if (sl == 0 || sl != ql)
+		return false;
+	const char c = t[s];
+	return c != '@' && c != '+' && c != '>';
+}
+
+inline bool
+kseq_space(char c)
+{
+	return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r';
+}
+
+// name and comment of the header line [b, e) (b = the '@'), as SeqReader::next() splits them
+inline void
+split_header(const char* t, uint32_t b, uint32_t e, std::string_view& name, std::string_view& comment)
+{
+	uint32_t i = b + 1;
+	while (i < e && !kseq_space(t[i]))
+		++i;
+	name = std::string_view(t + b + 1, i - b - 1);
+	comment = std::string_view();
+	if (i < e) { // the terminator is inside the line: the rest is the comment
+		uint32_t cb = i + 1, ce = e;
+		if (ce - cb > 1 && t[ce - 1] == '\r')
+			ce--;
+		comment = std::string_view(t + cb, ce > cb ? ce - cb : 0);
+	}
+}
+
+inline std::string_view
+strip_read_num_view(std::string_view name)
+{
+	const size_t pos = name.rfind('/');
+	if (pos == std::string_view::npos || pos == 0 || pos == name.length() - 1)
+		return name;
+	if (!std::isdigit((unsigned char)name[pos + 1]))
+		return name;
+	return name.substr(0, pos);
+}
+
+inline std::string_view
+bx_barcode_sv(std::string_view comment)
+{
+	const size_t tag = comment.find("BX:Z:");
+	if (tag == std::string_view::npos)
+		return std::string_view();
+	const size_t end = comment.find(' ', tag);
+	return comment.substr(tag + 5, end != std::string_view::npos ? end - tag - 5 : std::string_view::npos);
+}
+
+// The record-pair loop of chromiumRead (Arcs.cpp:1185-1268) over a batch of regular records: fills the
+// parsed fields of `b` exactly as produce_file does for the same records; `pre` (fused mode) = this batch's
+// share of what the barcode pre-pass would have seen.
+inline void
+parse_text_batch(
+    RawBatch& b, const BarcodeDict* dict, DynamicDict* dyn, std::unordered_map<std::string_view, uint32_t>& cache,
+    PrepassInfo* pre, bool verbose)
+{
+	const char* t = b.text.data();
+	const uint32_t* L = b.line.data();
+	const size_t np = (size_t)b.n_text_pairs;
+	b.off.resize(2 * np), b.len.resize(2 * np), b.pair_ok.resize(np), b.barcode_id.resize(np);
+	std::unordered_map<uint32_t, uint32_t> seen; // fused mode: reads per barcode id in this batch
+	auto record = [&](std::string_view comment) { // PrepassInfo::record for a record of positive length
+		if (comment.empty())
+			return;
+		if (comment.find("BX:Z:") == std::string_view::npos) {
+			if (pre->total == 0)
+				pre->lead++;
+			else
+				pre->untagged_at.push_back(pre->total);
+			return;
+		}
+		const std::string_view bc = bx_barcode_sv(comment);
+		auto it = cache.find(bc);
+		if (it == cache.end()) {
+			std::string_view stored;
+			const uint32_t id = dyn->get(bc, &stored);
+			it = cache.emplace(stored, id).first;
+		}
+		seen[it->second]++;
+		pre->total++;
+	};
+	for (size_t p = 0; p < np; ++p) {
+		const uint32_t* l = L + 8 * p;
+		std::string_view n1, c1, n2, c2;
+		split_header(t, l[0], l[1] - 1, n1, c1);
+		split_header(t, l[4], l[5] - 1, n2, c2);
+		if (pre) {
+			record(c1);
+			record(c2);
+		}
+		n1 = strip_read_num_view(n1);
+		n2 = strip_read_num_view(n2);
+		const bool paired = n1 == n2;
+		if (!paired) {
+			b.messages.append("File contains unpaired reads: ").append(n1).append(" ").append(n2).append("\n");
+			b.fc.skipped_unpaired++;
+		}
+		const uint64_t count = 2 * (b.first_pair + p + 1);
+		if (verbose && count % 10000000 == 0)
+			b.messages += "Processed " + std::to_string(count) + " read pairs.\n";
+		const std::string_view b1 = bx_barcode_sv(c1), b2 = bx_barcode_sv(c2);
+		bool valid = false;
+		uint32_t bid = 0;
+		if (b1.empty() || b2.empty())
+			b.fc.emptybarcode++;
+		else if (dict) {
+			const auto it = dict->id.find(b1);
+			valid = it != dict->id.end();
+			if (!valid)
+				b.fc.invalidbarcode++;
+			else
+				bid = it->second;
+		} else {
+			valid = true;
+			auto it = cache.find(b1);
+			if (it == cache.end()) {
+				std::string_view stored;
+				const uint32_t id = dyn->get(b1, &stored);
+				it = cache.emplace(stored, id).first;
+			}
+			bid = it->second;
+		}
+		const bool ok = paired && valid && b1 == b2;
+		b.off[2 * p] = l[1];
+		b.len[2 * p] = kseq_line_len(t, l[1], l[2] - 1);
+		b.off[2 * p + 1] = l[5];
+		b.len[2 * p + 1] = kseq_line_len(t, l[5], l[6] - 1);
+		b.pair_ok[p] = ok ? 1 : 0;
+		b.barcode_id[p] = ok ? bid : 0;
+	}
+	if (pre) {
+		pre->sparse_counts.assign(seen.begin(), seen.end());
+	}
+}
+
+// The same over a plain file mapped into memory: the batches are stretches of the mapping itself (no copy).
+// Returns the batches handed out; *consumed = the offset where the sequential loop continues.
+inline int64_t
+split_mapped(
+    const char* map, size_t size, int file_idx, long batch_pairs, const std::function<void(RawBatch&&)>& emit,
+    const std::function<bool(RawBatch&)>& recycled, uint64_t* pairs_out, size_t* consumed)
+{
+	int64_t seq = 0;
+	uint64_t pairs_done = 0;
+	size_t at = 0;
+	const size_t want_lines = (size_t)batch_pairs * 8;
+	for (;;) {
+		RawBatch b;
+		if (recycled)
+			(void)recycled(b);
+		b.bases.clear(), b.off.clear(), b.len.clear(), b.pair_ok.clear(), b.barcode_id.clear(), b.messages.clear();
+		b.fc = FileCounters();
+		b.last = false;
+		b.is_text = true;
+		b.file = file_idx;
+		b.text.clear();
+		b.line.resize(want_lines + 1);
+		// (offsets within a batch are 32-bit: look at no more than 3.5 GB of text per batch)
+		const size_t span = std::min<size_t>(size - at, 0xE0000000ull);
+		size_t scanned = 0;
+		const size_t nlines = newline_positions(map + at, span, 0, b.line.data() + 1, want_lines, &scanned);
+		b.line[0] = 0;
+		for (size_t i = 1; i <= nlines; ++i)
+			b.line[i] += 1;
+		size_t good = 0;
+		const size_t full = nlines / 8;
+		while (good < full && regular_record(map + at, b.line.data(), 8 * good) &&
+		       regular_record(map + at, b.line.data(), 8 * good + 4))
+			++good;
+		if (good) {
+			const size_t cut = b.line[8 * good];
+			b.text.view = map + at;
+			b.text.n = cut;
+			b.line.resize(8 * good + 1);
+			b.n_text_pairs = (int64_t)good;
+			b.first_pair = pairs_done;
+			b.seq = seq++;
+			pairs_done += good;
+			at += cut;
+			emit(std::move(b));
+		}
+		if (good < (size_t)batch_pairs)
+			break; // irregular text, or the end of the file: the sequential loop reads on from `at`
+	}
+	*pairs_out = pairs_done;
+	*consumed = at;
+	return seq;
+}
+
+// The producer of one file on the fast path: batches of `batch_pairs` regular record pairs as text
+// (`emit`), until the text stops being regular or ends; what is left goes back into the reader.  Returns
+// the number of batches handed out (the sequential loop continues the numbering) and, in *pairs, the pairs
+// they held.
+inline int64_t
+split_file(
+    SeqReader& rd, int file_idx, long batch_pairs, const std::function<void(RawBatch&&)>& emit,
+    const std::function<bool(RawBatch&)>& recycled, uint64_t* pairs_out)
+{
+	int64_t seq = 0;
+	uint64_t pairs_done = 0;
+	std::vector<char> carry; // text read beyond the batch that was cut
+	const size_t want_lines = (size_t)batch_pairs * 8;
+	size_t text_estimate = std::min<size_t>((size_t)batch_pairs * 680, (size_t)1 << 29); // 10x reads: ~630 B per pair
+	bool eof = false, irregular = false;
+	while (!eof && !irregular) {
+		RawBatch b;
+		if (recycled)
+			(void)recycled(b);
+		b.bases.clear(), b.off.clear(), b.len.clear(), b.pair_ok.clear(), b.barcode_id.clear(), b.messages.clear();
+		b.fc = FileCounters();
+		b.last = false;
+		b.is_text = true;
+		b.file = file_idx;
+		b.text.clear();
+		// one allocation per buffer, at the size the previous batch needed (a fresh buffer is one page fault per
+		// 4 KB on first touch: growing it step by step would pay that several times over)
+		b.text.reserve(std::max(text_estimate, carry.size() + ((size_t)1 << 22)) + 1);
+		b.text.append(carry.data(), carry.size());
+		carry.clear();
+		b.line.resize(want_lines + 1);
+		size_t nlines = 0, scanned = 0;
+		// line ends accumulate in b.line[1..]; b.line[0] = 0 is the first line's start
+		b.line[0] = 0;
+		for (;;) {
+			size_t adv = 0;
+			nlines += newline_positions(b.text.data() + scanned, b.text.size() - scanned, (uint32_t)scanned,
+			                            b.line.data() + 1 + nlines, want_lines - nlines, &adv);
+			scanned += adv;
+			if (nlines == want_lines || eof)
+				break;
+			const size_t old = b.text.size(), room = (size_t)1 << 22;
+			if (old + room > 0xF0000000ull) { // offsets are 32-bit: lines this long are not FASTQ reads
+				irregular = true;
+				break;
+			}
+			b.text.reserve(old + room + 1);
+			const int got = rd.read_raw((unsigned char*)b.text.data() + old, (int)room);
+			b.text.n = old + (size_t)std::max(got, 0);
+			if (got <= 0)
+				eof = true;
+		}
+		// line ends -> line starts (start of line i + 1 = end of line i + 1)
+		for (size_t i = 1; i <= nlines; ++i)
+			b.line[i] += 1;
+		// whole pairs that are regular
+		size_t good = 0;
+		const size_t full = nlines / 8;
+		while (good < full && regular_record(b.text.data(), b.line.data(), 8 * good) &&
+		       regular_record(b.text.data(), b.line.data(), 8 * good + 4))
+			++good;
+		if (good < full || nlines < want_lines)
+			irregular = true; // (or the end of the file: the sequential loop reads the last lines)
+		const size_t cut = good ? b.line[8 * good] : 0; // first byte that does not belong to the batch
+		if (good == (size_t)batch_pairs)
+			text_estimate = std::min<size_t>(b.text.size() + b.text.size() / 16, 0xE0000000ull);
+		carry.assign(b.text.data() + cut, b.text.data() + b.text.size());
+		if (good) {
+			b.text.n = cut;
+			b.line.resize(8 * good + 1);
+			b.n_text_pairs = (int64_t)good;
+			b.first_pair = pairs_done;
+			b.seq = seq++;
+			pairs_done += good;
+			emit(std::move(b));
+		}
+	}
+	if (!carry.empty())
+		rd.unread((const unsigned char*)carry.data(), carry.size());
+	*pairs_out = pairs_done;
+	return seq;
+}
+
 // Runs producers (one per file, at most `n_producers` at a time) and `n_packers` packers; calls
 // `consume` on the caller's thread for every packed batch (any file order; batches of one file in
 // order), then `recycle`d buffers go back to the packers.  Returns the first ABI error, or ARKS_OK.
@@ -486,6 +909,8 @@ class IngestPipeline
 	  : readers_(std::move(readers))
 	  , dict_(dict)
 	  , prepass_(dict ? 0 : readers_.size())
+	  , tail_pre_(dict ? 0 : readers_.size())
+	  , head_pre_(dict ? 0 : readers_.size())
 	  , batch_pairs_(batch_pairs)
 	  , verbose_(verbose)
 	  , alloc_(std::move(alloc))
@@ -494,7 +919,11 @@ class IngestPipeline
 	  , free_q_(1u << 20)
 	{
 		const unsigned nf = (unsigned)readers_.size();
-		n_producers_ = std::max(1u, std::min(nf, std::max(1u, threads / 2)));
+		// ARKS_SEQUENTIAL_INGEST=1: every file through the kseq-compatible loop alone (A/B runs, tests)
+		fast_path_ = std::getenv("ARKS_SEQUENTIAL_INGEST") == nullptr;
+		// a producer on the fast path only reads and finds lines (the workers parse): a quarter of the threads
+		// is plenty for them; without it a producer IS a parser: half
+		n_producers_ = std::max(1u, std::min(nf, std::max(1u, threads / (fast_path_ ? 4 : 2))));
 		n_packers_ = std::max(1u, threads > n_producers_ ? threads - n_producers_ : 1u);
 		n_buffers_ = n_packers_ + 3;
 	}
@@ -527,16 +956,39 @@ class IngestPipeline
 							return;
 						f = next_file++;
 					}
+					// the head of the file on the fast path (batches of lines, parsed by the workers), whatever is
+					// left -- at least the end of the file -- through the kseq-compatible loop
+					int64_t first_seq = 0;
+					uint64_t pairs_before = 0;
+					const auto emit = [&](RawBatch&& rb) { raw_q_.push(std::move(rb)); };
+					const auto reuse = [&](RawBatch& out) { return raw_free_.try_pop(out); };
+					if (fast_path_) {
+						size_t msize = 0, at = 0;
+						const char* map = readers_[f]->map_plain(&msize);
+						if (map) {
+							first_seq = split_mapped(map, msize, (int)f, batch_pairs_, emit, reuse, &pairs_before, &at);
+							readers_[f]->continue_at(at);
+						} else
+							first_seq = split_file(*readers_[f], (int)f, batch_pairs_, emit, reuse, &pairs_before);
+					}
 					produce_file(*readers_[f], (int)f, dict_, dict_ ? nullptr : &dynamic_,
-					             dict_ ? nullptr : &prepass_[f], batch_pairs_, verbose_,
-					             [&](RawBatch&& rb) { raw_q_.push(std::move(rb)); },
-					             [&](RawBatch& out) { return raw_free_.try_pop(out); });
+					             dict_ ? nullptr : &tail_pre_[f], batch_pairs_, verbose_, emit, reuse, first_seq,
+					             pairs_before);
 				}
 			});
 		for (unsigned t = 0; t < n_packers_; ++t)
 			packers.emplace_back([&] {
 				RawBatch rb;
+				std::unordered_map<std::string_view, uint32_t> cache; // fused mode: this worker's view of the dictionary
 				while (raw_q_.pop(rb)) {
+					if (rb.is_text) {
+						PrepassInfo part;
+						parse_text_batch(rb, dict_, dict_ ? nullptr : &dynamic_, cache, dict_ ? nullptr : &part, verbose_);
+						if (!dict_) {
+							std::lock_guard<std::mutex> lk(err_m);
+							head_pre_[(size_t)rb.file].emplace_back(rb.seq, std::move(part));
+						}
+					}
 					PackedBatch* pb = nullptr;
 					if (!free_q_.pop_newest(pb))
 						return;
@@ -574,6 +1026,16 @@ class IngestPipeline
 				recycle(pb);
 		}
 		closer.join();
+		// the barcode pre-pass of every file: its fast-path batches in file order, then the sequential rest
+		for (size_t f = 0; f < prepass_.size(); ++f) {
+			std::sort(head_pre_[f].begin(), head_pre_[f].end(),
+			          [](const std::pair<int64_t, PrepassInfo>& a, const std::pair<int64_t, PrepassInfo>& b) { return a.first < b.first; });
+			prepass_[f] = PrepassInfo();
+			for (const auto& part : head_pre_[f])
+				prepass_merge(prepass_[f], part.second);
+			prepass_merge(prepass_[f], tail_pre_[f]);
+			head_pre_[f].clear();
+		}
 		if (finish)
 			finish();
 		free_q_.close();
@@ -589,7 +1051,9 @@ class IngestPipeline
 	std::vector<SeqReader*> readers_;
 	const BarcodeDict* dict_;
 	DynamicDict dynamic_;
-	std::vector<PrepassInfo> prepass_;
+	std::vector<PrepassInfo> prepass_, tail_pre_;
+	std::vector<std::vector<std::pair<int64_t, PrepassInfo>>> head_pre_; // fast-path batches: (seq, share)
+	bool fast_path_ = true;
 	long batch_pairs_;
 	bool verbose_;
 	HostAllocator alloc_;

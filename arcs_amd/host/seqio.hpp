@@ -11,13 +11,18 @@
 #include "bgzf.hpp"
 #include "fast_inflate.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 namespace arks_host {
 
@@ -56,10 +61,15 @@ class SeqReader
 				}
 				else
 					std::fclose(f);
+			} else if (!gz) {
+				// plain text in a regular file: read(2) straight into the caller's buffers (zlib's transparent
+				// mode would copy every byte twice more)
+				std::fclose(f);
+				plain_fd_ = ::open(path, O_RDONLY);
 			} else
 				std::fclose(f);
 		}
-		if (!bgzf_file_ && !fast_ && !ahead_) {
+		if (!bgzf_file_ && !fast_ && !ahead_ && plain_fd_ < 0) {
 			fp_ = gzopen(path, "r");
 			if (fp_)
 				gzbuffer(fp_, 1u << 20);
@@ -69,12 +79,81 @@ class SeqReader
 	{
 		if (fp_)
 			gzclose(fp_);
+		if (map_)
+			(void)::munmap(map_, map_size_);
+		if (plain_fd_ >= 0)
+			::close(plain_fd_);
 		if (bgzf_file_ && !bgzf_)
 			std::fclose(bgzf_file_);
 	}
 	SeqReader(const SeqReader&) = delete;
 	SeqReader& operator=(const SeqReader&) = delete;
-	bool ok() const { return fp_ != nullptr || bgzf_file_ != nullptr || fast_ != nullptr || ahead_ != nullptr; }
+	bool ok() const { return fp_ != nullptr || bgzf_file_ != nullptr || fast_ != nullptr || ahead_ != nullptr || plain_fd_ >= 0; }
+
+	// The raw (inflated) text instead of records, for a caller that splits it itself (ingest.hpp): up to
+	// `cap` bytes, 0 at the end of the stream.  May be mixed with next(): both consume the same stream.
+	int read_raw(unsigned char* dst, int cap)
+	{
+		int got = 0;
+		while (got < cap) {
+			if (begin_ >= end_ && plain_fd_ >= 0 && pushback_pos_ >= pushback_.size() && !eof_) {
+				const ssize_t r = ::read(plain_fd_, dst + got, (size_t)(cap - got)); // no detour through buf_
+				if (r <= 0) {
+					eof_ = true;
+					break;
+				}
+				got += (int)r;
+				continue;
+			}
+			if (begin_ >= end_) {
+				if (got > 0 || !fill())
+					break; // (a short read once something was delivered: the next call fetches more)
+			}
+			const int n = std::min(cap - got, end_ - begin_);
+			std::memcpy(dst + got, buf_ + begin_, (size_t)n);
+			begin_ += n;
+			got += n;
+		}
+		return got;
+	}
+	// A plain text file as one read-only mapping (no copy at all: the caller splits and parses it in place);
+	// nullptr for any other source, or once something was read.  The mapping lives as long as the reader.
+	const char* map_plain(size_t* size)
+	{
+		if (plain_fd_ < 0 || begin_ < end_ || eof_ || map_ || !pushback_.empty())
+			return map_ ? (const char*)map_ : nullptr;
+		struct stat st;
+		if (::fstat(plain_fd_, &st) != 0 || st.st_size <= 0 || ::lseek(plain_fd_, 0, SEEK_CUR) != 0)
+			return nullptr;
+		void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, plain_fd_, 0);
+		if (m == MAP_FAILED)
+			return nullptr;
+		(void)::madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+		map_ = m;
+		map_size_ = (size_t)st.st_size;
+		*size = map_size_;
+		return (const char*)map_;
+	}
+	// after map_plain: the stream (next(), read_raw()) continues at this offset of the file
+	void continue_at(size_t offset)
+	{
+		(void)::lseek(plain_fd_, (off_t)offset, SEEK_SET);
+		begin_ = end_ = 0;
+		eof_ = false;
+	}
+	// gives `n` bytes back: they are the next the stream delivers (the text a splitting caller read ahead
+	// of the point where it hands the stream over to next())
+	void unread(const unsigned char* p, size_t n)
+	{
+		std::vector<unsigned char> rest(p, p + n);
+		rest.insert(rest.end(), buf_ + begin_, buf_ + end_); // what the reader itself holds comes after
+		rest.insert(rest.end(), pushback_.begin() + (std::ptrdiff_t)pushback_pos_, pushback_.end());
+		pushback_.swap(rest);
+		pushback_pos_ = 0;
+		begin_ = end_ = 0;
+		if (!pushback_.empty())
+			eof_ = false;
+	}
 	bool parallel_inflate() const { return bgzf_file_ != nullptr; }
 
 	int next()
@@ -136,6 +215,9 @@ class SeqReader
 
   private:
 	gzFile fp_ = nullptr;
+	int plain_fd_ = -1;
+	void* map_ = nullptr;
+	size_t map_size_ = 0;
 	std::unique_ptr<BgzfReader> bgzf_;
 	std::unique_ptr<GzInflater> fast_;
 	std::unique_ptr<InflateAhead> ahead_;
@@ -145,9 +227,23 @@ class SeqReader
 	int begin_ = 0, end_ = 0;
 	bool eof_ = false;
 	int last_ = 0;
+	std::vector<unsigned char> pushback_;
+	size_t pushback_pos_ = 0;
 
 	bool fill()
 	{
+		if (pushback_pos_ < pushback_.size()) {
+			const size_t n = std::min(sizeof buf_, pushback_.size() - pushback_pos_);
+			std::memcpy(buf_, pushback_.data() + pushback_pos_, n);
+			pushback_pos_ += n;
+			begin_ = 0;
+			end_ = (int)n;
+			if (pushback_pos_ == pushback_.size()) {
+				pushback_.clear();
+				pushback_pos_ = 0;
+			}
+			return true;
+		}
 		if (eof_ || !ok())
 			return false;
 		begin_ = 0;
@@ -155,7 +251,8 @@ class SeqReader
 			bgzf_.reset(new BgzfReader(bgzf_file_, bgzf_workers_)); // owns the file from here on
 		end_ = bgzf_ ? bgzf_->read(buf_, (int)sizeof buf_)
 		             : ahead_ ? ahead_->read(buf_, (int)sizeof buf_)
-		             : fast_ ? fast_->read(buf_, (int)sizeof buf_) : gzread(fp_, buf_, sizeof buf_);
+		             : fast_ ? fast_->read(buf_, (int)sizeof buf_)
+		             : plain_fd_ >= 0 ? (int)::read(plain_fd_, buf_, sizeof buf_) : gzread(fp_, buf_, sizeof buf_);
 		if (end_ <= 0) {
 			end_ = 0;
 			eof_ = true;

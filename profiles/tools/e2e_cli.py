@@ -1,7 +1,7 @@
 """End-to-end throughput of the `arcs --arks` CLI: FASTQ(.gz) files -> .gv, by -t."""
 import gzip, os, subprocess, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.getcwd())
 from arcs_amd import build as b, synth
 exe = b.build_host()
 tmp = "/tmp/e2e"; os.makedirs(tmp, exist_ok=True)
@@ -28,7 +28,7 @@ for fi in range(NF):
     with gzip.open(f"{tmp}/r{fi}.fq.gz", "wt", compresslevel=4) as f:
         f.write(text)
     if os.environ.get("E2E_BGZF"):
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
         from test_host_ingest import write_bgzf
         write_bgzf(f"{tmp}/r{fi}.bgzf.fq.gz", text.encode(), level=4)
 with open(f"{tmp}/mult.tsv", "w") as f:

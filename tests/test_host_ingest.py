@@ -150,8 +150,10 @@ def write_fastq(path, recs, tail=""):
             f.write(text)
 
 
-def run(exe, threads, batch, mult_path, files):
-    out = subprocess.check_output([exe, str(threads), str(batch), mult_path] + files, text=True)
+def run(exe, threads, batch, mult_path, files, sequential=False):
+    """sequential: ARKS_SEQUENTIAL_INGEST=1, every file through the kseq-compatible loop alone (no fast path)"""
+    env = dict(os.environ, ARKS_SEQUENTIAL_INGEST="1") if sequential else None
+    out = subprocess.check_output([exe, str(threads), str(batch), mult_path] + files, text=True, env=env)
     lines = [ln for ln in out.splitlines(keepends=True) if not ln.startswith(("prepass ", "mult\t"))]
     res, cur = [], None
     for ln in lines[1:]:
@@ -189,8 +191,9 @@ def test_pipeline_matches_restatement(exe, oracle, tmp_path):
         files.append(path)
         want.append(expected(exp_recs, mult, oracle))
     base = None
-    for threads, batch in [(1, 1 << 20), (2, 64), (8, 50), (3, 1), (6, 1000)]:
-        head, res = run(exe, threads, batch, mult_path, files)
+    for threads, batch, seql in [(1, 1 << 20, False), (2, 64, False), (8, 50, False), (3, 1, False), (6, 1000, False),
+                                 (1, 1 << 20, True), (4, 50, True)]:
+        head, res = run(exe, threads, batch, mult_path, files, sequential=seql)
         assert len(res) == len(files)
         for fi, r in enumerate(res):
             c, digest, msgs = want[fi]
@@ -206,7 +209,68 @@ def test_pipeline_matches_restatement(exe, oracle, tmp_path):
         base = base or res
     # the thread split the front end reports
     head, _ = run(exe, 8, 100, mult_path, files)
-    assert head.strip() == "threads producers=4 packers=4"   # five files, eight threads
+    assert head.strip() == "threads producers=2 packers=6"   # five files, eight threads: producers only find lines
+    head, _ = run(exe, 8, 100, mult_path, files, sequential=True)
+    assert head.strip() == "threads producers=4 packers=4"   # ... without the fast path they parse
+
+
+def test_fast_path_hands_over_to_the_kseq_loop(exe, tmp_path):
+    """The fast path takes whole batches of 4-line FASTQ records and stops at the first group of four lines
+    that is anything else; from there the kseq-compatible loop reads on.  Whatever the text and wherever the
+    irregular stretch starts, the stage's output equals the sequential loop's (which the tests above pin to
+    the restatement): digest of everything the GPU stage receives, counters, messages, fused pre-pass."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    barcodes = [f"{''.join('ACGT'[i] for i in rng.integers(0, 4, size=16))}-1" for _ in range(12)]
+    mult_path = str(tmp_path / "mult.tsv")
+    with open(mult_path, "w") as f:
+        f.writelines(f"{b}\t{7}\n" for b in barcodes[:10])
+
+    def text_of(recs):
+        return "".join(f"@{n}{' ' + c if c else ''}\n{s}\n+\n{'I' * len(s)}\n" for n, c, s in recs)
+
+    def rec(i, m, seq="ACGTACGTAGGCTTAACG" * 4):
+        return (f"r{i}/{m}", f"BX:Z:{barcodes[i % 12]}", seq)
+
+    regular = [rec(i, m) for i in range(300) for m in (1, 2)]
+    odd = {
+        "multiline_seq": "@m/1 BX:Z:%s\nACGTACGT\nACGTAC\n+\nIIIIIIII\nIIIIII\n@m/2 BX:Z:%s\nACGT\n+\nIIII\n" % (barcodes[0], barcodes[0]),
+        "fasta_records": ">f/1 BX:Z:%s\nACGTACGTACGT\n>f/2 BX:Z:%s\nACGTACGTAAAA\n" % (barcodes[1], barcodes[1]),
+        "blank_lines": "\n\n",
+        "qual_starts_with_at": "@q/1 BX:Z:%s\nACGTACGT\n+\n@IIIIIII\n@q/2 BX:Z:%s\nACGTACGG\n+q/2\n+IIIIIII\n" % (barcodes[2], barcodes[2]),
+        "empty_read": "@e/1 BX:Z:%s\n\n+\n\n@e/2 BX:Z:%s\n\n+\n\n" % (barcodes[3], barcodes[3]),
+        "long_quality": "@l/1 BX:Z:%s\nACGT\n+\nIIIIII\n@l/2 BX:Z:%s\nACGT\n+\nIIII\n" % (barcodes[4], barcodes[4]),
+        "cr_lf": "@c/1 BX:Z:%s\r\nACGTACGT\r\n+\r\nIIIIIIII\r\n@c/2 BX:Z:%s\r\nACGTACGA\r\n+\r\nIIIIIIII\r\n" % (barcodes[5], barcodes[5]),
+        "header_only_at": "@\nACGT\n+\nIIII\n@\nACGT\n+\nIIII\n",
+        "tabs_in_header": "@t/1\tBX:Z:%s\tx\nACGTACGT\n+\nIIIIIIII\n@t/2\tBX:Z:%s\nACGTACGA\n+\nIIIIIIII\n" % (barcodes[6], barcodes[6]),
+    }
+    files = []
+    for name, chunk in odd.items():
+        for where in (0, 7, 150, 300):          # irregular stretch at the start, early, in the middle, at the end
+            path = str(tmp_path / f"{name}_{where}.fq")
+            with open(path, "w") as f:
+                f.write(text_of(regular[:2 * where]) + chunk + text_of(regular[2 * where:]))
+            files.append(path)
+    nonl = str(tmp_path / "no_final_newline.fq")
+    with open(nonl, "w") as f:
+        f.write(text_of(regular)[:-1])
+    files.append(nonl)
+    oddcount = str(tmp_path / "odd_count.fq")
+    with open(oddcount, "w") as f:
+        f.write(text_of(regular[:-1]))
+    files.append(oddcount)
+    for mp in (mult_path, "-"):                  # with a multiplicity file, and fused
+        for threads, batch in ((1, 1 << 20), (6, 16), (3, 100)):
+            a = subprocess.check_output([exe, str(threads), str(batch), mp] + files, text=True)
+            b = subprocess.check_output([exe, str(threads), str(batch), mp] + files, text=True,
+                                        env=dict(os.environ, ARKS_SEQUENTIAL_INGEST="1"))
+            import re
+            # (the first line is the thread split; how many batches a file made is not part of the result)
+            a = re.sub(r" multibatch=\d", "", "\n".join(a.split("\n")[1:]))
+            b = re.sub(r" multibatch=\d", "", "\n".join(b.split("\n")[1:]))
+            assert a == b, (mp, threads, batch)
+    # and the fast path did take most batches of a mostly regular file (multibatch = more than one batch seen)
+    _, res = run(exe, 4, 16, mult_path, [files[2]])
+    assert res[0]["kv"]["multibatch"] == "1" and int(res[0]["kv"]["pairs"]) >= 300
 
 
 def test_fused_barcode_prepass(exe, oracle, tmp_path):
