@@ -216,35 +216,11 @@ check_same_format(const std::vector<std::string>& names, bool& all_alignment)
 	return true;
 }
 
-// Arcs.cpp:392-448
+// Arcs.cpp:392-448 (the parser itself: graph.hpp)
 void
 create_index_mult_map(const std::string& multfile, std::unordered_map<std::string, int>& mult)
 {
-	size_t numbarcodes = 0;
-	const bool tsv = multfile.find(".tsv") != std::string::npos;
-	std::ifstream in(multfile.c_str());
-	if (!in) {
-		std::cerr << "Could not open " << multfile << ". --fatal.\n";
-		exit(EXIT_FAILURE);
-	}
-	std::string line;
-	while (getline(in, line)) {
-		std::string barcode, ms;
-		if (tsv) {
-			std::stringstream sst(line);
-			sst >> barcode >> ms;
-		} else {
-			std::istringstream iss(line);
-			getline(iss, barcode, ',');
-			iss >> ms;
-		}
-		numbarcodes++;
-		const size_t m = (size_t)std::stoi(ms);
-		if (!barcode.empty())
-			mult[barcode] = (int)m;
-		else
-			std::cout << "Please check your multiplicity file." << std::endl;
-	}
+	const size_t numbarcodes = read_multiplicity_file(multfile, mult);
 	if (params.verbose)
 		std::cout << "Saw " << numbarcodes << "  distinct barcodes." << std::endl;
 }
@@ -392,6 +368,9 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 		if (params.verbose && total % 1000 == 0)
 			appendf(log, "Finished %d Contigs...\n", total);
 	}
+	if (rd.failed())
+		std::cerr << PROGRAM ": warning: " << params.file
+		          << ": the compressed stream is damaged or truncated; the contigs before the damage were used\n";
 	bases.push_back('\0');
 	if (params.verbose)
 		std::cerr << "Number of contigs:" << count << "\nSize of Contig Array:" << count * 2 + 1 << std::endl;
@@ -662,6 +641,10 @@ map_files(
 		std::cerr << PROGRAM ": device error while mapping\n";
 		exit(EXIT_FAILURE);
 	}
+	for (size_t i = 0; i < mine.size(); ++i)
+		if (readers[i]->failed()) // (the reference's gzread + kseq stop silently at the same place)
+			std::cerr << PROGRAM ": warning: " << files[mine[i]]
+			          << ": the compressed stream is damaged or truncated; the records before the damage were used\n";
 	if (fused) {
 		for (const PrepassInfo& pi : pipe.prepass())
 			if (pi.zero_len || pi.untagged_at.size() > (1u << 22)) {

@@ -340,4 +340,39 @@ add_opposite_ends(IndexMap& imap)
 	}
 }
 
+
+// createIndexMultMap, Arcs.cpp:392-448: barcode -> reads from a `-u` file; the name decides the format (".tsv"
+// anywhere in it: white-space separated, otherwise "barcode,reads").  Returns the number of lines read (what
+// the reference reports as "distinct barcodes"); exits like the reference when the file cannot be opened.
+inline size_t
+read_multiplicity_file(const std::string& multfile, std::unordered_map<std::string, int>& mult)
+{
+	size_t numbarcodes = 0;
+	const bool tsv = multfile.find(".tsv") != std::string::npos;
+	std::ifstream in(multfile.c_str());
+	if (!in) {
+		std::cerr << "Could not open " << multfile << ". --fatal.\n";
+		exit(EXIT_FAILURE);
+	}
+	std::string line;
+	while (getline(in, line)) {
+		std::string barcode, ms;
+		if (tsv) {
+			std::stringstream sst(line);
+			sst >> barcode >> ms;
+		} else {
+			std::istringstream iss(line);
+			getline(iss, barcode, ',');
+			iss >> ms;
+		}
+		numbarcodes++;
+		const size_t m = (size_t)std::stoi(ms);
+		if (!barcode.empty())
+			mult[barcode] = (int)m;
+		else
+			std::cout << "Please check your multiplicity file." << std::endl;
+	}
+	return numbarcodes;
+}
+
 } // namespace arks_host

@@ -4,11 +4,15 @@
 //       imap.tsv: barcode \t contig \t H|T \t count   (the post-pass for missing ends is applied)
 //       with e (end length), B (bin size) and upper (0|1): -D distance estimates as well
 //       (<out_base>_dist.tsv, <out_base>_samples.tsv, d= / maxd= in the graph files)
+//   graph_check mult  <multiplicity file> <out.tsv>
+//       the -u parser (createIndexMultMap) and the --barcode-counts writer: lines read, barcodes kept, sum of
+//       the reads on stdout; the map as the reference writes it (Arcs.cpp:1684-1706) to <out.tsv>
 //   graph_check gv    <original.gv> <lengths.tsv> <out.dist.gv> gap
 //       rebuilds the scaffold graph from an _original.gv and writes the ABySS dist.gv for it
 #include "dist_est.hpp"
 #include "graph.hpp"
 
+#include <cstdio>
 #include <cstring>
 
 using namespace arks_host;
@@ -26,6 +30,17 @@ read_lengths(const char* path, ContigToLength& len)
 int
 main(int argc, char** argv)
 {
+	if (argc >= 4 && std::strcmp(argv[1], "mult") == 0) {
+		std::unordered_map<std::string, int> mult;
+		const size_t lines = read_multiplicity_file(argv[2], mult);
+		long long total = 0;
+		for (const auto& kv : mult)
+			total += kv.second;
+		std::printf("%zu %zu %lld\n", lines, mult.size(), total);
+		std::ofstream out(argv[3]);
+		write_barcode_counts(out, mult);
+		return 0;
+	}
 	if (argc >= 6 && std::strcmp(argv[1], "gv") == 0) {
 		ScaffoldGraph g;
 		std::ifstream in(argv[2]);

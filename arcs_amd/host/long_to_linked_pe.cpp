@@ -149,6 +149,8 @@ main(int argc, char* argv[])
 		size_t num = 0;
 		for (; rd.next() >= 0; ++num) {
 			const size_t step = l * 2;
+			// (bytes as they are: the reference opens btllib::SeqReader with Flag::LONG_MODE alone, without
+			// FOLD_CASE or TRIM_MASKED -- src/long-to-linked-pe.cpp:186-188 -- so lower-case bases stay lower case)
 			const std::string& seq = rd.seq;
 			const size_t n = seq.size();
 			if (with_bx || with_bx_only) {

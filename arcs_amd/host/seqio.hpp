@@ -155,6 +155,8 @@ class SeqReader
 			eof_ = false;
 	}
 	bool parallel_inflate() const { return bgzf_file_ != nullptr; }
+	// the stream ended on an inflate error (damaged or truncated compressed input), not at its end
+	bool failed() const { return failed_; }
 
 	int next()
 	{
@@ -225,7 +227,7 @@ class SeqReader
 	unsigned bgzf_workers_ = 0;
 	unsigned char buf_[1 << 18];
 	int begin_ = 0, end_ = 0;
-	bool eof_ = false;
+	bool eof_ = false, failed_ = false;
 	int last_ = 0;
 	std::vector<unsigned char> pushback_;
 	size_t pushback_pos_ = 0;
@@ -254,6 +256,12 @@ class SeqReader
 		             : fast_ ? fast_->read(buf_, (int)sizeof buf_)
 		             : plain_fd_ >= 0 ? (int)::read(plain_fd_, buf_, sizeof buf_) : gzread(fp_, buf_, sizeof buf_);
 		if (end_ <= 0) {
+			// a negative count is damage (a CRC or length mismatch, a truncated member, a BGZF file that goes
+			// on as something else), not the end: zlib's gzread tells the reference's kseq the same way, and
+			// the reference reads on to what it takes for the end of the file -- so does this reader, but it
+			// remembers (failed()) so that the front end can say so
+			if (end_ < 0)
+				failed_ = true;
 			end_ = 0;
 			eof_ = true;
 			return false;

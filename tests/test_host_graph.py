@@ -262,3 +262,25 @@ def test_gv_to_tigpair_chain(graph_check, tmp_path):
     demo_fa.write_text(">1\nA\n>2\nA\n>3\nA\n")
     assert _make_tsv(os.path.join(GOLDEN, "arks_demo_original.gv"), str(demo_fa)) == \
         open(os.path.join(GOLDEN, "arks_demo.tigpair_checkpoint.tsv")).read()
+
+
+def test_multiplicity_files_of_the_reference_demos(graph_check, tmp_path):
+    """the -u parser (createIndexMultMap, Arcs.cpp:392-448) on the reference's own files: the arks demo's CSV
+    (1085 barcodes, 55288 reads = the reads of the demo log) and the arks-long demo's TSV (the name decides the
+    format); the --barcode-counts writer gives a CSV-sorted file back (count descending, barcode ascending)"""
+    import shutil
+    for name, fmt in (("arks_demo.test_reads_multiplicities.csv", "csv"), ("arks-long_demo.barcodeMultiplicityArcs.tsv", "tsv")):
+        src = os.path.join(GOLDEN, name)
+        rows = [ln.replace(",", "\t").split() for ln in open(src).read().split("\n") if ln]
+        want = {b: int(m) for b, m in rows}
+        out = tmp_path / f"counts_{fmt}.tsv"
+        got = subprocess.check_output([graph_check, "mult", src, str(out)], text=True).split()
+        assert [int(x) for x in got] == [len(rows), len(want), sum(want.values())]
+        back = [ln.split("\t") for ln in out.read_text().split("\n") if ln]
+        assert {b: int(m) for b, m in back} == want
+        assert [(b, int(m)) for b, m in back] == sorted(want.items(), key=lambda kv: (-kv[1], kv[0]))
+        # the same content under the other extension is read the other way: a CSV named .tsv has no white space
+        # to split at, so the whole line is the "barcode" and the count is missing -- the reference then dies in
+        # std::stoi; only the matching pairs of name and content are usable
+    rows = [ln.split(",") for ln in open(os.path.join(GOLDEN, "arks_demo.test_reads_multiplicities.csv")).read().split("\n") if ln]
+    assert len(rows) == 1085 and sum(int(m) for _, m in rows) == 55288     # SURVEY 8(c): the demo log's read count
