@@ -35,6 +35,8 @@ while time.time() < t_end:
         ends.append("".join(s))
     ends.append(base)
     ox = oracle.OracleIndex(k).build(ends)
+    # both layouts of the locality index take turns (the library reads the variable at every build)
+    os.environ["ARKS_INDEX_KIND"] = "seeds" if seed % 3 else "minimizer"
     ix = arcs_amd.ArksIndex.build(ends, k, device=0)
     assert {f: ix.build_stats[f] for f in ox.stats.as_dict()} == ox.stats.as_dict(), (seed, k, "build stats")
     genome = "".join(ends)
@@ -72,6 +74,28 @@ while time.time() < t_end:
             want = [ox.best_contig(r, j) for r in reads]
             bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
             assert not bad, (seed - 1, k, j, n_sh, "sharded", bad[:5])
+    if os.environ.get("FUZZ_SEED_SHARDS"):  # the seed table in 2..4 shards, every seed answered by its owner
+        n_sh = int(rng.integers(2, 5))
+        packed = arcs_amd.PackedReads.from_ascii(reads, device=0)
+        shards = [arcs_amd.ArksIndex.build_seed_shard(ends, k, r, n_sh, device=0) for r in range(n_sh)]
+        counts = arcs_amd.api.seed_counts(shards[0], packed)
+        seed_off = torch.zeros(packed.n_reads + 1, dtype=torch.int64, device="cuda")
+        seed_off[1:] = torch.cumsum(counts.to(torch.int64), 0)
+        mmer, owner = arcs_amd.api.seeds_fill(shards[0], packed, seed_off)
+        answers = torch.zeros(2 * mmer.numel(), dtype=torch.int64, device="cuda")
+        for r, sh in enumerate(shards):
+            sel = (owner == r).nonzero().flatten()
+            answers.view(-1, 2)[sel] = arcs_amd.api.seeds_probe(sh, mmer[sel].contiguous()).view(-1, 2)
+        for j in (0.55, 0.0):
+            stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+            got = arcs_amd.api.map_reads_seeded(shards[int(rng.integers(n_sh))], packed, j, seed_off, answers, stats=stats).cpu().tolist()
+            st = oracle.MapStats()
+            want = [ox.best_contig(r, j, st) for r in reads]
+            bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+            assert not bad, (seed - 1, k, j, n_sh, "seed shards", bad[:5])
+            assert dict(zip(("total_valid", "bad", "found", "recorded", "dups", "reads_pass", "reads_fail", "windows"), stats.cpu().tolist())) == st.as_dict(), (seed - 1, k, j, n_sh)
+        for sh in shards:
+            sh.close()
     ix.close()
     n_cases += 1; n_reads_total += len(reads)
 print("fuzz ok: %d cases, %d reads, last seed %d" % (n_cases, n_reads_total, seed - 1))
