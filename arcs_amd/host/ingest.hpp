@@ -758,54 +758,113 @@ parse_text_batch(
 	}
 }
 
-// The same over a plain file mapped into memory: the batches are stretches of the mapping itself (no copy).
-// Returns the batches handed out; *consumed = the offset where the sequential loop continues.
+// The same over a plain file mapped into memory: the batches are stretches of the mapping itself (no copy),
+// and the line scan is not bound to one thread either -- the file is taken a gigabyte at a time, `scan_threads`
+// threads find the newlines of a slice each, the line starts are put together, the slices' record groups are
+// verified in parallel, and only then (everything before the first irregular group being known to be regular)
+// the batches are cut.  Returns the batches handed out; *consumed = the offset where the sequential loop
+// continues.
 inline int64_t
 split_mapped(
     const char* map, size_t size, int file_idx, long batch_pairs, const std::function<void(RawBatch&&)>& emit,
-    const std::function<bool(RawBatch&)>& recycled, uint64_t* pairs_out, size_t* consumed)
+    const std::function<bool(RawBatch&)>& recycled, uint64_t* pairs_out, size_t* consumed, unsigned scan_threads = 1)
 {
 	int64_t seq = 0;
 	uint64_t pairs_done = 0;
 	size_t at = 0;
-	const size_t want_lines = (size_t)batch_pairs * 8;
+	// a stretch = at least one batch's worth of text (so that a stretch yields full batches) and enough for every
+	// scan thread, at most a gigabyte (offsets within it are 32-bit); the workers parse the batches of one
+	// stretch while the next is scanned
+	const size_t kSuper = std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)batch_pairs * 720, (size_t)scan_threads << 25));
+	std::vector<uint32_t> start; // line starts of the current stretch, relative to `at`
+	std::vector<std::vector<uint32_t>> nl(std::max(1u, scan_threads));
 	for (;;) {
-		RawBatch b;
-		if (recycled)
-			(void)recycled(b);
-		b.bases.clear(), b.off.clear(), b.len.clear(), b.pair_ok.clear(), b.barcode_id.clear(), b.messages.clear();
-		b.fc = FileCounters();
-		b.last = false;
-		b.is_text = true;
-		b.file = file_idx;
-		b.text.clear();
-		b.line.resize(want_lines + 1);
-		// (offsets within a batch are 32-bit: look at no more than 3.5 GB of text per batch)
-		const size_t span = std::min<size_t>(size - at, 0xE0000000ull);
-		size_t scanned = 0;
-		const size_t nlines = newline_positions(map + at, span, 0, b.line.data() + 1, want_lines, &scanned);
-		b.line[0] = 0;
-		for (size_t i = 1; i <= nlines; ++i)
-			b.line[i] += 1;
-		size_t good = 0;
+		const size_t span = std::min(size - at, kSuper);
+		if (span == 0)
+			break;
+		const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(scan_threads, span >> 22)); // >= 4 MB per thread
+		const size_t slice = ((span + T - 1) / T + 63) & ~(size_t)63;
+		auto scan = [&](unsigned i) {
+			const size_t lo = std::min(span, (size_t)i * slice), hi = std::min(span, lo + slice);
+			std::vector<uint32_t>& v = nl[i];
+			v.resize(std::max(v.capacity(), (hi - lo) / 24 + 64)); // grown below when the lines are shorter than that
+			size_t n = 0, pos = lo;
+			while (pos < hi) {
+				if (v.size() - n < 4096)
+					v.resize(v.size() * 2);
+				size_t adv = 0;
+				n += newline_positions(map + at + pos, hi - pos, (uint32_t)pos, v.data() + n, v.size() - n, &adv);
+				pos += adv;
+			}
+			v.resize(n);
+		};
+		{
+			std::vector<std::thread> th;
+			for (unsigned i = 1; i < T; ++i)
+				th.emplace_back(scan, i);
+			scan(0);
+			for (auto& t : th)
+				t.join();
+		}
+		std::vector<size_t> first(T + 1, 0);
+		for (unsigned i = 0; i < T; ++i)
+			first[i + 1] = first[i] + nl[i].size();
+		const size_t nlines = first[T];
+		start.resize(nlines + 1);
+		start[0] = 0;
 		const size_t full = nlines / 8;
-		while (good < full && regular_record(map + at, b.line.data(), 8 * good) &&
-		       regular_record(map + at, b.line.data(), 8 * good + 4))
-			++good;
-		if (good) {
-			const size_t cut = b.line[8 * good];
-			b.text.view = map + at;
-			b.text.n = cut;
-			b.line.resize(8 * good + 1);
-			b.n_text_pairs = (int64_t)good;
+		std::vector<size_t> bad(T, full); // first irregular pair each thread saw
+		auto stitch = [&](unsigned i) {
+			uint32_t* out = start.data() + 1 + first[i];
+			const std::vector<uint32_t>& v = nl[i];
+			for (size_t j = 0; j < v.size(); ++j)
+				out[j] = v[j] + 1;
+		};
+		auto verify = [&](unsigned i) {
+			const size_t lo = full * i / T, hi = full * (i + 1) / T;
+			for (size_t p = lo; p < hi; ++p)
+				if (!regular_record(map + at, start.data(), 8 * p) || !regular_record(map + at, start.data(), 8 * p + 4)) {
+					bad[i] = p;
+					return;
+				}
+		};
+		for (int phase = 0; phase < 2; ++phase) {
+			std::vector<std::thread> th;
+			for (unsigned i = 1; i < T; ++i)
+				th.emplace_back([&, i] { phase == 0 ? stitch(i) : verify(i); });
+			phase == 0 ? stitch(0) : verify(0);
+			for (auto& t : th)
+				t.join();
+		}
+		size_t good = full;
+		for (unsigned i = 0; i < T; ++i)
+			good = std::min(good, bad[i]);
+		for (size_t p0 = 0; p0 < good; p0 += (size_t)batch_pairs) {
+			const size_t P = std::min<size_t>((size_t)batch_pairs, good - p0);
+			RawBatch b;
+			if (recycled)
+				(void)recycled(b);
+			b.bases.clear(), b.off.clear(), b.len.clear(), b.pair_ok.clear(), b.barcode_id.clear(), b.messages.clear();
+			b.fc = FileCounters();
+			b.last = false;
+			b.is_text = true;
+			b.file = file_idx;
+			b.text.clear();
+			const uint32_t s0 = start[8 * p0];
+			b.line.resize(8 * P + 1);
+			for (size_t j = 0; j <= 8 * P; ++j)
+				b.line[j] = start[8 * p0 + j] - s0;
+			b.text.view = map + at + s0;
+			b.text.n = (size_t)(start[8 * (p0 + P)] - s0);
+			b.n_text_pairs = (int64_t)P;
 			b.first_pair = pairs_done;
 			b.seq = seq++;
-			pairs_done += good;
-			at += cut;
+			pairs_done += P;
 			emit(std::move(b));
 		}
-		if (good < (size_t)batch_pairs)
-			break; // irregular text, or the end of the file: the sequential loop reads on from `at`
+		at += start[8 * good];
+		if (good < full || good == 0 || at + 0 >= size || span < kSuper)
+			break; // irregular text, or the last lines of the file: the sequential loop reads on from `at`
 	}
 	*pairs_out = pairs_done;
 	*consumed = at;
@@ -926,6 +985,8 @@ class IngestPipeline
 		n_producers_ = std::max(1u, std::min(nf, std::max(1u, threads / (fast_path_ ? 4 : 2))));
 		n_packers_ = std::max(1u, threads > n_producers_ ? threads - n_producers_ : 1u);
 		n_buffers_ = n_packers_ + 3;
+		// short bursts of line scanning per gigabyte of a mapped file: what -t leaves per producer, at most 16
+		n_scan_ = std::max(1u, std::min(16u, threads / n_producers_));
 	}
 
 	DynamicDict& dynamic() { return dynamic_; }
@@ -966,7 +1027,7 @@ class IngestPipeline
 						size_t msize = 0, at = 0;
 						const char* map = readers_[f]->map_plain(&msize);
 						if (map) {
-							first_seq = split_mapped(map, msize, (int)f, batch_pairs_, emit, reuse, &pairs_before, &at);
+							first_seq = split_mapped(map, msize, (int)f, batch_pairs_, emit, reuse, &pairs_before, &at, n_scan_);
 							readers_[f]->continue_at(at);
 						} else
 							first_seq = split_file(*readers_[f], (int)f, batch_pairs_, emit, reuse, &pairs_before);
@@ -1057,7 +1118,7 @@ class IngestPipeline
 	long batch_pairs_;
 	bool verbose_;
 	HostAllocator alloc_;
-	unsigned n_producers_ = 1, n_packers_ = 1, n_buffers_ = 4;
+	unsigned n_producers_ = 1, n_packers_ = 1, n_buffers_ = 4, n_scan_ = 1;
 	BoundedQueue<RawBatch> raw_q_, raw_free_{ 8 };
 	BoundedQueue<PackedBatch*> packed_q_, free_q_;
 };
