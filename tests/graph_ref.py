@@ -102,6 +102,50 @@ def graph_text(ids, edges, dead=()):
     return "\n".join(out) + "\n"
 
 
+_UMAP_EXE = None
+
+
+def unordered_map_order(keys):
+    """the keys in the iteration order of a std::unordered_map<std::string, int> filled in the given order
+    (tests/umap_order.cpp, compiled on first use with the local g++: the same libstdc++ as the product)"""
+    global _UMAP_EXE
+    import os, subprocess, tempfile
+    if _UMAP_EXE is None:
+        d = tempfile.mkdtemp(prefix="umap_order_")
+        _UMAP_EXE = os.path.join(d, "umap_order")
+        subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(os.path.dirname(os.path.abspath(__file__)), "umap_order.cpp"),
+                               "-o", _UMAP_EXE])
+    out = subprocess.run([_UMAP_EXE], input="".join(k + "\n" for k in keys), capture_output=True, text=True, check=True).stdout
+    return out.split("\n")[:-1]
+
+
+def dist_graph_text(lengths, ids, edges, gap, dists=None):
+    """<base>.dist.gv as createAbyssGraph + write_dot write it (Arcs.cpp:1615-1659, Graph/DotIO.h:82-114):
+    two vertices per contig in the iteration order of the ContigToLength unordered_map (`lengths`: a dict in
+    FASTA order), every edge with its reverse-complement twin, out-edges per vertex in insertion order"""
+    names = unordered_map_order(list(lengths))
+    index = {n: i for i, n in enumerate(names)}
+    adj = [[] for _ in range(2 * len(names))]
+    vname = lambda v: names[v >> 1] + ("-" if v & 1 else "+")
+    for ei, (u, v, o, w) in enumerate(edges):
+        a = 2 * index[ids[u]] + (1 if o < 2 else 0)
+        b = 2 * index[ids[v]] + (o % 2)
+        d = gap if dists is None else dists[ei]
+        assert all(x[0] != b for x in adj[a]), "duplicate edge"
+        adj[a].append((b, w, d))
+        if a != (b ^ 1):
+            if all(x[0] != (a ^ 1) for x in adj[b ^ 1]):
+                adj[b ^ 1].append((a ^ 1, w, d))
+    out = ["digraph arcs {"]
+    for v in range(len(adj)):
+        out.append(f'"{vname(v)}" [l={lengths[names[v >> 1]]}]')
+    for u in range(len(adj)):
+        for (v, w, d) in adj[u]:
+            out.append(f'"{vname(u)}" -> "{vname(v)}" [d={d} e={float(gap):.1f} n={w}]')
+    out.append("}")
+    return "\n".join(out) + "\n"
+
+
 def dist_graph_lines(lengths, ids, edges, gap):
     """(vertex lines, edge lines) as sets: the vertex order is libstdc++'s unordered_map order"""
     vl = set()

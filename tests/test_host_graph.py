@@ -96,6 +96,8 @@ def test_graph_stage_vs_python(graph_check, tmp_path, seed, c, l, d, r):
     assert open(base + "_counts.tsv").read() == G.counts_text(mult)
     lines = open(base + ".dist.gv").read().split("\n")
     assert lines[0] == "digraph arcs {" and lines[-2] == "}" and lines[-1] == ""
+    # as text: the vertex order is the ContigToLength unordered_map's, taken from the local libstdc++ itself
+    assert open(base + ".dist.gv").read() == G.dist_graph_text(lengths, ids, edges, 77)
     vl, el = G.dist_graph_lines(lengths, ids, edges, 77)
     body = lines[1:-2]
     assert set(body[: 2 * len(lengths)]) == vl and len(body[: 2 * len(lengths)]) == len(vl)
