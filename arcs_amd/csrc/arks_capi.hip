@@ -23,8 +23,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace arks;
@@ -155,10 +157,18 @@ struct arks_index
 	int64_t n_keys = 0;
 	int64_t n_visited = 0;
 	int64_t n_minimizers = 0, n_fallback = 0;
-	// redo queue of the map kernel (indices of reads that need the slow path)
-	mutable u32* queue = nullptr;
-	mutable u32* queue_count = nullptr;
-	mutable int64_t queue_cap = 0;
+	// Work queues of the map kernels (indices of the reads that take the medium / slow path, their lengths,
+	// the work counters and the partial statistics): one set per stream that maps against this index, so that
+	// map calls on different streams may run at the same time (calls on one stream are ordered by the stream).
+	struct QueueSet
+	{
+		u32* queue = nullptr;
+		u32* queue_count = nullptr;
+		int64_t cap = 0;
+	};
+	mutable std::mutex queue_m;
+	mutable std::vector<std::pair<void*, QueueSet>> queues; // (stream, its set): a handful at most
+	mutable void* last_stream = nullptr;                   // for arks_debug_queue_counts
 };
 
 struct arks_imap
@@ -946,11 +956,6 @@ index_build_impl(
 			idx->bx.trec = idx->trec;
 		}
 	}
-	{
-		void* p = nullptr;
-		HIP_TRY(hipMalloc(&p, kMapScratchBytes)); // slow-queue length, work counter, medium-queue length, its work counter; partial statistics
-		idx->queue_count = static_cast<u32*>(p);
-	}
 	*out = idx;
 	idx = nullptr;
 done:
@@ -1051,10 +1056,12 @@ arks_index_free(arks_index* idx)
 		(void)hipFree(idx->trec);
 	if (idx->mtab_gen)
 		(void)hipFree(idx->mtab_gen);
-	if (idx->queue)
-		(void)hipFree(idx->queue);
-	if (idx->queue_count)
-		(void)hipFree(idx->queue_count);
+	for (auto& q : idx->queues) {
+		if (q.second.queue)
+			(void)hipFree(q.second.queue);
+		if (q.second.queue_count)
+			(void)hipFree(q.second.queue_count);
+	}
 	delete idx;
 	return ARKS_OK;
 }
@@ -1076,7 +1083,12 @@ arks_index_device_bytes(const arks_index* idx)
 {
 	if (!idx)
 		return 0;
-	int64_t b = (int64_t)(idx->table.cap * kSlotWords * sizeof(u64)) + idx->queue_cap * (int64_t)sizeof(u32);
+	int64_t b = (int64_t)(idx->table.cap * kSlotWords * sizeof(u64));
+	{
+		std::lock_guard<std::mutex> lk(idx->queue_m);
+		for (const auto& q : idx->queues)
+			b += 2 * q.second.cap * (int64_t)sizeof(u32) + (int64_t)kMapScratchBytes;
+	}
 	if (idx->kind >= 1)
 		b += (int64_t)(idx->alloc_words * (sizeof(u64) + 3 * sizeof(u32))) + (int64_t)(idx->bx.mtab_cap * sizeof(u64)) +
 		     (idx->trec ? (int64_t)(idx->alloc_words * 3 * sizeof(u64)) : 0) +
@@ -1168,24 +1180,44 @@ done:
 /* mapping                                                                                        */
 /* ---------------------------------------------------------------------------------------------- */
 
+// the queue set of `stream` for this index, large enough for n_reads (created / grown on demand)
 static int
-ensure_queue(const arks_index* idx, int64_t n_reads)
+ensure_queue(const arks_index* idx, void* stream, int64_t n_reads, arks_index::QueueSet* out)
 {
-	if (idx->queue_cap >= n_reads)
-		return ARKS_OK;
-	if (idx->queue) {
-		(void)hipDeviceSynchronize();
-		(void)hipFree(idx->queue);
-		idx->queue = nullptr;
-		idx->queue_cap = 0;
+	std::lock_guard<std::mutex> lk(idx->queue_m);
+	arks_index::QueueSet* qs = nullptr;
+	for (auto& q : idx->queues)
+		if (q.first == stream)
+			qs = &q.second;
+	if (!qs) {
+		idx->queues.emplace_back(stream, arks_index::QueueSet());
+		qs = &idx->queues.back().second;
 	}
-	void* p = nullptr;
-	const int64_t cap = n_reads + n_reads / 4 + 1024;
-	hipError_t e = hipMalloc(&p, 2 * sizeof(u32) * (size_t)cap); // slow queue + medium queue
-	if (e != hipSuccess)
-		return fail_hip(e, "hipMalloc(redo queues)");
-	idx->queue = static_cast<u32*>(p);
-	idx->queue_cap = cap;
+	idx->last_stream = stream;
+	if (!qs->queue_count) {
+		void* p = nullptr;
+		// slow-queue length, work counter, medium-queue length, its work counter; partial statistics; work counters
+		hipError_t e = hipMalloc(&p, kMapScratchBytes);
+		if (e != hipSuccess)
+			return fail_hip(e, "hipMalloc(map scratch)");
+		qs->queue_count = static_cast<u32*>(p);
+	}
+	if (qs->cap < n_reads) {
+		if (qs->queue) {
+			(void)hipStreamSynchronize(static_cast<hipStream_t>(stream)); // the stream's earlier call may still use it
+			(void)hipFree(qs->queue);
+			qs->queue = nullptr;
+			qs->cap = 0;
+		}
+		void* p = nullptr;
+		const int64_t cap = n_reads + n_reads / 4 + 1024;
+		hipError_t e = hipMalloc(&p, 2 * sizeof(u32) * (size_t)cap); // slow queue + medium queue
+		if (e != hipSuccess)
+			return fail_hip(e, "hipMalloc(redo queues)");
+		qs->queue = static_cast<u32*>(p);
+		qs->cap = cap;
+	}
+	*out = *qs;
 	return ARKS_OK;
 }
 
@@ -1212,13 +1244,14 @@ arks_map_reads_device(
 	if (idx->seed_ranks > 1)
 		return ARKS_ERR_BAD_ARG; // this rank holds a shard of the seed table: arks_map_reads_seeded_device
 	DeviceGuard guard(idx->device);
-	int rc = ensure_queue(idx, n_reads);
+	arks_index::QueueSet qs;
+	int rc = ensure_queue(idx, stream, n_reads, &qs);
 	if (rc != ARKS_OK)
 		return rc;
 	HIP_TRY(launch_map_reads(
 	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads,
 	    j_index, idx->geom, idx->table, idx->bx, d_out_conreci, reinterpret_cast<u64*>(d_stats),
-	    idx->queue, idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream)));
+	    qs.queue, qs.queue_count, idx->n_cu, static_cast<hipStream_t>(stream)));
 done:
 	return rc;
 }
@@ -1242,13 +1275,14 @@ arks_map_votes_device(
 	if (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_out_votes)
 		return ARKS_ERR_BAD_ARG;
 	DeviceGuard guard(idx->device);
-	int rc = ensure_queue(idx, n_reads);
+	arks_index::QueueSet qs;
+	int rc = ensure_queue(idx, stream, n_reads, &qs);
 	if (rc != ARKS_OK)
 		return rc;
 	HIP_TRY(launch_map_reads(
 	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, 0.0,
-	    idx->geom, idx->table, idx->bx, reinterpret_cast<int*>(d_out_votes), nullptr, idx->queue,
-	    idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream), true));
+	    idx->geom, idx->table, idx->bx, reinterpret_cast<int*>(d_out_votes), nullptr, qs.queue,
+	    qs.queue_count, idx->n_cu, static_cast<hipStream_t>(stream), true));
 done:
 	return rc;
 }
@@ -1338,13 +1372,14 @@ arks_map_reads_seeded_device(
 	if (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_out_conreci || !d_seed_off || !d_answers)
 		return ARKS_ERR_BAD_ARG;
 	DeviceGuard guard(idx->device);
-	int rc = ensure_queue(idx, n_reads);
+	arks_index::QueueSet qs;
+	int rc = ensure_queue(idx, stream, n_reads, &qs);
 	if (rc != ARKS_OK)
 		return rc;
 	HIP_TRY(launch_map_reads_seeded(
 	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, j_index, idx->geom,
 	    idx->bx, idx->bxg, (const long*)d_seed_off, (const u64*)d_answers, d_out_conreci, reinterpret_cast<u64*>(d_stats),
-	    idx->queue, idx->queue_count, idx->n_cu, static_cast<hipStream_t>(stream)));
+	    qs.queue, qs.queue_count, idx->n_cu, static_cast<hipStream_t>(stream)));
 done:
 	return rc;
 }
@@ -1751,7 +1786,12 @@ arks_debug_queue_counts(const arks_index* idx, unsigned* out4)
 		return ARKS_ERR_BAD_ARG;
 	DeviceGuard guard(idx->device);
 	(void)hipDeviceSynchronize();
-	return hipMemcpy(out4, idx->queue_count, 4 * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess ? ARKS_OK : ARKS_ERR_HIP;
+	std::lock_guard<std::mutex> lk(idx->queue_m);
+	for (const auto& q : idx->queues)
+		if (q.first == idx->last_stream && q.second.queue_count)
+			return hipMemcpy(out4, q.second.queue_count, 4 * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess ? ARKS_OK : ARKS_ERR_HIP;
+	out4[0] = out4[1] = out4[2] = out4[3] = 0;
+	return ARKS_OK;
 }
 
 #ifdef ARKS_PROFILE_SECTIONS

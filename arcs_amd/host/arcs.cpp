@@ -536,11 +536,8 @@ struct Mapper
 		up(s.d_class.p, pb->cls, (size_t)n);
 		up(s.d_ok.p, pb->pair_ok, (size_t)np);
 		up(s.d_bid.p, pb->barcode_id, (size_t)np * sizeof(uint32_t));
-		// the copies above overlap the other set's kernels; the kernels themselves are ordered: an index
-		// has ONE set of redo queues, so only one map call per index may be in flight (arks_hip.h)
-		DeviceSet& other = sets[turn & 1];
-		if (other.inflight && hipStreamWaitEvent(s.stream, other.done, 0) != hipSuccess)
-			return ARKS_ERR_HIP;
+		// (the copies above and the kernels below overlap the other set's: an index keeps one set of work
+		// queues per stream, and the IndexMap accumulator is updated with atomics)
 		int rc = arks_pair_gate_device(s.d_ok.p, s.d_class.p, np, s.d_eval.p, params.device, s.stream);
 		if (n_shards > 1) {
 			s.d_votes.reserve((size_t)n);

@@ -220,9 +220,8 @@ int arks_pack_reads_host(
  * the smallest index, total counts NULL windows too) or 0.  d_eval (may be NULL = all) selects the
  * reads bestContig is called for (Arcs.cpp:1268); the others get 0 and touch no counter.
  * d_stats (may be NULL) points to one arks_map_stats in device memory that is ADDED to.
- * Asynchronous on `stream`.  An index owns ONE set of work queues for this call: calls on the same
- * index must be ordered with respect to each other (same stream, or stream events) -- copies and
- * the other entry points may overlap them freely. */
+ * Asynchronous on `stream`.  An index keeps one set of work queues per stream it is mapped on: calls on
+ * different streams may run at the same time, calls on one stream are ordered by the stream. */
 int arks_map_reads_device(
     const arks_index* idx,
     const uint64_t* d_codes,
@@ -242,7 +241,7 @@ int arks_map_reads_device(
  * shards is the vote of the whole map: the larger count wins and a tie keeps the smaller conreci
  * (:1000, strict <).  That maximum is the only data-path exchange of the sharded configuration (one
  * 8-byte all-reduce(MAX) per read; reads are replicated to every shard), arks_votes_resolve_device
- * finishes the call.  Same ordering rule per index as arks_map_reads_device. */
+ * finishes the call.  Same rule per index and stream as arks_map_reads_device. */
 int arks_map_votes_device(
     const arks_index* idx,
     const uint64_t* d_codes,
@@ -328,8 +327,8 @@ int arks_map_reads(
  * the caller keeps the barcode string <-> id dictionary.  `capacity_entries` is a starting size only:
  * the table grows (arks_pairs_device rebuilds it larger before a launch could fill it beyond one half;
  * that is the one place where the call waits for the device), so no input can overflow it.
- * Calls that use one accumulator must be ordered with respect to each other, like the map calls of
- * one index. */
+ * Calls that use one accumulator must come from one host thread at a time; they may use different
+ * streams (the device side is atomic, a rebuild waits for the whole device first). */
 typedef struct arks_imap arks_imap;
 int arks_imap_create(arks_imap** out, int64_t capacity_entries, int device);
 int arks_imap_free(arks_imap* m);
