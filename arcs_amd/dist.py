@@ -153,7 +153,8 @@ def exchange_seeds(index, mmer, owner, group=None):
     import torch
     import torch.distributed as dist
     from . import api
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    import os
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not os.environ.get("ARKS_FORCE_EXCHANGE")):
         return api.seeds_probe(index, mmer.contiguous())               # one rank owns every seed
     world = dist.get_world_size(group)
     dev = mmer.device

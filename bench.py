@@ -277,7 +277,6 @@ def end_to_end(wl, dev, local, n_batches=8, pairs=2_000_000):
         reads = arcs_amd.PackedReads(d["codes"], d["nmask"], d["woff"], d["lens"], d["cls"], local)
         steps.append(arcs_amd.PairStep(wl.index, reads, wl.j, pair_ok=d["ok"], barcode_id=d["bid"]))
     bytes_in = sum(t.numel() * t.element_size() for t in host[0].values())
-    done = [None, None]          # the index's work queues take one map call at a time
 
     def run(nb):
         for b in range(nb):
@@ -285,11 +284,7 @@ def end_to_end(wl, dev, local, n_batches=8, pairs=2_000_000):
             with torch.cuda.stream(streams[s]):
                 for nm, t in host[s].items():
                     dbuf[s][nm].copy_(t, non_blocking=True)
-                if done[s ^ 1] is not None:
-                    streams[s].wait_event(done[s ^ 1])
-                steps[s].run()
-                done[s] = torch.cuda.Event()
-                done[s].record(streams[s])
+                steps[s].run()          # (an index keeps a set of work queues per stream: no ordering needed)
                 outs[s].copy_(steps[s].pair[:pairs], non_blocking=True)
         torch.cuda.synchronize(dev)
 

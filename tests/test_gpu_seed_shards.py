@@ -129,3 +129,48 @@ def test_three_ranks_route_their_seeds(arks, gpu, oracle, tmp_path):
     whole = arks.ArksIndex.build(ends, 60, device=gpu)
     sizes = [int(np.load(os.path.join(str(tmp_path), f"bytes{r}.npy"))[0]) for r in range(world)]
     assert whole.kind == 2 and max(sizes) < 0.7 * whole.device_bytes             # nobody holds the whole table
+
+
+def _rccl_worker(port):
+    """one rank, backend nccl (= RCCL): the exchange runs through all_to_all_single although the rank owns
+    every seed (ARKS_FORCE_EXCHANGE); in its own process, a hung RCCL start-up must not take the session along"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    import arcs_amd as arks
+    from arcs_amd import dist as adist
+    from oracle import pyoracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["ARKS_FORCE_EXCHANGE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cs, batch, reads = _case()
+    ends = arks.contig_ends(cs, 500, 30000)
+    sh = arks.ArksIndex.build_seed_shard(ends, 60, 0, 1, device=0)
+    packed = arks.PackedReads.from_ascii(reads, device=0)
+    stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+    got = adist.map_reads_seed_sharded(sh, packed, 0.55, stats=stats).cpu().tolist()
+    ox = O.OracleIndex(60).build(ends)
+    st = O.MapStats()
+    assert got == [ox.best_contig(r, 0.55, st) for r in reads]
+    assert dict(zip(STAT_NAMES, stats.cpu().tolist())) == st.as_dict()
+    dist.destroy_process_group()
+    print("rccl exchange ok")
+
+
+def test_exchange_over_rccl(arks, gpu, tmp_path):
+    """exchange_seeds over a real RCCL process group (one rank is what a single-GPU box offers)"""
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = subprocess.run([sys.executable, os.path.abspath(__file__), "rccl-worker", str(port)], capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and "rccl exchange ok" in res.stdout, res.stderr[-3000:]
+
+
+if __name__ == "__main__" and len(sys.argv) == 3 and sys.argv[1] == "rccl-worker":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    _rccl_worker(int(sys.argv[2]))
