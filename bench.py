@@ -403,9 +403,13 @@ def main():
                          "traffic": (traffic["hbm_bytes_per_launch"] / 1e9) if traffic else None,
                          "traffic_unit": "GB per launch (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE)",
                          "traffic_source": traffic["source"] if traffic else None,
+                         # what the kernel really moves per second: far below the algorithmic figure because the
+                         # locality index replaces the per-window key compare, and made of
+                         # random 24/32-byte gathers whose measured ceiling is ~2.8e10 sectors/s, not 8 TB/s
+                         "traffic_GBps": (traffic["hbm_bytes_per_launch"] / 1e9 / (kernel_ms * 1e-3)) if traffic else None,
                          "kernel_build_id": kernel_build_id(),
                          "alg_bytes_per_launch_GB": win_per_launch * b_alg / 1e9,
-                         "kernel": "map_reads_b_kernel" if wl.index.kind >= 1 else "map_reads_kernel",
+                         "kernel": {0: "map_reads_kernel", 1: "map_reads_b_kernel", 2: "map_reads_s_kernel"}[wl.index.kind],
                          "kernel_ms": kernel_ms, "launches_timed": len(launch_ms),
                          "alg_bytes_per_window": b_alg},
             "counters": st, "stored_pairs": stored,

@@ -18,7 +18,12 @@ a, _ = ap.parse_known_args(sys.argv[2:])
 def mean_of(path, counter):
     best = None
     for r in csv.DictReader(open(path)):
-        if r["counter"] == counter and "map_reads_b_kernel" in r["kernel"] and "false, false" in r["kernel"]:
+        # the hot map kernel without the -v counters (second template argument false): seed tile kernel, or the
+        # minimizer tile kernel (FULL = false)
+        k = r["kernel"]
+        hot = ("map_reads_s_kernel<" in k and ", false, " in k.split("map_reads_s_kernel<")[1][:12]) or \
+              ("map_reads_b_kernel<" in k and "false, false" in k)
+        if r["counter"] == counter and hot:
             v = float(r["mean_per_dispatch"])
             best = v if best is None else max(best, v)
     return best
