@@ -46,14 +46,14 @@ def build_host(force=False, verbose=False):
     cxx = os.environ.get("CXX", "g++")
     cmd = [cxx, "-O2", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "host"), HOST_SOURCES[0],
-           "-L" + os.path.dirname(OUT), "-larks_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz",
+           "-L" + os.path.dirname(OUT), "-larks_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz", "-ldl",
            "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-o", HOST_OUT]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     # the arks-long feeder (no GPU code)
     cmd2 = [cxx, "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(HERE, "host"),
-            os.path.join(HERE, "host", "long_to_linked_pe.cpp"), "-lz",
+            os.path.join(HERE, "host", "long_to_linked_pe.cpp"), "-lz", "-ldl",
             "-o", os.path.join(HERE, "bin", "long-to-linked-pe")]
     if verbose:
         print(" ".join(cmd2), file=sys.stderr)

@@ -582,6 +582,77 @@ struct Mapper
 	}
 };
 
+// Pinned host memory for the packed batches.  Pinning is slow (every page is locked and mapped for the device)
+// and the driver takes its calls one at a time, so the slabs are made once, by a thread that starts before the
+// draft is read (prefill), handed out to the pipeline's buffers and kept for the next pass (several k, a
+// second pass over the reads); they go back to the system at exit.
+class PinnedPool
+{
+  public:
+	~PinnedPool()
+	{
+		wait();
+		for (const Slab& s : slabs_)
+			(void)hipHostFree(s.p);
+	}
+	void prefill(unsigned n, size_t bytes)
+	{
+		filler_ = std::thread([this, n, bytes] {
+			(void)hipSetDevice(params.device);
+			for (unsigned i = 0; i < n; ++i) {
+				void* p = nullptr;
+				if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess)
+					return;
+				std::lock_guard<std::mutex> lk(m_);
+				slabs_.push_back(Slab{ p, bytes, false });
+				cv_.notify_all();
+			}
+		});
+	}
+	void* alloc(size_t n)
+	{
+		{
+			std::unique_lock<std::mutex> lk(m_);
+			for (Slab& s : slabs_)
+				if (!s.used && s.bytes >= n) {
+					s.used = true;
+					return s.p;
+				}
+		}
+		void* p = nullptr;
+		if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess)
+			return nullptr;
+		std::lock_guard<std::mutex> lk(m_);
+		slabs_.push_back(Slab{ p, n, true });
+		return p;
+	}
+	void release(void* p)
+	{
+		std::lock_guard<std::mutex> lk(m_);
+		for (Slab& s : slabs_)
+			if (s.p == p)
+				s.used = false;
+	}
+	void wait()
+	{
+		if (filler_.joinable())
+			filler_.join();
+	}
+
+  private:
+	struct Slab
+	{
+		void* p;
+		size_t bytes;
+		bool used;
+	};
+	std::mutex m_;
+	std::condition_variable cv_;
+	std::vector<Slab> slabs_;
+	std::thread filler_;
+};
+PinnedPool g_pinned;
+
 // fused == true: no multiplicity file; the reads per barcode come back in the result (pre_counts) and
 // `redo` is set when the input needs the exact two-pass flow instead
 RankResult
@@ -590,6 +661,15 @@ map_files(
     const std::unordered_map<std::string, int>& mult, bool fused, std::string* open_error)
 {
 	const size_t nf = files.size();
+	const bool timing = getenv("ARKS_TIMING") != nullptr;
+	auto t_prev = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		const auto t = std::chrono::steady_clock::now();
+		if (timing)
+			std::cerr << "[timing]   read stage, " << what << ": "
+			          << std::chrono::duration_cast<std::chrono::microseconds>(t - t_prev).count() / 1000.0 << " ms\n";
+		t_prev = t;
+	};
 	RankResult res;
 	res.files.resize(nf);
 	const size_t nk = idxs.size() / (size_t)std::max(1, params.index_shards);
@@ -612,15 +692,14 @@ map_files(
 	const size_t nm = std::max<size_t>(mine.size(), 1);
 	Mapper mapper(idxs, imap_cap, nm, mine);
 	HostAllocator pinned;
-	pinned.alloc = [](size_t n) {
-		void* p = nullptr;
-		return hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
-	};
-	pinned.release = [](void* p) { (void)hipHostFree(p); };
+	pinned.alloc = [](size_t n) { return g_pinned.alloc(n); };
+	pinned.release = [](void* p) { g_pinned.release(p); };
 	std::vector<SeqReader*> rdp;
 	for (auto& r : readers)
 		rdp.push_back(r.get());
 	IngestPipeline pipe(rdp, dict.get(), params.batch_pairs, params.verbose != 0, params.threads, pinned);
+	g_pinned.wait();
+	lap("open files, barcode dictionary, device buffers, pinned pool ready");
 	const int prc = pipe.run([&](PackedBatch* pb) {
 		FileResult& fr = res.files[mine[(size_t)pb->file]];
 		FileCounters& f = fr.fc;
@@ -632,12 +711,15 @@ map_files(
 		pb->messages.clear();
 		return mapper.submit(pb, pipe);
 	}, [&] { mapper.drain(pipe); }); // the in-flight batches are retired before their pinned buffers go
+	if (timing)
+		std::cerr << "[timing]   read stage threads: " << pipe.producers() << " producers + " << pipe.packers() << " workers\n";
 	if (prc != ARKS_OK)
 		die_arks(prc, "mapping a read batch");
 	if (hipDeviceSynchronize() != hipSuccess) {
 		std::cerr << PROGRAM ": device error while mapping\n";
 		exit(EXIT_FAILURE);
 	}
+	lap("pipeline (read, parse, pack, map)");
 	for (size_t i = 0; i < mine.size(); ++i)
 		if (readers[i]->failed()) // (the reference's gzread + kseq stop silently at the same place)
 			std::cerr << PROGRAM ": warning: " << files[mine[i]]
@@ -692,6 +774,7 @@ map_files(
 		res.first[ki].resize((size_t)n);
 		arks_imap_free(mapper.imaps[ki]);
 	}
+	lap("counters and IndexMap back to the host");
 	return res;
 }
 
@@ -855,6 +938,14 @@ run_arks(const std::vector<std::string>& filenames)
 			(void)hipSetDevice(params.device);
 		}
 	}
+	{
+		// the pinned buffers of the read stage, made while the draft is read and indexed
+		size_t n_mine = 0, words = 0, reads = 0;
+		for (size_t f = 0; f < filenames.size(); ++f)
+			n_mine += (int)(f % (size_t)g_world) == g_rank;
+		packed_estimate(params.batch_pairs, &words, &reads);
+		g_pinned.prefill(IngestPipeline::buffers_for(params.threads, (unsigned)n_mine), packed_slab_bytes(words + words / 8, reads + reads / 8));
+	}
 
 	std::vector<IndexMap> imaps;
 	std::unordered_map<std::string, int> mult;
@@ -1008,6 +1099,7 @@ run_arks(const std::vector<std::string>& filenames)
 		write_barcode_counts(f, mult);
 	}
 	std::cout << "\n=> Done.\n" << now();
+	lap("graph stage and output files");
 }
 
 } // namespace

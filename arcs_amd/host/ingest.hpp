@@ -22,7 +22,10 @@
 
 #include <immintrin.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -98,6 +101,18 @@ class BoundedQueue
 		not_full_.notify_one();
 		return true;
 	}
+	// pop that gives up after `us` microseconds: 1 = got an element, 0 = nothing yet, -1 = closed and drained
+	int pop_for(T& out, long us)
+	{
+		std::unique_lock<std::mutex> lk(m_);
+		not_empty_.wait_for(lk, std::chrono::microseconds(us), [&] { return !q_.empty() || closed_; });
+		if (q_.empty())
+			return closed_ ? -1 : 0;
+		out = std::move(q_.front());
+		q_.pop_front();
+		not_full_.notify_one();
+		return 1;
+	}
 	// like pop, but the element pushed LAST: for a pool of buffers that are allocated on first use, so
 	// that a buffer that has just come back (allocated, warm) is taken before one that was never used --
 	// the pool then grows to the number of buffers in flight, not to its capacity
@@ -112,7 +127,7 @@ class BoundedQueue
 		not_full_.notify_one();
 		return true;
 	}
-	// non-blocking variants (a recycling list: nothing waits on it)
+	// non-blocking variants
 	bool try_pop(T& out)
 	{
 		std::lock_guard<std::mutex> lk(m_);
@@ -120,6 +135,7 @@ class BoundedQueue
 			return false;
 		out = std::move(q_.front());
 		q_.pop_front();
+		not_full_.notify_one();
 		return true;
 	}
 	bool try_push(T&& v)
@@ -128,6 +144,7 @@ class BoundedQueue
 		if (q_.size() >= cap_)
 			return false;
 		q_.push_back(std::move(v));
+		not_empty_.notify_one();
 		return true;
 	}
 	void close()
@@ -143,6 +160,92 @@ class BoundedQueue
 	bool closed_ = false;
 	std::mutex m_;
 	std::condition_variable not_full_, not_empty_;
+};
+
+// The parallel phases of a producer (inflate the members of a stretch, find its newlines, verify its record
+// groups) are loops over chunks that any thread may take a share of: the producer publishes the loop here and
+// works on it itself; workers that find no batch to parse help out (help()).  So the pipeline runs on the -t
+// threads it was given, whichever stage is the slow one, and no thread is started per phase.
+class HelpDesk
+{
+  public:
+	// fn(i) for every i in [0, n), on the caller and on the threads that call help() meanwhile; returns when
+	// all of them are done
+	void parallel_for(size_t n, const std::function<void(size_t)>& fn)
+	{
+		if (n == 0)
+			return;
+		if (n == 1) {
+			fn(0);
+			return;
+		}
+		auto job = std::make_shared<Job>();
+		job->n = n;
+		job->fn = &fn;
+		{
+			std::lock_guard<std::mutex> lk(m_);
+			jobs_.push_back(job);
+		}
+		open_.fetch_add(1, std::memory_order_release);
+		run(*job);
+		{
+			std::unique_lock<std::mutex> lk(job->m);
+			job->cv.wait(lk, [&] { return job->done.load() == n; });
+		}
+		open_.fetch_sub(1, std::memory_order_release);
+		std::lock_guard<std::mutex> lk(m_);
+		for (size_t i = 0; i < jobs_.size(); ++i)
+			if (jobs_[i] == job) {
+				jobs_.erase(jobs_.begin() + (std::ptrdiff_t)i);
+				break;
+			}
+	}
+	// takes a share of a published loop, if there is one with chunks left: false when there was nothing to do
+	bool help()
+	{
+		if (open_.load(std::memory_order_acquire) == 0)
+			return false;
+		std::shared_ptr<Job> job;
+		{
+			std::lock_guard<std::mutex> lk(m_);
+			for (auto& j : jobs_)
+				if (j->next.load(std::memory_order_relaxed) < j->n) {
+					job = j;
+					break;
+				}
+		}
+		if (!job)
+			return false;
+		return run(*job);
+	}
+
+  private:
+	struct Job
+	{
+		size_t n = 0;
+		const std::function<void(size_t)>* fn = nullptr; // alive until done == n: its owner waits for that
+		std::atomic<size_t> next{ 0 }, done{ 0 };
+		std::mutex m;
+		std::condition_variable cv;
+	};
+	static bool run(Job& j)
+	{
+		bool any = false;
+		for (;;) {
+			const size_t i = j.next.fetch_add(1);
+			if (i >= j.n)
+				return any;
+			any = true;
+			(*j.fn)(i);
+			if (j.done.fetch_add(1) + 1 == j.n) {
+				std::lock_guard<std::mutex> lk(j.m);
+				j.cv.notify_all();
+			}
+		}
+	}
+	std::mutex m_;
+	std::vector<std::shared_ptr<Job>> jobs_;
+	std::atomic<int> open_{ 0 };
 };
 
 // barcode -> dense id, fixed before the reads are parsed: every barcode that can pass the gate is
@@ -279,11 +382,58 @@ struct FileCounters
 };
 
 // a growing byte buffer that does not clear what it hands out (a std::vector would zero 160 MB per batch)
+// ARKS_INGEST_PROFILE=1: thread-seconds per stage of the pipeline, printed to stderr at the end of run()
+struct IngestProfile
+{
+	enum Stage { SOURCE, SCAN, VERIFY, CUT, EMIT_WAIT, POP_WAIT, HELP, PARSE, BUF_WAIT, PACK, N_STAGES };
+	std::atomic<int64_t> ns[N_STAGES];
+	bool on = std::getenv("ARKS_INGEST_PROFILE") != nullptr;
+	IngestProfile()
+	{
+		for (auto& x : ns)
+			x = 0;
+	}
+	static IngestProfile& get()
+	{
+		static IngestProfile p;
+		return p;
+	}
+	static int64_t now()
+	{
+		return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	}
+	struct Scope
+	{
+		IngestProfile& p;
+		Stage s;
+		int64_t t0;
+		explicit Scope(Stage st)
+		  : p(get())
+		  , s(st)
+		  , t0(p.on ? now() : 0)
+		{}
+		~Scope()
+		{
+			if (p.on)
+				p.ns[s] += now() - t0;
+		}
+	};
+	void print() const
+	{
+		if (!on)
+			return;
+		static const char* names[] = { "source(inflate/map)", "scan", "stitch+verify", "cut", "emit wait", "pop wait", "help producers", "parse", "buffer wait", "pack" };
+		for (int i = 0; i < N_STAGES; ++i)
+			std::fprintf(stderr, "ingest profile: %-20s %9.1f ms (thread time)\n", names[i], (double)ns[i].load() / 1e6);
+	}
+};
+
 struct TextBuf
 {
 	std::unique_ptr<char[]> p;
 	size_t n = 0, cap = 0;
-	const char* view = nullptr; // not owned: a stretch of a mapped file (then p is unused)
+	const char* view = nullptr; // not owned: a stretch of a mapped file or of `keep` (then p is unused)
+	std::shared_ptr<const void> keep; // the buffer a view points into, when it is not a mapping
 	char* data() { return view ? const_cast<char*>(view) : p.get(); }
 	const char* data() const { return view ? view : p.get(); }
 	size_t size() const { return n; }
@@ -291,6 +441,7 @@ struct TextBuf
 	{
 		n = 0;
 		view = nullptr;
+		keep.reset();
 	}
 	void reserve(size_t want)
 	{
@@ -351,6 +502,7 @@ struct PackedBatch
 	uint8_t* pair_ok = nullptr;
 	uint32_t* barcode_id = nullptr;
 	size_t cap_words = 0, cap_reads = 0;
+	void* slab = nullptr; // the one allocation the arrays above live in
 	FileCounters fc;
 	std::string messages;
 };
@@ -364,44 +516,69 @@ struct HostAllocator
 inline void
 packed_free(PackedBatch& pb, const HostAllocator& a)
 {
-	void* ptrs[] = { pb.codes, pb.nmask, pb.woff, pb.len, pb.cls, pb.pair_ok, pb.barcode_id };
-	for (void* p : ptrs)
-		if (p)
-			a.release(p);
+	if (pb.slab)
+		a.release(pb.slab);
+	pb.slab = nullptr;
 	pb.codes = nullptr, pb.nmask = nullptr, pb.woff = nullptr, pb.len = nullptr, pb.cls = nullptr,
 	pb.pair_ok = nullptr, pb.barcode_id = nullptr, pb.cap_words = 0, pb.cap_reads = 0;
+}
+
+// The arrays of a packed batch are carved out of ONE allocation (pinning host memory is slow and the driver
+// serializes it: one call per buffer instead of seven).  Size of a slab for `words` and `reads`:
+inline size_t
+packed_slab_bytes(size_t words, size_t reads)
+{
+	auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+	return up(words * 8) + up(words * 4) + up((reads + 1) * 8) + up(reads * 4) + up(reads) + up(reads / 2 + 1) +
+	       up((reads / 2 + 1) * 4);
+}
+// what a batch of `batch_pairs` pairs of short reads needs (longer reads make the buffer grow when they come)
+inline void
+packed_estimate(long batch_pairs, size_t* words, size_t* reads)
+{
+	*reads = 2 * (size_t)batch_pairs + 64;
+	*words = *reads * 5 + 64; // reads of up to 128 bases after the gate's trim: 4 words + padding
 }
 
 inline bool
 packed_reserve(PackedBatch& pb, size_t words, size_t reads, const HostAllocator& a)
 {
-	if (words > pb.cap_words) {
-		if (pb.codes)
-			a.release(pb.codes);
-		if (pb.nmask)
-			a.release(pb.nmask);
-		const size_t cap = words + words / 8 + 64;
-		pb.codes = (uint64_t*)a.alloc(cap * sizeof(uint64_t));
-		pb.nmask = (uint32_t*)a.alloc(cap * sizeof(uint32_t));
-		pb.cap_words = cap;
-		if (!pb.codes || !pb.nmask)
-			return false;
+	if (words <= pb.cap_words && reads <= pb.cap_reads)
+		return true;
+	size_t cap_w = pb.cap_words, cap_r = pb.cap_reads;
+	if (reads > cap_r)
+		cap_r = reads + reads / 8 + 64;
+	if (words > cap_w)
+		cap_w = words + words / 8 + 64;
+	if (cap_w < cap_r * 5 + 64)
+		cap_w = cap_r * 5 + 64; // the word count is known only after the read count: room for short reads at once
+	char* slab = (char*)a.alloc(packed_slab_bytes(cap_w, cap_r));
+	if (!slab)
+		return false;
+	auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+	char* q = slab;
+	uint64_t* codes = (uint64_t*)q;
+	q += up(cap_w * 8);
+	uint32_t* nmask = (uint32_t*)q;
+	q += up(cap_w * 4);
+	uint64_t* woff = (uint64_t*)q;
+	q += up((cap_r + 1) * 8);
+	uint32_t* len = (uint32_t*)q;
+	q += up(cap_r * 4);
+	uint8_t* cls = (uint8_t*)q;
+	q += up(cap_r);
+	uint8_t* pair_ok = (uint8_t*)q;
+	q += up(cap_r / 2 + 1);
+	uint32_t* barcode_id = (uint32_t*)q;
+	if (pb.slab) {
+		if (pb.cap_reads) // pack_batch reserves for the words after it filled woff
+			std::memcpy(woff, pb.woff, (std::min(pb.cap_reads, cap_r) + 1) * sizeof(uint64_t));
+		a.release(pb.slab);
 	}
-	if (reads > pb.cap_reads) {
-		void* ptrs[] = { pb.woff, pb.len, pb.cls, pb.pair_ok, pb.barcode_id };
-		for (void* p : ptrs)
-			if (p)
-				a.release(p);
-		const size_t cap = reads + reads / 8 + 64;
-		pb.woff = (uint64_t*)a.alloc((cap + 1) * sizeof(uint64_t));
-		pb.len = (uint32_t*)a.alloc(cap * sizeof(uint32_t));
-		pb.cls = (uint8_t*)a.alloc(cap);
-		pb.pair_ok = (uint8_t*)a.alloc(cap / 2 + 1);
-		pb.barcode_id = (uint32_t*)a.alloc((cap / 2 + 1) * sizeof(uint32_t));
-		pb.cap_reads = cap;
-		if (!pb.woff || !pb.len || !pb.cls || !pb.pair_ok || !pb.barcode_id)
-			return false;
-	}
+	pb.slab = slab;
+	pb.codes = codes, pb.nmask = nmask, pb.woff = woff, pb.len = len, pb.cls = cls, pb.pair_ok = pair_ok,
+	pb.barcode_id = barcode_id;
+	pb.cap_words = cap_w, pb.cap_reads = cap_r;
 	return true;
 }
 
@@ -758,87 +935,238 @@ parse_text_batch(
 	}
 }
 
-// The same over a plain file mapped into memory: the batches are stretches of the mapping itself (no copy),
-// and the line scan is not bound to one thread either -- the file is taken a gigabyte at a time, `scan_threads`
-// threads find the newlines of a slice each, the line starts are put together, the slices' record groups are
-// verified in parallel, and only then (everything before the first irregular group being known to be regular)
-// the batches are cut.  Returns the batches handed out; *consumed = the offset where the sequential loop
-// continues.
+// The same over text that is in memory a stretch at a time, where the line scan is not bound to one thread
+// either: `scan_threads` threads find the newlines of a slice of the stretch each, the line starts are put
+// together, the slices' record groups are verified in parallel, and only then (everything before the first
+// irregular group being known to be regular) the batches are cut -- views of the stretch, no copy.  Two sources:
+// a plain file mapped into memory (MappedStretches), and a BGZF file whose members the same threads inflate
+// into a buffer per stretch (InflatedStretches).
+struct StretchSource
+{
+	virtual ~StretchSource() = default;
+	// the next stretch, beginning at the first byte no batch has taken: false when no text is left;
+	// *keep = what keeps the text alive (empty for a mapping), *last = no stretch follows this one
+	virtual bool next(const char** p, size_t* n, std::shared_ptr<const void>* keep, bool* last) = 0;
+	// the batches cut from that stretch end `used` bytes into it
+	virtual void consumed(size_t used) = 0;
+};
+
+// a stretch = at least one batch's worth of text (so that a stretch yields full batches) and enough for every
+// scan thread, at most a gigabyte (offsets within it are 32-bit); the workers parse the batches of one stretch
+// while the next is scanned
+inline size_t
+stretch_bytes(long batch_pairs, unsigned scan_threads)
+{
+	if (const char* e = std::getenv("ARKS_STRETCH_BYTES")) // tests: many short stretches
+		return std::max<size_t>(4096, (size_t)std::atoll(e));
+	return std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)batch_pairs * 720, (size_t)scan_threads << 25));
+}
+
+class MappedStretches : public StretchSource
+{
+  public:
+	MappedStretches(const char* map, size_t size, size_t stretch)
+	  : map_(map)
+	  , size_(size)
+	  , stretch_(stretch)
+	{}
+	bool next(const char** p, size_t* n, std::shared_ptr<const void>* keep, bool* last) override
+	{
+		const size_t span = std::min(size_ - at_, stretch_);
+		if (span == 0)
+			return false;
+		*p = map_ + at_;
+		*n = span;
+		keep->reset();
+		*last = at_ + span >= size_;
+		return true;
+	}
+	void consumed(size_t used) override { at_ += used; }
+	size_t offset() const { return at_; } // where the sequential loop reads on
+
+  private:
+	const char* map_;
+	size_t size_, stretch_, at_ = 0;
+};
+
+// Buffers for inflated stretches, reused once the batches cut from them are done: one pool for all producers.
+// A fresh buffer costs a page fault per page on first touch -- taken by the threads that inflate into it -- so
+// the buffers are mappings of their own for which the kernel is asked for huge pages (512x fewer faults where
+// transparent huge pages are available), and they are kept for the whole run.
+class StretchPool
+{
+  public:
+	struct Buf
+	{
+		unsigned char* p = nullptr;
+		size_t cap = 0;
+		Buf() = default;
+		Buf(const Buf&) = delete;
+		Buf& operator=(const Buf&) = delete;
+		~Buf()
+		{
+			if (p)
+				(void)::munmap(p, cap);
+		}
+	};
+	std::shared_ptr<Buf> get(size_t want)
+	{
+		std::lock_guard<std::mutex> lk(m_);
+		for (auto& b : bufs_)
+			if (b.use_count() == 1 && b->cap >= want)
+				return b;
+		for (auto& b : bufs_)
+			if (b.use_count() == 1) { // too small: replace it
+				b = make(want);
+				return b;
+			}
+		bufs_.push_back(make(want));
+		return bufs_.back();
+	}
+
+  private:
+	static std::shared_ptr<Buf> make(size_t want)
+	{
+		auto b = std::make_shared<Buf>();
+		const size_t huge = (size_t)2 << 20;
+		b->cap = (want + want / 8 + huge - 1) & ~(huge - 1);
+		void* m = ::mmap(nullptr, b->cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (m == MAP_FAILED)
+			throw std::bad_alloc();
+		(void)::madvise(m, b->cap, MADV_HUGEPAGE);
+		b->p = (unsigned char*)m;
+		return b;
+	}
+	std::mutex m_;
+	std::vector<std::shared_ptr<Buf>> bufs_;
+};
+
+// what a producer keeps from stretch to stretch and file to file (line ends per chunk, line starts): vectors
+// of tens of megabytes that would otherwise be allocated -- and faulted in -- again for every file
+struct SplitScratch
+{
+	std::vector<uint32_t> start;
+	std::vector<std::vector<uint32_t>> nl;
+};
+
+class InflatedStretches : public StretchSource
+{
+  public:
+	InflatedStretches(BgzfStretches& z, StretchPool& pool, size_t stretch, ParallelFor pf)
+	  : z_(z)
+	  , pool_(pool)
+	  , stretch_(stretch)
+	  , pf_(std::move(pf))
+	{}
+	bool next(const char** p, size_t* n, std::shared_ptr<const void>* keep, bool* last) override
+	{
+		// what the previous stretch left over goes in front (it is short: less than a group of records, unless
+		// the text stopped being regular -- and then no stretch follows)
+		const size_t carry = cur_ ? cur_n_ - cur_used_ : 0;
+		const size_t planned = z_.at_end() ? 0 : z_.plan(stretch_);
+		if (carry + planned == 0)
+			return false;
+		std::shared_ptr<StretchPool::Buf> nb = pool_.get(carry + planned + 64);
+		if (carry)
+			std::memcpy(nb->p, cur_->p + cur_used_, carry);
+		const size_t good = planned ? z_.inflate(nb->p + carry, pf_) : 0;
+		cur_ = std::move(nb);
+		cur_n_ = carry + good;
+		cur_used_ = 0;
+		*p = (const char*)cur_->p;
+		*n = cur_n_;
+		*keep = cur_;
+		*last = z_.at_end();
+		return cur_n_ > 0;
+	}
+	void consumed(size_t used) override { cur_used_ = used; }
+	// the text no batch has taken (to go back into the reader in front of what follows offset() in the file)
+	const unsigned char* rest(size_t* n) const
+	{
+		*n = cur_ ? cur_n_ - cur_used_ : 0;
+		return cur_ ? cur_->p + cur_used_ : nullptr;
+	}
+
+  private:
+	BgzfStretches& z_;
+	StretchPool& pool_;
+	size_t stretch_;
+	ParallelFor pf_;
+	std::shared_ptr<StretchPool::Buf> cur_;
+	size_t cur_n_ = 0, cur_used_ = 0;
+};
+
+// Returns the batches handed out and, in *pairs_out, the pairs they held; the source says where the
+// sequential loop continues.  `pf` runs the loops over chunks of the stretch.
 inline int64_t
-split_mapped(
-    const char* map, size_t size, int file_idx, long batch_pairs, const std::function<void(RawBatch&&)>& emit,
-    const std::function<bool(RawBatch&)>& recycled, uint64_t* pairs_out, size_t* consumed, unsigned scan_threads = 1)
+split_stretches(
+    StretchSource& src, int file_idx, long batch_pairs, const std::function<void(RawBatch&&)>& emit,
+    const std::function<bool(RawBatch&)>& recycled, uint64_t* pairs_out, const ParallelFor& pf, SplitScratch& scratch)
 {
 	int64_t seq = 0;
 	uint64_t pairs_done = 0;
-	size_t at = 0;
-	// a stretch = at least one batch's worth of text (so that a stretch yields full batches) and enough for every
-	// scan thread, at most a gigabyte (offsets within it are 32-bit); the workers parse the batches of one
-	// stretch while the next is scanned
-	const size_t kSuper = std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)batch_pairs * 720, (size_t)scan_threads << 25));
-	std::vector<uint32_t> start; // line starts of the current stretch, relative to `at`
-	std::vector<std::vector<uint32_t>> nl(std::max(1u, scan_threads));
+	std::vector<uint32_t>& start = scratch.start; // line starts of the current stretch, relative to its first byte
+	std::vector<std::vector<uint32_t>>& nl = scratch.nl;
 	for (;;) {
-		const size_t span = std::min(size - at, kSuper);
-		if (span == 0)
-			break;
-		const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(scan_threads, span >> 22)); // >= 4 MB per thread
-		const size_t slice = ((span + T - 1) / T + 63) & ~(size_t)63;
-		auto scan = [&](unsigned i) {
-			const size_t lo = std::min(span, (size_t)i * slice), hi = std::min(span, lo + slice);
-			std::vector<uint32_t>& v = nl[i];
-			v.resize(std::max(v.capacity(), (hi - lo) / 24 + 64)); // grown below when the lines are shorter than that
-			size_t n = 0, pos = lo;
-			while (pos < hi) {
-				if (v.size() - n < 4096)
-					v.resize(v.size() * 2);
-				size_t adv = 0;
-				n += newline_positions(map + at + pos, hi - pos, (uint32_t)pos, v.data() + n, v.size() - n, &adv);
-				pos += adv;
-			}
-			v.resize(n);
-		};
+		const char* text = nullptr;
+		size_t span = 0;
+		std::shared_ptr<const void> keep;
+		bool last = false;
 		{
-			std::vector<std::thread> th;
-			for (unsigned i = 1; i < T; ++i)
-				th.emplace_back(scan, i);
-			scan(0);
-			for (auto& t : th)
-				t.join();
+			IngestProfile::Scope sc(IngestProfile::SOURCE);
+			if (!src.next(&text, &span, &keep, &last))
+				break;
+		}
+		const size_t slice = (size_t)1 << 22; // 4 MB of text per chunk
+		const size_t T = (span + slice - 1) / slice;
+		if (nl.size() < T)
+			nl.resize(T);
+		{
+			IngestProfile::Scope sc(IngestProfile::SCAN);
+			pf(T, [&](size_t i) {
+				const size_t lo = i * slice, hi = std::min(span, lo + slice);
+				std::vector<uint32_t>& v = nl[i];
+				v.resize(std::max(v.capacity(), (hi - lo) / 24 + 64)); // grown below when the lines are shorter than that
+				size_t n = 0, pos = lo;
+				while (pos < hi) {
+					if (v.size() - n < 4096)
+						v.resize(v.size() * 2);
+					size_t adv = 0;
+					n += newline_positions(text + pos, hi - pos, (uint32_t)pos, v.data() + n, v.size() - n, &adv);
+					pos += adv;
+				}
+				v.resize(n);
+			});
 		}
 		std::vector<size_t> first(T + 1, 0);
-		for (unsigned i = 0; i < T; ++i)
+		for (size_t i = 0; i < T; ++i)
 			first[i + 1] = first[i] + nl[i].size();
 		const size_t nlines = first[T];
-		start.resize(nlines + 1);
-		start[0] = 0;
 		const size_t full = nlines / 8;
-		std::vector<size_t> bad(T, full); // first irregular pair each thread saw
-		auto stitch = [&](unsigned i) {
-			uint32_t* out = start.data() + 1 + first[i];
-			const std::vector<uint32_t>& v = nl[i];
-			for (size_t j = 0; j < v.size(); ++j)
-				out[j] = v[j] + 1;
-		};
-		auto verify = [&](unsigned i) {
-			const size_t lo = full * i / T, hi = full * (i + 1) / T;
-			for (size_t p = lo; p < hi; ++p)
-				if (!regular_record(map + at, start.data(), 8 * p) || !regular_record(map + at, start.data(), 8 * p + 4)) {
-					bad[i] = p;
-					return;
-				}
-		};
-		for (int phase = 0; phase < 2; ++phase) {
-			std::vector<std::thread> th;
-			for (unsigned i = 1; i < T; ++i)
-				th.emplace_back([&, i] { phase == 0 ? stitch(i) : verify(i); });
-			phase == 0 ? stitch(0) : verify(0);
-			for (auto& t : th)
-				t.join();
+		std::vector<size_t> bad(T, full); // first irregular pair each chunk saw
+		{
+			IngestProfile::Scope sc(IngestProfile::VERIFY);
+			start.resize(nlines + 1);
+			start[0] = 0;
+			pf(T, [&](size_t i) { // line ends -> line starts, all in one array
+				uint32_t* out = start.data() + 1 + first[i];
+				const std::vector<uint32_t>& v = nl[i];
+				for (size_t j = 0; j < v.size(); ++j)
+					out[j] = v[j] + 1;
+			});
+			pf(T, [&](size_t i) {
+				const size_t lo = full * i / T, hi = full * (i + 1) / T;
+				for (size_t p = lo; p < hi; ++p)
+					if (!regular_record(text, start.data(), 8 * p) || !regular_record(text, start.data(), 8 * p + 4)) {
+						bad[i] = p;
+						return;
+					}
+			});
 		}
 		size_t good = full;
-		for (unsigned i = 0; i < T; ++i)
+		for (size_t i = 0; i < T; ++i)
 			good = std::min(good, bad[i]);
+		std::unique_ptr<IngestProfile::Scope> cut_scope(new IngestProfile::Scope(IngestProfile::CUT));
 		for (size_t p0 = 0; p0 < good; p0 += (size_t)batch_pairs) {
 			const size_t P = std::min<size_t>((size_t)batch_pairs, good - p0);
 			RawBatch b;
@@ -854,20 +1182,26 @@ split_mapped(
 			b.line.resize(8 * P + 1);
 			for (size_t j = 0; j <= 8 * P; ++j)
 				b.line[j] = start[8 * p0 + j] - s0;
-			b.text.view = map + at + s0;
+			b.text.view = text + s0;
+			b.text.keep = keep;
 			b.text.n = (size_t)(start[8 * (p0 + P)] - s0);
 			b.n_text_pairs = (int64_t)P;
 			b.first_pair = pairs_done;
 			b.seq = seq++;
 			pairs_done += P;
-			emit(std::move(b));
+			cut_scope.reset();
+			{
+				IngestProfile::Scope sc(IngestProfile::EMIT_WAIT);
+				emit(std::move(b));
+			}
+			cut_scope.reset(new IngestProfile::Scope(IngestProfile::CUT));
 		}
-		at += start[8 * good];
-		if (good < full || good == 0 || at + 0 >= size || span < kSuper)
-			break; // irregular text, or the last lines of the file: the sequential loop reads on from `at`
+		cut_scope.reset();
+		src.consumed(start[8 * good]);
+		if (good < full || good == 0 || last)
+			break; // irregular text, or the last lines of the file: the sequential loop reads on from there
 	}
 	*pairs_out = pairs_done;
-	*consumed = at;
 	return seq;
 }
 
@@ -982,11 +1316,32 @@ class IngestPipeline
 		fast_path_ = std::getenv("ARKS_SEQUENTIAL_INGEST") == nullptr;
 		// a producer on the fast path only reads and finds lines (the workers parse): a quarter of the threads
 		// is plenty for them; without it a producer IS a parser: half
-		n_producers_ = std::max(1u, std::min(nf, std::max(1u, threads / (fast_path_ ? 4 : 2))));
-		n_packers_ = std::max(1u, threads > n_producers_ ? threads - n_producers_ : 1u);
+		unsigned n_serial = 0;
+		for (SeqReader* r : readers_)
+			n_serial += r->serial_source();
+		split_threads(threads, nf, fast_path_, &n_producers_, &n_packers_, n_serial);
 		n_buffers_ = n_packers_ + 3;
 		// short bursts of line scanning per gigabyte of a mapped file: what -t leaves per producer, at most 16
 		n_scan_ = std::max(1u, std::min(16u, threads / n_producers_));
+	}
+
+	// n_serial of the files are streams that one thread must inflate from end to end (ordinary .gz): their
+	// producers are busy threads, not coordinators, so up to half of the threads go to them
+	static void split_threads(
+	    unsigned threads, unsigned n_files, bool fast_path, unsigned* producers, unsigned* packers, unsigned n_serial = 0)
+	{
+		unsigned want = std::max(1u, threads / (fast_path ? 4 : 2));
+		if (fast_path)
+			want = std::max(want, std::min(n_serial, threads / 2));
+		*producers = std::max(1u, std::min(n_files, want));
+		*packers = std::max(1u, threads > *producers ? threads - *producers : 1u);
+	}
+	// packed-batch buffers a run over n_files files with `threads` threads keeps in flight
+	static unsigned buffers_for(unsigned threads, unsigned n_files)
+	{
+		unsigned producers = 1, packers = 1;
+		split_threads(threads, n_files, std::getenv("ARKS_SEQUENTIAL_INGEST") == nullptr, &producers, &packers);
+		return packers + 3;
 	}
 
 	DynamicDict& dynamic() { return dynamic_; }
@@ -1009,6 +1364,8 @@ class IngestPipeline
 		int first_err = ARKS_OK;
 		for (unsigned t = 0; t < n_producers_; ++t)
 			producers.emplace_back([&] {
+				SplitScratch scratch;
+				const ParallelFor pf = [&](size_t n, const std::function<void(size_t)>& fn) { desk_.parallel_for(n, fn); };
 				for (;;) {
 					size_t f;
 					{
@@ -1024,11 +1381,21 @@ class IngestPipeline
 					const auto emit = [&](RawBatch&& rb) { raw_q_.push(std::move(rb)); };
 					const auto reuse = [&](RawBatch& out) { return raw_free_.try_pop(out); };
 					if (fast_path_) {
-						size_t msize = 0, at = 0;
-						const char* map = readers_[f]->map_plain(&msize);
-						if (map) {
-							first_seq = split_mapped(map, msize, (int)f, batch_pairs_, emit, reuse, &pairs_before, &at, n_scan_);
-							readers_[f]->continue_at(at);
+						size_t msize = 0;
+						const size_t stretch = stretch_bytes(batch_pairs_, n_scan_);
+						std::unique_ptr<BgzfStretches> z;
+						if (const char* map = readers_[f]->map_plain(&msize)) {
+							MappedStretches src(map, msize, stretch);
+							first_seq = split_stretches(src, (int)f, batch_pairs_, emit, reuse, &pairs_before, pf, scratch);
+							readers_[f]->continue_at(src.offset());
+						} else if ((z = readers_[f]->bgzf_stretches())) {
+							InflatedStretches src(*z, stretch_pool_, stretch, pf);
+							first_seq = split_stretches(src, (int)f, batch_pairs_, emit, reuse, &pairs_before, pf, scratch);
+							size_t n_rest = 0;
+							const unsigned char* rest = src.rest(&n_rest);
+							readers_[f]->bgzf_continue_at(z->offset());
+							if (n_rest)
+								readers_[f]->unread(rest, n_rest);
 						} else
 							first_seq = split_file(*readers_[f], (int)f, batch_pairs_, emit, reuse, &pairs_before);
 					}
@@ -1041,8 +1408,27 @@ class IngestPipeline
 			packers.emplace_back([&] {
 				RawBatch rb;
 				std::unordered_map<std::string_view, uint32_t> cache; // fused mode: this worker's view of the dictionary
-				while (raw_q_.pop(rb)) {
+				for (;;) {
+					{
+						// a batch to parse if there is one; else a share of a producer's loop; else wait (briefly:
+						// a loop may be published meanwhile)
+						int got = raw_q_.try_pop(rb) ? 1 : 0;
+						if (!got) {
+							{
+								IngestProfile::Scope sc(IngestProfile::HELP);
+								if (desk_.help())
+									continue;
+							}
+							IngestProfile::Scope sc(IngestProfile::POP_WAIT);
+							got = raw_q_.pop_for(rb, 100);
+						}
+						if (got < 0)
+							break;
+						if (got == 0)
+							continue;
+					}
 					if (rb.is_text) {
+						IngestProfile::Scope sc(IngestProfile::PARSE);
 						PrepassInfo part;
 						parse_text_batch(rb, dict_, dict_ ? nullptr : &dynamic_, cache, dict_ ? nullptr : &part, verbose_);
 						if (!dict_) {
@@ -1051,8 +1437,12 @@ class IngestPipeline
 						}
 					}
 					PackedBatch* pb = nullptr;
-					if (!free_q_.pop_newest(pb))
-						return;
+					{
+						IngestProfile::Scope sc(IngestProfile::BUF_WAIT);
+						if (!free_q_.pop_newest(pb))
+							return;
+					}
+					IngestProfile::Scope sc(IngestProfile::PACK);
 					const int rc = pack_batch(rb, *pb, alloc_);
 					if (rc != ARKS_OK) {
 						std::lock_guard<std::mutex> lk(err_m);
@@ -1060,6 +1450,7 @@ class IngestPipeline
 							first_err = rc;
 					}
 					packed_q_.push(pb);
+					rb.text.clear();                   // (lets go of the stretch it was a view of)
 					raw_free_.try_push(std::move(rb)); // back to the producers, buffers and all
 					rb = RawBatch();
 				}
@@ -1099,6 +1490,7 @@ class IngestPipeline
 		}
 		if (finish)
 			finish();
+		IngestProfile::get().print();
 		free_q_.close();
 		for (auto& b : pool)
 			packed_free(b, alloc_);
@@ -1120,6 +1512,8 @@ class IngestPipeline
 	HostAllocator alloc_;
 	unsigned n_producers_ = 1, n_packers_ = 1, n_buffers_ = 4, n_scan_ = 1;
 	BoundedQueue<RawBatch> raw_q_, raw_free_{ 8 };
+	HelpDesk desk_;
+	StretchPool stretch_pool_;
 	BoundedQueue<PackedBatch*> packed_q_, free_q_;
 };
 

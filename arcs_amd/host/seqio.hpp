@@ -141,6 +141,18 @@ class SeqReader
 		begin_ = end_ = 0;
 		eof_ = false;
 	}
+	// A BGZF file nothing was read from yet, as stretches of text inflated by the caller's threads (bgzf.hpp);
+	// nullptr for any other source.  bgzf_continue_at(s->offset()) hands the file back to this reader.
+	std::unique_ptr<BgzfStretches> bgzf_stretches()
+	{
+		if (!bgzf_file_ || bgzf_ || begin_ < end_ || eof_ || !pushback_.empty())
+			return nullptr;
+		std::unique_ptr<BgzfStretches> s(new BgzfStretches(bgzf_file_));
+		if (!s->ok())
+			s.reset();
+		return s;
+	}
+	void bgzf_continue_at(size_t offset) { (void)std::fseek(bgzf_file_, (long)offset, SEEK_SET); }
 	// gives `n` bytes back: they are the next the stream delivers (the text a splitting caller read ahead
 	// of the point where it hands the stream over to next())
 	void unread(const unsigned char* p, size_t n)
@@ -155,6 +167,8 @@ class SeqReader
 			eof_ = false;
 	}
 	bool parallel_inflate() const { return bgzf_file_ != nullptr; }
+	// one stream that only one thread can read (an ordinary gzip file, a pipe): neither mapped nor inflated in stretches
+	bool serial_source() const { return bgzf_file_ == nullptr && plain_fd_ < 0; }
 	// the stream ended on an inflate error (damaged or truncated compressed input), not at its end
 	bool failed() const { return failed_; }
 

@@ -39,7 +39,7 @@ EXTS = os.environ.get("E2E_EXTS")
 PREFIX = os.environ.get("E2E_PREFIX", "").split()
 for ext in (EXTS.split(",") if EXTS else (".fq", ".fq.gz", ".bgzf.fq.gz") if os.environ.get("E2E_BGZF") else (".fq", ".fq.gz")):
     files = [f"{tmp}/r{fi}{ext}" for fi in range(NF)] * int(os.environ.get("E2E_REPEAT", 1))
-    for t in (1, 4, 16):
+    for t in [int(x) for x in os.environ.get('E2E_THREADS', '1,4,16').split(',')]:
         args = PREFIX + [exe, "--arks", "-f", f"{tmp}/draft.fa", "-u", f"{tmp}/mult.tsv", "-k", "60", "-j", "0.55", "-c", "5",
                 "-m", "50-10000", "-e", "30000", "-z", "500", "-t", str(t), "-b", f"{tmp}/out_{t}{ext.replace('.', '_')}"] + files
         t1 = time.time()
@@ -53,3 +53,6 @@ for ext in (EXTS.split(",") if EXTS else (".fq", ".fq.gz", ".bgzf.fq.gz") if os.
         rd = [l for l in out.stderr.splitlines() if 'read files' in l]
         ms = float(rd[0].split(':')[1].split()[0]) if rd else 0
         print('        reads stage %.0f ms -> %.2f M pairs/s' % (ms, len(files)*NP/ms/1e3), flush=True)
+        for l in out.stderr.splitlines():
+            if l.startswith('ingest profile') or (os.environ.get('E2E_TIMING') and l.startswith('[timing]')):
+                print('        ' + l)

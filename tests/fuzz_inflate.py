@@ -9,7 +9,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 700
 tmp = tempfile.mkdtemp()
 exe = os.path.join(tmp, "inflate_check_asan")
 subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17",
-                       "-I" + HOST, os.path.join(HOST, "inflate_check.cpp"), "-lz", "-o", exe])
+                       "-I" + HOST, os.path.join(HOST, "inflate_check.cpp"), "-lz", "-ldl", "-o", exe])
 random.seed(5)
 text = "".join(f"@r{i}\n{''.join(random.choice('ACGTN') for _ in range(random.randint(40, 160)))}\n+\n{'F' * 60}\n"
                for i in range(3000)).encode()

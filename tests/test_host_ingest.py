@@ -19,7 +19,7 @@ def exe(tmp_path_factory, arks):
     libdir = os.path.join(ROOT, "arcs_amd", "lib")
     subprocess.check_call(["g++", "-O1", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                            "-I" + os.path.join(ROOT, "include"), "-I" + HOST, os.path.join(HOST, "ingest_check.cpp"),
-                           "-L" + libdir, "-larks_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz",
+                           "-L" + libdir, "-larks_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz", "-ldl",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     return out
 
@@ -150,9 +150,10 @@ def write_fastq(path, recs, tail=""):
             f.write(text)
 
 
-def run(exe, threads, batch, mult_path, files, sequential=False):
+def run(exe, threads, batch, mult_path, files, sequential=False, extra_env=None):
     """sequential: ARKS_SEQUENTIAL_INGEST=1, every file through the kseq-compatible loop alone (no fast path)"""
-    env = dict(os.environ, ARKS_SEQUENTIAL_INGEST="1") if sequential else None
+    env = dict(os.environ, ARKS_SEQUENTIAL_INGEST="1") if sequential else dict(os.environ)
+    env.update(extra_env or {})
     out = subprocess.check_output([exe, str(threads), str(batch), mult_path] + files, text=True, env=env)
     lines = [ln for ln in out.splitlines(keepends=True) if not ln.startswith(("prepass ", "mult\t"))]
     res, cur = [], None
@@ -258,16 +259,25 @@ def test_fast_path_hands_over_to_the_kseq_loop(exe, tmp_path):
     with open(oddcount, "w") as f:
         f.write(text_of(regular[:-1]))
     files.append(oddcount)
+    # the same texts as BGZF files (members of 3000 bytes: they end anywhere in a line)
+    zfiles = []
+    for path in files:
+        zfiles.append(path + ".bgzf.gz")
+        write_bgzf(zfiles[-1], open(path, "rb").read(), block=3000)
+    import re
     for mp in (mult_path, "-"):                  # with a multiplicity file, and fused
         for threads, batch in ((1, 1 << 20), (6, 16), (3, 100)):
-            a = subprocess.check_output([exe, str(threads), str(batch), mp] + files, text=True)
             b = subprocess.check_output([exe, str(threads), str(batch), mp] + files, text=True,
                                         env=dict(os.environ, ARKS_SEQUENTIAL_INGEST="1"))
-            import re
             # (the first line is the thread split; how many batches a file made is not part of the result)
-            a = re.sub(r" multibatch=\d", "", "\n".join(a.split("\n")[1:]))
             b = re.sub(r" multibatch=\d", "", "\n".join(b.split("\n")[1:]))
-            assert a == b, (mp, threads, batch)
+            # whole files in one stretch, and stretches of a few thousand bytes (the hand-over then falls into any
+            # stretch, and the text between stretches is carried over or re-read)
+            for src, env in ((files, {}), (files, {"ARKS_STRETCH_BYTES": "9000"}), (zfiles, {}),
+                             (zfiles, {"ARKS_STRETCH_BYTES": "9000"})):
+                a = subprocess.check_output([exe, str(threads), str(batch), mp] + src, text=True, env=dict(os.environ, **env))
+                a = re.sub(r" multibatch=\d", "", "\n".join(a.split("\n")[1:]))
+                assert a == b, (mp, threads, batch, env, src is zfiles)
     # and the fast path did take most batches of a mostly regular file (multibatch = more than one batch seen)
     _, res = run(exe, 4, 16, mult_path, [files[2]])
     assert res[0]["kv"]["multibatch"] == "1" and int(res[0]["kv"]["pairs"]) >= 300
@@ -361,6 +371,20 @@ def test_bgzf_parallel_inflate(exe, oracle, tmp_path):
     open(bad, "wb").write(bytes(blob))
     _, res = run(exe, 4, 500, mult_path, [bad])
     assert 0 < int(res[0]["kv"]["pairs"]) < want[0]["pairs"]
+    # the members are inflated a stretch of text at a time by the scanning threads (BgzfStretches): stretches much
+    # shorter than the file (the text a stretch leaves over is carried into the next), with libdeflate and with
+    # zlib; and the damaged file gives what the sequential reader gives, whichever stretch the damage falls into
+    _, seq_bad = run(exe, 4, 500, mult_path, [bad], sequential=True)
+    for env in ({}, {"ARKS_ZLIB_INFLATE": "1"}):
+        for stretch in (4096, 70001, 300000):
+            e = dict(env, ARKS_STRETCH_BYTES=str(stretch))
+            for threads in (1, 3, 8):
+                _, res = run(exe, threads, 100, mult_path, [bg, small, bad], extra_env=e)
+                for r in res[:2]:
+                    kv = r["kv"]
+                    assert kv["digest"] == want[1] and int(kv["pairs"]) == want[0]["pairs"] and r["msgs"] == want[2], (e, threads)
+                assert res[2]["kv"]["digest"] == seq_bad[0]["kv"]["digest"] and res[2]["kv"]["pairs"] == seq_bad[0]["kv"]["pairs"], (e, threads)
+                assert res[2]["msgs"] == seq_bad[0]["msgs"]
 
 
 # ---- fast_inflate.hpp / crc32_fold.hpp ---------------------------------------------------------------
@@ -368,7 +392,7 @@ def test_bgzf_parallel_inflate(exe, oracle, tmp_path):
 @pytest.fixture(scope="module")
 def inflate_check(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("bin") / "inflate_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-I" + HOST, os.path.join(HOST, "inflate_check.cpp"), "-lz",
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-I" + HOST, os.path.join(HOST, "inflate_check.cpp"), "-lz", "-ldl",
                            "-o", out])
     return out
 
@@ -478,7 +502,7 @@ int main() {
 }
 ''')
     exe = str(tmp_path / "crc_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-I" + HOST, str(src), "-lz", "-o", exe])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-I" + HOST, str(src), "-lz", "-ldl", "-o", exe])
     assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == "bad=0"
 
 

@@ -16,7 +16,7 @@ COMP = str.maketrans("ACGTacgt", "TGCAtgca")
 def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("bin") / "long-to-linked-pe")
     subprocess.check_call(["g++", "-O1", "-std=c++17", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(), "-pthread", "-I" + os.path.join(ROOT, "arcs_amd", "host"),
-                           os.path.join(ROOT, "arcs_amd", "host", "long_to_linked_pe.cpp"), "-lz", "-o", out])
+                           os.path.join(ROOT, "arcs_amd", "host", "long_to_linked_pe.cpp"), "-lz", "-ldl", "-o", out])
     return out
 
 

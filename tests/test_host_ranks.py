@@ -17,7 +17,7 @@ def ranks_check(tmp_path_factory):
     flags = os.environ.get("ARKS_TEST_CXXFLAGS", "").split()
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", *flags,
                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "arcs_amd", "host"),
-                           os.path.join(ROOT, "arcs_amd", "host", "ranks_check.cpp"), "-lz", "-o", exe])
+                           os.path.join(ROOT, "arcs_amd", "host", "ranks_check.cpp"), "-lz", "-ldl", "-o", exe])
     return exe
 
 
