@@ -105,7 +105,10 @@ class BoundedQueue
 	int pop_for(T& out, long us)
 	{
 		std::unique_lock<std::mutex> lk(m_);
-		not_empty_.wait_for(lk, std::chrono::microseconds(us), [&] { return !q_.empty() || closed_; });
+		// (system_clock: pthread_cond_timedwait, which ThreadSanitizer follows; the steady-clock wait of wait_for
+		// is pthread_cond_clockwait, which GCC 11's does not)
+		not_empty_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(us),
+		                      [&] { return !q_.empty() || closed_; });
 		if (q_.empty())
 			return closed_ ? -1 : 0;
 		out = std::move(q_.front());

@@ -6,15 +6,17 @@ from arcs_amd import build as b, synth
 exe = b.build_host()
 tmp = "/tmp/e2e"; os.makedirs(tmp, exist_ok=True)
 NF, NP = int(os.environ.get("E2E_FILES", 4)), int(os.environ.get("E2E_PAIRS", 1000000))
-contigs = synth.make_draft(20_000_000, seed=7)
-cs = synth.contigs_to_strings(contigs)
-with open(f"{tmp}/draft.fa", "w") as f:
-    for i, s in enumerate(cs):
-        f.write(f">{i+1}\n{s}\n")
+DRAFT_MBP = float(os.environ.get("E2E_DRAFT_MBP", 20))     # 3000 = a human-size draft (BASELINE configs[2])
+contigs = synth.make_draft(int(DRAFT_MBP * 1e6), seed=7)
+with open(f"{tmp}/draft.fa", "wb") as f:
+    for i, c in enumerate(contigs):
+        f.write(b">%d\n" % (i + 1)); f.write(c.tobytes()); f.write(b"\n")
+print("draft: %d contigs, %.0f Mbp" % (len(contigs), sum(len(c) for c in contigs) / 1e6), flush=True)
 mult = {}
 t0 = time.time()
 for fi in range(NF):
-    batch = synth.make_read_pairs(contigs, NP, seed=100 + fi)
+    batch = synth.make_read_pairs(contigs, NP, seed=100 + fi, device="cuda" if DRAFT_MBP > 500 else "cpu")
+    batch = {k: v.cpu() for k, v in batch.items()}
     reads = synth.reads_to_strings(batch)
     bid = batch["barcode_id"].numpy()
     parts = []
