@@ -341,6 +341,15 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 	contigRecord.clear();
 	contigRecord.push_back(CI("null contig", false));
 	SeqReader rd(params.file.c_str(), std::max(1u, params.threads));
+	{
+		// the ends of a draft are most of it (two ends of up to -e bases per contig): room for them at once -- a
+		// string that doubles its way to gigabytes copies itself, and faults its pages in, several times over
+		struct stat st;
+		if (::stat(params.file.c_str(), &st) == 0 && S_ISREG(st.st_mode))
+			bases.reserve(std::min<size_t>((size_t)st.st_size * (rd.serial_source() || rd.parallel_inflate() ? 4 : 1) + 1,
+			                               (size_t)8 << 30));
+	}
+	const auto t_read0 = std::chrono::steady_clock::now();
 	size_t count = 0; // what initContigArray (Arcs.cpp:451-479) counts in a pass of its own; here in the same pass
 	while (rd.next() >= 0) {
 		total++;
@@ -372,6 +381,9 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 		std::cerr << PROGRAM ": warning: " << params.file
 		          << ": the compressed stream is damaged or truncated; the contigs before the damage were used\n";
 	bases.push_back('\0');
+	if (getenv("ARKS_TIMING"))
+		std::cerr << "[timing]   contig index, draft read (" << bases.size() << " bases of ends): "
+		          << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_read0).count() << " ms\n";
 	if (params.verbose)
 		std::cerr << "Number of contigs:" << count << "\nSize of Contig Array:" << count * 2 + 1 << std::endl;
 	std::vector<arks_index*> idxs;

@@ -262,3 +262,52 @@ def test_beyond_one_index_in_shards(arks, gpu, oracle):
     assert (conreci.cpu().numpy() == want_c).all()
     assert (pair.cpu().numpy() == want_p).all()
     assert int((want_p != 0).sum()) > n_pairs // 10
+
+
+def test_arks_long_human_scale_multi_k(arks, gpu, oracle):
+    """BASELINE configs[4] on ONE MI355X at the draft's full size: the 3 Gbp draft indexed for k = 40, 60 and 80
+    (three seed indexes resident together, as `arcs --arks -k 40,60,80` keeps them), 250-bp pseudo-linked pairs as
+    long-to-linked-pe cuts them from long reads (a read's two mates are adjacent stretches, the second one
+    reverse-complemented; 2 % substitutions: ONT-like), j = 0.05 (bin/arcs-make:299-313).  Every k against the
+    CPU oracle on 2 M pairs drawn from a sub-draft: conreci, pair rule, all eight counters."""
+    import torch
+    from arcs_amd import synth
+    j, L = 0.05, 250
+    dup_events = []
+    contigs = synth.make_draft(3_000_000_000, seed=synth.SEED, dup_events=dup_events)
+    ends = _ends_of(arks, contigs)
+    ixs = {k: arks.ArksIndex.build(ends, k, device=gpu) for k in (40, 60, 80)}
+    del ends
+    # the layout is chosen by what is free when an index is built: seed tables (46 GB each) while they fit beside
+    # the build's scratch, the minimizer layout after that -- both are under test here
+    assert ixs[40].kind == 2 and all(ix.kind in (1, 2) for ix in ixs.values())
+    acc, members = _sub_draft(synth, contigs, dup_events, 30.0)
+    n_sub = 0
+    while sum(len(c) for c in contigs[:n_sub]) < acc:
+        n_sub += 1
+    genome_sub = torch.from_numpy(np.concatenate(contigs[:n_sub])).cuda()
+    n_pairs = 2_000_000
+    batch = synth.make_read_pairs(genome_sub, n_pairs, seed=4545, device="cuda", r1_len=L, r2_len=L, frag=2 * L,
+                                  sub_rate=0.02)
+    batch["pair_ok"][synth.pairs_touching_microsatellite(batch, r1_len=L, r2_len=L)] = 0
+    reads = arks.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=gpu)
+    ok = batch["pair_ok"].cpu().numpy()
+    a = np.concatenate([batch["ascii"].cpu().numpy(), np.zeros(1, np.uint8)])
+    offs = batch["offsets"].cpu().numpy().astype(np.uint64)[:-1]
+    lens = batch["lens"].cpu().numpy().astype(np.uint32)
+    passed = 0
+    for k, ix in ixs.items():
+        stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+        conreci, pair = arks.map_pairs_packed(ix, reads, j, pair_ok=batch["pair_ok"], barcode_id=batch["barcode_id"],
+                                              stats=stats)
+        torch.cuda.synchronize()
+        ox = oracle.sub_draft_index(k, contigs, members)
+        want_c, want_p, want_st = ox.map_pairs(a, offs, lens, j, pair_ok=ok, threads=min(64, os.cpu_count() or 1))
+        assert (conreci.cpu().numpy() == want_c).all(), k
+        assert (pair.cpu().numpy() == want_p).all(), k
+        assert dict(zip(STAT_NAMES, stats.cpu().tolist())) == {f: want_st[f] for f in STAT_NAMES}, k
+        passed += int((want_p != 0).sum())
+        del ox
+    assert passed > n_pairs          # most pairs name an end at every k with j = 0.05
+    for ix in ixs.values():
+        ix.close()
