@@ -40,6 +40,35 @@ class GzInflater
 	GzInflater(const GzInflater&) = delete;
 	GzInflater& operator=(const GzInflater&) = delete;
 
+	FILE* file() const { return f_; }
+	// Goes on in the middle of the first member (nothing was read through this object yet): the block that
+	// starts at bit `bit` of the file is the next to decode, `window` is the text in front of it (its last
+	// 32 KiB, or all of it if there is less), `crc` / `member_out` the CRC-32 and length of the member's text so
+	// far.  For pgzip.hpp, which decodes the blocks in front of that point on several threads.
+	bool resume(size_t bit, const unsigned char* window, size_t window_len, uint32_t crc, uint64_t member_out)
+	{
+		if (std::fseek(f_, (long)(bit >> 3), SEEK_SET) != 0)
+			return false;
+		in_pos_ = in_end_ = 0;
+		in_eof_ = false;
+		bitbuf_ = 0;
+		bitcnt_ = 0;
+		window_len = std::min(window_len, kHistory);
+		if (window_len)
+			std::memcpy(out_.data() + kHistory - window_len, window, window_len);
+		out_pos_ = out_read_ = kHistory;
+		crc_ = crc;
+		member_out_ = member_out;
+		first_member_ = false;
+		state_ = BLOCK_START;
+		if (bit & 7) {
+			if (!need((int)(bit & 7)))
+				return false;
+			drop((int)(bit & 7));
+		}
+		return true;
+	}
+
 	// up to cap bytes of the inflated stream; 0 at the end, -1 on a damaged file
 	int read(unsigned char* dst, int cap)
 	{

@@ -1099,6 +1099,55 @@ class InflatedStretches : public StretchSource
 	size_t cur_n_ = 0, cur_used_ = 0;
 };
 
+// an ordinary gzip file: the blocks of a stretch decoded by the threads of `pf` (pgzip.hpp)
+class GzTextStretches : public StretchSource
+{
+  public:
+	GzTextStretches(GzStretches& z, StretchPool& pool, ParallelFor pf)
+	  : z_(z)
+	  , pool_(pool)
+	  , pf_(std::move(pf))
+	{}
+	bool next(const char** p, size_t* n, std::shared_ptr<const void>* keep, bool* last) override
+	{
+		const size_t carry = cur_ ? cur_n_ - cur_used_ : 0;
+		std::shared_ptr<StretchPool::Buf> nb;
+		size_t got = 0;
+		if (!z_.at_end())
+			got = z_.next(pf_, [&](size_t bytes) {
+				nb = pool_.get(carry + bytes + 64);
+				return nb->p + carry;
+			});
+		if (carry + got == 0)
+			return false;
+		if (!nb)
+			nb = pool_.get(carry + 64);
+		if (carry)
+			std::memcpy(nb->p, cur_->p + cur_used_, carry);
+		cur_ = std::move(nb);
+		cur_n_ = carry + got;
+		cur_used_ = 0;
+		*p = (const char*)cur_->p;
+		*n = cur_n_;
+		*keep = cur_;
+		*last = z_.at_end();
+		return true;
+	}
+	void consumed(size_t used) override { cur_used_ = used; }
+	const unsigned char* rest(size_t* n) const
+	{
+		*n = cur_ ? cur_n_ - cur_used_ : 0;
+		return cur_ ? cur_->p + cur_used_ : nullptr;
+	}
+
+  private:
+	GzStretches& z_;
+	StretchPool& pool_;
+	ParallelFor pf_;
+	std::shared_ptr<StretchPool::Buf> cur_;
+	size_t cur_n_ = 0, cur_used_ = 0;
+};
+
 // Returns the batches handed out and, in *pairs_out, the pairs they held; the source says where the
 // sequential loop continues.  `pf` runs the loops over chunks of the stretch.
 inline int64_t
@@ -1319,9 +1368,17 @@ class IngestPipeline
 		fast_path_ = std::getenv("ARKS_SEQUENTIAL_INGEST") == nullptr;
 		// a producer on the fast path only reads and finds lines (the workers parse): a quarter of the threads
 		// is plenty for them; without it a producer IS a parser: half
-		unsigned n_serial = 0;
+		// ordinary gzip files: with few of them (fewer than a quarter of the threads) each is decoded by several
+		// threads at once (pgzip.hpp: about twice the work per byte of the one-thread inflater, but it spreads);
+		// with many, a thread per file is the better use of the threads
+		unsigned n_serial = 0, n_gz = 0;
 		for (SeqReader* r : readers_)
-			n_serial += r->serial_source();
+			n_gz += r->splittable_gzip();
+		use_pgzip_ = fast_path_ && n_gz > 0 && 4 * n_gz < threads && !std::getenv("ARKS_NO_PGZIP");
+		if (const char* e = std::getenv("ARKS_PGZIP")) // 1 / 0: whatever the counts say (tests, A/B runs)
+			use_pgzip_ = fast_path_ && std::atoi(e) != 0;
+		for (SeqReader* r : readers_)
+			n_serial += r->serial_source() || (r->splittable_gzip() && !use_pgzip_);
 		split_threads(threads, nf, fast_path_, &n_producers_, &n_packers_, n_serial);
 		n_buffers_ = n_packers_ + 3;
 		// short bursts of line scanning per gigabyte of a mapped file: what -t leaves per producer, at most 16
@@ -1387,6 +1444,7 @@ class IngestPipeline
 						size_t msize = 0;
 						const size_t stretch = stretch_bytes(batch_pairs_, n_scan_);
 						std::unique_ptr<BgzfStretches> z;
+						std::unique_ptr<GzStretches> g;
 						if (const char* map = readers_[f]->map_plain(&msize)) {
 							MappedStretches src(map, msize, stretch);
 							first_seq = split_stretches(src, (int)f, batch_pairs_, emit, reuse, &pairs_before, pf, scratch);
@@ -1397,6 +1455,14 @@ class IngestPipeline
 							size_t n_rest = 0;
 							const unsigned char* rest = src.rest(&n_rest);
 							readers_[f]->bgzf_continue_at(z->offset());
+							if (n_rest)
+								readers_[f]->unread(rest, n_rest);
+						} else if (use_pgzip_ && (g = readers_[f]->gz_stretches(pgzip_chunk_, std::max(4u, std::min(64u, 4 * (n_producers_ + n_packers_)))))) {
+							GzTextStretches src(*g, stretch_pool_, pf);
+							first_seq = split_stretches(src, (int)f, batch_pairs_, emit, reuse, &pairs_before, pf, scratch);
+							size_t n_rest = 0;
+							const unsigned char* rest = src.rest(&n_rest);
+							readers_[f]->gz_continue(*g);
 							if (n_rest)
 								readers_[f]->unread(rest, n_rest);
 						} else
@@ -1514,6 +1580,9 @@ class IngestPipeline
 	bool verbose_;
 	HostAllocator alloc_;
 	unsigned n_producers_ = 1, n_packers_ = 1, n_buffers_ = 4, n_scan_ = 1;
+	// compressed bytes per chunk of an ordinary gzip file decoded in parallel (ARKS_PGZIP_CHUNK: tests)
+	size_t pgzip_chunk_ = std::getenv("ARKS_PGZIP_CHUNK") ? (size_t)std::atoll(std::getenv("ARKS_PGZIP_CHUNK")) : (size_t)1 << 20;
+	bool use_pgzip_ = false;
 	BoundedQueue<RawBatch> raw_q_, raw_free_{ 8 };
 	HelpDesk desk_;
 	StretchPool stretch_pool_;

@@ -10,6 +10,7 @@
 
 #include "bgzf.hpp"
 #include "fast_inflate.hpp"
+#include "pgzip.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -153,6 +154,30 @@ class SeqReader
 		return s;
 	}
 	void bgzf_continue_at(size_t offset) { (void)std::fseek(bgzf_file_, (long)offset, SEEK_SET); }
+	// An ordinary gzip file nothing was read from yet, as stretches of text decoded by the caller's threads
+	// (pgzip.hpp); nullptr for any other source (ARKS_NO_PGZIP=1: never).  gz_continue(*s) hands the stream
+	// back to this reader's own inflater, which goes on where the stretches ended.
+	std::unique_ptr<GzStretches> gz_stretches(size_t chunk_bytes, unsigned chunks_per_stretch)
+	{
+		if (!fast_ || begin_ < end_ || eof_ || !pushback_.empty() || gz_handed_out_ || std::getenv("ARKS_NO_PGZIP"))
+			return nullptr;
+		std::unique_ptr<GzStretches> s(new GzStretches(fast_->file(), chunk_bytes, chunks_per_stretch));
+		if (!s->ok())
+			s.reset();
+		else
+			gz_handed_out_ = true;
+		return s;
+	}
+	void gz_continue(const GzStretches& s)
+	{
+		if (!s.started())
+			return; // nothing was decoded there: the inflater starts at the head of the file as always
+		const GzResumePoint& r = s.resume();
+		if (!fast_->resume(r.bit, r.window.data(), r.window.size(), r.crc, r.member_out)) {
+			failed_ = true;
+			eof_ = true;
+		}
+	}
 	// gives `n` bytes back: they are the next the stream delivers (the text a splitting caller read ahead
 	// of the point where it hands the stream over to next())
 	void unread(const unsigned char* p, size_t n)
@@ -168,7 +193,9 @@ class SeqReader
 	}
 	bool parallel_inflate() const { return bgzf_file_ != nullptr; }
 	// one stream that only one thread can read (an ordinary gzip file, a pipe): neither mapped nor inflated in stretches
-	bool serial_source() const { return bgzf_file_ == nullptr && plain_fd_ < 0; }
+	bool serial_source() const { return bgzf_file_ == nullptr && plain_fd_ < 0 && !fast_; }
+	// an ordinary gzip file in a regular file: one thread's work, or several threads' through pgzip.hpp
+	bool splittable_gzip() const { return fast_ != nullptr; }
 	// the stream ended on an inflate error (damaged or truncated compressed input), not at its end
 	bool failed() const { return failed_; }
 
@@ -241,7 +268,7 @@ class SeqReader
 	unsigned bgzf_workers_ = 0;
 	unsigned char buf_[1 << 18];
 	int begin_ = 0, end_ = 0;
-	bool eof_ = false, failed_ = false;
+	bool eof_ = false, failed_ = false, gz_handed_out_ = false;
 	int last_ = 0;
 	std::vector<unsigned char> pushback_;
 	size_t pushback_pos_ = 0;

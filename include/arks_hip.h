@@ -241,7 +241,11 @@ int arks_map_reads_device(
  * shards is the vote of the whole map: the larger count wins and a tie keeps the smaller conreci
  * (:1000, strict <).  That maximum is the only data-path exchange of the sharded configuration (one
  * 8-byte all-reduce(MAX) per read; reads are replicated to every shard), arks_votes_resolve_device
- * finishes the call.  Same rule per index and stream as arks_map_reads_device. */
+ * finishes the call.  Same rule per index and stream as arks_map_reads_device.
+ * No arks_map_stats here (documented omission): total_valid / bad / windows are the same in every shard,
+ * recorded adds up over shards, but a key shared by two shards reads 0 -- found, duplicate -- in BOTH, so
+ * found and dups of the whole map are not the sums of the shards' and would need a per-key "first holder"
+ * mark that the build does not keep; `arcs --index-shards` prints that the counters are not collected. */
 int arks_map_votes_device(
     const arks_index* idx,
     const uint64_t* d_codes,

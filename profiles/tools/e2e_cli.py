@@ -56,5 +56,5 @@ for ext in (EXTS.split(",") if EXTS else (".fq", ".fq.gz", ".bgzf.fq.gz") if os.
         ms = float(rd[0].split(':')[1].split()[0]) if rd else 0
         print('        reads stage %.0f ms -> %.2f M pairs/s' % (ms, len(files)*NP/ms/1e3), flush=True)
         for l in out.stderr.splitlines():
-            if l.startswith('ingest profile') or (os.environ.get('E2E_TIMING') and l.startswith('[timing]')):
+            if l.startswith('ingest profile') or (os.environ.get('E2E_TIMING') and l.startswith(('[timing]', 'pgzip:'))):
                 print('        ' + l)

@@ -264,6 +264,12 @@ def test_fast_path_hands_over_to_the_kseq_loop(exe, tmp_path):
     for path in files:
         zfiles.append(path + ".bgzf.gz")
         write_bgzf(zfiles[-1], open(path, "rb").read(), block=3000)
+    # ... and as ordinary gzip files (decoded in chunks of a few kilobytes by several threads, pgzip.hpp)
+    gfiles = []
+    for path in files:
+        gfiles.append(path + ".gz")
+        with open(gfiles[-1], "wb") as f:
+            f.write(gzip.compress(open(path, "rb").read(), 6))
     import re
     for mp in (mult_path, "-"):                  # with a multiplicity file, and fused
         for threads, batch in ((1, 1 << 20), (6, 16), (3, 100)):
@@ -274,10 +280,11 @@ def test_fast_path_hands_over_to_the_kseq_loop(exe, tmp_path):
             # whole files in one stretch, and stretches of a few thousand bytes (the hand-over then falls into any
             # stretch, and the text between stretches is carried over or re-read)
             for src, env in ((files, {}), (files, {"ARKS_STRETCH_BYTES": "9000"}), (zfiles, {}),
-                             (zfiles, {"ARKS_STRETCH_BYTES": "9000"})):
+                             (zfiles, {"ARKS_STRETCH_BYTES": "9000"}), (gfiles, {"ARKS_PGZIP": "1"}),
+                             (gfiles, {"ARKS_PGZIP": "1", "ARKS_PGZIP_CHUNK": "4096"}), (gfiles, {})):
                 a = subprocess.check_output([exe, str(threads), str(batch), mp] + src, text=True, env=dict(os.environ, **env))
                 a = re.sub(r" multibatch=\d", "", "\n".join(a.split("\n")[1:]))
-                assert a == b, (mp, threads, batch, env, src is zfiles)
+                assert a == b, (mp, threads, batch, env, src[0][-8:])
     # and the fast path did take most batches of a mostly regular file (multibatch = more than one batch seen)
     _, res = run(exe, 4, 16, mult_path, [files[2]])
     assert res[0]["kv"]["multibatch"] == "1" and int(res[0]["kv"]["pairs"]) >= 300
@@ -441,6 +448,17 @@ def test_fast_inflate_equals_zlib(inflate_check, tmp_path):
         for chunk in ((1 << 18, 1, 7, 4096) if len(blob) < 5000 else (1 << 18, 4099)):
             out = subprocess.run([inflate_check, str(path), str(chunk)], capture_output=True, text=True, timeout=120)
             assert out.returncode == 0 and out.stdout.startswith("same "), (name, chunk, out.stdout)
+        # the same stream with its blocks decoded by several threads (pgzip.hpp: speculative block starts, 16-bit
+        # symbols with markers for the unknown window, hand-over to the sequential inflater): chunks of a few
+        # kilobytes put block searches, chain breaks and the hand-over everywhere in these files
+        for threads, pchunk, per in ((3, 4096, 5), (2, 20011, 4), (4, 1 << 20, 8)):
+            out = subprocess.run([inflate_check, str(path), str(1 << 18), "pgz", str(threads), str(pchunk), str(per)],
+                                 capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0 and "pgz same " in out.stdout, (name, threads, pchunk, out.stdout)
+            if name.startswith("fastq") and name != "fastq0" and pchunk < (1 << 20):
+                # ... and on FASTQ text most of the file does come from the parallel path
+                par = int(out.stdout.split("parallel ")[1].split()[0])
+                assert par > len(fastq) // 2, (name, pchunk, out.stdout)
     assert zlib.decompress(cases["all_header_fields"], 31) == fastq[:30000]
 
 
@@ -456,8 +474,9 @@ def test_fast_inflate_damaged_input(inflate_check, tmp_path):
     for i, cut in enumerate(cuts):
         path = tmp_path / f"cut{i}.gz"
         path.write_bytes(blob[:cut])
-        out = subprocess.run([inflate_check, str(path)], capture_output=True, text=True, timeout=60)
+        out = subprocess.run([inflate_check, str(path), str(1 << 18), "pgz", "3", "9001", "4"], capture_output=True, text=True, timeout=60)
         assert out.stdout.split()[0] in ("same", "DIFFERENT"), out.stdout          # ran to the end
+        assert "pgz same " in out.stdout, (cut, out.stdout)     # several threads deliver what the one inflater delivers
         rc = out.stdout.split("rc ")[1].split()[0].split("/")
         # gzread's return value calls a truncated stream a plain end of file (only gzerror tells); what counts for
         # the reader is that the same bytes were delivered before it
@@ -472,8 +491,9 @@ def test_fast_inflate_damaged_input(inflate_check, tmp_path):
         bad[pos] ^= 1 << int(rng.integers(8))
         path = tmp_path / f"flip{i}.gz"
         path.write_bytes(bytes(bad))
-        out = subprocess.run([inflate_check, str(path)], capture_output=True, text=True, timeout=60)
+        out = subprocess.run([inflate_check, str(path), str(1 << 18), "pgz", "3", "9001", "4"], capture_output=True, text=True, timeout=60)
         assert out.stdout.split()[0] in ("same", "DIFFERENT"), (pos, out.stdout, out.stderr)
+        assert "pgz same " in out.stdout, (pos, out.stdout)
         rc = out.stdout.split("rc ")[1].split()[0].split("/")
         if int(rc[1]) < 0:                     # zlib saw the damage: so must we (CRC-32 and length are checked)
             assert int(rc[0]) < 0, (pos, out.stdout)
