@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     return OUT
 
 
-HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("arcs.cpp", "graph.hpp", "dist_est.hpp", "seqio.hpp", "ingest.hpp", "rank_merge.hpp", "bgzf.hpp", "pgzip.hpp", "fast_inflate.hpp", "crc32_fold.hpp", "long_to_linked_pe.cpp")]
+HOST_SOURCES = [os.path.join(HERE, "host", f) for f in ("arcs.cpp", "graph.hpp", "dist_est.hpp", "seqio.hpp", "ingest.hpp", "graph_fast.hpp", "rank_merge.hpp", "bgzf.hpp", "pgzip.hpp", "fast_inflate.hpp", "crc32_fold.hpp", "long_to_linked_pe.cpp")]
 HOST_OUT = os.path.join(HERE, "bin", "arcs")
 
 

@@ -805,7 +805,7 @@ void
 read_stage(
     const std::vector<std::string>& files, const std::vector<arks_index*>& idxs, std::vector<IndexMap>& imaps,
     std::unordered_map<std::string, int>& mult, const std::vector<CI>& contigRecord, bool fused, std::string& out,
-    std::string& err, std::string& pre_out, std::string& pre_err, bool& redo)
+    std::string& err, std::string& pre_out, std::string& pre_err, bool& redo, std::vector<CompactIndex>* compact)
 {
 	// after a fall-back to two passes the workers are gone: rank 0 maps every file
 	const int world = g_workers.empty() && g_rank == 0 ? 1 : g_world;
@@ -850,7 +850,7 @@ read_stage(
 		redo = redo || r.redo;
 	if (redo)
 		return;
-	merge_results(files, ranks, imaps, mult, contigRecord, fused, MergeParams{ params.verbose != 0, params.k_list, params.index_shards }, out, err, &pre_out, &pre_err);
+	merge_results(files, ranks, imaps, mult, contigRecord, fused, MergeParams{ params.verbose != 0, params.k_list, params.index_shards }, out, err, &pre_out, &pre_err, compact);
 }
 
 // file names of one k: with a single -k exactly the reference's (Arcs.cpp:2144-2157); with a list
@@ -960,6 +960,10 @@ run_arks(const std::vector<std::string>& filenames)
 	}
 
 	std::vector<IndexMap> imaps;
+	// the stages behind the read stage run on numbers (graph_fast.hpp) unless the distance estimates are asked
+	// for, which walk the IndexMap itself (ARKS_LITERAL_GRAPH=1: graph.hpp's containers in any case)
+	const bool fast_graph = !params.dist_est && getenv("ARKS_LITERAL_GRAPH") == nullptr;
+	std::vector<CompactIndex> cix;
 	std::unordered_map<std::string, int> mult;
 	ContigToLength contigToLength;
 	std::vector<CI> contigRecord;
@@ -1002,18 +1006,19 @@ run_arks(const std::vector<std::string>& filenames)
 	{
 		std::string out, err, pre_out, pre_err;
 		bool redo = false;
-		read_stage(filenames, idxs, imaps, mult, contigRecord, fused, out, err, pre_out, pre_err, redo);
+		read_stage(filenames, idxs, imaps, mult, contigRecord, fused, out, err, pre_out, pre_err, redo, fast_graph ? &cix : nullptr);
 		if (fused && redo) {
 			// (a rank met an input the fused pass cannot reproduce: the literal two passes, in this process)
 			mult.clear();
 			imaps.clear();
+			cix.clear();
 			out.clear();
 			err.clear();
 			pre_out.clear();
 			pre_err.clear();
 			read_barcodes(filenames, mult);
 			std::cout << mid << std::flush;
-			read_stage(filenames, idxs, imaps, mult, contigRecord, false, out, err, pre_out, pre_err, redo);
+			read_stage(filenames, idxs, imaps, mult, contigRecord, false, out, err, pre_out, pre_err, redo, fast_graph ? &cix : nullptr);
 		} else if (fused) {
 			std::cout << pre_out;
 			std::cerr << pre_err;
@@ -1029,21 +1034,32 @@ run_arks(const std::vector<std::string>& filenames)
 
 	for (size_t ki = 0; ki < params.k_list.size(); ++ki) {
 		const OutputNames names = output_names(params.k_list[ki]);
-		IndexMap& imap = imaps[ki];
+		IndexMap literal_none;
+		IndexMap& imap = fast_graph ? literal_none : imaps[ki];
 		PairMap pmap;
+		CompactPairs cpairs;
 		ScaffoldGraph g;
 		if (params.k_list.size() > 1)
 			std::cout << "\n=> Graph stage for k = " << params.k_list[ki] << "\n";
 		std::cout << "\n=> Pairing scaffolds... " << now();
-		pair_contigs(imap, pmap, mult, params.g);
+		if (fast_graph)
+			cpairs = pair_contigs_compact(cix[ki], params.g);
+		else
+			pair_contigs(imap, pmap, mult, params.g);
 		if (params.output_pair) {
 			std::cout << "\n=> Outputting Pairing information... " << now();
 			std::ofstream out((names.base + "_pair.tsv").c_str());
-			write_pair_map(out, pmap);
+			if (fast_graph)
+				write_pair_map_compact(out, cix[ki], cpairs);
+			else
+				write_pair_map(out, pmap);
 		}
 		const std::string t_graph = now(); // the reference reuses this time stamp for the next heading (Arcs.cpp:1917-1924)
 		std::cout << "\n=> Creating the graph... " << t_graph;
-		create_graph(pmap, g, params.g);
+		if (fast_graph)
+			create_graph_compact(cpairs, cix[ki], g, params.g);
+		else
+			create_graph(pmap, g, params.g);
 		if (params.dist_est) { // calcDistanceEstimates, Arcs.cpp:1767-1808
 			const bool multi = params.k_list.size() > 1;
 			std::cout << "\n=> Calculating distance estimates... " << t_graph;
@@ -1097,10 +1113,13 @@ run_arks(const std::vector<std::string>& filenames)
 			}
 		}
 		if (!names.tsv.empty()) {
-			const size_t barcode_count = count_barcodes(imap, mult, params.g);
+			const size_t barcode_count = fast_graph ? count_barcodes_compact(cix[ki], mult, params.g) : count_barcodes(imap, mult, params.g);
 			std::cout << "\n=> Writing TSV file... " << now();
 			std::ofstream f(names.tsv.c_str());
-			write_tsv(f, imap, pmap, barcode_count, params.g);
+			if (fast_graph)
+				write_tsv_compact(f, cix[ki], cpairs, barcode_count, params.g);
+			else
+				write_tsv(f, imap, pmap, barcode_count, params.g);
 		}
 	}
 	if (!params.barcode_counts_name.empty()) {

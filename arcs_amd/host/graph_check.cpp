@@ -4,13 +4,14 @@
 //       imap.tsv: barcode \t contig \t H|T \t count   (the post-pass for missing ends is applied)
 //       with e (end length), B (bin size) and upper (0|1): -D distance estimates as well
 //       (<out_base>_dist.tsv, <out_base>_samples.tsv, d= / maxd= in the graph files)
+//   graph_check imapfast ...   the same through graph_fast.hpp (numbers instead of strings; no distance estimates)
 //   graph_check mult  <multiplicity file> <out.tsv>
 //       the -u parser (createIndexMultMap) and the --barcode-counts writer: lines read, barcodes kept, sum of
 //       the reads on stdout; the map as the reference writes it (Arcs.cpp:1684-1706) to <out.tsv>
 //   graph_check gv    <original.gv> <lengths.tsv> <out.dist.gv> gap
 //       rebuilds the scaffold graph from an _original.gv and writes the ABySS dist.gv for it
 #include "dist_est.hpp"
-#include "graph.hpp"
+#include "graph_fast.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -65,7 +66,8 @@ main(int argc, char** argv)
 		}
 		return 0;
 	}
-	if (argc >= 14 && std::strcmp(argv[1], "imap") == 0) {
+	if (argc >= 14 && (std::strcmp(argv[1], "imap") == 0 || std::strcmp(argv[1], "imapfast") == 0)) {
+		const bool fast = std::strcmp(argv[1], "imapfast") == 0; // graph_fast.hpp instead of graph.hpp (no -D there)
 		IndexMap imap;
 		std::unordered_map<std::string, int> mult;
 		ContigToLength len;
@@ -93,6 +95,42 @@ main(int argc, char** argv)
 		P.max_degree = std::atoi(argv[10]);
 		P.error_percent = (float)std::atof(argv[11]);
 		P.gap = (unsigned)std::atoi(argv[12]);
+		if (fast) {
+			if (argc >= 17)
+				return 2;
+			const CompactIndex ix = compact_from_imap(imap, mult); // (the post-pass for missing ends is implied)
+			const CompactPairs pairs = pair_contigs_compact(ix, P);
+			{
+				std::ofstream out(base + "_pair.tsv");
+				write_pair_map_compact(out, ix, pairs);
+			}
+			ScaffoldGraph g;
+			create_graph_compact(pairs, ix, g, P);
+			if (P.max_degree != 0)
+				remove_degree_nodes(g, P.max_degree);
+			{
+				std::ofstream out(base + "_original.gv");
+				write_graph(out, g);
+			}
+			{
+				std::ofstream out(base + ".dist.gv");
+				std::string err;
+				if (!write_dist_graph(out, len, g, P.gap, &err, false, false)) {
+					std::cerr << err << "\n";
+					return 1;
+				}
+			}
+			{
+				const size_t n = count_barcodes_compact(ix, mult, P);
+				std::ofstream f(base + "_main.tsv");
+				write_tsv_compact(f, ix, pairs, n, P);
+			}
+			{
+				std::ofstream f(base + "_counts.tsv");
+				write_barcode_counts(f, mult);
+			}
+			return 0;
+		}
 		add_opposite_ends(imap);
 		PairMap pmap;
 		pair_contigs(imap, pmap, mult, P);

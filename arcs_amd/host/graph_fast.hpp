@@ -1,0 +1,313 @@
+// graph_fast.hpp -- the stages between the read stage and the graph (IndexMap -> PairMap -> graph, _main.tsv,
+// pair TSV) on integers instead of strings.
+//
+// graph.hpp restates the reference literally: unordered_map<barcode string, map<(contig string, bool), int>>
+// and map<pair<string, string>, vector<unsigned>> (Arcs/Arcs.h:105-113, Arcs.cpp:1378-1435).  At human scale
+// (6 M barcodes, 17 M (barcode, end) entries, 12 M contig pairs -- most seen by one barcode) those containers
+// are minutes of single-threaded string hashing and tree walking, an order of magnitude more than the read
+// stage in front of them.  Nothing in what the stages compute needs the strings: contig ids are replaced by
+// their rank in std::string order (the order of the PairMap's keys, hence of every output line), barcodes
+// by a number, and the maps by sorted vectors --
+//   CompactIndex   per (barcode, contig): reads at the head and at the tail   = IndexMap after its post-pass
+//   CompactPairs   per (contig a < contig b): barcodes per orientation        = PairMap, in its iteration order
+// The output functions write byte for byte what graph.hpp's write for the same input (tests/test_host_graph.py
+// runs both on the reference's demo data and on random IndexMaps).  -D (distance estimates) walks the IndexMap
+// itself, in its container's order: that path keeps graph.hpp / dist_est.hpp.
+#pragma once
+
+#include "graph.hpp"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace arks_host {
+
+struct CompactEntry
+{
+	uint32_t barcode; // a number per barcode (any: only equality matters)
+	uint32_t contig;  // rank of the contig id in std::string order
+	int head, tail;   // read pairs at the two ends (0: the end the post-pass of chromiumRead would add)
+};
+
+struct CompactIndex
+{
+	std::vector<std::string> contig;   // rank -> id
+	std::vector<CompactEntry> entries; // by (barcode, contig)
+	std::vector<int> barcode_mult;     // barcode -> its multiplicity (0: not in the multiplicity map)
+	size_t n_barcodes = 0;             // barcodes that have entries = IndexMap::size()
+};
+
+struct CompactPair
+{
+	uint32_t a, b; // contig ranks, a < b
+	unsigned cnt[4]; // HH, HT, TH, TT
+};
+typedef std::vector<CompactPair> CompactPairs;
+
+// One (barcode, conreci, count) entry of a read-stage result, the barcode already numbered over all ranks
+struct RawEntry
+{
+	uint32_t barcode, conreci, count;
+};
+
+// contigRecord[conreci] = (contig id, is head) as getContigKmers fills it (Arcs.cpp:1079-1081); `mult_of`
+// = multiplicity per barcode number.  Contigs are told apart by their ID, as the reference's maps do: two
+// FASTA records of one name share their entries.
+inline CompactIndex
+build_compact_index(std::vector<RawEntry>& raw, const std::vector<CI>& contigRecord, std::vector<int> mult_of)
+{
+	CompactIndex ix;
+	// rank of every contig id
+	std::vector<std::string_view> ids;
+	ids.reserve(contigRecord.size());
+	for (size_t c = 1; c < contigRecord.size(); ++c)
+		ids.push_back(contigRecord[c].first);
+	std::sort(ids.begin(), ids.end());
+	ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+	ix.contig.assign(ids.begin(), ids.end());
+	std::vector<uint32_t> rank_of(contigRecord.size(), 0);
+	for (size_t c = 1; c < contigRecord.size(); ++c)
+		rank_of[c] = (uint32_t)(std::lower_bound(ids.begin(), ids.end(), std::string_view(contigRecord[c].first)) - ids.begin());
+	// (barcode, contig) groups: sort, then add up heads and tails
+	struct Rec
+	{
+		uint64_t key; // barcode << 32 | contig rank
+		uint32_t count;
+		uint32_t head;
+	};
+	std::vector<Rec> recs(raw.size());
+	for (size_t i = 0; i < raw.size(); ++i)
+		recs[i] = Rec{ ((uint64_t)raw[i].barcode << 32) | rank_of[raw[i].conreci], raw[i].count, contigRecord[raw[i].conreci].second ? 1u : 0u };
+	std::vector<RawEntry>().swap(raw);
+	std::sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.key < y.key; });
+	ix.entries.reserve(recs.size());
+	for (size_t i = 0; i < recs.size();) {
+		CompactEntry e{ (uint32_t)(recs[i].key >> 32), (uint32_t)recs[i].key, 0, 0 };
+		size_t j = i;
+		for (; j < recs.size() && recs[j].key == recs[i].key; ++j)
+			(recs[j].head ? e.head : e.tail) += (int)recs[j].count;
+		if (ix.entries.empty() || ix.entries.back().barcode != e.barcode)
+			ix.n_barcodes++;
+		ix.entries.push_back(e);
+		i = j;
+	}
+	ix.barcode_mult = std::move(mult_of);
+	return ix;
+}
+
+// pairContigs (Arcs.cpp:1378-1435) on a CompactIndex: per barcode within the multiplicity bounds, every pair of
+// its contigs whose reads sit significantly at one end (head_or_tail) adds one to that orientation's count
+inline CompactPairs
+pair_contigs_compact(const CompactIndex& ix, const GraphParams& P)
+{
+	struct Hit
+	{
+		uint64_t key; // a << 32 | b
+		uint32_t orientation;
+	};
+	std::vector<Hit> hits;
+	struct Valid
+	{
+		uint32_t contig;
+		bool head;
+	};
+	std::vector<Valid> valid;
+	const std::vector<CompactEntry>& E = ix.entries;
+	for (size_t i = 0; i < E.size();) {
+		size_t j = i;
+		while (j < E.size() && E[j].barcode == E[i].barcode)
+			++j;
+		const int m = E[i].barcode < ix.barcode_mult.size() ? ix.barcode_mult[E[i].barcode] : 0;
+		if (m >= P.min_mult && m <= P.max_mult && j - i > 1) {
+			valid.clear();
+			for (size_t e = i; e < j; ++e) {
+				const auto v = head_or_tail(E[e].head, E[e].tail, P);
+				if (v.first)
+					valid.push_back(Valid{ E[e].contig, v.second });
+			}
+			for (size_t x = 0; x < valid.size(); ++x)
+				for (size_t y = x + 1; y < valid.size(); ++y) // entries are in contig order: x is `a`, y is `b`
+					hits.push_back(Hit{ ((uint64_t)valid[x].contig << 32) | valid[y].contig,
+					                    (valid[x].head ? 0u : 2u) + (valid[y].head ? 0u : 1u) });
+		}
+		i = j;
+	}
+	std::sort(hits.begin(), hits.end(), [](const Hit& x, const Hit& y) { return x.key < y.key; });
+	CompactPairs pairs;
+	for (size_t i = 0; i < hits.size();) {
+		CompactPair p{ (uint32_t)(hits[i].key >> 32), (uint32_t)hits[i].key, { 0, 0, 0, 0 } };
+		size_t j = i;
+		for (; j < hits.size() && hits[j].key == hits[i].key; ++j)
+			p.cnt[hits[j].orientation]++;
+		pairs.push_back(p);
+		i = j;
+	}
+	return pairs;
+}
+
+// createGraph (Arcs.cpp:1475-1526)
+inline void
+create_graph_compact(const CompactPairs& pairs, const CompactIndex& ix, ScaffoldGraph& g, const GraphParams& P)
+{
+	std::vector<int> vertex(ix.contig.size(), -1);
+	for (const CompactPair& p : pairs) {
+		unsigned mx = 0, index = 0;
+		for (unsigned i = 0; i < 4; ++i)
+			if (p.cnt[i] > mx) {
+				mx = p.cnt[i];
+				index = i;
+			}
+		unsigned second = 0;
+		for (unsigned i = 0; i < 4; ++i)
+			if (p.cnt[i] != mx && p.cnt[i] > second)
+				second = p.cnt[i];
+		if (!check_significance((int)mx, (int)(mx + second), P))
+			continue;
+		for (const uint32_t c : { p.a, p.b })
+			if (vertex[c] < 0) {
+				vertex[c] = (int)g.id.size();
+				g.id.push_back(ix.contig[c]);
+				g.alive.push_back(true);
+			}
+		g.edges.push_back(Edge{ vertex[p.a], vertex[p.b], (int)index, (int)mx });
+	}
+}
+
+// text is put together in a buffer of its own and written in large pieces (the TSV of a human-size run is a
+// gigabyte: an ostream insertion per field is most of the time otherwise)
+class TextOut
+{
+  public:
+	explicit TextOut(std::ostream& f)
+	  : f_(f)
+	{
+		buf_.reserve(kFlush + 4096);
+	}
+	~TextOut() { flush(); }
+	void str(const std::string& s) { buf_.append(s); }
+	void ch(char c) { buf_.push_back(c); }
+	void num(unsigned long long v)
+	{
+		char tmp[24];
+		int n = 0;
+		do {
+			tmp[n++] = (char)('0' + v % 10);
+			v /= 10;
+		} while (v);
+		while (n)
+			buf_.push_back(tmp[--n]);
+	}
+	void end_line()
+	{
+		buf_.push_back('\n');
+		if (buf_.size() >= kFlush)
+			flush();
+	}
+	void flush()
+	{
+		f_.write(buf_.data(), (std::streamsize)buf_.size());
+		buf_.clear();
+	}
+
+  private:
+	static constexpr size_t kFlush = 1u << 20;
+	std::ostream& f_;
+	std::string buf_;
+};
+
+// writeTSV (Arcs.cpp:1709-1757).  The per-end barcode counts run over EVERY barcode of the IndexMap, whatever
+// its multiplicity, and over the ends the post-pass added (count 0: they pass only with -c 0).
+inline void
+write_tsv_compact(std::ostream& f, const CompactIndex& ix, const CompactPairs& pairs, size_t barcode_count, const GraphParams& P)
+{
+	std::vector<unsigned> per_head(ix.contig.size(), 0), per_tail(ix.contig.size(), 0);
+	for (const CompactEntry& e : ix.entries) {
+		if (e.head >= P.min_reads)
+			per_head[e.contig]++;
+		if (e.tail >= P.min_reads)
+			per_tail[e.contig]++;
+	}
+	TextOut o(f);
+	o.str("U\tV\tBest_orientation\tShared_barcodes\tU_barcodes\tV_barcodes\tAll_barcodes");
+	o.end_line();
+	for (const CompactPair& p : pairs) {
+		const std::string& u = ix.contig[p.a];
+		const std::string& v = ix.contig[p.b];
+		const unsigned mx = *std::max_element(p.cnt, p.cnt + 4);
+		for (unsigned i = 0; i < 4; ++i) {
+			if (p.cnt[i] == 0)
+				continue;
+			const bool usense = i < 2, vsense = i % 2;
+			const char best = p.cnt[i] == mx ? 'T' : 'F';
+			const unsigned ub = usense ? per_head[p.a] : per_tail[p.a], vb = !vsense ? per_head[p.b] : per_tail[p.b];
+			o.str(u), o.ch(usense ? '-' : '+'), o.ch('\t'), o.str(v), o.ch(vsense ? '-' : '+'), o.ch('\t'), o.ch(best), o.ch('\t');
+			o.num(p.cnt[i]), o.ch('\t'), o.num(ub), o.ch('\t'), o.num(vb), o.ch('\t'), o.num(barcode_count);
+			o.end_line();
+			o.str(v), o.ch(vsense ? '+' : '-'), o.ch('\t'), o.str(u), o.ch(usense ? '+' : '-'), o.ch('\t'), o.ch(best), o.ch('\t');
+			o.num(p.cnt[i]), o.ch('\t'), o.num(vb), o.ch('\t'), o.num(ub), o.ch('\t'), o.num(barcode_count);
+			o.end_line();
+		}
+	}
+}
+
+// the -P pair TSV (Arcs.cpp:1531-1544)
+inline void
+write_pair_map_compact(std::ostream& out, const CompactIndex& ix, const CompactPairs& pairs)
+{
+	TextOut o(out);
+	for (const CompactPair& p : pairs) {
+		o.str(ix.contig[p.a]), o.ch('\t'), o.str(ix.contig[p.b]);
+		for (unsigned i = 0; i < 4; ++i)
+			o.ch('\t'), o.num(p.cnt[i]);
+		o.end_line();
+	}
+}
+
+// countBarcodes (Arcs.cpp:815-830; also prints the summary line)
+inline size_t
+count_barcodes_compact(const CompactIndex& ix, const std::unordered_map<std::string, int>& mult, const GraphParams& P)
+{
+	size_t n = 0;
+	for (const auto& x : mult)
+		if (x.second >= P.min_mult && x.second <= P.max_mult)
+			++n;
+	std::cout << "{ \"All_barcodes_unfiltered\":" << mult.size() << ", \"All_barcodes_filtered\":" << n
+	          << ", \"Scaffold_end_barcodes\":" << ix.n_barcodes << ", \"Min_barcode_reads_threshold\":" << P.min_mult
+	          << ", \"Max_barcode_reads_threshold\":" << P.max_mult << " }\n";
+	return n;
+}
+
+// an IndexMap as a CompactIndex (tests; graph_check)
+inline CompactIndex
+compact_from_imap(const IndexMap& imap, const std::unordered_map<std::string, int>& mult)
+{
+	std::vector<CI> record;
+	record.push_back(CI("null contig", false));
+	std::unordered_map<std::string, uint32_t> conreci_of; // id + 'H' / 'T'
+	std::vector<RawEntry> raw;
+	std::vector<int> mult_of;
+	uint32_t b = 0;
+	for (const auto& it : imap) {
+		const auto m = mult.find(it.first);
+		mult_of.push_back(m == mult.end() ? 0 : m->second);
+		for (const auto& sc : it.second) {
+			const std::string key = sc.first.first + (sc.first.second ? "\tH" : "\tT");
+			auto f = conreci_of.find(key);
+			if (f == conreci_of.end()) {
+				f = conreci_of.emplace(key, (uint32_t)record.size()).first;
+				record.push_back(sc.first);
+			}
+			raw.push_back(RawEntry{ b, f->second, (uint32_t)sc.second });
+		}
+		++b;
+	}
+	return build_compact_index(raw, record, std::move(mult_of));
+}
+
+} // namespace arks_host

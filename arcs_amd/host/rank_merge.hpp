@@ -5,7 +5,7 @@
 #pragma once
 
 #include "arks_hip.h"
-#include "graph.hpp"
+#include "graph_fast.hpp"
 #include "ingest.hpp"
 
 #include <unistd.h>
@@ -264,7 +264,7 @@ inline void
 merge_results(
     const std::vector<std::string>& files, const std::vector<RankResult>& ranks, std::vector<IndexMap>& imaps,
     std::unordered_map<std::string, int>& mult, const std::vector<CI>& contigRecord, bool fused, const MergeParams& params,
-    std::string& out, std::string& err, std::string* pre_out, std::string* pre_err)
+    std::string& out, std::string& err, std::string* pre_out, std::string* pre_err, std::vector<CompactIndex>* compact = nullptr)
 {
 	const size_t nf = files.size();
 	const size_t nk = ranks.empty() ? 0 : ranks[0].triples.size();
@@ -336,6 +336,52 @@ merge_results(
 	// IndexMap in the order of their first stored pair (pairs are numbered file, batch, pair), as in a
 	// single-threaded reference run: the container's iteration order -- which -D's tie handling sees,
 	// Arcs/DistanceEst.h:230-262 -- is then the reference's for the same libstdc++.
+	if (compact) {
+		// graph_fast.hpp: the same content as numbers (no IndexMap is built; -D needs the map itself and does
+		// not come here).  Barcodes are numbered over all ranks, by name; one rank's numbers are kept as they are.
+		std::vector<std::vector<uint32_t>> gid(ranks.size());
+		size_t n_gid = 0;
+		if (ranks.size() == 1)
+			n_gid = ranks[0].names.size();
+		else {
+			std::unordered_map<std::string_view, uint32_t> gid_of;
+			for (size_t r = 0; r < ranks.size(); ++r) {
+				gid[r].resize(ranks[r].names.size());
+				for (size_t i = 0; i < ranks[r].names.size(); ++i)
+					gid[r][i] = gid_of.emplace(std::string_view(ranks[r].names[i]), (uint32_t)gid_of.size()).first->second;
+			}
+			n_gid = gid_of.size();
+		}
+		std::vector<int> mult_of(n_gid, 0);
+		for (size_t r = 0; r < ranks.size(); ++r) {
+			const std::vector<std::string>& names = ranks[r].names;
+			const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(16, names.size() >> 16));
+			std::vector<std::thread> th;
+			for (unsigned t = 0; t < T; ++t)
+				th.emplace_back([&, t] { // (finds only: the map is not changed)
+					for (size_t i = names.size() * t / T; i < names.size() * (t + 1) / T; ++i) {
+						const auto m = mult.find(names[i]);
+						if (m != mult.end())
+							mult_of[ranks.size() == 1 ? i : gid[r][i]] = m->second;
+					}
+				});
+			for (auto& x : th)
+				x.join();
+		}
+		compact->clear();
+		for (size_t ki = 0; ki < nk; ++ki) {
+			std::vector<RawEntry> raw;
+			for (size_t r = 0; r < ranks.size(); ++r) {
+				const std::vector<uint32_t>& t = ranks[r].triples[ki];
+				raw.reserve(raw.size() + t.size() / 3);
+				for (size_t i = 0; 3 * i < t.size(); ++i)
+					raw.push_back(RawEntry{ ranks.size() == 1 ? t[3 * i] : gid[r][t[3 * i]], t[3 * i + 1], t[3 * i + 2] });
+			}
+			compact->push_back(build_compact_index(raw, contigRecord, mult_of));
+		}
+		imaps.clear();
+		return;
+	}
 	imaps.assign(nk, IndexMap());
 	for (size_t ki = 0; ki < nk; ++ki) {
 		struct Entry

@@ -8,6 +8,8 @@
 // usage: ranks_check <world> <seed> <fused 0|1>
 #include "rank_merge.hpp"
 
+#include <sstream>
+
 #include <sys/wait.h>
 
 #include <cstdio>
@@ -177,5 +179,31 @@ main(int argc, char** argv)
 		for (const auto& b : imaps[ki]) // iteration order of the unordered container: depends on the creation order
 			for (const auto& e : b.second)
 				std::printf("IMAP %zu %s %s %c %d\n", ki, b.first.c_str(), e.first.first.c_str(), e.first.second ? 'H' : 'T', e.second);
+	// the same content through the number-based merge (graph_fast.hpp): what its pairing and TSV stages see must
+	// not depend on the number of ranks either, and must be what the IndexMap above gives
+	{
+		std::vector<CompactIndex> cix;
+		std::vector<IndexMap> none;
+		std::unordered_map<std::string, int> mult2 = mult;
+		std::string o2, e2, po2, pe2;
+		merge_results(names, ranks, none, mult2, contigRecord, false, mp, o2, e2, &po2, &pe2, &cix);
+		GraphParams P;
+		P.min_mult = 1;
+		P.min_reads = 1;
+		for (size_t ki = 0; ki < cix.size(); ++ki) {
+			const CompactPairs a = pair_contigs_compact(cix[ki], P), b = pair_contigs_compact(compact_from_imap(imaps[ki], mult), P);
+			const CompactIndex lit = compact_from_imap(imaps[ki], mult);
+			bool same = a.size() == b.size() && cix[ki].n_barcodes == imaps[ki].size() && cix[ki].entries.size() == lit.entries.size();
+			for (size_t i = 0; same && i < a.size(); ++i)
+				same = cix[ki].contig[a[i].a] == lit.contig[b[i].a] && cix[ki].contig[a[i].b] == lit.contig[b[i].b] &&
+				       std::equal(a[i].cnt, a[i].cnt + 4, b[i].cnt);
+			std::printf("COMPACT %zu %s barcodes %zu entries %zu pairs %zu\n", ki, same ? "same" : "DIFFERENT", cix[ki].n_barcodes,
+			            cix[ki].entries.size(), a.size());
+			std::ostringstream t1, t2;
+			write_tsv_compact(t1, cix[ki], a, 7, P);
+			write_tsv_compact(t2, lit, b, 7, P);
+			std::printf("COMPACT %zu tsv %s %zu bytes\n", ki, t1.str() == t2.str() ? "same" : "DIFFERENT", t1.str().size());
+		}
+	}
 	return 0;
 }

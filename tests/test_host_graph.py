@@ -51,9 +51,10 @@ def test_gv_format_matches_reference_demo():
     assert G.graph_text(ids, edges) == want
 
 
+@pytest.mark.parametrize("mode", ["imap", "imapfast"])    # graph.hpp (the reference's containers) / graph_fast.hpp
 @pytest.mark.parametrize("seed,c,l,d,r", [(1, 5, 0, 0, 0.05), (2, 3, 2, 0, 0.05), (3, 5, 0, 3, 0.05),
-                                          (4, 1, 0, 0, 0.5), (5, 4, 1, 2, 0.01)])
-def test_graph_stage_vs_python(graph_check, tmp_path, seed, c, l, d, r):
+                                          (4, 1, 0, 0, 0.5), (5, 4, 1, 2, 0.01), (6, 0, 0, 0, 0.05)])
+def test_graph_stage_vs_python(graph_check, tmp_path, seed, c, l, d, r, mode):
     rng = np.random.Generator(np.random.PCG64(seed))
     contigs = [str(x) for x in rng.permutation(40)[:25] + 1] + ["ctgA", "scaf_10", "9"]
     lengths = {x: int(rng.integers(500, 200000)) for x in contigs}
@@ -80,9 +81,10 @@ def test_graph_stage_vs_python(graph_check, tmp_path, seed, c, l, d, r):
     (tmp_path / "mult.tsv").write_text("".join(f"{b}\t{m}\n" for b, m in mult.items()))
     (tmp_path / "len.tsv").write_text("".join(f"{k}\t{v}\n" for k, v in lengths.items()))
     base = str(tmp_path / "out")
-    subprocess.check_call([graph_check, "imap", str(tmp_path / "imap.tsv"), str(tmp_path / "mult.tsv"),
-                           str(tmp_path / "len.tsv"), base, str(c), str(l), "20", "250", str(d), str(r),
-                           "77", "x"], stdout=subprocess.DEVNULL)
+    summary = subprocess.check_output([graph_check, mode, str(tmp_path / "imap.tsv"), str(tmp_path / "mult.tsv"),
+                                       str(tmp_path / "len.tsv"), base, str(c), str(l), "20", "250", str(d), str(r),
+                                       "77", "x"], text=True)
+    assert f'"Scaffold_end_barcodes":{len(imap)},' in summary and f'"All_barcodes_unfiltered":{len(mult)},' in summary
     G.add_opposite_ends(imap)
     pmap = G.pair_contigs(imap, mult, P)
     assert len(pmap) > 5
@@ -247,12 +249,13 @@ def _make_tsv(gv_path, fasta_path):
     return "".join(out)
 
 
-def test_gv_to_tigpair_chain(graph_check, tmp_path):
+@pytest.mark.parametrize("mode", ["imap", "imapfast"])
+def test_gv_to_tigpair_chain(graph_check, tmp_path, mode):
     """fixed IndexMap -> host graph stage -> _original.gv identical to the committed one, whose
     tigpair_checkpoint.tsv was written by the reference's bin/makeTSVfile.py; and the reference demo's
     own (_original.gv, tigpair_checkpoint.tsv) pair"""
     base = str(tmp_path / "out")
-    subprocess.check_call([graph_check, "imap", os.path.join(GOLDEN, "tigpair_imap.tsv"),
+    subprocess.check_call([graph_check, mode, os.path.join(GOLDEN, "tigpair_imap.tsv"),
                            os.path.join(GOLDEN, "tigpair_mult.tsv"), os.path.join(GOLDEN, "tigpair_lengths.tsv"),
                            base, "5", "0", "50", "10000", "0", "0.05", "100", "x"], stdout=subprocess.DEVNULL)
     gv = open(base + "_original.gv").read()

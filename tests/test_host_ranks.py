@@ -58,6 +58,10 @@ def test_ranks_merge_like_one_process(ranks_check, seed, fused):
             if not order[int(ki)] or order[int(ki)][-1] != bc:
                 order[int(ki)].append(bc)
     assert got == want
+    # the number-based merge (graph_fast.hpp) holds the same content: its pairs and its TSV equal those of the
+    # IndexMap above, whatever the number of ranks
+    compact = [ln for ln in lines if ln.startswith("COMPACT ")]
+    assert len(compact) == 4 and all(" same " in ln for ln in compact), compact
     # multiplicities of the fused mode are the per-file read counts summed; the log names every file once
     assert outs[0].stdout.count("Reading chrom reads") == (10 if fused else 5)
     assert "Stored read pairs: 0\n" in outs[0].stdout   # the empty file
