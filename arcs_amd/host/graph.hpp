@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
@@ -307,13 +308,29 @@ write_tsv(std::ostream& f, const IndexMap& imap, const PairMap& pmap, size_t bar
 inline void
 write_barcode_counts(std::ostream& f, const std::unordered_map<std::string, int>& mult)
 {
-	typedef std::vector<std::pair<std::string, unsigned>> Sorted;
-	Sorted sorted(mult.begin(), mult.end());
-	std::sort(sorted.begin(), sorted.end(), [](const Sorted::value_type& a, const Sorted::value_type& b) {
-		return a.second != b.second ? a.second > b.second : a.first < b.first;
+	// (the reference copies the map into a vector of pairs and sorts that; pointers to the keys sort the same
+	// way without copying millions of strings, and the lines go out through one buffer)
+	typedef std::pair<const std::string*, unsigned> Item;
+	std::vector<Item> sorted;
+	sorted.reserve(mult.size());
+	for (const auto& kv : mult)
+		sorted.emplace_back(&kv.first, (unsigned)kv.second);
+	std::sort(sorted.begin(), sorted.end(), [](const Item& a, const Item& b) {
+		return a.second != b.second ? a.second > b.second : *a.first < *b.first;
 	});
-	for (const auto& x : sorted)
-		f << x.first << '\t' << x.second << '\n';
+	std::string buf;
+	buf.reserve((1u << 20) + 256);
+	for (const Item& x : sorted) {
+		buf.append(*x.first);
+		buf.push_back('\t');
+		buf.append(std::to_string(x.second));
+		buf.push_back('\n');
+		if (buf.size() >= (1u << 20)) {
+			f.write(buf.data(), (std::streamsize)buf.size());
+			buf.clear();
+		}
+	}
+	f.write(buf.data(), (std::streamsize)buf.size());
 }
 
 // Arcs.cpp:1531-1544
@@ -349,13 +366,58 @@ read_multiplicity_file(const std::string& multfile, std::unordered_map<std::stri
 {
 	size_t numbarcodes = 0;
 	const bool tsv = multfile.find(".tsv") != std::string::npos;
-	std::ifstream in(multfile.c_str());
+	std::ifstream in(multfile.c_str(), std::ios::binary);
 	if (!in) {
 		std::cerr << "Could not open " << multfile << ". --fatal.\n";
 		exit(EXIT_FAILURE);
 	}
-	std::string line;
-	while (getline(in, line)) {
+	// the whole file at once, line by line out of memory: a stringstream per line is a microsecond, and a
+	// linked-read run has millions of barcodes.  A line of the usual shape -- barcode, separator, a short run
+	// of digits -- is taken apart here; any other line goes through the reference's own calls (below), so that
+	// what they make of it (including the exception std::stoi throws at a line without a number) is unchanged.
+	std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+	mult.reserve(mult.size() + text.size() / 24);
+	auto space = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+	size_t at = 0;
+	while (at < text.size()) {
+		const char* nl = (const char*)std::memchr(text.data() + at, '\n', text.size() - at);
+		const size_t begin = at, end = nl ? (size_t)(nl - text.data()) : text.size();
+		const char* p = text.data() + begin;
+		const char* const e = text.data() + end;
+		at = end + 1;
+		numbarcodes++;
+		const char *b0, *b1; // barcode
+		bool plain = true;
+		if (tsv) {
+			while (p < e && space(*p))
+				++p;
+			b0 = p;
+			while (p < e && !space(*p))
+				++p;
+			b1 = p;
+		} else {
+			b0 = p;
+			const char* comma = (const char*)std::memchr(p, ',', (size_t)(e - p));
+			plain = comma != nullptr;
+			b1 = p = comma ? comma : e;
+			if (comma)
+				++p;
+		}
+		while (p < e && space(*p))
+			++p;
+		const char* d0 = p;
+		while (p < e && *p >= '0' && *p <= '9')
+			++p;
+		plain = plain && p > d0 && p - d0 <= 9 && (p == e || space(*p)) && b1 > b0;
+		if (plain) {
+			int m = 0;
+			for (const char* q = d0; q < p; ++q)
+				m = m * 10 + (*q - '0');
+			mult[std::string(b0, b1)] = m;
+			continue;
+		}
+		// (Arcs.cpp:404-427, literally)
+		const std::string line(text, begin, end - begin);
 		std::string barcode, ms;
 		if (tsv) {
 			std::stringstream sst(line);
@@ -365,7 +427,6 @@ read_multiplicity_file(const std::string& multfile, std::unordered_map<std::stri
 			getline(iss, barcode, ',');
 			iss >> ms;
 		}
-		numbarcodes++;
 		const size_t m = (size_t)std::stoi(ms);
 		if (!barcode.empty())
 			mult[barcode] = (int)m;

@@ -884,6 +884,9 @@ parse_text_batch(
 		seen[it->second]++;
 		pre->total++;
 	};
+	bool have_last = false, last_valid = false;
+	uint32_t last_id = 0;
+	std::string_view last_bc; // (a view of this batch's text)
 	for (size_t p = 0; p < np; ++p) {
 		const uint32_t* l = L + 8 * p;
 		std::string_view n1, c1, n2, c2;
@@ -908,13 +911,21 @@ parse_text_batch(
 		uint32_t bid = 0;
 		if (b1.empty() || b2.empty())
 			b.fc.emptybarcode++;
-		else if (dict) {
+		else if (have_last && b1 == last_bc) {
+			// linked-read files are sorted by barcode: the pair in front answers most lookups (with millions of
+			// barcodes a lookup in the dictionary is a chain of cache misses)
+			valid = last_valid;
+			bid = last_id;
+			if (!valid)
+				b.fc.invalidbarcode++;
+		} else if (dict) {
 			const auto it = dict->id.find(b1);
 			valid = it != dict->id.end();
 			if (!valid)
 				b.fc.invalidbarcode++;
 			else
 				bid = it->second;
+			have_last = true, last_bc = b1, last_valid = valid, last_id = bid;
 		} else {
 			valid = true;
 			auto it = cache.find(b1);
@@ -924,6 +935,7 @@ parse_text_batch(
 				it = cache.emplace(stored, id).first;
 			}
 			bid = it->second;
+			have_last = true, last_bc = b1, last_valid = true, last_id = bid;
 		}
 		const bool ok = paired && valid && b1 == b2;
 		b.off[2 * p] = l[1];
