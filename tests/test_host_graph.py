@@ -289,3 +289,27 @@ def test_multiplicity_files_of_the_reference_demos(graph_check, tmp_path):
         # std::stoi; only the matching pairs of name and content are usable
     rows = [ln.split(",") for ln in open(os.path.join(GOLDEN, "arks_demo.test_reads_multiplicities.csv")).read().split("\n") if ln]
     assert len(rows) == 1085 and sum(int(m) for _, m in rows) == 55288     # the demo log's read count
+
+
+def test_multiplicity_lines_of_unusual_shape(graph_check, tmp_path):
+    """the -u parser takes the usual line apart itself and hands any other line to the calls the reference makes
+    (stringstream >>, getline(',') and std::stoi, Arcs.cpp:404-427): leading blanks, extra fields, digits followed
+    by letters, signs, ten digits, carriage returns, a barcode with a blank in a CSV, an empty CSV barcode; a
+    line without a number ends the program as the reference's uncaught std::invalid_argument does"""
+    tsv = tmp_path / "m.tsv"
+    tsv.write_bytes(b"BX1\t12\n  BX2   34  extra\nBX3\t56abc\nBX4\t+7\nBX5\t-8\nBX6\t0012\nBX7\t1234567890\nBX8\t9\r\nBX1 13")
+    want = {"BX1": 13, "BX2": 34, "BX3": 56, "BX4": 7, "BX5": -8, "BX6": 12, "BX7": 1234567890, "BX8": 9}
+    got = subprocess.check_output([graph_check, "mult", str(tsv), str(tmp_path / "o1.tsv")], text=True).split()
+    assert [int(x) for x in got] == [9, len(want), sum(want.values())]
+    csv = tmp_path / "m.csv"
+    csv.write_bytes(b"BY1,12\nBY2, 34\nBY3,56abc\n,78\nBY4 with space,5\nBY5,6\r\nBY1,1\n")
+    want = {"BY1": 1, "BY2": 34, "BY3": 56, "BY4 with space": 5, "BY5": 6}
+    out = subprocess.check_output([graph_check, "mult", str(csv), str(tmp_path / "o2.tsv")], text=True)
+    assert "Please check your multiplicity file." in out          # the line with the empty barcode
+    assert [int(x) for x in out.split()[-3:]] == [7, len(want), sum(want.values())]
+    back = dict(ln.rsplit("\t", 1) for ln in (tmp_path / "o2.tsv").read_text().split("\n") if ln)
+    assert {k: int(v) for k, v in back.items()} == want
+    for bad in (b"BX1\t12\nBX2\n", b"BX1\t12\n\nBX3\t4\n", b"BX1\tabc\n"):
+        tsv.write_bytes(bad)
+        r = subprocess.run([graph_check, "mult", str(tsv), str(tmp_path / "o3.tsv")], capture_output=True)
+        assert r.returncode != 0                                   # terminate: std::invalid_argument from stoi
