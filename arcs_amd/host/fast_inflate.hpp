@@ -69,6 +69,24 @@ class GzInflater
 		return true;
 	}
 
+	// Goes on at byte `offset` of the file, where a member ended: another member's header, the end of the file
+	// or something else (which ends the stream as it does behind any member but the first).
+	bool resume_member(size_t offset)
+	{
+		if (std::fseek(f_, (long)offset, SEEK_SET) != 0)
+			return false;
+		in_pos_ = in_end_ = 0;
+		in_eof_ = false;
+		bitbuf_ = 0;
+		bitcnt_ = 0;
+		out_pos_ = out_read_ = kHistory;
+		crc_ = 0;
+		member_out_ = 0;
+		first_member_ = false;
+		state_ = HEADER;
+		return true;
+	}
+
 	// up to cap bytes of the inflated stream; 0 at the end, -1 on a damaged file
 	int read(unsigned char* dst, int cap)
 	{

@@ -110,7 +110,7 @@ main(int argc, char** argv)
 			bool ok = true;
 			if (z.ok() && z.started()) {
 				const arks_host::GzResumePoint& r = z.resume();
-				ok = g.resume(r.bit, r.window.data(), r.window.size(), r.crc, r.member_out);
+				ok = r.member_start ? g.resume_member(r.bit >> 3) : g.resume(r.bit, r.window.data(), r.window.size(), r.crc, r.member_out);
 			}
 			int n = -1;
 			while (ok && (n = g.read(buf.data(), chunk)) > 0)

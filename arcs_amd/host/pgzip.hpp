@@ -596,6 +596,24 @@ decode_chunk(const unsigned char* in, size_t size, size_t start_bit, size_t stop
 	}
 }
 
+// the member's last block (BFINAL = 1) at start_bit: r.end_bit = the first bit behind it
+inline void
+decode_last_block(const unsigned char* in, size_t size, size_t start_bit, ChunkResult& r)
+{
+	std::unique_ptr<Tables> t(new Tables);
+	BitIn b(in, size);
+	b.seek_bit(start_bit);
+	r.start_bit = r.end_bit = start_bit;
+	bool last = false;
+	int type = 0;
+	bool ok = b.bc >= 3 && read_block_header(b, *t, &last, &type, false) && last;
+	if (ok)
+		ok = type == 0 ? stored_block(b, r.out) : huffman_block<false>(b, *t, r.out);
+	r.error = !ok;
+	if (ok)
+		r.end_bit = b.bit_position();
+}
+
 // the start of the deflate stream of the gzip member at in[at ...] (RFC 1952 2.3), or kNone
 inline size_t
 member_data_offset(const unsigned char* in, size_t size, size_t at)
@@ -629,6 +647,7 @@ struct GzResumePoint
 	std::vector<unsigned char> window; // the (up to) 32 KiB of text in front of it
 	uint32_t crc = 0;          // CRC-32 of the member's text so far
 	uint64_t member_out = 0;   // its length
+	bool member_start = false; // instead: `bit` is the first bit behind a complete member (GzInflater::resume_member)
 };
 
 // One gzip file taken a stretch of text at a time by the threads of `pf` (see the head of this file).
@@ -728,8 +747,11 @@ class GzStretches
 		}
 		size_t good = acc.size();
 		// text that keeps breaking the chain (stored blocks, something that is not text): one thread does better
-		if (chain_broke && nc >= 4 && good < std::max<size_t>(2, nc / 4) && ++poor_stretches_ >= 2)
-			stop_here = true;
+		if (chain_broke && nc >= 4 && good < std::max<size_t>(2, nc / 4)) {
+			if (++poor_stretches_ >= 2)
+				stop_here = true;
+		} else if (good >= nc / 2)
+			poor_stretches_ = 0;
 		// windows, chunk after chunk; a reference in front of the member's first byte is damage
 		std::vector<std::vector<unsigned char>> win(good + 1);
 		win[0] = resume_.window;
@@ -748,13 +770,23 @@ class GzStretches
 			stop_here = true;
 		}
 		lap("windows");
-		const size_t total = off[good];
+		// the member's last block, if it comes next: decoded here too, so that a file of several members (lanes
+		// put together with cat) stays on this path; taken only if the member's CRC and length then agree
+		bool have_fin = false;
+		if (good > 0 && usable == good && acc[good - 1]->final_ahead && !acc[good - 1]->error) {
+			if (!fin_)
+				fin_.reset(new pgz::ChunkResult(1 << 20));
+			fin_->reset();
+			pgz::decode_last_block(map_, size_, acc[good - 1]->end_bit, *fin_);
+			have_fin = !fin_->error && (fin_->end_bit + 7) / 8 + 8 <= size_;
+		}
+		const size_t total = off[good] + (have_fin ? fin_->out.n : 0);
 		unsigned char* dst = total ? place(total) : nullptr;
 		lap("place");
-		std::vector<uint32_t> crc(good, 0);
-		std::vector<char> bad(good, 0);
-		pf(good, [&](size_t i) {
-			const pgz::Symbols& s = acc[i]->out;
+		std::vector<uint32_t> crc(good + 1, 0);
+		std::vector<char> bad(good + 1, 0);
+		pf(good + (have_fin ? 1 : 0), [&](size_t i) {
+			const pgz::Symbols& s = i < good ? acc[i]->out : fin_->out;
 			unsigned char* o = dst + off[i];
 			const uint16_t* sym = s.sym();
 			const std::vector<unsigned char>& w = win[i];
@@ -789,6 +821,8 @@ class GzStretches
 				kept = i;
 				break;
 			}
+		have_fin = have_fin && kept == good && !bad[good];
+		const uint32_t fin_crc = crc[good];
 		if (kept < good) {
 			good = kept;
 			stop_here = true;
@@ -801,6 +835,35 @@ class GzStretches
 			resume_.bit = acc[good - 1]->end_bit;
 			resume_.window = win[good];
 			started_ = true;
+		}
+		if (have_fin) {
+			const size_t trailer = (fin_->end_bit + 7) / 8;
+			const unsigned char* t = map_ + trailer;
+			const uint32_t want_crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+			const uint32_t want_len = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+			const uint32_t all_crc = (uint32_t)crc32_combine(resume_.crc, fin_crc, (z_off_t)fin_->out.n);
+			if (all_crc == want_crc && (uint32_t)(resume_.member_out + fin_->out.n) == want_len) {
+				// the member is complete: the next one (if the bytes behind it are a member's head) starts a text
+				// of its own; anything else is the sequential inflater's to judge
+				const size_t next_member = trailer + 8;
+				const size_t data = next_member < size_ ? pgz::member_data_offset(map_, size_, next_member) : pgz::kNone;
+				resume_ = GzResumePoint();
+				// (members of a few chunks each -- a blocked gzip without the BGZF field -- leave nothing to spread)
+				const bool small = next_member - member_begin_ < 4 * chunk_;
+				tiny_members_ = small ? tiny_members_ + 1 : 0;
+				const bool tiny = tiny_members_ >= 2;
+				member_begin_ = next_member;
+				if (data != pgz::kNone && !tiny) {
+					resume_.bit = data * 8;
+					done_ = false;
+				} else {
+					resume_.bit = next_member * 8;
+					resume_.member_start = true;
+					done_ = true;
+				}
+				return total;
+			}
+			// (damage somewhere in the member: the sequential inflater decodes the last block again and reports)
 		}
 		if (stop_here || good == 0 || resume_.bit >= size_ * 8)
 			done_ = true;
@@ -837,9 +900,11 @@ class GzStretches
 	size_t size_ = 0, chunk_;
 	unsigned per_stretch_;
 	bool done_ = false, started_ = false;
-	unsigned poor_stretches_ = 0;
+	unsigned poor_stretches_ = 0, tiny_members_ = 0;
+	size_t member_begin_ = 0;
 	GzResumePoint resume_;
 	std::vector<std::unique_ptr<pgz::ChunkResult>> results_;
+	std::unique_ptr<pgz::ChunkResult> fin_;
 };
 
 } // namespace arks_host

@@ -173,7 +173,7 @@ class SeqReader
 		if (!s.started())
 			return; // nothing was decoded there: the inflater starts at the head of the file as always
 		const GzResumePoint& r = s.resume();
-		if (!fast_->resume(r.bit, r.window.data(), r.window.size(), r.crc, r.member_out)) {
+		if (!(r.member_start ? fast_->resume_member(r.bit >> 3) : fast_->resume(r.bit, r.window.data(), r.window.size(), r.crc, r.member_out))) {
 			failed_ = true;
 			eof_ = true;
 		}

@@ -438,6 +438,9 @@ def test_fast_inflate_equals_zlib(inflate_check, tmp_path):
     cases["empty_member"] = _gz(b"", 6)
     cases["members"] = _gz(fastq[:70000], 1) + _gz(b"", 6) + _gz(noise[:70000], 6) + _gz(runs[:99999], 9) + _gz(b"x", 6)
     cases["garbage_after"] = _gz(fastq[:50000], 6) + b"\0\0\0not gzip"
+    third = len(fastq) // 3
+    cases["lanes_cat"] = _gz(fastq[:third], 6) + _gz(fastq[third:2 * third], 4) + _gz(fastq[2 * third:], 9)   # cat a.gz b.gz c.gz
+    cases["blocked"] = b"".join(_gz(fastq[i:i + 3000], 6) for i in range(0, 300000, 3000))                    # a member per 3 KB
     # every optional header field (RFC 1952): FEXTRA, FNAME, FCOMMENT, FHCRC
     body = _gz(fastq[:30000], 6)[10:]
     hdr = bytes([0x1f, 0x8b, 8, 2 | 4 | 8 | 16, 0, 0, 0, 0, 0, 3]) + bytes([5, 0]) + b"EXTRA" + b"name.fq\0" + b"a comment\0"
@@ -455,6 +458,9 @@ def test_fast_inflate_equals_zlib(inflate_check, tmp_path):
             out = subprocess.run([inflate_check, str(path), str(1 << 18), "pgz", str(threads), str(pchunk), str(per)],
                                  capture_output=True, text=True, timeout=120)
             assert out.returncode == 0 and "pgz same " in out.stdout, (name, threads, pchunk, out.stdout)
+            if name == "lanes_cat" and pchunk < (1 << 20):
+                # every member of a file of several is decoded on the parallel path, its last block and trailer included
+                assert int(out.stdout.split("parallel ")[1].split()[0]) == len(fastq), (name, pchunk, out.stdout)
             if name.startswith("fastq") and name != "fastq0" and pchunk < (1 << 20):
                 # ... and on FASTQ text most of the file does come from the parallel path
                 par = int(out.stdout.split("parallel ")[1].split()[0])
