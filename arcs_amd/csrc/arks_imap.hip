@@ -72,17 +72,30 @@ pairs_kernel(
 	if (im.keys == nullptr)
 		return;
 	const u64 key = ok ? (((u64)barcode_id[p] << 32) | (u32)agreed) : 0ull;
-	const u64 prev = __shfl_up(key, 1);
-	const bool head = lane == 0 || key != prev;
-	const u64 heads = __ballot(head);
-	if (head && key != 0) {
-		const u64 later = lane == 63 ? 0ull : (heads >> (lane + 1));
-		const int run = later ? (__ffsll((long long)later)) : (64 - lane);
+	// One table update per DISTINCT key of the wave, not per pair: linked reads come sorted by barcode, so the 64
+	// pairs of a wave hold a few barcodes and a few contig ends -- a handful of keys -- but in any order and
+	// with unstored pairs in between (runs of equal neighbours are short).  The lowest lane of every key leads:
+	// it adds the number of lanes that hold the key, and its pair is the key's first of the wave.
+	bool leader = false;
+	u32 group = 0;
+	u64 remaining = __ballot(key != 0);
+	while (remaining) { // (wave-uniform: at most one round per distinct key, no memory traffic inside)
+		const int first_lane = __ffsll((long long)remaining) - 1;
+		const u32 klo = (u32)__builtin_amdgcn_readlane((int)(u32)key, first_lane);
+		const u32 khi = (u32)__builtin_amdgcn_readlane((int)(u32)(key >> 32), first_lane);
+		const u64 same = __ballot(key == (((u64)khi << 32) | klo));
+		if (lane == first_lane) {
+			leader = true;
+			group = (u32)__popcll(same);
+		}
+		remaining &= ~same;
+	}
+	if (leader) {
 		const u64 s = imap_slot(im.keys, im.cap, key, im.n_entries);
 		if (s == ~0ull) {
 			atomicOr(im.overflow, 1u);
 		} else {
-			atomicAdd(im.counts + s, (u32)run);
+			atomicAdd(im.counts + s, group);
 			atomicMin(reinterpret_cast<unsigned long long*>(im.first + s), (unsigned long long)(seq_base + (u64)p));
 		}
 	}
