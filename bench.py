@@ -304,7 +304,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=500_000_000, help="read pairs (per GPU; in total with --strong)")
-    ap.add_argument("--chunk", type=int, default=20_000_000, help="read pairs per launch")
+    ap.add_argument("--chunk", type=int, default=100_000_000,
+                    help="read pairs per launch (100 M: 5 launches per pass; launches of 20 M pairs -- rounds 1-2's "
+                         "default -- cost 3-4 %% more per pair in fixed per-launch work)")
     ap.add_argument("--draft-mbp", type=float, default=3000.0)
     ap.add_argument("--k", type=int, default=60)
     ap.add_argument("--j", type=float, default=0.55)
@@ -411,6 +413,7 @@ def main():
                          "alg_bytes_per_launch_GB": win_per_launch * b_alg / 1e9,
                          "kernel": {0: "map_reads_kernel", 1: "map_reads_b_kernel", 2: "map_reads_s_kernel"}[wl.index.kind],
                          "kernel_ms": kernel_ms, "launches_timed": len(launch_ms),
+                         "kernel_ms_per_20M_pairs": kernel_ms * 20_000_000 / max(1, min(args.chunk, my_pairs)),
                          "alg_bytes_per_window": b_alg},
             "counters": st, "stored_pairs": stored,
         }

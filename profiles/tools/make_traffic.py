@@ -9,7 +9,7 @@ import bench
 tag = sys.argv[1]
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=500_000_000)
-ap.add_argument("--chunk", type=int, default=20_000_000)
+ap.add_argument("--chunk", type=int, default=100_000_000)  # bench.py's default
 ap.add_argument("--draft-mbp", type=float, default=3000.0)
 ap.add_argument("--k", type=int, default=60)
 a, _ = ap.parse_known_args(sys.argv[2:])
