@@ -436,6 +436,18 @@ arks_pack_reads_host(
 				other |= bad & ~isn;
 				continue;
 			}
+			if (wide && r + 1 < n_reads && h_offsets[r + 1] >= h_offsets[r] + w * 32 + 32) {
+				// the last, partial word the same way: the 32 bytes lie in front of the next read's text, i.e.
+				// inside the caller's buffer; what is behind the read's end is masked out
+				uint32_t bad, isn;
+				pack32_avx2(s + w * 32, &c, &bad, &isn);
+				const uint32_t in = (1u << n) - 1u; // n < 32 here
+				cw[w] = c & ~(~0ull >> (2 * n));
+				mw[w] = bitrev32(bad & in);
+				nn += (uint32_t)__builtin_popcount(isn & in);
+				other |= bad & ~isn & in;
+				continue;
+			}
 			if (fast)
 				for (; i + 8 <= n; i += 8) {
 					uint32_t codes16, bad8, n8;
