@@ -570,17 +570,19 @@ decode_chunk(const unsigned char* in, size_t size, size_t start_bit, size_t stop
 	r.start_bit = start_bit;
 	for (;;) {
 		r.end_bit = pos;
-		if (pos >= stop_bit)
-			return;
 		b.seek_bit(pos);
 		if (b.bc < 3) {
-			r.error = true;
+			r.error = pos < stop_bit;
 			return;
 		}
 		if (b.peek(1)) {
 			r.final_ahead = true;
 			return;
 		}
+		// behind the stop: up to the next block of the kind a chunk can start with (find_block_start: dynamic,
+		// not the last) -- the empty stored blocks of a flushed stream (pigz) and fixed blocks belong to this chunk
+		if (pos >= stop_bit && b.peek(3) == 4u)
+			return;
 		bool last = false;
 		int type = 0;
 		const size_t n0 = r.out.n;

@@ -438,6 +438,11 @@ def test_fast_inflate_equals_zlib(inflate_check, tmp_path):
     cases["empty_member"] = _gz(b"", 6)
     cases["members"] = _gz(fastq[:70000], 1) + _gz(b"", 6) + _gz(noise[:70000], 6) + _gz(runs[:99999], 9) + _gz(b"x", 6)
     cases["garbage_after"] = _gz(fastq[:50000], 6) + b"\0\0\0not gzip"
+    def flushed(data, mode, step=60000):             # as pigz writes: a flush (an empty stored block) every so often
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)
+        return b"".join(c.compress(data[i:i + step]) + c.flush(mode) for i in range(0, len(data), step)) + c.flush()
+    cases["sync_flushed"] = flushed(fastq, zlib.Z_SYNC_FLUSH)
+    cases["full_flushed"] = flushed(fastq, zlib.Z_FULL_FLUSH)
     third = len(fastq) // 3
     cases["lanes_cat"] = _gz(fastq[:third], 6) + _gz(fastq[third:2 * third], 4) + _gz(fastq[2 * third:], 9)   # cat a.gz b.gz c.gz
     cases["blocked"] = b"".join(_gz(fastq[i:i + 3000], 6) for i in range(0, 300000, 3000))                    # a member per 3 KB
