@@ -78,6 +78,7 @@ SYMBOLS = {
     "arks_imap_export_ordered": (_I, [_VP, _VP, _VP]),
     "arks_debug_queue_counts": (_I, [_VP, _VP]),
     "arks_pair_gate_device": (_I, [_VP, _VP, _I64, _VP, _I, _VP]),
+    "arks_gate_count_device": (_I, [_VP, _VP, _I64, _VP, _I, _VP]),
     "arks_pairs_device": (_I, [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _I, _VP]),
 }
 

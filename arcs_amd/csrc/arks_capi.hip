@@ -29,6 +29,9 @@
 #include <utility>
 #include <vector>
 
+namespace arks {
+hipError_t launch_gate_count(const uint8_t* pair_ok, const uint8_t* eval, long n_pairs, u64* counter, hipStream_t st); // arks_imap.hip
+}
 using namespace arks;
 
 namespace {
@@ -1746,6 +1749,24 @@ arks_pair_gate_device(
 		return rc;
 	DeviceGuard guard(device);
 	HIP_TRY(launch_pair_gate(d_pair_ok, d_read_class, (long)n_pairs, d_eval, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+int
+arks_gate_count_device(const uint8_t* d_pair_ok, const uint8_t* d_eval, int64_t n_pairs, uint64_t* d_counter, int device, void* stream)
+{
+	if (n_pairs < 0)
+		return ARKS_ERR_BAD_ARG;
+	if (n_pairs == 0)
+		return ARKS_OK;
+	if (!d_eval || !d_counter)
+		return ARKS_ERR_BAD_ARG;
+	int rc = require_device(device);
+	if (rc != ARKS_OK)
+		return rc;
+	DeviceGuard guard(device);
+	HIP_TRY(arks::launch_gate_count(d_pair_ok, d_eval, (long)n_pairs, reinterpret_cast<u64*>(d_counter), static_cast<hipStream_t>(stream)));
 done:
 	return rc;
 }

@@ -185,4 +185,25 @@ launch_imap_compact(const ImapView& im, u64* out_keys, u64* out_first, u32* out_
 	return hipSuccess;
 }
 
+// gated pairs one of whose mates checkReadSequence rejects (Arcs.cpp:1273-1276: skipped_invalidreadpair):
+// pair_ok[p] set (NULL = every pair) and eval[2p] clear, for a front end that packs -- and classifies -- the
+// reads on the device and so cannot count them itself
+__global__ void
+gate_count_kernel(const uint8_t* __restrict__ pair_ok, const uint8_t* __restrict__ eval, long n_pairs, u64* __restrict__ counter)
+{
+	const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool hit = p < n_pairs && (pair_ok ? pair_ok[p] != 0 : true) && eval[2 * p] == 0;
+	const u64 m = __ballot(hit);
+	if ((threadIdx.x & 63) == 0 && m)
+		atomicAdd(counter, (u64)__popcll(m));
+}
+
+hipError_t
+launch_gate_count(const uint8_t* pair_ok, const uint8_t* eval, long n_pairs, u64* counter, hipStream_t st)
+{
+	gate_count_kernel<<<blocks_for((u64)n_pairs, 256), 256, 0, st>>>(pair_ok, eval, n_pairs, counter);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
 } // namespace arks

@@ -436,7 +436,8 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 // device buffers of one in-flight batch
 struct DeviceSet
 {
-	DevArray<uint64_t> d_codes, d_woff;
+	DevArray<uint64_t> d_codes, d_woff, d_aoff;
+	DevArray<uint8_t> d_ascii; // device-pack mode: the reads' bases as they are
 	DevArray<uint32_t> d_nmask, d_len, d_bid;
 	DevArray<uint8_t> d_class, d_ok, d_eval;
 	DevArray<int32_t> d_conreci;
@@ -455,6 +456,7 @@ struct Mapper
 	size_t n_shards, n_k;
 	DeviceSet sets[2];
 	size_t turn = 0;
+	uint64_t* d_skipped = nullptr;     // [n_files]: skipped_invalidreadpair, counted on the device in device-pack mode
 	uint64_t* d_stored = nullptr;      // [n_k][n_files]
 	arks_map_stats* d_stats = nullptr; // [n_k][n_files]
 	size_t n_files;
@@ -477,11 +479,13 @@ struct Mapper
 		}
 		const size_t nc = n_k * nfiles;
 		if (hipMalloc((void**)&d_stored, nc * sizeof(uint64_t)) != hipSuccess ||
+		    hipMalloc((void**)&d_skipped, nfiles * sizeof(uint64_t)) != hipSuccess ||
 		    hipMalloc((void**)&d_stats, nc * sizeof(arks_map_stats)) != hipSuccess) {
 			std::cerr << PROGRAM ": out of device memory\n";
 			exit(EXIT_FAILURE);
 		}
 		(void)hipMemset(d_stored, 0, nc * sizeof(uint64_t));
+		(void)hipMemset(d_skipped, 0, nfiles * sizeof(uint64_t));
 		(void)hipMemset(d_stats, 0, nc * sizeof(arks_map_stats));
 		for (auto& s : sets)
 			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -500,6 +504,7 @@ struct Mapper
 				(void)hipStreamDestroy(s.stream);
 		}
 		(void)hipFree(d_stored);
+		(void)hipFree(d_skipped);
 		(void)hipFree(d_stats);
 	}
 
@@ -541,16 +546,34 @@ struct Mapper
 				exit(EXIT_FAILURE);
 			}
 		};
-		up(s.d_codes.p, pb->codes, words * sizeof(uint64_t));
-		up(s.d_nmask.p, pb->nmask, words * sizeof(uint32_t));
+		int rc = ARKS_OK;
 		up(s.d_woff.p, pb->woff, ((size_t)n + 1) * sizeof(uint64_t));
 		up(s.d_len.p, pb->len, (size_t)n * sizeof(uint32_t));
-		up(s.d_class.p, pb->cls, (size_t)n);
 		up(s.d_ok.p, pb->pair_ok, (size_t)np);
 		up(s.d_bid.p, pb->barcode_id, (size_t)np * sizeof(uint32_t));
+		if (pb->ascii) {
+			// device-pack mode: the bases come as text (8 bits each over the link instead of 3) and the 2-bit
+			// packing, the N mask and checkReadSequence run here -- the host threads only gather them
+			s.d_ascii.reserve(pb->ascii_bytes);
+			s.d_aoff.reserve((size_t)n + 1);
+			up(s.d_ascii.p, pb->ascii, pb->ascii_bytes);
+			up(s.d_aoff.p, pb->aoff, ((size_t)n + 1) * sizeof(uint64_t));
+			if (hipMemsetAsync(s.d_codes.p, 0, words * sizeof(uint64_t), s.stream) != hipSuccess ||
+			    hipMemsetAsync(s.d_nmask.p, 0, words * sizeof(uint32_t), s.stream) != hipSuccess)
+				return ARKS_ERR_HIP;
+			rc = arks_pack_reads_device(s.d_ascii.p, s.d_aoff.p, s.d_len.p, s.d_woff.p, n, s.d_codes.p, s.d_nmask.p, s.d_class.p,
+			                            params.device, s.stream);
+		} else {
+			up(s.d_codes.p, pb->codes, words * sizeof(uint64_t));
+			up(s.d_nmask.p, pb->nmask, words * sizeof(uint32_t));
+			up(s.d_class.p, pb->cls, (size_t)n);
+		}
 		// (the copies above and the kernels below overlap the other set's: an index keeps one set of work
 		// queues per stream, and the IndexMap accumulator is updated with atomics)
-		int rc = arks_pair_gate_device(s.d_ok.p, s.d_class.p, np, s.d_eval.p, params.device, s.stream);
+		if (rc == ARKS_OK)
+			rc = arks_pair_gate_device(s.d_ok.p, s.d_class.p, np, s.d_eval.p, params.device, s.stream);
+		if (rc == ARKS_OK && pb->ascii)
+			rc = arks_gate_count_device(s.d_ok.p, s.d_eval.p, np, d_skipped + pb->file, params.device, s.stream);
 		if (n_shards > 1) {
 			s.d_votes.reserve((size_t)n);
 			s.d_votes2.reserve((size_t)n);
@@ -664,6 +687,11 @@ class PinnedPool
 	std::thread filler_;
 };
 PinnedPool g_pinned;
+// ARKS_DEVICE_PACK=1: the 2-bit packing and checkReadSequence of the reads on the device (the worker threads
+// only gather the bases: a third less of their work per read pair, 2.3x the bytes over the link).  Off by
+// default: on the GPU box it gained 13 % at -t 1 and nothing from -t 4 on, where the producers' line scan
+// bounds the stage, and the pinned pool it needs is 2.4x the size.
+const bool g_device_pack = getenv("ARKS_DEVICE_PACK") != nullptr;
 
 // fused == true: no multiplicity file; the reads per barcode come back in the result (pre_counts) and
 // `redo` is set when the input needs the exact two-pass flow instead
@@ -710,6 +738,7 @@ map_files(
 	for (auto& r : readers)
 		rdp.push_back(r.get());
 	IngestPipeline pipe(rdp, dict.get(), params.batch_pairs, params.verbose != 0, params.threads, pinned);
+	pipe.set_device_pack(g_device_pack);
 	g_pinned.wait();
 	lap("open files, barcode dictionary, device buffers, pinned pool ready");
 	const int prc = pipe.run([&](PackedBatch* pb) {
@@ -761,8 +790,11 @@ map_files(
 		for (const std::string* s : dict->name)
 			res.names.push_back(*s);
 	}
-	std::vector<uint64_t> stored(nk * nm);
+	std::vector<uint64_t> stored(nk * nm), skipped(nm, 0);
 	std::vector<arks_map_stats> st(nk * nm);
+	(void)hipMemcpy(skipped.data(), mapper.d_skipped, nm * sizeof(uint64_t), hipMemcpyDeviceToHost);
+	for (size_t i = 0; i < mine.size(); ++i)
+		res.files[mine[i]].fc.skipped_invalid += skipped[i]; // (device-pack mode; 0 otherwise)
 	(void)hipMemcpy(stored.data(), mapper.d_stored, nk * nm * sizeof(uint64_t), hipMemcpyDeviceToHost);
 	(void)hipMemcpy(st.data(), mapper.d_stats, nk * nm * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
 	for (size_t i = 0; i < mine.size(); ++i) {
@@ -956,7 +988,13 @@ run_arks(const std::vector<std::string>& filenames)
 		for (size_t f = 0; f < filenames.size(); ++f)
 			n_mine += (int)(f % (size_t)g_world) == g_rank;
 		packed_estimate(params.batch_pairs, &words, &reads);
-		g_pinned.prefill(IngestPipeline::buffers_for(params.threads, (unsigned)n_mine), packed_slab_bytes(words + words / 8, reads + reads / 8));
+		size_t slab = packed_slab_bytes(words + words / 8, reads + reads / 8);
+		if (g_device_pack) {
+			size_t bases = 0;
+			raw_estimate(params.batch_pairs, &bases, &reads);
+			slab = raw_slab_bytes(bases + bases / 8 + 64, reads + reads / 8 + 64);
+		}
+		g_pinned.prefill(IngestPipeline::buffers_for(params.threads, (unsigned)n_mine), slab);
 	}
 
 	std::vector<IndexMap> imaps;

@@ -505,6 +505,11 @@ struct PackedBatch
 	uint8_t* pair_ok = nullptr;
 	uint32_t* barcode_id = nullptr;
 	size_t cap_words = 0, cap_reads = 0;
+	// device-pack mode (the front end packs on the GPU, arks_pack_reads_device): the reads' bases as they are,
+	// back to back, instead of codes / nmask / cls
+	unsigned char* ascii = nullptr;
+	uint64_t* aoff = nullptr; // first base of every read in `ascii`
+	size_t ascii_bytes = 0, cap_ascii = 0;
 	void* slab = nullptr; // the one allocation the arrays above live in
 	FileCounters fc;
 	std::string messages;
@@ -524,6 +529,7 @@ packed_free(PackedBatch& pb, const HostAllocator& a)
 	pb.slab = nullptr;
 	pb.codes = nullptr, pb.nmask = nullptr, pb.woff = nullptr, pb.len = nullptr, pb.cls = nullptr,
 	pb.pair_ok = nullptr, pb.barcode_id = nullptr, pb.cap_words = 0, pb.cap_reads = 0;
+	pb.ascii = nullptr, pb.aoff = nullptr, pb.cap_ascii = 0;
 }
 
 // The arrays of a packed batch are carved out of ONE allocation (pinning host memory is slow and the driver
@@ -583,6 +589,91 @@ packed_reserve(PackedBatch& pb, size_t words, size_t reads, const HostAllocator&
 	pb.barcode_id = barcode_id;
 	pb.cap_words = cap_w, pb.cap_reads = cap_r;
 	return true;
+}
+
+// device-pack mode: bases (+ 64 bytes the device packer may read past the last one), offsets, word offsets,
+// lengths, gate and barcode per pair in one slab
+inline size_t
+raw_slab_bytes(size_t bases, size_t reads)
+{
+	auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+	return up(bases + 64) + 2 * up((reads + 1) * 8) + up(reads * 4) + up(reads / 2 + 1) + up((reads / 2 + 1) * 4);
+}
+inline void
+raw_estimate(long batch_pairs, size_t* bases, size_t* reads)
+{
+	*reads = 2 * (size_t)batch_pairs + 64;
+	*bases = *reads * 160; // 10x reads: 128 + 151 bases per pair
+}
+inline bool
+raw_reserve(PackedBatch& pb, size_t bases, size_t reads, const HostAllocator& a)
+{
+	if (bases <= pb.cap_ascii && reads <= pb.cap_reads && pb.ascii)
+		return true;
+	size_t cap_b = std::max(pb.cap_ascii, bases + bases / 8 + 64), cap_r = std::max(pb.cap_reads, reads + reads / 8 + 64);
+	if (cap_b < cap_r * 160)
+		cap_b = cap_r * 160;
+	char* slab = (char*)a.alloc(raw_slab_bytes(cap_b, cap_r));
+	if (!slab)
+		return false;
+	auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+	char* q = slab;
+	unsigned char* ascii = (unsigned char*)q;
+	q += up(cap_b + 64);
+	uint64_t* aoff = (uint64_t*)q;
+	q += up((cap_r + 1) * 8);
+	uint64_t* woff = (uint64_t*)q;
+	q += up((cap_r + 1) * 8);
+	uint32_t* len = (uint32_t*)q;
+	q += up(cap_r * 4);
+	uint8_t* pair_ok = (uint8_t*)q;
+	q += up(cap_r / 2 + 1);
+	uint32_t* barcode_id = (uint32_t*)q;
+	if (pb.slab)
+		a.release(pb.slab); // (nothing of the old batch is kept: the caller fills everything after this)
+	pb.slab = slab;
+	pb.ascii = ascii, pb.aoff = aoff, pb.woff = woff, pb.len = len, pb.pair_ok = pair_ok, pb.barcode_id = barcode_id;
+	pb.codes = nullptr, pb.nmask = nullptr, pb.cls = nullptr;
+	pb.cap_ascii = cap_b, pb.cap_reads = cap_r, pb.cap_words = 0;
+	return true;
+}
+
+// RawBatch -> PackedBatch for the device packer: the reads' bases gathered back to back, their offsets and
+// word offsets; class, codes and N mask are the device's to make
+inline int
+gather_batch(RawBatch& rb, PackedBatch& pb, const HostAllocator& a)
+{
+	const int64_t n = (int64_t)rb.len.size(), np = (int64_t)rb.pairs();
+	pb.file = rb.file, pb.seq = rb.seq, pb.last = rb.last, pb.n_reads = n, pb.n_pairs = np, pb.fc = rb.fc;
+	pb.messages.swap(rb.messages);
+	pb.words = 0;
+	pb.ascii_bytes = 0;
+	if (n == 0)
+		return ARKS_OK;
+	size_t bases = 0;
+	for (int64_t r = 0; r < n; ++r)
+		bases += rb.len[(size_t)r];
+	if (!raw_reserve(pb, bases, (size_t)n, a))
+		return ARKS_ERR_OOM;
+	arks_word_offsets(rb.len.data(), n, pb.woff);
+	pb.words = (size_t)pb.woff[n] + ARKS_PAD_WORDS;
+	const char* base = rb.base_ptr();
+	size_t pos = 0;
+	for (int64_t r = 0; r < n; ++r) {
+		const uint32_t l = rb.len[(size_t)r];
+		pb.aoff[r] = pos;
+		std::memcpy(pb.ascii + pos, base + rb.off[(size_t)r], l);
+		pos += l;
+	}
+	pb.aoff[n] = pos;
+	std::memset(pb.ascii + pos, 'N', 64);
+	pb.ascii_bytes = pos + 64;
+	std::memcpy(pb.len, rb.len.data(), (size_t)n * sizeof(uint32_t));
+	std::memcpy(pb.pair_ok, rb.pair_ok.data(), (size_t)np);
+	std::memcpy(pb.barcode_id, rb.barcode_id.data(), (size_t)np * sizeof(uint32_t));
+	for (int64_t p = 0; p < np; ++p)
+		pb.fc.gated += rb.pair_ok[(size_t)p] != 0; // (skipped_invalid needs the read classes: counted on the device)
+	return ARKS_OK;
 }
 
 // RawBatch -> PackedBatch: word layout, 2-bit codes + N mask + read class (checkReadSequence,
@@ -1416,6 +1507,9 @@ class IngestPipeline
 		return packers + 3;
 	}
 
+	// the batches carry the reads' bases instead of packed words: the caller packs (and classifies) on the device
+	void set_device_pack(bool on) { device_pack_ = on; }
+
 	DynamicDict& dynamic() { return dynamic_; }
 	const std::vector<PrepassInfo>& prepass() const { return prepass_; }
 	unsigned producers() const { return n_producers_; }
@@ -1524,7 +1618,7 @@ class IngestPipeline
 							return;
 					}
 					IngestProfile::Scope sc(IngestProfile::PACK);
-					const int rc = pack_batch(rb, *pb, alloc_);
+					const int rc = device_pack_ ? gather_batch(rb, *pb, alloc_) : pack_batch(rb, *pb, alloc_);
 					if (rc != ARKS_OK) {
 						std::lock_guard<std::mutex> lk(err_m);
 						if (first_err == ARKS_OK)
@@ -1595,6 +1689,7 @@ class IngestPipeline
 	// compressed bytes per chunk of an ordinary gzip file decoded in parallel (ARKS_PGZIP_CHUNK: tests)
 	size_t pgzip_chunk_ = std::getenv("ARKS_PGZIP_CHUNK") ? (size_t)std::atoll(std::getenv("ARKS_PGZIP_CHUNK")) : (size_t)1 << 20;
 	bool use_pgzip_ = false;
+	bool device_pack_ = false;
 	BoundedQueue<RawBatch> raw_q_, raw_free_{ 8 };
 	HelpDesk desk_;
 	StretchPool stretch_pool_;

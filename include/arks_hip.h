@@ -360,6 +360,18 @@ int arks_pair_gate_device(
     int device,
     void* stream);
 
+/* *d_counter += the gated pairs one of whose mates checkReadSequence rejected (skipped_invalidreadpair,
+ * Arcs/Arcs.cpp:1273-1276): d_pair_ok[p] (NULL = every pair) && !d_eval[2p], d_eval from arks_pair_gate_device.
+ * For a front end that packs and classifies the reads on the device (arks_pack_reads_device) and so has no
+ * read classes on the host to count with. */
+int arks_gate_count_device(
+    const uint8_t* d_pair_ok,
+    const uint8_t* d_eval,
+    int64_t n_pairs,
+    uint64_t* d_counter,
+    int device,
+    void* stream);
+
 /* The pair rule of chromiumRead, Arcs/Arcs.cpp:1280-1292: reads 2p, 2p+1 are mates;
  * d_out_pair[p] = c1 if (c1 != 0 && c1 == c2) else 0; for stored pairs with d_pair_ok[p] != 0
  * (NULL = all) imap[(d_barcode_id[p], c1)]++ (imap and d_barcode_id may both be NULL).

@@ -165,6 +165,19 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
     args2[args2.index("--barcode-counts") + 1] = str(tmp_path / "counts2")
     res2 = subprocess.run(args2 + [str(x) for x in paths], capture_output=True, text=True, timeout=300)
     assert res2.returncode == 0, res2.stderr[-2000:]
+    # ... and with the reads packed and classified on the device (ARKS_DEVICE_PACK=1: the workers ship the bases
+    # as text, "Skipped invalid read pairs" is then counted by arks_gate_count_device): the same log and files
+    args3 = list(args2)
+    args3[args3.index("-b") + 1] = str(tmp_path / "multi_dp")
+    args3[args3.index("--barcode-counts") + 1] = str(tmp_path / "counts3")
+    res3 = subprocess.run(args3 + [str(x) for x in paths], capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, ARKS_DEVICE_PACK="1"))
+    assert res3.returncode == 0, res3.stderr[-2000:]
+    counters = lambda t: [ln for ln in t.split("\n") if ln.startswith(("Stored ", "Skipped ", "Total valid", "Number ", "File contains", "WARNING"))]
+    assert counters(res3.stdout) == counters(res2.stdout) and len(counters(res3.stdout)) > 20
+    assert any(ln.startswith("Skipped invalid read pairs: ") and not ln.endswith(": 0") for ln in counters(res3.stdout))
+    for suffix in ("_original.gv", "_pair.tsv", "_main.tsv"):
+        assert open(str(tmp_path / "multi_dp") + suffix).read() == open(base + suffix).read(), suffix
     for suffix in ("_original.gv", "_pair.tsv", "_main.tsv"):
         assert open(str(tmp_path / "multi") + suffix).read() == open(base + suffix).read(), suffix
     assert open(str(tmp_path / "counts2.tsv")).read() == open(str(tmp_path / "counts.tsv")).read()
