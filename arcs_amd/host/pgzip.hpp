@@ -186,9 +186,29 @@ build_table(const uint8_t* lens, int n, int primary_bits, uint32_t* table, size_
 // strict: what a compressor writes -- complete codes (a distance code may also be a single code, or none).
 // Otherwise what an inflater must take: anything that is not over-subscribed (a code that is not there is
 // an INVALID entry and fails when it is met).
+// unused code space of the canonical code `lens` (0 = complete, < 0 = over-subscribed)
+inline long
+code_space(const uint8_t* lens, int n)
+{
+	int count[16] = { 0 };
+	for (int s = 0; s < n; ++s)
+		count[lens[s]]++;
+	long space = 1;
+	for (int l = 1; l <= 15; ++l) {
+		space = (space << 1) - count[l];
+		if (space < 0)
+			return -1;
+	}
+	return space;
+}
+
 inline bool
 build_tables(Tables& t, const uint8_t* litlen, int n_lit, const uint8_t* dist, int n_dist, bool strict)
 {
+	// (the search for block starts comes here for every bit position that looks like a header: the codes are
+	// weighed before 40 KB of tables are filled for them)
+	if (strict && (code_space(litlen, n_lit) != 0 || code_space(dist, n_dist) < 0))
+		return false;
 	static const uint16_t len_base[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
 	static const uint8_t len_extra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
 	static const uint16_t dist_base[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
@@ -349,6 +369,24 @@ struct Symbols
 	}
 };
 
+__attribute__((target("avx2"))) inline void
+copy_symbols_avx2(uint16_t* to, const uint16_t* from, const uint16_t* end)
+{
+	do {
+		_mm256_storeu_si256((__m256i*)to, _mm256_loadu_si256((const __m256i*)from));
+		to += 16, from += 16;
+	} while (to < end);
+}
+__attribute__((target("avx2"))) inline void
+fill_symbols_avx2(uint16_t* to, uint16_t v, const uint16_t* end)
+{
+	const __m256i x = _mm256_set1_epi16((short)v);
+	do {
+		_mm256_storeu_si256((__m256i*)to, x);
+		to += 16;
+	} while (to < end);
+}
+
 // the body of a Huffman block (the header was read) appended to `out`; kText: every literal must be text
 template <bool kText>
 inline bool
@@ -364,9 +402,10 @@ huffman_block(BitIn& b, const Tables& t, Symbols& out)
 	int bc = b.bc;
 	const uint32_t* const lit = t.lit;
 	const uint32_t* const dist = t.dist;
+	static const bool wide = __builtin_cpu_supports("avx2");
 	bool ok = false;
 	for (;;) {
-		if (n + 280 > cap) {
+		if (n + 296 > cap) {
 			out.n = n;
 			out.room(1 << 16);
 			sym = out.sym();
@@ -444,7 +483,9 @@ huffman_block(BitIn& b, const Tables& t, Symbols& out)
 		uint16_t* to = sym + n;
 		n += length;
 		uint16_t* const end = to + length;
-		if (distance >= 8) { // eight symbols at a time (the room asked for above covers the overshoot)
+		if (distance >= 16 && wide) { // sixteen symbols at a time (the room asked for above covers the overshoot)
+			copy_symbols_avx2(to, from, end);
+		} else if (distance >= 8) {
 			do {
 				_mm_storeu_si128((__m128i*)to, _mm_loadu_si128((const __m128i*)from));
 				to += 8, from += 8;
@@ -455,11 +496,15 @@ huffman_block(BitIn& b, const Tables& t, Symbols& out)
 				to += 4, from += 4;
 			} while (to < end);
 		} else if (distance == 1) { // a run (base qualities)
-			const __m128i v = _mm_set1_epi16((short)*from);
-			do {
-				_mm_storeu_si128((__m128i*)to, v);
-				to += 8;
-			} while (to < end);
+			if (wide)
+				fill_symbols_avx2(to, *from, end);
+			else {
+				const __m128i v = _mm_set1_epi16((short)*from);
+				do {
+					_mm_storeu_si128((__m128i*)to, v);
+					to += 8;
+				} while (to < end);
+			}
 		} else
 			for (uint32_t i = 0; i < length; ++i)
 				to[i] = from[i];
@@ -506,6 +551,26 @@ find_block_start(const unsigned char* in, size_t size, size_t from_bit, size_t t
 		const unsigned w = (unsigned)in[byte] | ((unsigned)in[byte + 1] << 8);
 		if (((w >> (p & 7)) & 7u) != 4u)
 			continue;
+		if (byte + 16 <= size) {
+			// the fixed part of the header out of two words, before anything is built: HLIT and HDIST in range, and
+			// the code of the code lengths (HCLEN + 4 lengths of 3 bits) complete -- one position in hundreds is
+			unsigned __int128 v;
+			std::memcpy(&v, in + byte, 16);
+			v >>= (p & 7);
+			const unsigned hlit = (unsigned)(v >> 3) & 31u, hdist = (unsigned)(v >> 8) & 31u, hclen = ((unsigned)(v >> 13) & 15u) + 4u;
+			if (hlit > 29u || hdist > 29u)
+				continue;
+			v >>= 17;
+			int space = 128;
+			for (unsigned i = 0; i < hclen; ++i) {
+				const unsigned l = (unsigned)v & 7u;
+				v >>= 3;
+				if (l)
+					space -= 128 >> l;
+			}
+			if (space != 0)
+				continue;
+		}
 		b.seek_bit(p);
 		bool last = false;
 		int type = 0;
