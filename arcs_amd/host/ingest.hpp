@@ -1471,13 +1471,14 @@ class IngestPipeline
 		fast_path_ = std::getenv("ARKS_SEQUENTIAL_INGEST") == nullptr;
 		// a producer on the fast path only reads and finds lines (the workers parse): a quarter of the threads
 		// is plenty for them; without it a producer IS a parser: half
-		// ordinary gzip files: with few of them (fewer than a quarter of the threads) each is decoded by several
-		// threads at once (pgzip.hpp: about twice the work per byte of the one-thread inflater, but it spreads);
-		// with many, a thread per file is the better use of the threads
+		// ordinary gzip files: with few of them (fewer than a third of the threads; one file from two threads on)
+		// each is decoded by several threads at once (pgzip.hpp: more work per byte than the one-thread inflater,
+		// but it spreads: one file reads at 2.5 / 4.1 / 5.4 / 7.2 / 9.8 M pairs/s with 2 / 4 / 6 / 8 / 16 threads
+		// against 2.1 for the one thread); with many, a thread per file is the better use of the threads
 		unsigned n_serial = 0, n_gz = 0;
 		for (SeqReader* r : readers_)
 			n_gz += r->splittable_gzip();
-		use_pgzip_ = fast_path_ && n_gz > 0 && 4 * n_gz < threads && !std::getenv("ARKS_NO_PGZIP");
+		use_pgzip_ = fast_path_ && n_gz > 0 && (3 * n_gz < threads || (n_gz == 1 && threads >= 2)) && !std::getenv("ARKS_NO_PGZIP");
 		if (const char* e = std::getenv("ARKS_PGZIP")) // 1 / 0: whatever the counts say (tests, A/B runs)
 			use_pgzip_ = fast_path_ && std::atoi(e) != 0;
 		for (SeqReader* r : readers_)
