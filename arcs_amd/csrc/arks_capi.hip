@@ -34,6 +34,38 @@ hipError_t launch_gate_count(const uint8_t* pair_ok, const uint8_t* eval, long n
 }
 using namespace arks;
 
+// ARKS_DEBUG_POISON_LDS=<hex word>: before every map launch the LDS of every CU is filled with that word (LDS is
+// not cleared between kernels: a workgroup sees what the last one on its CU left, of this process or another's).
+// A read of LDS the kernel did not write then meets the same garbage on every run -- the debugging aid for the
+// kind of fault that only shows with other processes on the GPU.
+__global__ void
+poison_lds_kernel(unsigned word)
+{
+	extern __shared__ unsigned poison_words[];
+	for (unsigned i = threadIdx.x; i < 16384u; i += blockDim.x)
+		poison_words[i] = word;
+	__syncthreads();
+	if (poison_words[(threadIdx.x * 7u) & 16383u] != word) // (keep the stores)
+		__builtin_trap();
+}
+static hipError_t
+poison_lds(int n_cu, hipStream_t st)
+{
+	static const char* e = std::getenv("ARKS_DEBUG_POISON_LDS");
+	if (!e)
+		return hipSuccess;
+	const unsigned word = (unsigned)std::strtoul(e, nullptr, 16);
+	poison_lds_kernel<<<(unsigned)(n_cu > 0 ? n_cu : 256) * 12u, 256, 65536, st>>>(word);
+	// ... and more of it on a stream of its own, to get between the launches of the call (hot, medium, slow
+	// kernel) the way another process's workgroups would
+	static hipStream_t side = nullptr;
+	if (!side && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess)
+		return hipGetLastError();
+	for (int i = 0; i < 6; ++i)
+		poison_lds_kernel<<<(unsigned)(n_cu > 0 ? n_cu : 256) * 4u, 256, 65536, side>>>(word ^ (unsigned)i * 0x01010101u);
+	return hipGetLastError();
+}
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -1269,6 +1301,7 @@ arks_map_reads_device(
 	int rc = ensure_queue(idx, stream, n_reads, &qs);
 	if (rc != ARKS_OK)
 		return rc;
+	HIP_TRY(poison_lds(idx->n_cu, static_cast<hipStream_t>(stream)));
 	HIP_TRY(launch_map_reads(
 	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads,
 	    j_index, idx->geom, idx->table, idx->bx, d_out_conreci, reinterpret_cast<u64*>(d_stats),

@@ -14,6 +14,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n_cases = n_reads_total = 0
 while time.time() < t_end:
     rng = np.random.Generator(np.random.PCG64(seed)); seed += 1
+    if os.environ.get("FUZZ_TRACE"):                      # the case under way, for a run that dies in a kernel
+        open(os.environ["FUZZ_TRACE"], "w").write(str(seed - 1))
     k = int(rng.choice([20, 21, 22, 23, 24, 25, 27, 30, 31, 32, 33, 40, 45, 59, 60, 61, 63, 64, 65, 72, 80, 95, 96]))
     def rnd(n): return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
     ends = []
