@@ -453,12 +453,6 @@ arks_pack_reads_host(
 	for (int64_t r = 0; r < n_reads; ++r) {
 		const unsigned char* s = reinterpret_cast<const unsigned char*>(h_ascii) + h_offsets[r];
 		const uint32_t len = h_lens[r];
-		if (r + 4 < n_reads) { // the bases of a read further on (three cache lines of a 151-base read)
-			const unsigned char* q = reinterpret_cast<const unsigned char*>(h_ascii) + h_offsets[r + 4];
-			__builtin_prefetch(q);
-			__builtin_prefetch(q + 64);
-			__builtin_prefetch(q + 128);
-		}
 		uint64_t* cw = h_codes + h_word_off[r];
 		uint32_t* mw = h_nmask + h_word_off[r];
 		const uint64_t nw = ((uint64_t)len + 31) / 32;

@@ -980,10 +980,6 @@ parse_text_batch(
 	std::string_view last_bc; // (a view of this batch's text)
 	for (size_t p = 0; p < np; ++p) {
 		const uint32_t* l = L + 8 * p;
-		if (p + 6 < np) { // the header lines of a pair further on: this thread has not seen the text before
-			__builtin_prefetch(t + l[48]);
-			__builtin_prefetch(t + l[52]);
-		}
 		std::string_view n1, c1, n2, c2;
 		split_header(t, l[0], l[1] - 1, n1, c1);
 		split_header(t, l[4], l[5] - 1, n2, c2);
