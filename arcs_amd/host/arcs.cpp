@@ -882,7 +882,7 @@ read_stage(
 		redo = redo || r.redo;
 	if (redo)
 		return;
-	merge_results(files, ranks, imaps, mult, contigRecord, fused, MergeParams{ params.verbose != 0, params.k_list, params.index_shards }, out, err, &pre_out, &pre_err, compact);
+	merge_results(files, ranks, imaps, mult, contigRecord, fused, MergeParams{ params.verbose != 0, params.k_list, params.index_shards, params.threads }, out, err, &pre_out, &pre_err, compact);
 }
 
 // file names of one k: with a single -k exactly the reference's (Arcs.cpp:2144-2157); with a list
@@ -1081,7 +1081,7 @@ run_arks(const std::vector<std::string>& filenames)
 			std::cout << "\n=> Graph stage for k = " << params.k_list[ki] << "\n";
 		std::cout << "\n=> Pairing scaffolds... " << now();
 		if (fast_graph)
-			cpairs = pair_contigs_compact(cix[ki], params.g);
+			cpairs = pair_contigs_compact(cix[ki], params.g, params.threads);
 		else
 			pair_contigs(imap, pmap, mult, params.g);
 		if (params.output_pair) {

@@ -28,6 +28,52 @@
 
 namespace arks_host {
 
+// std::sort over `threads` threads: the keys are cut into ranges by sampled splitters, every range is gathered
+// and sorted by a thread of its own, and the ranges are laid out one after the other -- the result is the sorted
+// array (equal keys may sit in any order among themselves, as with std::sort)
+template <typename T, typename Key>
+inline void
+parallel_sort_by(std::vector<T>& v, Key key, unsigned threads)
+{
+	const size_t n = v.size();
+	if (threads < 2 || n < (1u << 16)) {
+		std::sort(v.begin(), v.end(), [&](const T& a, const T& b) { return key(a) < key(b); });
+		return;
+	}
+	const unsigned B = std::min<unsigned>(threads, 64);
+	std::vector<uint64_t> sample;
+	for (size_t i = 0; i < (size_t)B * 64; ++i)
+		sample.push_back(key(v[(i * 2654435761ull) % n]));
+	std::sort(sample.begin(), sample.end());
+	std::vector<uint64_t> split; // bucket b holds keys in (split[b-1], split[b]]
+	for (unsigned b = 1; b < B; ++b)
+		split.push_back(sample[(size_t)b * 64]);
+	auto bucket_of = [&](uint64_t k) { return (size_t)(std::lower_bound(split.begin(), split.end(), k) - split.begin()); };
+	std::vector<size_t> count(B + 1, 0);
+	std::vector<uint8_t> which(n);
+	for (size_t i = 0; i < n; ++i) {
+		which[i] = (uint8_t)bucket_of(key(v[i]));
+		count[which[i] + 1]++;
+	}
+	for (unsigned b = 0; b < B; ++b)
+		count[b + 1] += count[b];
+	std::vector<T> out(n);
+	{
+		std::vector<size_t> at(count.begin(), count.end() - 1);
+		for (size_t i = 0; i < n; ++i)
+			out[at[which[i]]++] = v[i];
+	}
+	std::vector<std::thread> th;
+	for (unsigned b = 0; b < B; ++b)
+		th.emplace_back([&, b] {
+			std::sort(out.begin() + (std::ptrdiff_t)count[b], out.begin() + (std::ptrdiff_t)count[b + 1],
+			          [&](const T& x, const T& y) { return key(x) < key(y); });
+		});
+	for (auto& t : th)
+		t.join();
+	v.swap(out);
+}
+
 struct CompactEntry
 {
 	uint32_t barcode; // a number per barcode (any: only equality matters)
@@ -60,7 +106,7 @@ struct RawEntry
 // = multiplicity per barcode number.  Contigs are told apart by their ID, as the reference's maps do: two
 // FASTA records of one name share their entries.
 inline CompactIndex
-build_compact_index(std::vector<RawEntry>& raw, const std::vector<CI>& contigRecord, std::vector<int> mult_of)
+build_compact_index(std::vector<RawEntry>& raw, const std::vector<CI>& contigRecord, std::vector<int> mult_of, unsigned threads = 1)
 {
 	CompactIndex ix;
 	// rank of every contig id
@@ -85,7 +131,7 @@ build_compact_index(std::vector<RawEntry>& raw, const std::vector<CI>& contigRec
 	for (size_t i = 0; i < raw.size(); ++i)
 		recs[i] = Rec{ ((uint64_t)raw[i].barcode << 32) | rank_of[raw[i].conreci], raw[i].count, contigRecord[raw[i].conreci].second ? 1u : 0u };
 	std::vector<RawEntry>().swap(raw);
-	std::sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.key < y.key; });
+	parallel_sort_by(recs, [](const Rec& x) { return x.key; }, threads); // (records of one key are added up: their order does not matter)
 	ix.entries.reserve(recs.size());
 	for (size_t i = 0; i < recs.size();) {
 		CompactEntry e{ (uint32_t)(recs[i].key >> 32), (uint32_t)recs[i].key, 0, 0 };
@@ -104,7 +150,7 @@ build_compact_index(std::vector<RawEntry>& raw, const std::vector<CI>& contigRec
 // pairContigs (Arcs.cpp:1378-1435) on a CompactIndex: per barcode within the multiplicity bounds, every pair of
 // its contigs whose reads sit significantly at one end (head_or_tail) adds one to that orientation's count
 inline CompactPairs
-pair_contigs_compact(const CompactIndex& ix, const GraphParams& P)
+pair_contigs_compact(const CompactIndex& ix, const GraphParams& P, unsigned threads = 1)
 {
 	struct Hit
 	{
@@ -138,7 +184,7 @@ pair_contigs_compact(const CompactIndex& ix, const GraphParams& P)
 		}
 		i = j;
 	}
-	std::sort(hits.begin(), hits.end(), [](const Hit& x, const Hit& y) { return x.key < y.key; });
+	parallel_sort_by(hits, [](const Hit& x) { return x.key; }, threads); // (hits of one key are counted: any order)
 	CompactPairs pairs;
 	for (size_t i = 0; i < hits.size();) {
 		CompactPair p{ (uint32_t)(hits[i].key >> 32), (uint32_t)hits[i].key, { 0, 0, 0, 0 } };

@@ -224,6 +224,7 @@ struct MergeParams
 	bool verbose;
 	std::vector<int> k_list;
 	int index_shards;
+	unsigned threads = 1; // for the sorts of the number-based merge
 };
 
 inline void
@@ -377,7 +378,7 @@ merge_results(
 				for (size_t i = 0; 3 * i < t.size(); ++i)
 					raw.push_back(RawEntry{ ranks.size() == 1 ? t[3 * i] : gid[r][t[3 * i]], t[3 * i + 1], t[3 * i + 2] });
 			}
-			compact->push_back(build_compact_index(raw, contigRecord, mult_of));
+			compact->push_back(build_compact_index(raw, contigRecord, mult_of, params.threads));
 		}
 		imaps.clear();
 		return;

@@ -66,11 +66,12 @@ main(int argc, char** argv)
 	std::string out, err, pre_out, pre_err;
 	GraphParams P;
 	const bool literal = argc > 2 && std::string(argv[2]) == "literal";
+	const unsigned T = argc > 3 ? (unsigned)std::atoi(argv[3]) : 1; // threads of the sorts (graph_fast.hpp)
 	if (!literal) { // graph_fast.hpp
 		std::vector<CompactIndex> cix;
-		merge_results({ "reads.fq" }, ranks, imaps, mult, contigRecord, false, MergeParams{ false, { 60 }, 1 }, out, err, &pre_out, &pre_err, &cix);
+		merge_results({ "reads.fq" }, ranks, imaps, mult, contigRecord, false, MergeParams{ false, { 60 }, 1, T }, out, err, &pre_out, &pre_err, &cix);
 		lap("merge_results (CompactIndex)");
-		const CompactPairs pairs = pair_contigs_compact(cix[0], P);
+		const CompactPairs pairs = pair_contigs_compact(cix[0], P, T);
 		lap("pair_contigs_compact");
 		ScaffoldGraph g;
 		create_graph_compact(pairs, cix[0], g, P);

@@ -313,3 +313,43 @@ def test_multiplicity_lines_of_unusual_shape(graph_check, tmp_path):
         tsv.write_bytes(bad)
         r = subprocess.run([graph_check, "mult", str(tsv), str(tmp_path / "o3.tsv")], capture_output=True)
         assert r.returncode != 0                                   # terminate: std::invalid_argument from stoi
+
+
+def test_parallel_sort_of_the_number_based_stages(tmp_path):
+    """graph_fast.hpp sorts its (barcode, contig) records and its contig-pair hits over the -t threads by sampled
+    splitters (parallel_sort_by): the same order of keys as std::sort, every record kept, for skewed keys too"""
+    src = tmp_path / "psort.cpp"
+    src.write_text(r'''
+#include "graph_fast.hpp"
+#include <random>
+struct R { uint64_t key; uint32_t payload; };
+int main() {
+	std::mt19937_64 rng(5);
+	for (int mode = 0; mode < 4; ++mode)
+		for (unsigned threads : { 1u, 2u, 5u, 16u, 100u }) {
+			const size_t n = mode == 3 ? 70000 : 600000;
+			std::vector<R> v(n);
+			for (size_t i = 0; i < n; ++i) {
+				uint64_t k = rng();
+				if (mode == 1) k %= 7;                   // seven keys
+				if (mode == 2) k = (k % 100 < 90) ? 42 : k; // one key holds most records
+				v[i] = R{ k, (uint32_t)i };
+			}
+			std::vector<R> w = v;
+			std::sort(w.begin(), w.end(), [](const R& a, const R& b) { return a.key < b.key; });
+			arks_host::parallel_sort_by(v, [](const R& r) { return r.key; }, threads);
+			uint64_t s1 = 0, s2 = 0;
+			for (size_t i = 0; i < n; ++i) {
+				if (v[i].key != w[i].key) { std::printf("order differs mode %d threads %u at %zu\n", mode, threads, i); return 1; }
+				s1 += (uint64_t)v[i].payload * 2654435761ull; s2 += (uint64_t)w[i].payload * 2654435761ull;
+			}
+			if (s1 != s2) { std::printf("records lost mode %d threads %u\n", mode, threads); return 1; }
+		}
+	std::printf("ok\n");
+	return 0;
+}
+''')
+    exe = str(tmp_path / "psort")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", *os.environ.get("ARKS_TEST_CXXFLAGS", "").split(),
+                           "-I" + os.path.join(ROOT, "arcs_amd", "host"), str(src), "-o", exe])
+    assert subprocess.check_output([exe], text=True).strip() == "ok"
