@@ -1155,7 +1155,7 @@ run_arks(const std::vector<std::string>& filenames)
 			std::cout << "\n=> Writing TSV file... " << now();
 			std::ofstream f(names.tsv.c_str());
 			if (fast_graph)
-				write_tsv_compact(f, cix[ki], cpairs, barcode_count, params.g);
+				write_tsv_compact(f, cix[ki], cpairs, barcode_count, params.g, params.threads);
 			else
 				write_tsv(f, imap, pmap, barcode_count, params.g);
 		}

@@ -270,7 +270,8 @@ class TextOut
 // writeTSV (Arcs.cpp:1709-1757).  The per-end barcode counts run over EVERY barcode of the IndexMap, whatever
 // its multiplicity, and over the ends the post-pass added (count 0: they pass only with -c 0).
 inline void
-write_tsv_compact(std::ostream& f, const CompactIndex& ix, const CompactPairs& pairs, size_t barcode_count, const GraphParams& P)
+write_tsv_compact(std::ostream& f, const CompactIndex& ix, const CompactPairs& pairs, size_t barcode_count, const GraphParams& P,
+                  unsigned threads = 1)
 {
 	std::vector<unsigned> per_head(ix.contig.size(), 0), per_tail(ix.contig.size(), 0);
 	for (const CompactEntry& e : ix.entries) {
@@ -279,26 +280,58 @@ write_tsv_compact(std::ostream& f, const CompactIndex& ix, const CompactPairs& p
 		if (e.tail >= P.min_reads)
 			per_tail[e.contig]++;
 	}
-	TextOut o(f);
-	o.str("U\tV\tBest_orientation\tShared_barcodes\tU_barcodes\tV_barcodes\tAll_barcodes");
-	o.end_line();
-	for (const CompactPair& p : pairs) {
-		const std::string& u = ix.contig[p.a];
-		const std::string& v = ix.contig[p.b];
-		const unsigned mx = *std::max_element(p.cnt, p.cnt + 4);
-		for (unsigned i = 0; i < 4; ++i) {
-			if (p.cnt[i] == 0)
-				continue;
-			const bool usense = i < 2, vsense = i % 2;
-			const char best = p.cnt[i] == mx ? 'T' : 'F';
-			const unsigned ub = usense ? per_head[p.a] : per_tail[p.a], vb = !vsense ? per_head[p.b] : per_tail[p.b];
-			o.str(u), o.ch(usense ? '-' : '+'), o.ch('\t'), o.str(v), o.ch(vsense ? '-' : '+'), o.ch('\t'), o.ch(best), o.ch('\t');
-			o.num(p.cnt[i]), o.ch('\t'), o.num(ub), o.ch('\t'), o.num(vb), o.ch('\t'), o.num(barcode_count);
-			o.end_line();
-			o.str(v), o.ch(vsense ? '+' : '-'), o.ch('\t'), o.str(u), o.ch(usense ? '+' : '-'), o.ch('\t'), o.ch(best), o.ch('\t');
-			o.num(p.cnt[i]), o.ch('\t'), o.num(vb), o.ch('\t'), o.num(ub), o.ch('\t'), o.num(barcode_count);
-			o.end_line();
+	// the lines of a range of pairs (the file of a human-size run is a gigabyte: the ranges are put into text by
+	// the -t threads and written one after the other)
+	auto lines = [&](size_t lo, size_t hi, std::string& text) {
+		auto num = [&](unsigned long long v) {
+			char tmp[24];
+			int n = 0;
+			do {
+				tmp[n++] = (char)('0' + v % 10);
+				v /= 10;
+			} while (v);
+			while (n)
+				text.push_back(tmp[--n]);
+		};
+		for (size_t q = lo; q < hi; ++q) {
+			const CompactPair& p = pairs[q];
+			const std::string& u = ix.contig[p.a];
+			const std::string& v = ix.contig[p.b];
+			const unsigned mx = *std::max_element(p.cnt, p.cnt + 4);
+			for (unsigned i = 0; i < 4; ++i) {
+				if (p.cnt[i] == 0)
+					continue;
+				const bool usense = i < 2, vsense = i % 2;
+				const char best = p.cnt[i] == mx ? 'T' : 'F';
+				const unsigned ub = usense ? per_head[p.a] : per_tail[p.a], vb = !vsense ? per_head[p.b] : per_tail[p.b];
+				text.append(u), text.push_back(usense ? '-' : '+'), text.push_back('\t'), text.append(v), text.push_back(vsense ? '-' : '+');
+				text.push_back('\t'), text.push_back(best), text.push_back('\t');
+				num(p.cnt[i]), text.push_back('\t'), num(ub), text.push_back('\t'), num(vb), text.push_back('\t'), num(barcode_count);
+				text.push_back('\n');
+				text.append(v), text.push_back(vsense ? '+' : '-'), text.push_back('\t'), text.append(u), text.push_back(usense ? '+' : '-');
+				text.push_back('\t'), text.push_back(best), text.push_back('\t');
+				num(p.cnt[i]), text.push_back('\t'), num(vb), text.push_back('\t'), num(ub), text.push_back('\t'), num(barcode_count);
+				text.push_back('\n');
+			}
 		}
+	};
+	f << "U\tV\tBest_orientation\tShared_barcodes\tU_barcodes\tV_barcodes\tAll_barcodes\n";
+	const size_t block = (size_t)1 << 16; // pairs per piece of text
+	const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, (pairs.size() + block - 1) / block));
+	for (size_t base = 0; base < pairs.size(); base += block * T) {
+		std::vector<std::string> text(T);
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < T; ++t) {
+			const size_t lo = std::min(pairs.size(), base + block * t), hi = std::min(pairs.size(), lo + block);
+			if (t + 1 < T)
+				th.emplace_back([&, t, lo, hi] { lines(lo, hi, text[t]); });
+			else
+				lines(lo, hi, text[t]);
+		}
+		for (auto& x : th)
+			x.join();
+		for (const std::string& x : text)
+			f.write(x.data(), (std::streamsize)x.size());
 	}
 }
 

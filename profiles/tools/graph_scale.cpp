@@ -89,7 +89,7 @@ main(int argc, char** argv)
 		{
 			const size_t nb = count_barcodes_compact(cix[0], mult, P);
 			std::ofstream f("/tmp/gs/fast_main.tsv");
-			write_tsv_compact(f, cix[0], pairs, nb, P);
+			write_tsv_compact(f, cix[0], pairs, nb, P, T);
 		}
 		lap("count_barcodes + write_tsv_compact");
 		{
