@@ -123,7 +123,10 @@ main(int argc, char** argv)
 			{
 				const size_t n = count_barcodes_compact(ix, mult, P);
 				std::ofstream f(base + "_main.tsv");
-				write_tsv_compact(f, ix, pairs, n, P);
+				// (GRAPH_THREADS / GRAPH_TSV_BLOCK: the text of the file put together by several threads, in small pieces)
+				const char* gt = std::getenv("GRAPH_THREADS");
+				const char* gb = std::getenv("GRAPH_TSV_BLOCK");
+				write_tsv_compact(f, ix, pairs, n, P, gt ? (unsigned)std::atoi(gt) : 1u, gb ? (size_t)std::atoll(gb) : (size_t)1 << 16);
 			}
 			{
 				std::ofstream f(base + "_counts.tsv");

@@ -271,7 +271,7 @@ class TextOut
 // its multiplicity, and over the ends the post-pass added (count 0: they pass only with -c 0).
 inline void
 write_tsv_compact(std::ostream& f, const CompactIndex& ix, const CompactPairs& pairs, size_t barcode_count, const GraphParams& P,
-                  unsigned threads = 1)
+                  unsigned threads = 1, size_t block = (size_t)1 << 16 /* pairs per piece of text */)
 {
 	std::vector<unsigned> per_head(ix.contig.size(), 0), per_tail(ix.contig.size(), 0);
 	for (const CompactEntry& e : ix.entries) {
@@ -316,7 +316,7 @@ write_tsv_compact(std::ostream& f, const CompactIndex& ix, const CompactPairs& p
 		}
 	};
 	f << "U\tV\tBest_orientation\tShared_barcodes\tU_barcodes\tV_barcodes\tAll_barcodes\n";
-	const size_t block = (size_t)1 << 16; // pairs per piece of text
+	block = std::max<size_t>(block, 1);
 	const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, (pairs.size() + block - 1) / block));
 	for (size_t base = 0; base < pairs.size(); base += block * T) {
 		std::vector<std::string> text(T);

@@ -81,9 +81,10 @@ def test_graph_stage_vs_python(graph_check, tmp_path, seed, c, l, d, r, mode):
     (tmp_path / "mult.tsv").write_text("".join(f"{b}\t{m}\n" for b, m in mult.items()))
     (tmp_path / "len.tsv").write_text("".join(f"{k}\t{v}\n" for k, v in lengths.items()))
     base = str(tmp_path / "out")
+    # (graph_fast.hpp puts the TSV together on several threads, a block of pairs each: blocks of 3 pairs here)
     summary = subprocess.check_output([graph_check, mode, str(tmp_path / "imap.tsv"), str(tmp_path / "mult.tsv"),
                                        str(tmp_path / "len.tsv"), base, str(c), str(l), "20", "250", str(d), str(r),
-                                       "77", "x"], text=True)
+                                       "77", "x"], text=True, env=dict(os.environ, GRAPH_THREADS=str(1 + seed % 4), GRAPH_TSV_BLOCK="3"))
     assert f'"Scaffold_end_barcodes":{len(imap)},' in summary and f'"All_barcodes_unfiltered":{len(mult)},' in summary
     G.add_opposite_ends(imap)
     pmap = G.pair_contigs(imap, mult, P)
