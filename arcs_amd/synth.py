@@ -197,6 +197,37 @@ def pairs_touching_microsatellite(batch, r1_len=128, r2_len=151, run=14, chunk=5
     return out
 
 
+def alternating_at_runs(genome, run=14, chunk=1 << 28):
+    """int64[n, 2] numpy array of the maximal stretches [start, end) of `genome` (a uint8 torch tensor of
+    ASCII bases, e.g. the concatenated draft; any device) in which A and T alternate over at least `run`
+    bases: the injected (AT)n microsatellites, their copies inside duplicated segments, and the few
+    stretches that arise by chance.  A k-mer that holds such a stretch recurs between sites all over a
+    draft, so its index value is a function of the WHOLE draft: a sub-draft oracle is given the windows
+    around every one of these stretches (oracle.pyoracle.sub_draft_index)."""
+    import torch
+    G = int(genome.numel())
+    starts, ends = [], []
+    for lo in range(0, max(G - 1, 0), chunk):
+        hi = min(G - 1, lo + chunk)                       # alt[i] for i in [lo, hi): bases i, i + 1
+        a = max(lo - 1, 0)
+        b = min(hi + 1, G - 1)
+        x = genome[a:b + 1]
+        isa, ist = x == ord("A"), x == ord("T")
+        alt = (isa[:-1] & ist[1:]) | (ist[:-1] & isa[1:])  # alt[i - a] for i in [a, b)
+        cur = alt[lo - a:hi - a]
+        prev = alt[lo - a - 1:hi - a - 1] if lo > a else torch.cat([alt.new_zeros(1), alt[:hi - a - 1]])
+        nxt = alt[lo - a + 1:hi - a + 1] if b > hi else torch.cat([alt[lo - a + 1:hi - a], alt.new_zeros(1)])
+        starts.append(torch.nonzero(cur & ~prev).flatten() + lo)
+        ends.append(torch.nonzero(cur & ~nxt).flatten() + lo)
+    if not starts:
+        return np.zeros((0, 2), dtype=np.int64)
+    s = torch.cat(starts).cpu().numpy()
+    e = torch.cat(ends).cpu().numpy()
+    assert len(s) == len(e)
+    keep = (e - s + 2) >= run                              # alt[s..e] true: bases s .. e + 1
+    return np.stack([s[keep], e[keep] + 2], axis=1).astype(np.int64)
+
+
 def reads_to_strings(batch):
     """list of python str, one per read (small batches only)"""
     a = batch["ascii"].cpu().numpy()

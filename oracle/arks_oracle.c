@@ -234,12 +234,15 @@ arks_oracle_index_dump(const arks_oracle_index* idx, unsigned char* keys, int32_
 }
 
 /* mapKmers, Arcs/Arcs.cpp:869-929 */
-int
-arks_oracle_map_kmers(
+/* the scan of mapKmers over the whole sequence; only the windows that start in [lo, hi) are put into the map */
+static int
+map_kmers_scan(
     arks_oracle_index* idx,
     const char* seq,
     int len,
     int conreci,
+    int lo,
+    int hi,
     arks_oracle_build_stats* st)
 {
 	unsigned char key[ARKS_ORACLE_MAX_KEY_BYTES];
@@ -250,6 +253,10 @@ arks_oracle_map_kmers(
 	int i = 0;
 	while (i <= len - k) { /* :887 */
 		if (arks_oracle_key(seq, (size_t)i, k, key)) {
+			if (i < lo || i >= hi) { /* visited, but not asked for (arks_oracle_map_kmers_range) */
+				i++;
+				continue;
+			}
 			num++;
 			if ((idx->size + 1) * 2 > idx->cap)
 				grow(idx);
@@ -286,6 +293,29 @@ arks_oracle_map_kmers(
 	if (st)
 		st->total_kmers += (uint32_t)num;
 	return num;
+}
+
+int
+arks_oracle_map_kmers(
+    arks_oracle_index* idx,
+    const char* seq,
+    int len,
+    int conreci,
+    arks_oracle_build_stats* st)
+{
+	return map_kmers_scan(idx, seq, len, conreci, 0, len, st);
+}
+
+int
+arks_oracle_map_kmers_range(
+    arks_oracle_index* idx,
+    const char* seq,
+    int len,
+    int conreci,
+    int lo,
+    int hi)
+{
+	return map_kmers_scan(idx, seq, len, conreci, lo, hi, NULL);
 }
 
 /* Arcs/Arcs.cpp:1056, :1072-1074 */

@@ -75,6 +75,18 @@ int arks_oracle_map_kmers(
     int conreci,
     arks_oracle_build_stats* st);
 
+/* The same scan (the i += k jumps are those of the whole sequence), but only the windows that start in
+ * [lo, hi) are inserted: lets a test give a sub-draft index the whole draft's windows around chosen sites
+ * (the (AT)n microsatellites, whose flank + repeat k-mers recur between sites all over a draft) without
+ * holding the whole map.  Not a function of the reference; owner-or-0 does not depend on insertion order. */
+int arks_oracle_map_kmers_range(
+    arks_oracle_index* idx,
+    const char* seq,
+    int len,
+    int conreci,
+    int lo,
+    int hi);
+
 /* The head/tail split of getContigKmers, Arcs/Arcs.cpp:1056-1093: for a contig of length len
  * writes the cut-off (length of both end substrings); returns 0 when the contig is skipped
  * (len < min_size). */

@@ -62,6 +62,7 @@ def lib():
         L.arks_oracle_index_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.arks_oracle_map_kmers.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int,
                                             C.POINTER(BuildStats)]
+        L.arks_oracle_map_kmers_range.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.arks_oracle_end_cutoff.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.arks_oracle_best_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_double,
                                               C.POINTER(MapStats)]
@@ -134,6 +135,12 @@ class OracleIndex:
             seq = seq.encode()
         return lib().arks_oracle_map_kmers(self.h, seq, len(seq), conreci, C.byref(self.stats))
 
+    def map_kmers_range(self, seq, conreci, lo, hi):
+        """the scan of map_kmers over the whole end, inserting only the windows that start in [lo, hi)"""
+        if isinstance(seq, str):
+            seq = seq.encode()
+        return lib().arks_oracle_map_kmers_range(self.h, seq, len(seq), conreci, int(lo), int(hi))
+
     def build(self, ends):
         for i, e in enumerate(ends):
             self.map_kmers(e, i + 1)
@@ -183,14 +190,34 @@ class OracleIndex:
         return out_c, out_p, d
 
 
-def sub_draft_index(k, contigs, members, min_size=500, end_length=30000):
+def sub_draft_index(k, contigs, members, min_size=500, end_length=30000, at_runs=None):
     """OracleIndex over the ends of the contigs whose index is in `members` (contigs: uint8 arrays or
     bytes, FASTA order), numbered as getContigKmers numbers them in the WHOLE draft (head of the n-th
     valid contig = 2n-1, tail = 2n): what a human-scale index is checked against when the whole map
     (1.4 G keys) is out of a test's reach -- see arcs_amd.synth.closed_contig_set for which contigs a
-    set of reads needs."""
+    set of reads needs.
+
+    at_runs (arcs_amd.synth.alternating_at_runs of the concatenated draft): the stretches whose k-mers
+    (short flank + (AT)n, and the reverse-complement palindromes inside) recur between sites all over
+    the draft.  For every contig that is NOT a member, the windows of its ends that overlap such a
+    stretch are inserted too -- under the visit rule of the whole end (map_kmers_range) -- so that these
+    keys carry the whole draft's value (owner or 0) and reads that reach into a microsatellite need not
+    be left out of the comparison."""
     members = set(members)
     ox = OracleIndex(k)
+    lens = np.fromiter((len(c) for c in contigs), dtype=np.int64, count=len(contigs))
+    cstart = np.zeros(len(contigs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=cstart[1:])
+    per_contig = {}
+    if at_runs is not None:
+        for s, e in np.asarray(at_runs, dtype=np.int64):
+            ci = int(np.searchsorted(cstart, s, side="right") - 1)
+            while s < e and ci < len(contigs):               # a stretch that runs over a contig border is cut there
+                stop = min(e, cstart[ci + 1])
+                if stop > s:
+                    per_contig.setdefault(ci, []).append((int(s - cstart[ci]), int(stop - cstart[ci])))
+                s = stop
+                ci += 1
     n = 0
     for ci, c in enumerate(contigs):
         cut = end_cutoff(len(c), min_size, end_length)
@@ -201,6 +228,16 @@ def sub_draft_index(k, contigs, members, min_size=500, end_length=30000):
             b = c.tobytes() if hasattr(c, "tobytes") else bytes(c)
             ox.map_kmers(b[:cut], 2 * n - 1)
             ox.map_kmers(b[len(b) - cut:], 2 * n)
+        elif ci in per_contig:
+            b = c.tobytes() if hasattr(c, "tobytes") else bytes(c)
+            L = len(b)
+            for (a, z) in per_contig[ci]:                    # contig coordinates [a, z)
+                # head = b[:cut]: windows that start in [a - k + 1, z), as far as they lie in the end
+                if a - k + 1 < cut:
+                    ox.map_kmers_range(b[:cut], 2 * n - 1, max(a - k + 1, 0), min(z, cut))
+                t0 = L - cut                                 # tail = b[t0:]
+                if z > t0:
+                    ox.map_kmers_range(b[t0:], 2 * n, max(a - k + 1 - t0, 0), max(z - t0, 0))
     return ox
 
 
