@@ -151,7 +151,8 @@ class ArksIndex:
 
     @property
     def kind(self):
-        """0 = hash table, 1 = locality index"""
+        """0 = exact hash table, 1 = locality index with a minimizer table, 2 = locality index with a seed table
+        (every m-mer position of a visited window)"""
         return lib().arks_index_kind(self._h)
 
     @property
@@ -255,6 +256,27 @@ class PackedReads:
               "arks_pack_reads_device")
         torch.cuda.synchronize(device)
         return cls(codes, nmask, woff, d_lens.contiguous(), rclass[:n], device)
+
+    @classmethod
+    def concat(cls, parts):
+        """one batch out of several resident ones (reads start on word boundaries, so the packed words are
+        simply put one behind the other and the word offsets shifted)"""
+        torch = _torch()
+        if len(parts) == 1:
+            return parts[0]
+        dev = parts[0].codes.device
+        totals = [int(p.word_off[-1].item()) for p in parts]
+        codes = torch.cat([p.codes[:t] for p, t in zip(parts, totals)] +
+                          [torch.zeros(4, dtype=torch.int64, device=dev)])
+        nmask = torch.cat([p.nmask[:t] for p, t in zip(parts, totals)] +
+                          [torch.zeros(4, dtype=torch.int32, device=dev)])
+        woff, base = [], 0
+        for i, (p, t) in enumerate(zip(parts, totals)):
+            w = p.word_off if i == len(parts) - 1 else p.word_off[:-1]
+            woff.append(w + base)
+            base += t
+        return cls(codes, nmask, torch.cat(woff), torch.cat([p.lens for p in parts]),
+                   torch.cat([p.read_class for p in parts]), parts[0].device)
 
     @classmethod
     def from_host_packed(cls, packed, device=0):

@@ -1,9 +1,10 @@
 #!/bin/bash
 # usage: profiles/prof.sh <tag> [bench args...]   -> gpurun_out/<tag>_{kernel_stats.csv,pmc_*.csv,bench.json}
-# PROF_PMC_ARGS: extra bench args of the counter passes (default: one step, no warm-up)
+# PROF_PMC_ARGS: extra bench args of the counter passes (default: two steps, no warm-up: the means of the counter
+# passes are over every dispatch of the run -- 10 of the hot kernel at the default 5 launches per step)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-PMC_ARGS=${PROF_PMC_ARGS:---steps 1 --warmup 0}
+PMC_ARGS=${PROF_PMC_ARGS:---steps 2 --warmup 0}
 mkdir -p gpurun_out /tmp/prof_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/kt -o kt -- python bench.py --no-cpu-baseline --no-extras "$@" > gpurun_out/${tag}_bench_under_rocprof.json 2>/tmp/prof_$tag/kt_err.log
 find /tmp/prof_$tag/kt -name '*kernel_stats.csv' -exec cp {} gpurun_out/${tag}_kernel_stats.csv \;

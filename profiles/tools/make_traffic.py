@@ -29,12 +29,22 @@ def mean_of(path, counter):
     return best
 
 
+def dispatches_of(path, counter):
+    return max([int(r["dispatches"]) for r in csv.DictReader(open(path)) if r["counter"] == counter] or [0])
+
+
 f = mean_of(f"gpurun_out/{tag}_pmc_FETCH_SIZE.csv", "FETCH_SIZE")
 w = mean_of(f"gpurun_out/{tag}_pmc_WRITE_SIZE.csv", "WRITE_SIZE")
+try:
+    miss = mean_of(f"gpurun_out/{tag}_pmc_TCC_HIT_sum_TCC_MISS_sum.csv", "TCC_MISS_sum")
+except OSError:
+    miss = None
 out = {"workload": {"draft_mbp": a.draft_mbp, "pairs_per_launch": min(a.chunk, a.pairs), "k": a.k},
        "kernel_build_id": bench.kernel_build_id(),
        "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
        "hbm_bytes_per_launch": (f + w) * 1024.0,
+       "TCC_MISS_per_launch": miss,
+       "dispatches_profiled": dispatches_of(f"gpurun_out/{tag}_pmc_FETCH_SIZE.csv", "FETCH_SIZE"),
        "note": "x1: random 8..64-byte gathers, not a wide coalesced stream (the guide's x2 applies to those)",
        "source": f"profiles/{tag}_pmc_FETCH_SIZE.csv + {tag}_pmc_WRITE_SIZE.csv (rocprofv3 --pmc, separate passes)"}
 json.dump(out, open(f"gpurun_out/traffic_{tag.split('_')[0]}.json", "w"), indent=1)

@@ -1,0 +1,49 @@
+"""bench.py's multi-rank control flow on ONE GPU: `python bench.py --gpus N` starts its N ranks itself
+(torch.distributed.run), the one read set is dealt to the ranks in blocks (strong scaling), and the summed
+counters and stored pairs of the N-rank run equal the one-rank run's.  ARKS_BENCH_BACKEND=gloo lets the ranks
+share the box's single device; the driver's runs use nccl (RCCL), one rank per GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--steps", "2", "--warmup", "1", "--pairs", "400000", "--chunk", "150000", "--draft-mbp", "5",
+        "--no-cpu-baseline", "--no-extras"]
+
+
+def _bench(extra, env_extra=None):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS + extra, env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_starts_the_ranks(arks, gpu):
+    one = _bench([])
+    assert one["n_gpus"] == 1 and one["scaling"] == "strong"
+    assert one["config"]["pairs_job"] == 400000
+    r = one["roofline"]
+    assert r["frac"] is None or 0.0 < r["frac"] <= 1.0       # a fraction (None: no counter summary for this workload)
+    assert r["alg_frac"] > 0
+    for n in (2, 3):
+        many = _bench(["--gpus", str(n)], {"ARKS_BENCH_BACKEND": "gloo"})
+        assert many["n_gpus"] == n and many["scaling"] == "strong"
+        assert many["config"]["pairs_job"] == 400000
+        assert many["counters"] == one["counters"]            # the same pairs, whoever maps them
+        assert many["stored_pairs"] == one["stored_pairs"]
+        assert many["config"]["launches_per_step"] >= 1
+    weak = _bench(["--gpus", "2", "--weak"], {"ARKS_BENCH_BACKEND": "gloo"})
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak"
+    assert weak["config"]["pairs_job"] == 800000
+    assert weak["counters"]["windows"] > one["counters"]["windows"]
