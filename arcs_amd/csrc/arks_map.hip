@@ -360,7 +360,7 @@ clear_spans32(u32 m0, u32 m1, u32 m2, u32 m3, int k)
 }
 
 #ifndef ARKS_TILE_WAVES
-#define ARKS_TILE_WAVES 8
+#define ARKS_TILE_WAVES 7 // 72 VGPRs: at 8 waves (64) the kernel keeps two or three registers in scratch memory -- no kernel of the library uses scratch (tests/test_abi.py)
 #endif
 
 template <bool FULL>
@@ -859,12 +859,18 @@ map_reads_b_kernel(
 		// lane_id l holds the metadata of read c0 + l (lane_id nchunk: the end offset)
 		u64 wo = 0;
 		int rl = 0;
-		if (lane_id <= nchunk)
-			wo = word_off[c0 + lane_id];
-		if (lane_id < nchunk) {
-			rl = (int)lens[c0 + lane_id];
-			if (!FULL && eval && !eval[c0 + lane_id])
-				rl = -1; // not evaluated: output 0, no counters
+		{
+			// (the lane number as an opaque value: the addresses are formed per chunk, not kept -- and spilled to
+			// scratch memory -- as invariants of the chunk loop; see map_reads_s_kernel)
+			int cl = lane_id;
+			asm volatile("" : "+v"(cl));
+			if (cl <= nchunk)
+				wo = word_off[c0 + cl];
+			if (cl < nchunk) {
+				rl = (int)lens[c0 + cl];
+				if (!FULL && eval && !eval[c0 + cl])
+					rl = -1; // not evaluated: output 0, no counters
+			}
 		}
 		int cur = 0;
 		while (cur < nchunk) {
@@ -913,8 +919,10 @@ map_reads_b_kernel(
 			if (lane >= cur && lane < nxt)
 				S.rlen[lane - cur] = rl;
 			if (lane == 0) {
-				S.redo = 0;
-				S.redo2 = 0;
+				u32 z; // (made here: as a loop-invariant constant pair the zero was spilled to scratch memory)
+				asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+				S.redo = z;
+				S.redo2 = z;
 			}
 			if (!FULL) { // per-read counters of T6c' (S.b + 128 ..: clear of the T3 block minima and the owners)
 				S.b[128 + lane] = lane < 32 ? 0u : 0xFFFFFFFFu; // rcnt, rmin
@@ -1787,12 +1795,19 @@ map_reads_s_kernel(
 		// lane l holds read c0 + l: first word, length (-1 = not evaluated), seeds; lane nchunk the end offset
 		u64 wo = 0;
 		int rl = 0;
-		if (lane_id <= nchunk)
-			wo = word_off[c0 + lane_id];
-		if (lane_id < nchunk) {
-			rl = (int)lens[c0 + lane_id];
-			if (eval && !eval[c0 + lane_id])
-				rl = -1;
+		{
+			// the lane number as an opaque value: addresses built from it are formed here, per chunk, instead of
+			// being hoisted out of the chunk loop as loop invariants -- which is what put two registers into
+			// scratch memory at 64 VGPRs (the only scratch use of the kernel)
+			int cl = lane_id;
+			asm volatile("" : "+v"(cl));
+			if (cl <= nchunk)
+				wo = word_off[c0 + cl];
+			if (cl < nchunk) {
+				rl = (int)lens[c0 + cl];
+				if (eval && !eval[c0 + cl])
+					rl = -1;
+			}
 		}
 		const long soff0 = REMOTE ? seed_off[c0] : 0; // index of the chunk's first seed in `ans`
 		const int nwin_l = rl - k + 1;
@@ -1873,8 +1888,11 @@ map_reads_s_kernel(
 					S.rmax[j][0] = 0u, S.rmax[j][1] = 0u;
 				}
 				if (lane == 0) {
-					S.redo = 0;
-					S.redo2 = 0;
+					// (a zero made here: as a loop-invariant constant pair it was kept in -- and spilled from -- registers)
+					u32 z;
+					asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+					S.redo = z;
+					S.redo2 = z;
 				}
 				asm volatile("" : "+v"(c_in), "+v"(m_in), "+v"(c_pad), "+v"(m_pad)); // all four loads in flight
 				if (lane < tw) {
