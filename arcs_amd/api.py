@@ -182,6 +182,14 @@ class ArksIndex:
         return (out, st.as_dict()) if want_stats else out
 
 
+def queue_counts(index):
+    """(slow, medium): reads the hot kernel left to the general kernels in the last map call on `index`
+    (arks_debug_queue_counts, include/arks_hip_debug.h: a diagnostic, not part of the boundary)"""
+    out = (C.c_uint * 4)()
+    check(lib().arks_debug_queue_counts(index.handle, out), "arks_debug_queue_counts")
+    return int(out[0]), int(out[2])
+
+
 def _torch():
     import torch
     return torch

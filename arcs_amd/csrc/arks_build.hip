@@ -98,7 +98,9 @@ read_class_kernel(
 	if (r >= n)
 		return;
 	const double ar = (double)seq_n_count[r] / (double)lens[r]; // 0/0 = NaN -> "> 0.02" false
-	out[r] = (seq_other[r] == 0 && !(ar > 0.02)) ? 1 : 0;
+	// bit 0: accepted; bit 1: ACGT only (the map kernels then skip the read's N masks)
+	const uint8_t ok = (seq_other[r] == 0 && !(ar > 0.02)) ? 1 : 0;
+	out[r] = (uint8_t)(ok | ((ok && seq_n_count[r] == 0) ? 2 : 0));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 // arks_kernels.hip.  No CPU fallback exists: without a gfx950 device every compute entry point
 // returns ARKS_ERR_NO_DEVICE.
 #include "arks_hip.h"
+#include "arks_hip_debug.h"
 #include "arks_kernels.hpp"
 
 // minimizer-table slots per entry: the map kernel's probe is a dependent HBM round trip per group of 4
@@ -504,7 +505,8 @@ arks_pack_reads_host(
 		}
 		if (h_read_class) { // checkReadSequence, Arcs/Arcs.cpp:366-389
 			const double ar = (double)nn / (double)len;
-			h_read_class[r] = (other == 0 && !(ar > 0.02)) ? 1 : 0;
+			const uint8_t ok = (other == 0 && !(ar > 0.02)) ? 1 : 0;
+			h_read_class[r] = (uint8_t)(ok | ((ok && nn == 0) ? 2 : 0)); // bit 1: ACGT only
 		}
 	}
 	return ARKS_OK;

@@ -1795,6 +1795,7 @@ map_reads_s_kernel(
 		// lane l holds read c0 + l: first word, length (-1 = not evaluated), seeds; lane nchunk the end offset
 		u64 wo = 0;
 		int rl = 0;
+		bool may_n = false; // (lanes beyond the chunk: no read)
 		{
 			// the lane number as an opaque value: addresses built from it are formed here, per chunk, instead of
 			// being hoisted out of the chunk loop as loop invariants -- which is what put two registers into
@@ -1805,10 +1806,18 @@ map_reads_s_kernel(
 				wo = word_off[c0 + cl];
 			if (cl < nchunk) {
 				rl = (int)lens[c0 + cl];
-				if (eval && !eval[c0 + cl])
-					rl = -1;
+				may_n = true; // (without an eval array nothing is known: the masks are fetched)
+				if (eval) {
+					const uint8_t ev = eval[c0 + cl];
+					if (!ev)
+						rl = -1;
+					may_n = (ev & 2) == 0; // bit 1: known to hold ACGT only (arks_pair_gate_device from the read class)
+				}
 			}
 		}
+		// reads of the chunk that may hold an invalid base: only a tile with one of them fetches its N masks (a
+		// third of the read stream, and zero for > 98 % of the reads)
+		const u64 nreads_mask = __ballot(may_n);
 		const long soff0 = REMOTE ? seed_off[c0] : 0; // index of the chunk's first seed in `ans`
 		const int nwin_l = rl - k + 1;
 		const int G = nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
@@ -1851,16 +1860,20 @@ map_reads_s_kernel(
 			const int tw = (int)(lane_value_u64(wo, nxt) - base_w);
 			const int nh = __builtin_amdgcn_readlane(gex, nxt) - gbase;
 			// ---- S1: words, metadata, seeds ----------------------------------------------------------
+			// (wave-uniform) does a read of the tile hold an invalid base?  nr <= 16 reads from cur on
+			const bool want_nm = ((nreads_mask >> cur) & ((1ull << nr) - 1ull)) != 0;
 			{
 				u64 c_in = 0, c_pad = 0;
 				u32 m_in = 0, m_pad = 0;
 				if (lane < tw) {
 					c_in = codes[base_w + (u64)lane];
-					m_in = nmask[base_w + (u64)lane];
+					if (want_nm)
+						m_in = nmask[base_w + (u64)lane];
 				}
 				if (lane < 4) { // the windows of the last words read past the tile
 					c_pad = codes[base_w + (u64)(tw + lane)];
-					m_pad = nmask[base_w + (u64)(tw + lane)];
+					if (want_nm)
+						m_pad = nmask[base_w + (u64)(tw + lane)];
 				}
 				if (lane >= cur && lane < nxt) {
 					const int j = lane - cur;
@@ -1897,15 +1910,18 @@ map_reads_s_kernel(
 				asm volatile("" : "+v"(c_in), "+v"(m_in), "+v"(c_pad), "+v"(m_pad)); // all four loads in flight
 				if (lane < tw) {
 					S.cw[lane] = c_in;
-					S.nm[lane] = m_in;
+					if (want_nm)
+						S.nm[lane] = m_in;
 				}
 				if (lane < 4) {
 					S.cw[tw + lane] = c_pad;
-					S.nm[tw + lane] = m_pad;
+					if (want_nm)
+						S.nm[tw + lane] = m_pad;
 				}
 			}
 			ARKS_WAVE_SYNC();
-			const bool has_n = __ballot(lane < tw && S.nm[lane] != 0) != 0;
+			// (S.nm is only read under has_n)
+			const bool has_n = want_nm && __ballot(lane < tw && S.nm[lane] != 0) != 0;
 			if (bx.has_img && !(k & 1)) {
 				// a reverse-complement palindrome carries its seed twice, mirrored about its centre: necessary
 				// condition for a palindromic window (the slow kernel decides exactly); only looked for when the
@@ -2234,9 +2250,13 @@ pair_gate_kernel(
 	const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= n_pairs)
 		return;
-	const uint8_t e = ((pair_ok ? pair_ok[p] : 1) && read_class[2 * p] && read_class[2 * p + 1]) ? 1 : 0;
-	eval[2 * p] = e;
-	eval[2 * p + 1] = e;
+	// class: bit 0 = checkReadSequence accepts the read, bit 1 = it is known to hold ACGT only; eval: 0 = the pair is
+	// gated, else 1 | (class & 2) -- the map kernels skip the N masks of a tile all of whose reads have bit 1 (a caller's
+	// own eval array of 0 / 1 says nothing about the bases: the masks are fetched)
+	const uint8_t c0 = read_class[2 * p], c1 = read_class[2 * p + 1];
+	const bool e = (pair_ok ? pair_ok[p] : 1) && (c0 & 1) && (c1 & 1);
+	eval[2 * p] = e ? (uint8_t)(1 | (c0 & 2)) : (uint8_t)0;
+	eval[2 * p + 1] = e ? (uint8_t)(1 | (c1 & 2)) : (uint8_t)0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,11 +17,74 @@ def revcomp_ascii(a):
     return _COMP[a[::-1]]
 
 
+def plant_repeats(contigs, seed, scale=1.0, sites=None, alu_copies=100_000, l1_copies=1_000, sat_arrays=100):
+    """Repeat families of a human-like draft, planted in place into `contigs` (uint8 arrays); `scale` =
+    draft size / 3 Gbp scales the copy numbers.  `sites` (a list) receives (contig, start, end) of every copy.
+      * a 300-bp SINE-like element, alu_copies copies, each 10-15 % diverged from the consensus: its 21-mers
+        recur thousands of times (heavy seeds), its 60-mers almost never;
+      * a 6-kbp LINE-like element, l1_copies copies at 3-12 % divergence, most of them 5'-truncated;
+      * tandem arrays of a 171-bp satellite monomer (20-60 kbp each), monomers 1-4 % diverged: windows that
+        recur inside an array and between arrays (value 0), second and third diagonals a few bases apart."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED5EED))
+    big = np.array([j for j, c in enumerate(contigs) if len(c) >= 12000], dtype=np.int64)
+    if len(big) == 0:
+        return
+
+    def mutated(cons, n, dlo, dhi):
+        d = rng.uniform(dlo, dhi, size=(n, 1))
+        out = np.broadcast_to(cons, (n, len(cons))).copy()
+        hit = rng.random(out.shape) < d
+        out[hit] = _ACGT[rng.integers(0, 4, size=int(hit.sum()), dtype=np.uint8)]
+        return out
+
+    def place(block, lens=None):
+        n = len(block)
+        cj = big[rng.integers(0, len(big), size=n)]
+        for i in range(n):
+            L = int(lens[i]) if lens is not None else block.shape[1]
+            c = contigs[int(cj[i])]
+            p = int(rng.integers(0, len(c) - L))
+            c[p:p + L] = block[i][block.shape[1] - L:] if lens is not None else block[i]
+            if sites is not None:
+                sites.append((int(cj[i]), p, p + L))
+
+    n_alu = max(1, int(alu_copies * scale))
+    alu = _ACGT[rng.integers(0, 4, size=300, dtype=np.uint8)]
+    for lo in range(0, n_alu, 20000):
+        place(mutated(alu, min(20000, n_alu - lo), 0.10, 0.15))
+    n_l1 = max(1, int(l1_copies * scale))
+    l1 = _ACGT[rng.integers(0, 4, size=6000, dtype=np.uint8)]
+    place(mutated(l1, n_l1, 0.03, 0.12), lens=np.where(rng.random(n_l1) < 0.7, rng.integers(500, 6000, size=n_l1), 6000))
+    mono = _ACGT[rng.integers(0, 4, size=171, dtype=np.uint8)]
+    for _ in range(max(1, int(sat_arrays * scale))):
+        j = int(big[rng.integers(0, len(big))])
+        c = contigs[j]
+        L = int(min(rng.integers(20000, 60000), len(c) - 200))
+        p = int(rng.integers(0, len(c) - L))
+        arr = mutated(mono, L // 171 + 1, 0.01, 0.04).reshape(-1)[:L]
+        c[p:p + L] = arr
+        if sites is not None:
+            sites.append((j, p, p + L))
+
+
+def sites_to_runs(contigs, sites):
+    """(contig, start, end) -> int64[n, 2] intervals of the concatenated draft (what sub_draft_index takes)"""
+    lens = np.fromiter((len(c) for c in contigs), dtype=np.int64, count=len(contigs))
+    cstart = np.zeros(len(contigs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=cstart[1:])
+    if not sites:
+        return np.zeros((0, 2), dtype=np.int64)
+    a = np.asarray(sites, dtype=np.int64)
+    return np.stack([cstart[a[:, 0]] + a[:, 1], cstart[a[:, 0]] + a[:, 2]], axis=1)
+
+
 def make_draft(total_bp, seed=SEED, lengths=(20000, 50000, 100000, 230000), small_frac=0.005,
-               inject=True, dup_events=None, touched=None):
+               inject=True, dup_events=None, touched=None, repeats=False, repeat_sites=None):
     """list of uint8 ASCII arrays (contigs, FASTA order).  dup_events (a list) receives the
     (source contig, destination contig) of every copied segment, so that a caller can find the
-    contigs that share k-mers with a given set (closed_contig_set)."""
+    contigs that share k-mers with a given set (closed_contig_set).  repeats=True plants human-like
+    repeat families (plant_repeats; copy numbers scaled by total_bp / 3 Gbp) before the other quirks
+    are injected; repeat_sites (a list) receives their (contig, start, end)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     contigs = []
     acc = 0
@@ -34,6 +97,8 @@ def make_draft(total_bp, seed=SEED, lengths=(20000, 50000, 100000, 230000), smal
         i += 1
         if rng.random() < small_frac:  # a contig shorter than -z 500: skipped by the index
             contigs.append(_ACGT[rng.integers(0, 4, size=int(rng.integers(50, 499)), dtype=np.uint8)])
+    if repeats:
+        plant_repeats(contigs, seed, scale=total_bp / 3e9, sites=repeat_sites)
     if inject:
         big = [j for j, c in enumerate(contigs) if len(c) >= 12000]
         n_events = max(1, total_bp // 1_000_000)

@@ -137,11 +137,13 @@ class Workload:
     a single rank would map there."""
 
     def __init__(self, draft_mbp, pairs, chunk, k, j, dev, local, log, blocks=None, set_id=0, want_stats=True,
-                 keep_draft=False):
+                 keep_draft=False, repeats=False):
         self.k, self.j = k, j
         t0 = time.time()
         self.dup_events = []
-        contigs = synth.make_draft(int(draft_mbp * 1e6), seed=synth.SEED, dup_events=self.dup_events)
+        self.repeat_sites = []
+        contigs = synth.make_draft(int(draft_mbp * 1e6), seed=synth.SEED, dup_events=self.dup_events,
+                                   repeats=repeats, repeat_sites=self.repeat_sites)
         self.n_contigs = len(contigs)
         ends = []
         for c in contigs:
@@ -213,63 +215,82 @@ class Workload:
         return elapsed, launch_ms, st, int(stored.item())
 
 
-def cpu_baseline(wl, dev, local, log, sub_mbp=50.0):
-    """The CPU oracle (a literal port of the reference path: per-window O(k) re-encode, exact hash map,
-    ordered histogram; OpenMP over pairs, Arcs.cpp:1169) timed at t=1 and on the physical cores of ONE
-    socket ON THE SAME SAMPLE: reads of the workload's shape drawn from the first `sub_mbp` of the draft,
-    as many pairs as one thread maps in ~15 s.  The oracle indexes the ends of those contigs plus the
-    contigs they share copied segments with, plus the windows around every (AT)n stretch of the whole draft
-    (the whole 1.4 G-key map does not fit a bench run), numbered as in the whole draft.  Sample parity: the
-    GPU maps a larger sample (4 M pairs, microsatellite reads included) against the WHOLE index and must
-    agree read for read with the oracle.  Test infrastructure, never the product path."""
+def sub_draft_oracle(wl, log, sub_mbp):
+    """(oracle index, bases of the sub-draft): the ends of the contigs of the first `sub_mbp` of the draft plus the
+    contigs they share copied segments with, plus the windows around every (AT)n stretch and every planted repeat
+    copy of the WHOLE draft (their k-mers recur between sites), numbered as in the whole draft -- gives the whole
+    index's answers for reads drawn from the sub-draft (tests/test_oracle_subdraft.py)."""
     from oracle import pyoracle as O
     O.build_oracle()
-    k, j = wl.k, wl.j
     contigs = wl.contigs
     acc, n_first = 0, 0
     while n_first < len(contigs) and acc < sub_mbp * 1e6:
         acc += len(contigs[n_first])
         n_first += 1
     members = set(synth.closed_contig_set(n_first, wl.dup_events))
+    t0 = time.time()
+    runs = synth.alternating_at_runs(wl.genome, run=12)
+    n_at = len(runs)
+    if wl.repeat_sites:
+        runs = np.concatenate([runs, synth.sites_to_runs(contigs, wl.repeat_sites)])
+    ox = O.sub_draft_index(wl.k, contigs, members, site_runs=runs)
+    log(f"cpu oracle index: ends of {len(members)} contigs + the windows around {n_at} (AT)n stretches and "
+        f"{len(wl.repeat_sites)} repeat copies, {len(ox)} keys in {time.time() - t0:.1f}s")
+    return ox, acc
+
+
+def sample_against_oracle(wl, ox, acc, n_pairs, seed, threads, dev, local):
+    """n_pairs read pairs of the workload's shape drawn from the sub-draft: the oracle on `threads` threads, the GPU
+    against the WHOLE index -> (identical?, oracle seconds, oracle counters, pairs that reach into a microsatellite,
+    host arrays for further oracle runs)"""
+    batch = synth.make_read_pairs(wl.genome[:acc], n_pairs, seed=seed, device=dev)
+    n_at = int(synth.pairs_touching_microsatellite(batch).sum().item())
+    a = np.concatenate([batch["ascii"].cpu().numpy(), np.zeros(1, np.uint8)])
+    lens = batch["lens"].cpu().numpy().astype(np.uint32)
+    offs = batch["offsets"].cpu().numpy().astype(np.uint64)
+    ok = batch["pair_ok"].cpu().numpy()
+    t = time.time()
+    c, p, st = ox.map_pairs(a, offs[: 2 * n_pairs], lens, wl.j, pair_ok=ok, threads=threads)
+    dt = time.time() - t
+    reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
+    got_c, got_p = arcs_amd.map_pairs_packed(wl.index, reads, wl.j, pair_ok=batch["pair_ok"])
+    torch.cuda.synchronize(dev)
+    same = bool((got_c.cpu().numpy() == c).all() and (got_p.cpu().numpy() == p).all())
+    return same, dt, st, n_at, (a, offs, lens, ok)
+
+
+def cpu_baseline(wl, dev, local, log, sub_mbp=50.0):
+    """The CPU oracle (a literal port of the reference path: per-window O(k) re-encode, exact hash map,
+    ordered histogram; OpenMP over pairs, Arcs.cpp:1169) timed at t=1 and on the physical cores of ONE
+    socket ON THE SAME SAMPLE: reads of the workload's shape drawn from the first `sub_mbp` of the draft,
+    as many pairs as one thread maps in ~15 s (sub_draft_oracle: the whole 1.4 G-key map does not fit a bench
+    run).  Sample parity: the GPU maps a larger sample (4 M pairs, microsatellite reads included) against the
+    WHOLE index and must agree read for read with the oracle.  Test infrastructure, never the product path."""
+    k, j = wl.k, wl.j
     model, sockets = cpu_topology()
     sock = sorted(sockets)[0]
     cores = sockets[sock]
     saved = os.sched_getaffinity(0)
     os.sched_setaffinity(0, cores)             # OpenMP workers are created after this and inherit it
     try:
-        t0 = time.time()
-        at_runs = synth.alternating_at_runs(wl.genome, run=12)
-        ox = O.sub_draft_index(k, contigs, members, at_runs=at_runs)
-        log(f"cpu oracle index: ends of {len(members)} contigs + the windows around {len(at_runs)} (AT)n stretches, "
-            f"{len(ox)} keys in {time.time() - t0:.1f}s")
-        sub_genome = wl.genome[:acc]
-        probe = 20000
+        ox, acc = sub_draft_oracle(wl, log, sub_mbp)
         n_max = 4_000_000
-        batch = synth.make_read_pairs(sub_genome, n_max, seed=synth.SEED + 777, device=dev)
-        n_at = int(synth.pairs_touching_microsatellite(batch).sum().item())
-        a_all = np.concatenate([batch["ascii"].cpu().numpy(), np.zeros(1, np.uint8)])
-        lens_all = batch["lens"].cpu().numpy().astype(np.uint32)
-        offs_all = batch["offsets"].cpu().numpy().astype(np.uint64)
-        ok_all = batch["pair_ok"].cpu().numpy()
+        parity, dtl, stl, n_at, (a_all, offs_all, lens_all, ok_all) = sample_against_oracle(
+            wl, ox, acc, n_max, synth.SEED + 777, len(cores), dev, local)
 
         def run(n_pairs, threads):
             t = time.time()
-            c, p, st = ox.map_pairs(a_all, offs_all[: 2 * n_pairs], lens_all[: 2 * n_pairs], j,
+            _, _, st = ox.map_pairs(a_all, offs_all[: 2 * n_pairs], lens_all[: 2 * n_pairs], j,
                                     pair_ok=ok_all[:n_pairs], threads=threads)
-            return time.time() - t, c, p, st
+            return time.time() - t, st
 
-        dt, _, _, _ = run(probe, 1)
+        probe = 20000
+        dt, _ = run(probe, 1)
         n_same = int(min(1_000_000, max(100_000, 15.0 * probe / max(dt, 1e-9))))
-        dt1, _, _, st1 = run(n_same, 1)
+        dt1, st1 = run(n_same, 1)
         dts_same = min(run(n_same, len(cores))[0] for _ in range(3))
-        dtl, c, p, stl = run(n_max, len(cores))
     finally:
         os.sched_setaffinity(0, saved)
-    # the GPU on the same reads, against the whole index
-    reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
-    got_c, got_p = arcs_amd.map_pairs_packed(wl.index, reads, j, pair_ok=batch["pair_ok"])
-    torch.cuda.synchronize(dev)
-    parity = bool((got_c.cpu().numpy() == c).all() and (got_p.cpu().numpy() == p).all())
     what = (f"{n_same} pairs ({st1['windows']} windows) of the workload's shape drawn from the first "
             f"{acc / 1e6:.0f} Mbp of the draft")
     out = {"value": st1["windows"] / dts_same, "unit": "k-mers/s", "cores": len(cores), "kind": "port",
@@ -285,6 +306,30 @@ def cpu_baseline(wl, dev, local, log, sub_mbp=50.0):
                                       f"into an (AT)n microsatellite; the GPU mapped the same reads against the "
                                       f"whole index: {'identical' if parity else 'DIFFERENT'}"}}
     return out, parity
+
+
+def repeats_key(args, k, j, dev, local, log, barrier):
+    """Secondary key `configs2_repeats`: the same 3 Gbp draft with human-like repeat families planted
+    (synth.plant_repeats: 1e5 copies of a 300-bp element at 10-15 % divergence, 1e3 of a 6-kbp element, satellite
+    arrays) -- reads that touch them carry heavy seeds and leave the hot kernel for the general ones -- and
+    100 M read pairs in one launch; sample parity on 1 M pairs as for the headline."""
+    pairs = min(args.pairs, 100_000_000)
+    wl = Workload(args.draft_mbp, pairs, pairs, k, j, dev, local, log, want_stats=False, keep_draft=True, repeats=True)
+    el, l_ms, st, _ = wl.timed(max(2, args.steps // 2), 1, barrier)
+    steps = max(2, args.steps // 2)
+    q = arcs_amd.queue_counts(wl.index)
+    ox, acc = sub_draft_oracle(wl, log, 30.0)
+    same, dt, sto, n_at, _ = sample_against_oracle(wl, ox, acc, 1_000_000, synth.SEED + 778,
+                                                   min(64, os.cpu_count() or 1), dev, local)
+    return {"workload": f"synthetic {args.draft_mbp:g} Mbp draft with planted repeat families "
+                        f"({len(wl.repeat_sites)} copies) + {pairs} linked-read pairs in one launch, k={k} j={j}",
+            "value": st["windows"] * steps / el, "unit": "k-mers/s", "kernel_ms": float(np.mean(l_ms)),
+            "kernel_ms_per_20M_pairs": float(np.mean(l_ms)) * 20_000_000 / max(1, pairs),
+            "reads_left_to_general_kernels": {"medium": q[1], "slow": q[0], "of": 2 * pairs},
+            "index_keys": len(wl.index), "index_bytes": wl.index.device_bytes,
+            "sample_parity": same, "sample": f"1000000 pairs drawn from the first {acc / 1e6:.0f} Mbp, oracle "
+                                             f"{dt:.1f}s; GPU against the whole index: "
+                                             f"{'identical' if same else 'DIFFERENT'}"}
 
 
 def end_to_end(wl, dev, local, n_batches=8, pairs=2_000_000):
@@ -509,6 +554,9 @@ def main():
             c2 = Workload(50.0, 20_000_000, 20_000_000, k, j, dev, local, log, want_stats=False)
             e2, l2, s2, _ = c2.timed(args.steps, args.warmup, barrier)
             b2 = alg_bytes_per_window(k, c2.bases, c2.windows_all)
+            del c2
+            torch.cuda.empty_cache()
+            out["configs2_repeats"] = repeats_key(args, k, j, dev, local, log, barrier)
             out["configs1"] = {"workload": "synthetic 50 Mbp draft + 20000000 linked-read pairs, k=60 j=0.55",
                                "value": s2["windows"] * args.steps / e2, "unit": "k-mers/s",
                                "kernel_ms": float(np.mean(l2)),
@@ -516,6 +564,8 @@ def main():
         print(json.dumps(out), flush=True)
         if cpu_leg:
             assert out["sample_parity"], "GPU results differ from the CPU oracle on the sample"
+        if "configs2_repeats" in out:
+            assert out["configs2_repeats"]["sample_parity"], "repeat-rich draft: GPU results differ from the CPU oracle"
     if world > 1:
         dist.destroy_process_group()
 

@@ -188,8 +188,10 @@ int arks_end_cutoff(int len, int min_size, int end_length, int* cutoff);
 int arks_word_offsets(const uint32_t* h_lens, int64_t n, uint64_t* h_word_off);
 
 /* ASCII -> packed, on the device.  d_read_class[r] (may be NULL) receives what
- * checkReadSequence (Arcs/Arcs.cpp:366-389) decides for read r: 1 = accepted (only ACGTN,
- * N fraction <= 0.02), 0 = rejected. */
+ * checkReadSequence (Arcs/Arcs.cpp:366-389) decides for read r in bit 0: 1 = accepted (only ACGTN,
+ * N fraction <= 0.02), 0 = rejected; bit 1 is set for an accepted read that holds ACGT only (values
+ * 0, 1, 3): arks_pair_gate_device hands it on, and the map kernels do not fetch the N masks of such
+ * reads. */
 int arks_pack_reads_device(
     const uint8_t* d_ascii,
     const uint64_t* d_offsets,
@@ -350,8 +352,11 @@ int arks_imap_export(const arks_imap* m, uint32_t* h_triples);
 int arks_imap_set_pair_base(arks_imap* m, uint64_t first_pair);
 int arks_imap_export_ordered(const arks_imap* m, uint32_t* h_triples, uint64_t* h_first_pair);
 
-/* The gate of chromiumRead, Arcs/Arcs.cpp:1264-1268: d_eval[2p] = d_eval[2p+1] =
- * pair_ok[p] && class[2p] && class[2p+1]  (goodmult is always true, :1267). */
+/* The gate of chromiumRead, Arcs/Arcs.cpp:1264-1268: d_eval[2p], d_eval[2p+1] nonzero iff
+ * pair_ok[p] && (class[2p] & 1) && (class[2p+1] & 1)  (goodmult is always true, :1267); a nonzero
+ * d_eval[r] is 1 | (class[r] & 2): bit 1 = "read r holds ACGT only".  Any nonzero value means
+ * "evaluate" to arks_map_reads_device; a caller's own array of 0 / 1 is as good (the N masks of
+ * every read are fetched then). */
 int arks_pair_gate_device(
     const uint8_t* d_pair_ok,
     const uint8_t* d_read_class,
@@ -386,13 +391,6 @@ int arks_pairs_device(
     uint64_t* d_stored,
     int device,
     void* stream);
-
-/* ---- debugging aid --------------------------------------------------------------------------- */
-
-/* Lengths of the work queues after the last map call on `idx` (waits for the device): out4[0] = reads
- * that took the slow kernel, out4[2] = reads that took the medium kernel ([1], [3]: their work
- * counters).  For tests and profiling; results never depend on it. */
-int arks_debug_queue_counts(const arks_index* idx, unsigned* out4);
 
 #ifdef __cplusplus
 }

@@ -251,12 +251,28 @@ map_kmers_scan(
 	if (len < k) /* :877-882 (the reference also prints a warning) */
 		return 0;
 	int i = 0;
-	while (i <= len - k) { /* :887 */
-		if (arks_oracle_key(seq, (size_t)i, k, key)) {
-			if (i < lo || i >= hi) { /* visited, but not asked for (arks_oracle_map_kmers_range) */
-				i++;
-				continue;
+	init_code();
+	if (lo > 0) {
+		/* arks_oracle_map_kmers_range: the windows in front of lo only steer the walk (i + 1 after a window
+		 * without an invalid character, i + k after one with: the only NULL condition of the key function),
+		 * so no key is made for them */
+		int next_bad = -1; /* first invalid position >= i, found lazily */
+		while (i < lo && i <= len - k) {
+			if (next_bad < i) {
+				next_bad = i;
+				while (next_bad < len && g_code[(unsigned char)seq[next_bad]] != 0xFF)
+					next_bad++;
 			}
+			if (next_bad >= i + k)
+				i = next_bad - k + 1 < lo ? next_bad - k + 1 : lo; /* every window up to there is valid */
+			else
+				i += k;
+		}
+	}
+	while (i <= len - k) { /* :887 */
+		if (i >= hi)
+			break; /* (range variant) nothing behind hi is asked for */
+		if (arks_oracle_key(seq, (size_t)i, k, key)) {
 			num++;
 			if ((idx->size + 1) * 2 > idx->cap)
 				grow(idx);

@@ -190,16 +190,17 @@ class OracleIndex:
         return out_c, out_p, d
 
 
-def sub_draft_index(k, contigs, members, min_size=500, end_length=30000, at_runs=None):
+def sub_draft_index(k, contigs, members, min_size=500, end_length=30000, site_runs=None):
     """OracleIndex over the ends of the contigs whose index is in `members` (contigs: uint8 arrays or
     bytes, FASTA order), numbered as getContigKmers numbers them in the WHOLE draft (head of the n-th
     valid contig = 2n-1, tail = 2n): what a human-scale index is checked against when the whole map
     (1.4 G keys) is out of a test's reach -- see arcs_amd.synth.closed_contig_set for which contigs a
     set of reads needs.
 
-    at_runs (arcs_amd.synth.alternating_at_runs of the concatenated draft): the stretches whose k-mers
-    (short flank + (AT)n, and the reverse-complement palindromes inside) recur between sites all over
-    the draft.  For every contig that is NOT a member, the windows of its ends that overlap such a
+    site_runs (int64[n, 2] intervals of the concatenated draft: arcs_amd.synth.alternating_at_runs, and
+    synth.sites_to_runs of a draft's planted repeat copies): the stretches whose k-mers (short flank +
+    (AT)n and the reverse-complement palindromes inside; windows of repeat copies) recur between sites
+    all over the draft.  For every contig that is NOT a member, the windows of its ends that overlap such a
     stretch are inserted too -- under the visit rule of the whole end (map_kmers_range) -- so that these
     keys carry the whole draft's value (owner or 0) and reads that reach into a microsatellite need not
     be left out of the comparison."""
@@ -209,8 +210,8 @@ def sub_draft_index(k, contigs, members, min_size=500, end_length=30000, at_runs
     cstart = np.zeros(len(contigs) + 1, dtype=np.int64)
     np.cumsum(lens, out=cstart[1:])
     per_contig = {}
-    if at_runs is not None:
-        for s, e in np.asarray(at_runs, dtype=np.int64):
+    if site_runs is not None:
+        for s, e in np.asarray(site_runs, dtype=np.int64):
             ci = int(np.searchsorted(cstart, s, side="right") - 1)
             while s < e and ci < len(contigs):               # a stretch that runs over a contig border is cut there
                 stop = min(e, cstart[ci + 1])

@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_functions():
+    # the boundary (arks_hip.h) and the diagnostics header beside it (arks_hip_debug.h: tests / profiling only)
     text = open(os.path.join(ROOT, "include", "arks_hip.h")).read()
+    assert "arks_debug_" not in text
+    text += open(os.path.join(ROOT, "include", "arks_hip_debug.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(arks_[a-z0-9_]+)\s*\(", text)))
 

@@ -141,7 +141,7 @@ def test_human_scale_draft(arks, gpu, oracle):
     # medium and slow kernels at a 1.4 G-key index)
     at_runs = synth.alternating_at_runs(genome, run=12)
     assert len(at_runs) >= 2500
-    ox = oracle.sub_draft_index(k, contigs, members, at_runs=at_runs)
+    ox = oracle.sub_draft_index(k, contigs, members, site_runs=at_runs)
     n_pairs = 4_000_000
     batch = synth.make_read_pairs(genome[:acc], n_pairs, seed=4242, device="cuda")
     n_at = int(synth.pairs_touching_microsatellite(batch).sum().item())
@@ -237,7 +237,7 @@ def test_beyond_one_index_in_shards(arks, gpu, oracle):
     del parts
     acc, members = _sub_draft(synth, contigs, dup_events, 30.0)
     at_runs = synth.alternating_at_runs(torch.from_numpy(np.concatenate(contigs)).cuda(), run=12)
-    ox = oracle.sub_draft_index(k, contigs, members, end_length=END, at_runs=at_runs)
+    ox = oracle.sub_draft_index(k, contigs, members, end_length=END, site_runs=at_runs)
     n_pairs = 2_000_000
     n_sub = 0
     while sum(len(c) for c in contigs[:n_sub]) < acc:
@@ -307,7 +307,7 @@ def test_arks_long_human_scale_multi_k(arks, gpu, oracle):
         conreci, pair = arks.map_pairs_packed(ix, reads, j, pair_ok=batch["pair_ok"], barcode_id=batch["barcode_id"],
                                               stats=stats)
         torch.cuda.synchronize()
-        ox = oracle.sub_draft_index(k, contigs, members, at_runs=at_runs)
+        ox = oracle.sub_draft_index(k, contigs, members, site_runs=at_runs)
         want_c, want_p, want_st = ox.map_pairs(a, offs, lens, j, pair_ok=ok, threads=min(64, os.cpu_count() or 1))
         assert (conreci.cpu().numpy() == want_c).all(), k
         assert (pair.cpu().numpy() == want_p).all(), k
