@@ -317,3 +317,69 @@ def test_arks_long_human_scale_multi_k(arks, gpu, oracle):
     assert passed > n_pairs          # most pairs name an end at every k with j = 0.05
     for ix in ixs.values():
         ix.close()
+
+
+def test_seed_table_in_eight_shards_human_scale(arks, gpu, oracle):
+    """BASELINE configs[3] at its size on ONE MI355X: the 3 Gbp draft's seed table split into 8 shards by the hash
+    prefix of the m-mer (arks_index_build_seed_shard, what 8 ranks would hold one each) -- all eight resident here --,
+    2 M read pairs mapped on a home shard with every seed answered by the shard that owns it (the all-to-all of
+    arcs_amd.dist.exchange_seeds done by hand, as tests/test_gpu_seed_shards.py does at 0.4 Mbp).  Against the
+    sub-draft oracle: conreci, pair rule, all eight counters, IndexMap; microsatellite reads included."""
+    import torch
+    from arcs_amd import synth
+    k, j, n_ranks = 60, 0.55, 8
+    dup_events = []
+    contigs = synth.make_draft(3_000_000_000, seed=synth.SEED, dup_events=dup_events)
+    ends = _ends_of(arks, contigs)
+    shards = []
+    for r in range(n_ranks):
+        shards.append(arks.ArksIndex.build_seed_shard(ends, k, r, n_ranks, device=gpu))
+        assert shards[-1].kind == 2 and shards[-1].seed_ranks == n_ranks
+    del ends
+    sizes = [sh.device_bytes for sh in shards]
+    assert len(shards[0]) > 1_400_000_000
+    # nobody holds the whole 43 GB table: a shard is the replicated text / fallback / minimizer table + 1/8 of the seeds
+    assert max(sizes) < 14 * 2**30, sizes
+    genome = torch.from_numpy(np.concatenate(contigs)).cuda()
+    acc, members = _sub_draft(synth, contigs, dup_events, 30.0)
+    ox = oracle.sub_draft_index(k, contigs, members, site_runs=synth.alternating_at_runs(genome, run=12))
+    n_pairs = 2_000_000
+    batch = synth.make_read_pairs(genome[:acc], n_pairs, seed=4646, device="cuda")
+    del genome
+    reads = arks.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=gpu)
+    ev = arks.pair_gate(reads, batch["pair_ok"])
+    home = shards[3]
+    counts = arks.api.seed_counts(home, reads, ev)
+    seed_off = torch.zeros(reads.n_reads + 1, dtype=torch.int64, device="cuda")
+    seed_off[1:] = torch.cumsum(counts.to(torch.int64), 0)
+    mmer, owner = arks.api.seeds_fill(home, reads, seed_off, ev)
+    per_owner = torch.bincount(owner.to(torch.int64), minlength=n_ranks).cpu().numpy()
+    assert per_owner.min() > 0.8 * per_owner.mean() and per_owner.max() < 1.2 * per_owner.mean()   # the hash spreads
+    answers = torch.zeros(2 * mmer.numel(), dtype=torch.int64, device="cuda")
+    for r, sh in enumerate(shards):                       # the exchange, by hand: owner r answers its seeds
+        sel = (owner == r).nonzero().flatten()
+        answers.view(-1, 2)[sel] = arks.api.seeds_probe(sh, mmer[sel].contiguous()).view(-1, 2)
+    # a foreign shard knows nothing of a seed it does not own
+    foreign = arks.api.seeds_probe(shards[1], mmer[(owner == 0).nonzero().flatten()[:100000]].contiguous())
+    assert int((foreign.view(-1, 2)[:, 0] != 0).sum()) == 0
+    stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+    imap = arks.ImapAccumulator(1 << 20, device=gpu)
+    conreci = arks.api.map_reads_seeded(home, reads, j, seed_off, answers, eval_mask=ev, stats=stats)
+    pair = arks.pairs_rule(conreci, reads, batch["pair_ok"], batch["barcode_id"], imap)
+    torch.cuda.synchronize()
+    ok = batch["pair_ok"].cpu().numpy()
+    a = np.concatenate([batch["ascii"].cpu().numpy(), np.zeros(1, np.uint8)])
+    want_c, want_p, want_st = ox.map_pairs(a, batch["offsets"].cpu().numpy().astype(np.uint64)[:-1],
+                                           batch["lens"].cpu().numpy().astype(np.uint32), j, pair_ok=ok,
+                                           threads=min(64, os.cpu_count() or 1))
+    assert (conreci.cpu().numpy() == want_c).all()
+    assert (pair.cpu().numpy() == want_p).all()
+    assert dict(zip(STAT_NAMES, stats.cpu().tolist())) == {f: want_st[f] for f in STAT_NAMES}
+    sel = (want_p != 0) & (ok != 0)
+    key = batch["barcode_id"].cpu().numpy().astype(np.int64)[sel] * (1 << 32) + want_p[sel]
+    uk, cnt = np.unique(key, return_counts=True)
+    t = imap.triples()
+    assert len(t) == len(uk) and (t[:, 0].astype(np.int64) * (1 << 32) + t[:, 1] == uk).all() and (t[:, 2] == cnt).all()
+    assert int((want_p != 0).sum()) > n_pairs // 10
+    for sh in shards:
+        sh.close()

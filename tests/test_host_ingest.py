@@ -91,7 +91,9 @@ def expected(records, mult, oracle, fused=False):
             if not valid:
                 c["invalid"] += 1
         ok = n1 == n2 and valid and b1 == b2
+        # the packers' class byte: bit 0 = checkReadSequence accepts, bit 1 = accepted and ACGT only (include/arks_hip.h)
         cls = [int(oracle.check_read_sequence(r[2])) for r in (r1, r2)]
+        cls = [c | (2 if c and not set(r[2]) - set("ACGTacgt") else 0) for c, r in zip(cls, (r1, r2))]
         rh += [read_hash(r1[2], cls[0]), read_hash(r2[2], cls[1])]
         ph.append(fnv(fnv(FNV0, bytes([1])), b1.encode()) if ok else fnv(FNV0, bytes([0])))
         c["pairs"] += 1
