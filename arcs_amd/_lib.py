@@ -55,6 +55,12 @@ SYMBOLS = {
     "arks_seeds_fill_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     "arks_seeds_probe_device": (_I, [_VP, _VP, _I64, _VP, _VP]),
     "arks_map_reads_seeded_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _D, _VP, _VP, _VP]),
+    "arks_exchange_unique_id": (_I, [_VP]),
+    "arks_exchange_create": (_I, [C.POINTER(_VP), _VP, _VP, _I, _I]),
+    "arks_exchange_create_local": (_I, [_VP, _VP, _I]),
+    "arks_exchange_free": (_I, [_VP]),
+    "arks_exchange_last_stats": (_I, [_VP, _VP]),
+    "arks_map_reads_exchanged_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
     "arks_index_free": (_I, [_VP]),
     "arks_index_k": (_I, [_VP]),
     "arks_index_size": (_I64, [_VP]),

@@ -363,6 +363,80 @@ def map_reads_seeded(index, reads, j_index, seed_off, answers, eval_mask=None, s
     return out[:n]
 
 
+class ExchangeStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("seeds", "sent", "received")]
+
+
+class SeedExchange:
+    """arks_exchange: one rank of a seed table sharded over `world` ranks (ArksIndex.build_seed_shard), with the
+    transport to the others -- RCCL between processes (create), device copies between the ranks of one process
+    that share a device (create_local: one host thread per rank).  map_reads is the whole step for a batch of
+    this rank's reads and is collective: every rank calls it in step."""
+
+    def __init__(self, handle, index):
+        self._h = handle
+        self.index = index
+
+    @staticmethod
+    def unique_id():
+        """rank 0: the 128-byte id every rank passes to create (ncclGetUniqueId)"""
+        buf = (C.c_ubyte * 128)()
+        check(lib().arks_exchange_unique_id(buf), "arks_exchange_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, index, rank, world, unique_id=None):
+        h = C.c_void_p()
+        idb = (C.c_ubyte * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        check(lib().arks_exchange_create(C.byref(h), index.handle, idb, int(rank), int(world)), "arks_exchange_create")
+        return cls(h, index)
+
+    @classmethod
+    def create_local(cls, shards):
+        world = len(shards)
+        hs = (C.c_void_p * world)()
+        ix = (C.c_void_p * world)(*[sh.handle for sh in shards])
+        check(lib().arks_exchange_create_local(hs, ix, world), "arks_exchange_create_local")
+        return [cls(C.c_void_p(hs[r]), shards[r]) for r in range(world)]
+
+    def close(self):
+        if self._h:
+            lib().arks_exchange_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_stats(self):
+        st = ExchangeStats()
+        check(lib().arks_exchange_last_stats(self._h, C.byref(st)), "arks_exchange_last_stats")
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+
+    def map_reads(self, reads, j_index, eval_mask=None, stats=None, out=None):
+        """arks_map_reads_exchanged_device on the current torch stream -> int32 conreci tensor"""
+        torch = _torch()
+        n = reads.n_reads
+        if out is None:
+            out = torch.empty(max(n, 1), dtype=torch.int32, device=reads.codes.device)
+        check(lib().arks_map_reads_exchanged_device(
+            self._h, reads.codes.data_ptr(), reads.nmask.data_ptr(), reads.word_off.data_ptr(), reads.lens.data_ptr(),
+            eval_mask.data_ptr() if eval_mask is not None else None, n, float(j_index), out.data_ptr(),
+            stats.data_ptr() if stats is not None else None, _stream_ptr(reads.device)),
+            "arks_map_reads_exchanged_device")
+        return out[:n]
+
+    def map_pairs(self, reads, j_index, pair_ok=None, barcode_id=None, imap=None, stored=None, stats=None):
+        """chromiumRead's per-pair flow (Arcs.cpp:1264-1292) for this rank's read pairs: gate -> exchanged map ->
+        pair rule + IndexMap update.  Returns (conreci, pair)."""
+        ev = pair_gate(reads, pair_ok)
+        conreci = self.map_reads(reads, j_index, eval_mask=ev, stats=stats)
+        pair = pairs_rule(conreci, reads, pair_ok, barcode_id, imap, stored)
+        return conreci, pair
+
+
 def map_votes_packed(index, reads, eval_mask=None, out=None):
     """arks_map_votes_device against one shard of the index, on the current torch stream: int64[n]
     (bit pattern: count << 32 | ~conreci, 0 = nothing recorded); the maximum over shards is the vote

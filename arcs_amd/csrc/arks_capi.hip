@@ -1873,3 +1873,5 @@ arks_debug_section_cycles(unsigned long long* out16)
 #endif
 
 } /* extern "C" */
+
+#include "arks_exchange.hpp"

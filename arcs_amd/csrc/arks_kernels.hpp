@@ -38,7 +38,12 @@ hipError_t launch_seeds_probe(int mm, const BIndexView& bx, const u64* cm, long 
 hipError_t launch_map_reads_seeded(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval,
     long n_reads, double j_index, const KeyGeom& g, const BIndexView& bx, const BIndexView& bxg, const long* seed_off,
-    const u64* ans, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st);
+    const u64* ans, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st,
+    const u32* seed_slot = nullptr);
+long seed_bucket_blocks(long n_reads);
+hipError_t launch_seed_buckets(
+    int mm, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval, long n_reads,
+    int k, int w, u32 n_owners, u32* cols, u64* totals, long* seed_off, u32* slot, u64* send, int phase, hipStream_t st);
 hipError_t launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner, hipStream_t st);
 hipError_t launch_bmark(
     int kw, int mm, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,

@@ -414,8 +414,13 @@ def main():
                     help="N > 1: every rank maps its own --pairs read pairs (per-GPU work fixed) instead of a share "
                          "of the one read set (the default: strong scaling on the fixed workload)")
     ap.add_argument("--strong", action="store_true", help="(the default; kept for older command lines)")
+    ap.add_argument("--repeats", action="store_true",
+                    help="the headline workload on the draft with planted repeat families (what the configs2_repeats "
+                         "key runs at 100 M pairs): for profiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] line and the end-to-end figure")
+    ap.add_argument("--shards", type=int, default=8,
+                    help="--sharded-index with one process: shards (local ranks) the seed table is cut into")
     ap.add_argument("--sharded-index", action="store_true",
                     help="BASELINE configs[3]: the index's seed table sharded over the ranks by a hash prefix of the "
                          "m-mer, the --pairs read pairs split over the ranks, every seed routed to its owner and "
@@ -461,7 +466,7 @@ def main():
     blocks = None if weak else blocks_of_rank(n_blocks, rank, world)
     cpu_leg = (not args.no_cpu_baseline) and world == 1
     wl = Workload(args.draft_mbp, args.pairs, args.chunk, k, j, dev, local, log, blocks=blocks,
-                  set_id=rank if weak else 0, want_stats=(rank == 0), keep_draft=cpu_leg)
+                  set_id=rank if weak else 0, want_stats=(rank == 0), keep_draft=cpu_leg, repeats=args.repeats)
     elapsed, launch_ms, st, stored = wl.timed(args.steps, args.warmup, barrier)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -485,6 +490,8 @@ def main():
         win_per_launch = st["windows"] / n_launch
         alg_achieved = win_per_launch * b_alg / (kernel_ms * 1e-3) / 1e9
         workload = {"draft_mbp": args.draft_mbp, "pairs_per_launch": wl.pairs_per_launch, "k": k}
+        if args.repeats:
+            workload["repeats"] = True
         traffic, build_match = pmc_traffic(workload)
         hbm_gb = (traffic["hbm_bytes_per_launch"] / 1e9) if traffic else None
         achieved = (hbm_gb / (kernel_ms * 1e-3)) if traffic else None
@@ -571,14 +578,21 @@ def main():
 
 
 def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
-    """BASELINE configs[3]: the seed table of the index sharded over the ranks by a hash prefix of the m-mer
-    (arks_index_build_seed_shard), the --pairs read pairs split over the ranks (strong scaling), every seed
-    routed to its owner and answered there (all_to_all_single over RCCL), DESIGN.md 6.  One step = gate ->
-    seeds -> exchange -> map -> pair rule over this rank's reads, in launches of --chunk pairs."""
+    """BASELINE configs[3]: the seed table of the index sharded by a hash prefix of the m-mer
+    (arks_index_build_seed_shard), the --pairs read pairs dealt to the ranks in blocks (strong scaling), every seed
+    routed to its owner and answered there -- arks_exchange (include/arks_hip.h): seeds bucketed by owner on the
+    device, ncclSend / ncclRecv groups over RCCL, owner-side probe, answers back, map_reads_s_kernel<REMOTE>;
+    DESIGN.md 6.  One step = gate -> exchanged map -> pair rule over a rank's reads, in launches of --chunk pairs.
+    With ONE process (N = 1) the table is cut into --shards shards all the same (default 8), every shard a local
+    rank with a host thread of its own on the one device: the data path of 8 ranks, timed on one GPU."""
+    import threading
     import torch.distributed as dist
     from arcs_amd import dist as adist
     k, j = args.k, args.j
-    lo, hi = adist.shard_pairs(args.pairs, rank, world)
+    n_local = max(1, args.shards) if world == 1 else 1
+    if n_local > 1:
+        args.chunk = min(args.chunk, 25_000_000)      # the exchange buffers of all local ranks live on the one device
+    n_ranks = world * n_local
     contigs = synth.make_draft(int(args.draft_mbp * 1e6), seed=synth.SEED)
     ends = []
     for c in contigs:
@@ -587,71 +601,133 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
             ends.append(c[:cut].tobytes())
             ends.append(c[len(c) - cut:].tobytes())
     t0 = time.time()
-    index = arcs_amd.ArksIndex.build_seed_shard(ends, k, rank, world, device=local)
+    my_ranks = [rank * n_local + i for i in range(n_local)]
+    shards = [arcs_amd.ArksIndex.build_seed_shard(ends, k, r, n_ranks, device=local) for r in my_ranks]
     del ends
-    log(f"seed shard {rank}/{world}: {index.device_bytes / 2**30:.2f} GiB, built in {time.time() - t0:.1f}s")
+    log(f"seed shards {my_ranks} of {n_ranks}: {[round(sh.device_bytes / 2**30, 2) for sh in shards]} GiB, built in "
+        f"{time.time() - t0:.1f}s")
     genome = torch.from_numpy(np.concatenate(contigs)).to(dev)
     del contigs
-    chunks, windows, bases, done = [], 0, 0, 0
-    while done < hi - lo:
-        n = min(args.chunk, hi - lo - done)
-        batch = synth.make_read_pairs(genome, n, seed=synth.SEED + 1 + 1000 * rank + done // args.chunk, device=dev)
-        reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
-        bid = (batch["barcode_id"] + (lo + done) // 80).to(torch.int32)
-        chunks.append((reads, batch["pair_ok"], bid))
-        bases += int(batch["lens"].to(torch.int64).sum().item())
-        done += n
-        del batch
-    # every rank runs the same number of exchanges per step: ranks with fewer launches add empty ones
-    n_launch = torch.tensor([len(chunks)], dtype=torch.int64, device=red_dev)
+    use_exchange = world == 1 or dist.get_backend() == "nccl"
+    if world == 1:
+        xs = arcs_amd.SeedExchange.create_local(shards)
+    elif use_exchange:
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(arcs_amd.SeedExchange.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        xs = [arcs_amd.SeedExchange.create(shards[0], rank, world, unique_id=bytes(uid.cpu().numpy().tobytes()))]
+    else:
+        xs = [None]          # gloo (ranks sharing one GPU in tests): the torch.distributed driver of arcs_amd/dist.py
+    all_blocks = read_blocks(args.pairs)
+    per_rank, bases = [], 0
+    for r in my_ranks:
+        lo, hi = blocks_of_rank(len(all_blocks), r, n_ranks)
+        launches, cur, cur_pairs = [], [], 0
+        for b in range(lo, hi):
+            first, n = all_blocks[b]
+            batch = synth.make_read_pairs(genome, n, seed=synth.SEED + 1 + b, device=dev)
+            reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
+            bid = ((torch.arange(n, device=dev, dtype=torch.int64) + first) // 80).to(torch.int32)
+            bases += int(batch["lens"].to(torch.int64).sum().item())
+            cur.append((reads, batch["pair_ok"], bid))
+            cur_pairs += n
+            del batch
+            if cur_pairs >= args.chunk or b == hi - 1:
+                launches.append((arcs_amd.PackedReads.concat([c[0] for c in cur]), torch.cat([c[1] for c in cur]),
+                                 torch.cat([c[2] for c in cur])))
+                cur, cur_pairs = [], 0
+        per_rank.append(launches)
+    # every rank makes the same number of (collective) calls per step: ranks with fewer launches add empty ones
+    n_launch = torch.tensor([max(len(l) for l in per_rank)], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(n_launch, op=dist.ReduceOp.MAX)
+    n_launch = int(n_launch.item())
     empty = arcs_amd.PackedReads.from_arrays_device(
         torch.zeros(0, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
         torch.zeros(0, dtype=torch.int32, device=dev), device=local)
-    imap = arcs_amd.ImapAccumulator(1 << 20, device=local)
-    stats = torch.zeros(8, dtype=torch.int64, device=dev)
+    empty_ok = torch.zeros(0, dtype=torch.uint8, device=dev)
+    imaps = [arcs_amd.ImapAccumulator(1 << 20, device=local) for _ in my_ranks]
+    stats = [torch.zeros(8, dtype=torch.int64, device=dev) for _ in my_ranks]
+    streams = [torch.cuda.Stream(dev) for _ in my_ranks]
 
-    def step(st=None):
-        for i in range(int(n_launch.item())):
-            if i < len(chunks):
-                reads, ok, bid = chunks[i]
-                adist.map_pairs_seed_sharded(index, reads, j, pair_ok=ok, barcode_id=bid, imap=imap, stats=st)
-            else:
-                adist.map_reads_seed_sharded(index, empty, j)
+    def rank_step(i, st):
+        with torch.cuda.stream(streams[i]):
+            for l in range(n_launch):
+                reads, ok, bid = per_rank[i][l] if l < len(per_rank[i]) else (empty, empty_ok, None)
+                if xs[i] is not None:
+                    xs[i].map_pairs(reads, j, pair_ok=ok, barcode_id=bid, imap=imaps[i] if bid is not None else None, stats=st)
+                else:
+                    adist.map_pairs_seed_sharded(shards[i], reads, j, pair_ok=ok, barcode_id=bid,
+                                                 imap=imaps[i] if bid is not None else None, stats=st)
+            streams[i].synchronize()
+
+    def step(with_stats=False):
+        if n_local == 1:
+            rank_step(0, stats[0] if with_stats else None)
+            return
+        errs = []
+
+        def run(i):
+            try:
+                torch.cuda.set_device(local)
+                rank_step(i, stats[i] if with_stats else None)
+            except Exception as e:           # noqa: BLE001
+                errs.append(e)
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(n_local)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
 
     for _ in range(args.warmup):
         step()
-    step(stats)
+    step(True)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
         step()
     barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
-    win = torch.tensor([float(stats[7].item())], dtype=torch.float64, device=red_dev)
+    tot = torch.stack(stats).sum(0).to(torch.float64).to(red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(win, op=dist.ReduceOp.SUM)
-    elapsed, windows = float(el.item()), float(win.item())
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    st_job = dict(zip(STAT_NAMES, [int(x) for x in tot.tolist()]))
+    windows = st_job["windows"]
     if rank == 0:
         b_alg = alg_bytes_per_window(k, 279, 161)
         ms = 1e3 * elapsed / args.steps
-        achieved = windows * b_alg / (ms * 1e-3) / 1e9 / world       # per GPU
+        ex = xs[0].last_stats() if xs[0] is not None else None
         print(json.dumps({
             "metric": METRIC, "value": windows * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"synthetic {args.draft_mbp:g} Mbp draft + {args.pairs} linked-read pairs in total "
-                                   f"(R1 128 / R2 151 bp), k={k} j={j}, seed table sharded over {world} rank(s)"
+                                   f"(R1 128 / R2 151 bp), k={k} j={j}, seed table in {n_ranks} hash shards"
+                                   + (f" on {world} GPU(s)" if world > 1 else f", all {n_ranks} on this one GPU "
+                                      "(a local rank and host thread each)")
                                    + (" [BASELINE configs[3]]" if args.draft_mbp == 3000 and args.pairs == 500_000_000 else ""),
-                       "k": k, "j": j, "windows": windows, "shard_bytes": index.device_bytes,
-                       "parallelism": f"seed table hash-sharded x{world}, reads dealt to ranks, seeds routed to their "
-                                      "owners and back (all_to_all_single)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "whole step (seeds, exchange, probe, map_reads_s_kernel, pair rule)",
+                       "k": k, "j": j, "shards": n_ranks, "launches_per_rank_and_step": n_launch,
+                       "shard_bytes": [sh.device_bytes for sh in shards],
+                       "transport": ("RCCL ncclSend/ncclRecv groups" if (world > 1 and use_exchange) else
+                                     "device copies between the local ranks of one process" if world == 1 else
+                                     "torch.distributed gloo through host memory (test transport)"),
+                       "last_batch_of_rank0": ex,
+                       "parallelism": f"seed table hash-sharded x{n_ranks}, reads dealt to the ranks in blocks, seeds "
+                                      "routed to their owners and back (arks_exchange)"},
+            "counters": st_job,
+            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                         "traffic": None, "kernel": "whole step (bucket, exchange, probe, map_reads_s_kernel<REMOTE>, pair rule)",
+                         "alg_achieved": windows * b_alg / (ms * 1e-3) / 1e9 / world,
+                         "alg_frac": windows * b_alg / (ms * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
                          "alg_bytes_per_window": b_alg}}), flush=True)
+    for x in xs:
+        if x is not None:
+            x.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -299,6 +299,50 @@ int arks_map_reads_seeded_device(
     arks_map_stats* d_stats,
     void* stream);
 
+/* ---- the sharded seed table as one call per batch (the product path of BASELINE configs[3]) ---------------- */
+
+/* One arks_exchange per rank: its shard of the seed table, device buffers for the seeds that travel, and the
+ * transport to the other ranks -- RCCL (ncclSend / ncclRecv groups over xGMI, one process per GPU; librccl is
+ * opened on demand) or, for the ranks of ONE process that share a device (tests, single-GPU runs), device copies
+ * behind a host barrier.  The host program that starts the ranks (arcs --ranks N: forked processes and pipes;
+ * bench.py: torch.distributed) carries the 128-byte id of rank 0 to the others, as an MPI or NCCL program does. */
+typedef struct arks_exchange arks_exchange;
+#define ARKS_EXCHANGE_ID_BYTES 128
+typedef struct
+{
+	uint64_t seeds;    /* seeds of the last batch of this rank */
+	uint64_t sent;     /* ... of which asked of other ranks (8 B out, 16 B back each) */
+	uint64_t received; /* seeds other ranks asked of this one */
+} arks_exchange_stats;
+
+/* rank 0: a fresh id for arks_exchange_create on every rank (ncclGetUniqueId) */
+int arks_exchange_unique_id(unsigned char* out_id /* ARKS_EXCHANGE_ID_BYTES */);
+/* shard = arks_index_build_seed_shard(..., rank, world, device); unique_id may be NULL when world == 1 */
+int arks_exchange_create(arks_exchange** out, const arks_index* shard, const unsigned char* unique_id, int rank, int world);
+/* out[r] for r in [0, world): the ranks of one process (shards[r] = shard r, all on one device); each is driven by
+ * its own host thread, arks_map_reads_exchanged_device blocks until all of them have called it */
+int arks_exchange_create_local(arks_exchange** out, const arks_index* const* shards, int world);
+int arks_exchange_free(arks_exchange* x);
+int arks_exchange_last_stats(const arks_exchange* x, arks_exchange_stats* out);
+
+/* bestContig (Arcs/Arcs.cpp:939-1014) of this rank's reads against the sharded seed table: the same results and
+ * counters as arks_map_reads_device against the whole index.  COLLECTIVE: every rank calls it, in the same order,
+ * each with its own batch (n_reads may be 0).  On `stream`: seeds listed and bucketed by owner (three kernels),
+ * all-to-all of the seeds (8 B), owner-side probe, all-to-all of the answers (16 B), map; one small
+ * device-to-host copy (the per-owner counts) is the call's only wait for the device. */
+int arks_map_reads_exchanged_device(
+    arks_exchange* x,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream);
+
 /* d_acc[r] = max(d_acc[r], d_in[r]) (unsigned): folds another shard's votes in, for a driver that
  * moves votes between GPUs itself (hipMemcpyPeerAsync) instead of calling RCCL's all-reduce(MAX). */
 int arks_votes_max_device(uint64_t* d_acc, const uint64_t* d_in, int64_t n_reads, int device, void* stream);

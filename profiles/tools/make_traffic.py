@@ -12,6 +12,7 @@ ap.add_argument("--pairs", type=int, default=500_000_000)
 ap.add_argument("--chunk", type=int, default=100_000_000)  # bench.py's default
 ap.add_argument("--draft-mbp", type=float, default=3000.0)
 ap.add_argument("--k", type=int, default=60)
+ap.add_argument("--repeats", action="store_true")
 a, _ = ap.parse_known_args(sys.argv[2:])
 
 
@@ -30,7 +31,15 @@ def mean_of(path, counter):
 
 
 def dispatches_of(path, counter):
-    return max([int(r["dispatches"]) for r in csv.DictReader(open(path)) if r["counter"] == counter] or [0])
+    """dispatches of the hot kernel the means are taken over"""
+    best = 0
+    for r in csv.DictReader(open(path)):
+        k = r["kernel"]
+        hot = ("map_reads_s_kernel<" in k and ", false, " in k.split("map_reads_s_kernel<")[1][:12]) or \
+              ("map_reads_b_kernel<" in k and "false, false" in k)
+        if r["counter"] == counter and hot:
+            best = max(best, int(r["dispatches"]))
+    return best
 
 
 f = mean_of(f"gpurun_out/{tag}_pmc_FETCH_SIZE.csv", "FETCH_SIZE")
@@ -39,7 +48,10 @@ try:
     miss = mean_of(f"gpurun_out/{tag}_pmc_TCC_HIT_sum_TCC_MISS_sum.csv", "TCC_MISS_sum")
 except OSError:
     miss = None
-out = {"workload": {"draft_mbp": a.draft_mbp, "pairs_per_launch": min(a.chunk, a.pairs), "k": a.k},
+wk = {"draft_mbp": a.draft_mbp, "pairs_per_launch": min(a.chunk, a.pairs), "k": a.k}
+if a.repeats:
+    wk["repeats"] = True
+out = {"workload": wk,
        "kernel_build_id": bench.kernel_build_id(),
        "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
        "hbm_bytes_per_launch": (f + w) * 1024.0,
