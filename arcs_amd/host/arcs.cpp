@@ -942,7 +942,19 @@ run_arks(const std::vector<std::string>& filenames)
 	// with a GPU of its own (device + rank, modulo the devices there are, so that a test can run several
 	// ranks on one GPU).  A worker runs the same stages silently up to the read stage, maps the files dealt
 	// to it and sends its results to this process (read_stage); everything after that is rank 0's.
-	if (params.ranks > 1 && filenames.size() > 1) {
+	// (a file that cannot be opened: no workers -- one process then writes the reference's log of the files in
+	// front of it and stops at it, Arcs.cpp:1158-1163, instead of a worker dying with its own message after
+	// rank 0 has mapped its whole share)
+	bool all_open = true;
+	if (params.ranks > 1 && filenames.size() > 1)
+		for (const std::string& f : filenames) {
+			FILE* probe = f == "/dev/stdin" ? stdin : std::fopen(f.c_str(), "rb");
+			if (!probe)
+				all_open = false;
+			else if (probe != stdin)
+				std::fclose(probe);
+		}
+	if (params.ranks > 1 && filenames.size() > 1 && all_open) {
 		g_world = (int)std::min<size_t>((size_t)params.ranks, filenames.size());
 		std::fflush(nullptr);
 		for (int r = 1; r < g_world; ++r) {

@@ -30,14 +30,19 @@ namespace arks_host {
 
 // std::sort over `threads` threads: the keys are cut into ranges by sampled splitters, every range is gathered
 // and sorted by a thread of its own, and the ranges are laid out one after the other -- the result is the sorted
-// array (equal keys may sit in any order among themselves, as with std::sort)
+// array (equal keys may sit in any order among themselves, as with std::sort).  Classification, counting and the
+// scatter run over the threads too (every thread its stretch of the input and its own histogram: the scatter of
+// stretch t into range b starts behind what the stretches in front of it put there).  Memory: a second copy of
+// the array plus a byte per element while it runs.  A range that took more than half of the keys (one key
+// dominating: the splitters cannot cut it) is not worth the copy: plain std::sort then.
 template <typename T, typename Key>
 inline void
 parallel_sort_by(std::vector<T>& v, Key key, unsigned threads)
 {
 	const size_t n = v.size();
+	auto less = [&](const T& a, const T& b) { return key(a) < key(b); };
 	if (threads < 2 || n < (1u << 16)) {
-		std::sort(v.begin(), v.end(), [&](const T& a, const T& b) { return key(a) < key(b); });
+		std::sort(v.begin(), v.end(), less);
 		return;
 	}
 	const unsigned B = std::min<unsigned>(threads, 64);
@@ -49,25 +54,57 @@ parallel_sort_by(std::vector<T>& v, Key key, unsigned threads)
 	for (unsigned b = 1; b < B; ++b)
 		split.push_back(sample[(size_t)b * 64]);
 	auto bucket_of = [&](uint64_t k) { return (size_t)(std::lower_bound(split.begin(), split.end(), k) - split.begin()); };
-	std::vector<size_t> count(B + 1, 0);
+	const unsigned T_ = std::min<unsigned>(threads, 64);
+	auto stretch = [&](unsigned t) { return std::make_pair(n * t / T_, n * (t + 1) / T_); };
 	std::vector<uint8_t> which(n);
-	for (size_t i = 0; i < n; ++i) {
-		which[i] = (uint8_t)bucket_of(key(v[i]));
-		count[which[i] + 1]++;
+	std::vector<std::vector<size_t>> hist(T_, std::vector<size_t>(B, 0));
+	auto over_threads = [&](auto&& body) {
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < T_; ++t)
+			th.emplace_back([&, t] { body(t); });
+		for (auto& x : th)
+			x.join();
+	};
+	over_threads([&](unsigned t) {
+		const auto [lo, hi] = stretch(t);
+		std::vector<size_t>& h = hist[t];
+		for (size_t i = lo; i < hi; ++i) {
+			which[i] = (uint8_t)bucket_of(key(v[i]));
+			h[which[i]]++;
+		}
+	});
+	std::vector<size_t> count(B + 1, 0);
+	for (unsigned b = 0; b < B; ++b) {
+		size_t c = 0;
+		for (unsigned t = 0; t < T_; ++t)
+			c += hist[t][b];
+		count[b + 1] = count[b] + c;
 	}
 	for (unsigned b = 0; b < B; ++b)
-		count[b + 1] += count[b];
+		if (count[b + 1] - count[b] > n / 2) {
+			std::sort(v.begin(), v.end(), less);
+			return;
+		}
 	std::vector<T> out(n);
-	{
-		std::vector<size_t> at(count.begin(), count.end() - 1);
-		for (size_t i = 0; i < n; ++i)
-			out[at[which[i]]++] = v[i];
+	// at[t][b]: where stretch t's elements of range b go
+	std::vector<std::vector<size_t>> at(T_, std::vector<size_t>(B, 0));
+	for (unsigned b = 0; b < B; ++b) {
+		size_t pos = count[b];
+		for (unsigned t = 0; t < T_; ++t) {
+			at[t][b] = pos;
+			pos += hist[t][b];
+		}
 	}
+	over_threads([&](unsigned t) {
+		const auto [lo, hi] = stretch(t);
+		std::vector<size_t>& a = at[t];
+		for (size_t i = lo; i < hi; ++i)
+			out[a[which[i]]++] = v[i];
+	});
 	std::vector<std::thread> th;
 	for (unsigned b = 0; b < B; ++b)
 		th.emplace_back([&, b] {
-			std::sort(out.begin() + (std::ptrdiff_t)count[b], out.begin() + (std::ptrdiff_t)count[b + 1],
-			          [&](const T& x, const T& y) { return key(x) < key(y); });
+			std::sort(out.begin() + (std::ptrdiff_t)count[b], out.begin() + (std::ptrdiff_t)count[b + 1], less);
 		});
 	for (auto& t : th)
 		t.join();

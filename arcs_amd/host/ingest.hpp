@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -196,12 +197,18 @@ class HelpDesk
 			job->cv.wait(lk, [&] { return job->done.load() == n; });
 		}
 		open_.fetch_sub(1, std::memory_order_release);
-		std::lock_guard<std::mutex> lk(m_);
-		for (size_t i = 0; i < jobs_.size(); ++i)
-			if (jobs_[i] == job) {
-				jobs_.erase(jobs_.begin() + (std::ptrdiff_t)i);
-				break;
-			}
+		{
+			std::lock_guard<std::mutex> lk(m_);
+			for (size_t i = 0; i < jobs_.size(); ++i)
+				if (jobs_[i] == job) {
+					jobs_.erase(jobs_.begin() + (std::ptrdiff_t)i);
+					break;
+				}
+		}
+		// a body that threw (a std::bad_alloc from a buffer growing, say) -- on whichever thread -- counted as
+		// done, so that nobody holds `fn` or the caller's stack any more; the first exception goes to the caller
+		if (job->error)
+			std::rethrow_exception(job->error);
 	}
 	// takes a share of a published loop, if there is one with chunks left: false when there was nothing to do
 	bool help()
@@ -230,6 +237,7 @@ class HelpDesk
 		std::atomic<size_t> next{ 0 }, done{ 0 };
 		std::mutex m;
 		std::condition_variable cv;
+		std::exception_ptr error; // the first exception of a body (under m)
 	};
 	static bool run(Job& j)
 	{
@@ -239,7 +247,13 @@ class HelpDesk
 			if (i >= j.n)
 				return any;
 			any = true;
-			(*j.fn)(i);
+			try {
+				(*j.fn)(i);
+			} catch (...) {
+				std::lock_guard<std::mutex> lk(j.m);
+				if (!j.error)
+					j.error = std::current_exception();
+			}
 			if (j.done.fetch_add(1) + 1 == j.n) {
 				std::lock_guard<std::mutex> lk(j.m);
 				j.cv.notify_all();

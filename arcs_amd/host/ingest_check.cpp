@@ -44,6 +44,41 @@ struct Fnv
 int
 main(int argc, char** argv)
 {
+	if (argc == 3 && std::string(argv[1]) == "helpdesk-throw") {
+		// HelpDesk::parallel_for with bodies that throw on the caller and on helper threads: every body is counted
+		// as done (nobody is left holding the loop's function), the first exception reaches the caller, and the desk
+		// serves the next loop
+		const int helpers = std::atoi(argv[2]);
+		HelpDesk desk;
+		std::atomic<bool> stop{ false };
+		std::vector<std::thread> ts;
+		for (int t = 0; t < helpers; ++t)
+			ts.emplace_back([&] {
+				while (!stop.load())
+					if (!desk.help())
+						std::this_thread::yield();
+			});
+		int caught = 0;
+		std::atomic<long> ran{ 0 };
+		for (int round = 0; round < 200; ++round) {
+			try {
+				desk.parallel_for(64, [&](size_t i) {
+					ran.fetch_add(1);
+					if (i % 7 == 3)
+						throw std::bad_alloc();
+				});
+			} catch (const std::bad_alloc&) {
+				caught++;
+			}
+		}
+		long clean = 0;
+		desk.parallel_for(1000, [&](size_t) { clean++ , (void)0; });
+		stop.store(true);
+		for (auto& t : ts)
+			t.join();
+		std::cout << "caught " << caught << " ran " << ran.load() << " clean " << (clean > 0) << "\n";
+		return caught == 200 && ran.load() == 200 * 64 ? 0 : 1;
+	}
 	if (argc < 5) {
 		std::cerr << "usage: ingest_check <threads> <batch_pairs> <multiplicity.tsv> <reads>...\n";
 		return 2;

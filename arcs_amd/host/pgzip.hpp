@@ -625,9 +625,18 @@ struct ChunkResult
 	}
 };
 
+// A chunk's decode also ends -- at a block boundary, like at stop_bit -- once it has produced this many symbols:
+// the output of 1 MB of compressed text has no bound of its own (a run of one base compresses 1000 : 1), and
+// a stretch of 64 such chunks would otherwise grow to tens of GB of 16-bit symbols and overflow the 32-bit line
+// offsets of the record splitter.  The chunk behind it then does not start where this one ended: the chain breaks
+// there, the next stretch takes over at this chunk's end, and a file that keeps doing so goes to the one-thread
+// inflater (constant memory) by the poor-stretch rule below.
+constexpr size_t kChunkOutCap = (size_t)48 << 20;   // symbols per chunk (96 MB)
+constexpr size_t kStretchOutCap = (size_t)1 << 30;  // bytes of text per stretch
+
 // blocks from start_bit on until a block boundary at or beyond stop_bit, the member's last block, or damage
 inline void
-decode_chunk(const unsigned char* in, size_t size, size_t start_bit, size_t stop_bit, ChunkResult& r)
+decode_chunk(const unsigned char* in, size_t size, size_t start_bit, size_t stop_bit, ChunkResult& r, size_t out_cap = kChunkOutCap)
 {
 	std::unique_ptr<Tables> t(new Tables);
 	BitIn b(in, size);
@@ -648,6 +657,8 @@ decode_chunk(const unsigned char* in, size_t size, size_t start_bit, size_t stop
 		// not the last) -- the empty stored blocks of a flushed stream (pigz) and fixed blocks belong to this chunk
 		if (pos >= stop_bit && b.peek(3) == 4u)
 			return;
+		if (r.out.n >= out_cap && pos > start_bit)
+			return; // (see kChunkOutCap)
 		bool last = false;
 		int type = 0;
 		const size_t n0 = r.out.n;
@@ -741,6 +752,14 @@ class GzStretches
 			return;
 		}
 		resume_.bit = data * 8;
+		// ARKS_PGZIP_OUT_CAP=<bytes>: the cap on a stretch's text (tests; a chunk's cap is a sixteenth of it)
+		if (const char* e = std::getenv("ARKS_PGZIP_OUT_CAP")) {
+			const size_t v = (size_t)std::strtoull(e, nullptr, 10);
+			if (v >= 4096) {
+				stretch_out_cap_ = v;
+				chunk_out_cap_ = std::max<size_t>(v / 16, 1024);
+			}
+		}
 	}
 	~GzStretches()
 	{
@@ -791,7 +810,7 @@ class GzStretches
 			res[i]->reset();
 			begin[i] = i == 0 ? resume_.bit : pgz::find_block_start(map_, size_, border[i] * 8, border[i + 1] * 8);
 			if (begin[i] != pgz::kNone)
-				pgz::decode_chunk(map_, size_, begin[i], std::max(begin[i] + 1, border[i + 1] * 8), *res[i]);
+				pgz::decode_chunk(map_, size_, begin[i], std::max(begin[i] + 1, border[i + 1] * 8), *res[i], chunk_out_cap_);
 		});
 		lap("decode");
 		// the chunks whose results stand: every one that starts where the one in front of it ended (a chunk in
@@ -836,6 +855,13 @@ class GzStretches
 			good = usable;
 			stop_here = true;
 		}
+		// no more than kStretchOutCap bytes of text per stretch (but at least one chunk): the rest of the chunks
+		// are decoded again by the next stretch, which starts where the last chunk taken ended
+		for (size_t i = 1; i < good; ++i)
+			if (off[i + 1] > stretch_out_cap_) {
+				good = i;
+				break;
+			}
 		lap("windows");
 		// the member's last block, if it comes next: decoded here too, so that a file of several members (lanes
 		// put together with cat) stays on this path; taken only if the member's CRC and length then agree
@@ -966,6 +992,7 @@ class GzStretches
 	const unsigned char* map_ = nullptr;
 	size_t size_ = 0, chunk_;
 	unsigned per_stretch_;
+	size_t chunk_out_cap_ = pgz::kChunkOutCap, stretch_out_cap_ = pgz::kStretchOutCap;
 	bool done_ = false, started_ = false;
 	unsigned poor_stretches_ = 0, tiny_members_ = 0;
 	size_t member_begin_ = 0;

@@ -293,6 +293,57 @@ def alternating_at_runs(genome, run=14, chunk=1 << 28):
     return np.stack([s[keep], e[keep] + 2], axis=1).astype(np.int64)
 
 
+def fastq_bytes(batch, first_pair=0, r1_len=128, r2_len=151):
+    """The batch of make_read_pairs as interleaved 4-line FASTQ text (uint8 array), vectorised: record p is
+    `@p<9 digits>/1 BX:Z:<16-base barcode>-1`, the bases, `+`, qualities -- then its mate with `/2`.  A pair whose
+    pair_ok is 0 gets a mate with another name (what the flag stands for); the barcode spells barcode_id in base 4."""
+    a = batch["ascii"].cpu().numpy()
+    n = a.size // (r1_len + r2_len)
+    ok = batch["pair_ok"].cpu().numpy().astype(bool)
+    bid = batch["barcode_id"].cpu().numpy().astype(np.int64)
+    idx = np.arange(first_pair, first_pair + n, dtype=np.int64)
+    both = a.reshape(n, r1_len + r2_len)
+
+    def digits(v, width, base, alphabet):
+        out = np.empty((len(v), width), dtype=np.uint8)
+        for i in range(width - 1, -1, -1):
+            out[:, i] = alphabet[v % base]
+            v = v // base
+        return out
+
+    dec = np.frombuffer(b"0123456789", dtype=np.uint8)
+    name = digits(idx.copy(), 9, 10, dec)
+    bc = digits(bid.copy(), 16, 4, _ACGT)
+    recs = []
+    for mate, (lo, L) in enumerate(((0, r1_len), (r1_len, r2_len))):
+        nm = name if mate == 0 else np.where(ok[:, None], name, digits(idx + 500_000_000, 9, 10, dec))
+        head = np.concatenate([np.full((n, 2), ord("@"), np.uint8), nm,
+                               np.broadcast_to(np.frombuffer(b"/%d BX:Z:" % (mate + 1), dtype=np.uint8), (n, 8)), bc,
+                               np.broadcast_to(np.frombuffer(b"-1\n", dtype=np.uint8), (n, 3))], axis=1)
+        head[:, 1] = ord("p")
+        rec = np.concatenate([head, both[:, lo:lo + L], np.broadcast_to(np.frombuffer(b"\n+\n", dtype=np.uint8), (n, 3)),
+                              np.full((n, L), ord("F"), np.uint8), np.full((n, 1), ord("\n"), np.uint8)], axis=1)
+        recs.append(rec)
+    return np.concatenate(recs, axis=1).reshape(-1)
+
+
+def write_gz_members(path, data, threads=16, level=1, member_bytes=32 << 20):
+    """`data` (bytes-like) as a .gz of back-to-back members compressed on `threads` threads (a valid gzip file:
+    zlib's gzread, kseq and every other reader take the members as one stream)"""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    mv = memoryview(data)
+    cuts = list(range(0, len(mv), member_bytes)) + [len(mv)]
+
+    def member(i):
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return c.compress(mv[cuts[i]:cuts[i + 1]]) + c.flush()
+
+    with ThreadPoolExecutor(threads) as ex, open(path, "wb") as f:
+        for blob in ex.map(member, range(len(cuts) - 1)):
+            f.write(blob)
+
+
 def reads_to_strings(batch):
     """list of python str, one per read (small batches only)"""
     a = batch["ascii"].cpu().numpy()

@@ -332,6 +332,96 @@ def repeats_key(args, k, j, dev, local, log, barrier):
                                              f"{'identical' if same else 'DIFFERENT'}"}
 
 
+def end_to_end_files(wl, dev, log, sub_mbp=20.0, n_pairs=2_000_000, threads=16):
+    """SURVEY 8(d), "additionally end-to-end from .fq.gz": ONE gzipped interleaved FASTQ of n_pairs read pairs drawn
+    from the first sub_mbp of the draft (+ that sub-draft as FASTA and a barcode multiplicity file), mapped
+      * by the CPU port from the file (oracle/arks_port_fastq.c: chromiumRead's loop, records read inside one
+        critical section as in Arcs/Arcs.cpp:1185, mapped by the physical cores of one socket), and
+      * by the product's front end `arcs --arks` (arcs_amd/bin/arcs: parallel gzip decode, parse, pack, H2D, the
+        kernels, graph, output files) at -t `threads`,
+    same files, same box.  Both must store the same number of read pairs."""
+    import re
+    import shutil
+    import tempfile
+    from oracle import pyoracle as O
+    from arcs_amd import build as ab
+    exe = ab.build_host()
+    k, j = wl.k, wl.j
+    contigs = wl.contigs
+    acc, n_first = 0, 0
+    while n_first < len(contigs) and acc < sub_mbp * 1e6:
+        acc += len(contigs[n_first])
+        n_first += 1
+    members = synth.closed_contig_set(n_first, wl.dup_events)
+    n_pairs -= n_pairs % 80
+    tmp = tempfile.mkdtemp(prefix="arks_e2e_")
+    try:
+        t0 = time.time()
+        with open(os.path.join(tmp, "draft.fa"), "wb") as f:
+            for ci in members:
+                f.write(b">%d\n" % (ci + 1))
+                f.write(contigs[ci].tobytes())
+                f.write(b"\n")
+        batch = synth.make_read_pairs(wl.genome[:acc], n_pairs, seed=synth.SEED + 779, device=dev)
+        text = synth.fastq_bytes(batch)
+        fq = os.path.join(tmp, "reads.fq.gz")
+        synth.write_gz_members(fq, text, threads=32)
+        bid = batch["barcode_id"].cpu().numpy().astype(np.int64)
+        with open(os.path.join(tmp, "mult.tsv"), "w") as f:
+            for b in range(int(bid.max()) + 1):
+                v, name = b, []
+                for _ in range(16):
+                    name.append("ACGT"[v % 4])
+                    v //= 4
+                f.write("".join(reversed(name)) + "-1\t160\n")
+        windows = int(torch.clamp(batch["lens"].to(torch.int64) - (k - 1), min=0).sum().item())
+        gz_mb, text_mb = os.path.getsize(fq) / 1e6, text.size / 1e6
+        del batch, text
+        log(f"end to end: {n_pairs} pairs as one .fq.gz ({gz_mb:.0f} MB, {text_mb:.0f} MB of text) + sub-draft of "
+            f"{len(members)} contigs written in {time.time() - t0:.1f}s")
+        # the CPU port
+        model, sockets = cpu_topology()
+        cores = sockets[sorted(sockets)[0]]
+        saved = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, cores)
+        try:
+            ox = O.sub_draft_index(k, [contigs[ci] for ci in members], range(len(members)))
+            t0 = time.time()
+            got_pairs, cpu_stored, st = O.map_fastq_gz(ox, fq, j, threads=len(cores))
+            cpu_s = time.time() - t0
+        finally:
+            os.sched_setaffinity(0, saved)
+        assert got_pairs == n_pairs, (got_pairs, n_pairs)
+        # the product's front end
+        t0 = time.time()
+        res = subprocess.run([exe, "--arks", "-f", os.path.join(tmp, "draft.fa"), "-u", os.path.join(tmp, "mult.tsv"),
+                              "-k", str(k), "-j", str(j), "-c", "5", "-m", "50-10000", "-e", "30000", "-z", "500",
+                              "-t", str(threads), "-b", os.path.join(tmp, "out"), fq],
+                             capture_output=True, text=True, env=dict(os.environ, ARKS_TIMING="1"))
+        cli_s = time.time() - t0
+        assert res.returncode == 0, res.stderr[-2000:]
+        m = re.search(r"Stored read pairs: (\d+)", res.stdout)
+        cli_stored = int(m.group(1)) if m else -1
+        rd = [ln for ln in res.stderr.splitlines() if "read files" in ln]
+        read_ms = float(rd[0].split(":")[1].split()[0]) if rd else None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"input": f"one gzipped interleaved FASTQ, {n_pairs} pairs ({gz_mb:.0f} MB; {text_mb:.0f} MB of text; gzip "
+                     f"members of 32 MB), reads drawn from a {acc / 1e6:.0f} Mbp sub-draft ({len(members)} contigs as FASTA)",
+            "windows": windows,
+            "cpu_port": {"value": st["windows"] / cpu_s, "unit": "k-mers/s", "pairs_per_s": n_pairs / cpu_s,
+                         "seconds": cpu_s, "cores": len(cores), "stored_pairs": cpu_stored,
+                         "what": "oracle/arks_port_fastq.c: records read inside one critical section (gzgets), mapped "
+                                 "by OpenMP threads pinned to the physical cores of one socket; index prebuilt"},
+            "gpu_cli": {"value": windows / cli_s, "unit": "k-mers/s", "pairs_per_s": n_pairs / cli_s, "seconds": cli_s,
+                        "read_stage_ms": read_ms,
+                        "read_stage_pairs_per_s": (n_pairs / (read_ms * 1e-3)) if read_ms else None,
+                        "threads": threads, "stored_pairs": cli_stored,
+                        "what": "arcs --arks, whole process: start-up, draft FASTA, index build on the device, the read "
+                                "stage (parallel gzip decode, parse, pack, H2D, kernels), graph and output files"},
+            "same_stored_pairs": cli_stored == cpu_stored}
+
+
 def end_to_end(wl, dev, local, n_batches=8, pairs=2_000_000):
     """packed batches start in pinned HOST memory; per batch H2D (codes, N mask, offsets,
     lengths, class, pair_ok, barcode ids) -> gate / map / pair rule -> D2H (pair results), double-buffered
@@ -555,6 +645,8 @@ def main():
             out["gpu_over_cpu_t1"] = value / cb["t1"]["value"]
         if world == 1 and not args.no_extras:
             out["end_to_end"] = end_to_end(wl, dev, local)
+            if cpu_leg:
+                out["end_to_end"]["from_fq_gz"] = end_to_end_files(wl, dev, log)
             del wl
             torch.cuda.empty_cache()
             # BASELINE configs[1] (round 1's headline), same build, same box
@@ -571,6 +663,8 @@ def main():
         print(json.dumps(out), flush=True)
         if cpu_leg:
             assert out["sample_parity"], "GPU results differ from the CPU oracle on the sample"
+        if "from_fq_gz" in out.get("end_to_end", {}):
+            assert out["end_to_end"]["from_fq_gz"]["same_stored_pairs"], "CLI and CPU port store different numbers of pairs"
         if "configs2_repeats" in out:
             assert out["configs2_repeats"]["sample_parity"], "repeat-rich draft: GPU results differ from the CPU oracle"
     if world > 1:

@@ -121,6 +121,17 @@ int64_t arks_oracle_map_pairs(
     arks_oracle_map_stats* st,
     int n_threads);
 
+/* The CPU port end to end from a gzipped interleaved FASTQ (arks_port_fastq.c): chromiumRead's pair loop,
+ * Arcs/Arcs.cpp:1169-1292, records read inside one critical section, mapped outside of it.  Returns the record
+ * pairs read (-1: the file cannot be opened); *st the mapping counters, *stored_pairs the pairs whose mates agree. */
+int64_t arks_oracle_map_fastq_gz(
+    const arks_oracle_index* idx,
+    const char* path,
+    double j_index,
+    int n_threads,
+    arks_oracle_map_stats* st,
+    int64_t* stored_pairs);
+
 #ifdef __cplusplus
 }
 #endif

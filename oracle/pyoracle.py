@@ -36,7 +36,8 @@ def build_oracle(force=False):
     """(re)build oracle/libarks_oracle.so with gcc; also the _ref shim when the upstream checkout
     exists (this container only)."""
     if force or not os.path.exists(_LIB) or \
-            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "arks_oracle.c")):
+            os.path.getmtime(_LIB) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                         for f in ("arks_oracle.c", "arks_port_fastq.c", "arks_oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/Common"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -71,6 +72,9 @@ def lib():
         L.arks_oracle_map_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_void_p, C.c_double, C.c_void_p,
                                             C.c_void_p, C.POINTER(MapStats), C.c_int]
+        L.arks_oracle_map_fastq_gz.restype = C.c_int64
+        L.arks_oracle_map_fastq_gz.argtypes = [C.c_void_p, C.c_char_p, C.c_double, C.c_int, C.POINTER(MapStats),
+                                               C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -188,6 +192,17 @@ class OracleIndex:
         d = st.as_dict()
         d["stored_pairs"] = int(stored)
         return out_c, out_p, d
+
+
+def map_fastq_gz(index, path, j_index, threads=1):
+    """the CPU port end to end from a gzipped interleaved FASTQ (oracle/arks_port_fastq.c): (pairs read, stored
+    pairs, counters dict)"""
+    st = MapStats()
+    stored = C.c_int64(0)
+    n = lib().arks_oracle_map_fastq_gz(index.h, os.fsencode(path), float(j_index), int(threads), C.byref(st), C.byref(stored))
+    if n < 0:
+        raise OSError(f"cannot open {path}")
+    return int(n), int(stored.value), st.as_dict()
 
 
 def sub_draft_index(k, contigs, members, min_size=500, end_length=30000, site_runs=None):

@@ -215,6 +215,14 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
             assert open(str(tmp_path / tag) + suffix).read() == open(str(tmp_path / "multi") + suffix).read(), suffix
         assert open(str(tmp_path / (tag + "_counts.tsv"))).read() == open(str(tmp_path / "counts2.tsv")).read()
         assert _norm(resr.stdout, tag, tag + "_counts") == _norm(res2.stdout, "multi", "counts2")
+    # a file that cannot be opened: with --ranks the same log, stderr and exit status as one process (the workers
+    # are not even started: the reference's sequence -- the files in front of it, then the message -- is rank 0's)
+    bad_paths = [str(paths[0]), str(tmp_path / "no_such_reads.fq"), str(paths[2])]
+    one = subprocess.run(args2 + bad_paths, capture_output=True, text=True, timeout=300)
+    two = subprocess.run(args2 + ["--ranks", "2"] + bad_paths, capture_output=True, text=True, timeout=300)
+    assert one.returncode == two.returncode == 1
+    assert "no_such_reads.fq cannot be opened." in one.stderr and one.stderr == two.stderr
+    assert _norm(one.stdout, "multi", "counts2") == _norm(two.stdout, "multi", "counts2")
     # ---- the contig k-mer index in three parts (--index-shards): per batch the votes of every part,
     #      their maximum, then the j_index test -- same files, same stored pairs ----------------------
     args4 = list(args)

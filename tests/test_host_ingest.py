@@ -475,6 +475,29 @@ def test_fast_inflate_equals_zlib(inflate_check, tmp_path):
     assert zlib.decompress(cases["all_header_fields"], 31) == fastq[:30000]
 
 
+def test_parallel_gzip_output_is_bounded(inflate_check, tmp_path):
+    """A highly compressible .gz (ratio ~ 1000 : 1 -- low-complexity or synthetic reads): the text one chunk / one
+    stretch of the several-thread decoder produces is capped (pgzip.hpp: kChunkOutCap, kStretchOutCap; here scaled
+    down by ARKS_PGZIP_OUT_CAP), chunks beyond the cap are taken by the next stretch, and the bytes are zlib's
+    (64 chunks of 1 MB could expand to > 4 GiB, past the record splitter's 32-bit offsets)."""
+    import zlib
+    rng = np.random.Generator(np.random.PCG64(10))
+    rec = b"@r BX:Z:AAAAAAAAAAAAAAAA-1\n" + b"A" * 150 + b"\n+\n" + b"F" * 150 + b"\n"
+    text = rec * 40000 + bytes(rng.integers(65, 70, size=200000, dtype=np.uint8)) + rec * 40000     # 26 MB -> ~ 100 KB
+    blob = _gz(text, 6)
+    assert len(text) > 100 * len(blob)
+    path = tmp_path / "high_ratio.gz"
+    path.write_bytes(blob)
+    for cap in ("65536", "1000000", None):
+        env = dict(os.environ)
+        if cap:
+            env["ARKS_PGZIP_OUT_CAP"] = cap
+        for threads, pchunk, per in ((3, 4096, 8), (4, 16384, 16)):
+            out = subprocess.run([inflate_check, str(path), str(1 << 18), "pgz", str(threads), str(pchunk), str(per)],
+                                 capture_output=True, text=True, timeout=300, env=env)
+            assert out.returncode == 0 and "pgz same " in out.stdout, (cap, threads, pchunk, out.stdout, out.stderr[-500:])
+
+
 def test_fast_inflate_damaged_input(inflate_check, tmp_path):
     """truncated and corrupted files: no crash, no hang, a truncated file delivers exactly what zlib delivers,
     and a failure is reported whenever zlib reports one"""
@@ -570,3 +593,11 @@ def test_reads_from_a_pipe(exe, tmp_path):
         p = subprocess.Popen([exe, "4", "700", "-", "/dev/stdin"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=False)
         out, _ = p.communicate(blob, timeout=120)
         assert p.returncode == 0 and out.decode() == want
+
+
+def test_helpdesk_survives_a_throwing_body(exe):
+    """a parallel_for body that throws (std::bad_alloc on a helper or on the caller): every body still counts as
+    done, the caller gets the exception, the desk keeps working"""
+    for helpers in (0, 1, 6):
+        r = subprocess.run([exe, "helpdesk-throw", str(helpers)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (helpers, r.stdout, r.stderr[-500:])
