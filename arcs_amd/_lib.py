@@ -59,6 +59,7 @@ SYMBOLS = {
     "arks_exchange_create": (_I, [C.POINTER(_VP), _VP, _VP, _I, _I]),
     "arks_exchange_create_local": (_I, [_VP, _VP, _I]),
     "arks_exchange_free": (_I, [_VP]),
+    "arks_exchange_abort": (_I, [_VP]),
     "arks_exchange_last_stats": (_I, [_VP, _VP]),
     "arks_map_reads_exchanged_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
     "arks_index_free": (_I, [_VP]),

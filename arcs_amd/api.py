@@ -410,6 +410,11 @@ class SeedExchange:
         except Exception:
             pass
 
+    def abort(self):
+        """this rank's driver gives up: the other local ranks get an error instead of waiting for it"""
+        if self._h:
+            lib().arks_exchange_abort(self._h)
+
     def last_stats(self):
         st = ExchangeStats()
         check(lib().arks_exchange_last_stats(self._h, C.byref(st)), "arks_exchange_last_stats")

@@ -19,6 +19,7 @@
 // all_to_all_single calls ("what's weak" 10).  Reference seam: the reads are independent
 // (Arcs/Arcs.cpp:1169), the index is read-only while mapping (:969-971).
 #pragma once
+#include <chrono>
 #include <condition_variable>
 #include <dlfcn.h>
 
@@ -108,17 +109,36 @@ struct LocalGroup
 	std::vector<const u64*> ans_out;     // answers to the seeds received
 	std::vector<int> failed;
 
-	void
+	bool aborted = false; // a rank left with an error (or never came): nobody waits for it again
+
+	// false: the group is broken (a rank failed in an earlier call, or did not arrive within ten minutes)
+	bool
 	barrier()
 	{
 		std::unique_lock<std::mutex> lk(m);
+		if (aborted)
+			return false;
 		const u64 gen = generation;
 		if (++arrived == world) {
 			arrived = 0;
 			++generation;
 			cv.notify_all();
-		} else
-			cv.wait(lk, [&] { return generation != gen; });
+			return true;
+		}
+		if (!cv.wait_for(lk, std::chrono::minutes(10), [&] { return generation != gen || aborted; }))
+			aborted = true; // the ranks of a process call in step: one that is missing this long has died
+		if (aborted) {
+			cv.notify_all();
+			return false;
+		}
+		return true;
+	}
+	void
+	abort()
+	{
+		std::lock_guard<std::mutex> lk(m);
+		aborted = true;
+		cv.notify_all();
 	}
 };
 
@@ -204,6 +224,13 @@ exchange_release(arks_exchange* x)
 	if (x->h_totals)
 		(void)hipHostFree(x->h_totals);
 	delete x;
+}
+
+int
+exchange_broken()
+{
+	g_last_error = "the local group is broken: a rank failed in this or an earlier call, or did not arrive";
+	return ARKS_ERR_HIP;
 }
 
 int
@@ -328,6 +355,16 @@ arks_exchange_free(arks_exchange* x)
 }
 
 int
+arks_exchange_abort(arks_exchange* x)
+{
+	if (!x)
+		return ARKS_ERR_BAD_ARG;
+	if (x->group)
+		x->group->abort();
+	return ARKS_OK;
+}
+
+int
 arks_exchange_last_stats(const arks_exchange* x, arks_exchange_stats* out)
 {
 	if (!x || !out)
@@ -394,7 +431,8 @@ arks_map_reads_exchanged_device(
 	if (g) {
 		g->counts_host[(size_t)me] = x->h_totals;
 		g->failed[(size_t)me] = rc != ARKS_OK;
-		g->barrier();
+		if (!g->barrier())
+			return exchange_broken();
 		for (int p = 0; p < W; ++p) {
 			if (g->failed[(size_t)p] && rc == ARKS_OK) {
 				g_last_error = "another rank of the local group failed";
@@ -403,7 +441,8 @@ arks_map_reads_exchanged_device(
 			for (int o = 0; o < W; ++o)
 				x->h_totals[1 + W + p * W + o] = g->failed[(size_t)p] ? 0 : g->counts_host[(size_t)p][1 + o];
 		}
-		g->barrier(); // everybody has read everybody's counts
+		if (!g->barrier()) // everybody has read everybody's counts
+			return exchange_broken();
 	} else if (W == 1)
 		x->h_totals[2] = x->h_totals[1];
 	if (rc != ARKS_OK && !g)
@@ -449,7 +488,8 @@ arks_map_reads_exchanged_device(
 		EX_TRY(hipStreamSynchronize(st)); // my send buffer is complete
 		g->send[(size_t)me] = x->send.as<u64>();
 		g->failed[(size_t)me] = rc != ARKS_OK;
-		g->barrier();
+		if (!g->barrier())
+			return exchange_broken();
 		for (int p = 0; p < W; ++p) {
 			if (g->failed[(size_t)p] && rc == ARKS_OK) {
 				g_last_error = "another rank of the local group failed";
@@ -486,7 +526,8 @@ arks_map_reads_exchanged_device(
 		EX_TRY(hipStreamSynchronize(st)); // my answers are complete (and I have read the others' seeds)
 		g->ans_out[(size_t)me] = x->ans_out.as<u64>();
 		g->failed[(size_t)me] = rc != ARKS_OK;
-		g->barrier();
+		if (!g->barrier())
+			return exchange_broken();
 		for (int p = 0; p < W; ++p) {
 			if (g->failed[(size_t)p] && rc == ARKS_OK) {
 				g_last_error = "another rank of the local group failed";
@@ -502,7 +543,8 @@ arks_map_reads_exchanged_device(
 			                      2 * sizeof(u64) * sc[(size_t)p], hipMemcpyDeviceToDevice, st));
 		}
 		EX_TRY(hipStreamSynchronize(st)); // I have read the others' answers ...
-		g->barrier();                     // ... and they mine: the buffers may be reused
+		if (!g->barrier())                // ... and they mine: the buffers may be reused
+			return exchange_broken();
 	}
 	// ---- 6. the home finishes -------------------------------------------------------------------------------
 	if (rc == ARKS_OK && n_reads > 0) {
@@ -516,6 +558,8 @@ arks_map_reads_exchanged_device(
 	}
 done:
 #undef EX_TRY
+	if (rc != ARKS_OK && g)
+		g->abort(); // this rank's caller will not call again: the others must not wait for it
 	return rc;
 }
 

@@ -685,7 +685,7 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
     k, j = args.k, args.j
     n_local = max(1, args.shards) if world == 1 else 1
     if n_local > 1:
-        args.chunk = min(args.chunk, 25_000_000)      # the exchange buffers of all local ranks live on the one device
+        args.chunk = min(args.chunk, 12_500_000)      # the exchange buffers of all local ranks live on the one device
     n_ranks = world * n_local
     contigs = synth.make_draft(int(args.draft_mbp * 1e6), seed=synth.SEED)
     ends = []
@@ -768,6 +768,7 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
                 rank_step(i, stats[i] if with_stats else None)
             except Exception as e:           # noqa: BLE001
                 errs.append(e)
+                xs[i].abort()                # the other local ranks must not wait for this one
         ts = [threading.Thread(target=run, args=(i,)) for i in range(n_local)]
         for t in ts:
             t.start()
@@ -776,6 +777,8 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
         if errs:
             raise errs[0]
 
+    del genome
+    torch.cuda.empty_cache()         # the exchange buffers are the library's own allocations
     for _ in range(args.warmup):
         step()
     step(True)

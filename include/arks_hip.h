@@ -323,6 +323,10 @@ int arks_exchange_create(arks_exchange** out, const arks_index* shard, const uns
  * its own host thread, arks_map_reads_exchanged_device blocks until all of them have called it */
 int arks_exchange_create_local(arks_exchange** out, const arks_index* const* shards, int world);
 int arks_exchange_free(arks_exchange* x);
+/* a local rank whose driver gives up (an error outside the library): the other ranks of its group get an error from
+ * arks_map_reads_exchanged_device instead of waiting for it (a rank that is missing for ten minutes has the same
+ * effect); no-op for an RCCL exchange, whose communicator has time-outs of its own */
+int arks_exchange_abort(arks_exchange* x);
 int arks_exchange_last_stats(const arks_exchange* x, arks_exchange_stats* out);
 
 /* bestContig (Arcs/Arcs.cpp:939-1014) of this rank's reads against the sharded seed table: the same results and

@@ -131,6 +131,42 @@ def test_pairs_flow_with_the_indexmap(arks, gpu, oracle):
         x.close()
 
 
+def test_a_rank_that_gives_up_does_not_hang_the_others(arks, gpu):
+    """a local rank whose driver fails outside the library (here: it simply aborts) -- the other ranks' call returns an
+    error instead of waiting at the barrier for ever, and so does every later call on the group"""
+    import torch
+    k, world = 60, 3
+    cs = _draft(k, seed=33)
+    ends = arks.contig_ends(cs, 500, 3000)
+    reads = _reads(cs, ends, k, seed=34, n=300)
+    shards = [arks.ArksIndex.build_seed_shard(ends, k, r, world, device=gpu) for r in range(world)]
+    xs = arks.SeedExchange.create_local(shards)
+    packed = arks.PackedReads.from_ascii(reads, device=gpu)
+    res = [None] * world
+
+    def work(r):
+        try:
+            if r == 2:
+                xs[r].abort()
+                res[r] = "gave up"
+                return
+            with torch.cuda.stream(torch.cuda.Stream()):
+                xs[r].map_reads(packed, 0.55)
+            res[r] = "mapped"
+        except arks.ArksError as e:
+            res[r] = "error: " + str(e)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert not any(t.is_alive() for t in ts)
+    assert res[2] == "gave up" and all(str(res[r]).startswith("error") for r in (0, 1)), res
+    with pytest.raises(arks.ArksError):
+        xs[0].map_reads(packed, 0.55)
+    for x in xs:
+        x.close()
+
+
 def _rccl_worker():
     """one rank with a real RCCL communicator (ncclCommInitRank through the library's dlopen of librccl)"""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
