@@ -2545,6 +2545,18 @@ fold_stats_kernel(const u64* __restrict__ rows, u64* __restrict__ stats)
 		atomicAdd(stats + c, v);
 }
 
+// ARKS_DEBUG_MEDIUM_BLOCKS=<n>: the medium kernel on n waves only, so that even a test's short queue gives every
+// wave several reads per grab (tiles of several gathered reads: the path a long queue takes); read per launch
+static unsigned
+medium_blocks(unsigned bb)
+{
+	const char* e = std::getenv("ARKS_DEBUG_MEDIUM_BLOCKS");
+	if (!e)
+		return bb;
+	const long v = std::atol(e);
+	return v >= 1 && (unsigned long)v < bb ? (unsigned)v : bb;
+}
+
 hipError_t
 launch_map_reads(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens,
@@ -2609,7 +2621,7 @@ launch_map_reads(
 			    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,    \
 			    queue + n_reads, queue_count);                                                     \
 		ARKS_DEBUG_STAGE("hot");                                                                   \
-		map_reads_b_kernel<KWV, ST, true, MMV, RAWV, DN><<<bb, 64, 0, st>>>(                       \
+		map_reads_b_kernel<KWV, ST, true, MMV, RAWV, DN><<<medium_blocks(bb), 64, 0, st>>>(        \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue + n_reads, queue_count);                                                         \
 		ARKS_DEBUG_STAGE("medium");                                                                \
@@ -2793,7 +2805,7 @@ launch_map_reads_seeded(
 		map_reads_s_kernel<KWV, ST, MMV, false, true><<<bh, 64, 0, st>>>(                          \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
 		    queue + n_reads, queue_count, seed_off, ans, seed_slot);                               \
-		map_reads_b_kernel<KWV, ST, true, MMV, false, false><<<bb, 64, 0, st>>>(                   \
+		map_reads_b_kernel<KWV, ST, true, MMV, false, false><<<medium_blocks(bb), 64, 0, st>>>(    \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bxg, out, stats, queue,       \
 		    queue + n_reads, queue_count);                                                         \
 		map_reads_kernel<KWV, ST, false, true, MMV, false><<<bs, 256, 0, st>>>(                    \

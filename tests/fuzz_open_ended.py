@@ -39,6 +39,12 @@ while time.time() < t_end:
     ox = oracle.OracleIndex(k).build(ends)
     # both layouts of the locality index take turns (the library reads the variable at every build)
     os.environ["ARKS_INDEX_KIND"] = "seeds" if seed % 3 else "minimizer"
+    # every other case: the medium kernel on a few waves only, so that its (short) queue is taken several reads per
+    # grab -- tiles of several gathered reads
+    if seed % 2:
+        os.environ["ARKS_DEBUG_MEDIUM_BLOCKS"] = str(1 + seed % 5)
+    else:
+        os.environ.pop("ARKS_DEBUG_MEDIUM_BLOCKS", None)
     ix = arcs_amd.ArksIndex.build(ends, k, device=0)
     assert {f: ix.build_stats[f] for f in ox.stats.as_dict()} == ox.stats.as_dict(), (seed, k, "build stats")
     genome = "".join(ends)

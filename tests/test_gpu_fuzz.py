@@ -15,9 +15,13 @@ def rc(s):
     return s[::-1].translate(COMP)
 
 
-@pytest.mark.parametrize("first_seed", [1, 5000, 90000])
-def test_fuzz_vs_oracle(arks, gpu, oracle, first_seed, index_layout):
+@pytest.mark.parametrize("first_seed", [1, 5000, 90000, 130000])
+def test_fuzz_vs_oracle(arks, gpu, oracle, first_seed, index_layout, monkeypatch):
     arcs_amd = arks
+    if first_seed in (5000, 130000):
+        # the medium kernel on three waves: its queue, short in these cases, then gives every wave several reads per
+        # grab -- tiles of several gathered reads, the path a long queue (a repeat-rich draft) takes
+        monkeypatch.setenv("ARKS_DEBUG_MEDIUM_BLOCKS", "3")
     seed = first_seed
     for _case in range(60):
         rng = np.random.Generator(np.random.PCG64(seed)); seed += 1
