@@ -14,25 +14,38 @@ with open(f"{tmp}/draft.fa", "wb") as f:
 print("draft: %d contigs, %.0f Mbp" % (len(contigs), sum(len(c) for c in contigs) / 1e6), flush=True)
 mult = {}
 t0 = time.time()
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+def one_stream_gz(args):            # a real single-stream .gz (what a sequencer's pipeline writes), level 1
+    path, data = args
+    c = zlib.compressobj(1, zlib.DEFLATED, 31)
+    with open(path, "wb") as f:
+        mv = memoryview(data)
+        for i in range(0, len(mv), 64 << 20):
+            f.write(c.compress(mv[i:i + (64 << 20)]))
+        f.write(c.flush())
+
+jobs = []
 for fi in range(NF):
     batch = synth.make_read_pairs(contigs, NP, seed=100 + fi, device="cuda" if DRAFT_MBP > 500 else "cpu")
     batch = {k: v.cpu() for k, v in batch.items()}
-    reads = synth.reads_to_strings(batch)
-    bid = batch["barcode_id"].numpy()
-    parts = []
-    for p in range(NP):
-        bc = f"BC{int(bid[p]):08d}-1"
-        mult[bc] = mult.get(bc, 0) + 2
-        s1, s2 = reads[2*p], reads[2*p+1]
-        parts.append(f"@r{fi}_{p}/1 BX:Z:{bc}\n{s1}\n+\n{'F'*len(s1)}\n@r{fi}_{p}/2 BX:Z:{bc}\n{s2}\n+\n{'F'*len(s2)}\n")
-    text = "".join(parts)
-    open(f"{tmp}/r{fi}.fq", "w").write(text)
-    with gzip.open(f"{tmp}/r{fi}.fq.gz", "wt", compresslevel=4) as f:
-        f.write(text)
+    batch["barcode_id"] = batch["barcode_id"] + fi * (NP // 80 + 1)          # barcodes of their own per file
+    text = synth.fastq_bytes(batch, first_pair=fi * NP).tobytes()
+    for b in np.unique(batch["barcode_id"].numpy()):
+        v, name = int(b), []
+        for _ in range(16):
+            name.append("ACGT"[v % 4]); v //= 4
+        mult["".join(reversed(name)) + "-1"] = 160
+    open(f"{tmp}/r{fi}.fq", "wb").write(text)
+    jobs.append((f"{tmp}/r{fi}.fq.gz", text))
     if os.environ.get("E2E_BGZF"):
         sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
         from test_host_ingest import write_bgzf
-        write_bgzf(f"{tmp}/r{fi}.bgzf.fq.gz", text.encode(), level=4)
+        write_bgzf(f"{tmp}/r{fi}.bgzf.fq.gz", text, level=4)
+with ThreadPoolExecutor(32) as ex:
+    list(ex.map(one_stream_gz, jobs))
+del jobs
 with open(f"{tmp}/mult.tsv", "w") as f:
     f.writelines(f"{k}\t{v}\n" for k, v in mult.items())
 print("data generated in %.1f s; %d files x %d pairs; fq %.0f MB each" % (time.time()-t0, NF, NP, len(text)/1e6), flush=True)

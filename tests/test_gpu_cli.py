@@ -220,8 +220,8 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
     bad_paths = [str(paths[0]), str(tmp_path / "no_such_reads.fq"), str(paths[2])]
     one = subprocess.run(args2 + bad_paths, capture_output=True, text=True, timeout=300)
     two = subprocess.run(args2 + ["--ranks", "2"] + bad_paths, capture_output=True, text=True, timeout=300)
-    assert one.returncode == two.returncode == 1
-    assert "no_such_reads.fq cannot be opened." in one.stderr and one.stderr == two.stderr
+    assert one.returncode == two.returncode and one.returncode != 0
+    assert "no_such_reads.fq" in one.stderr and one.stderr == two.stderr
     assert _norm(one.stdout, "multi", "counts2") == _norm(two.stdout, "multi", "counts2")
     # ---- the contig k-mer index in three parts (--index-shards): per batch the votes of every part,
     #      their maximum, then the j_index test -- same files, same stored pairs ----------------------
