@@ -623,10 +623,15 @@ def main():
                                          "profiled dispatches)",
                          "traffic_source": traffic["source"] if traffic else None,
                          "traffic_build_match": build_match,
-                         "random_access": ({"achieved": misses / (kernel_ms * 1e-3), "ceiling": RANDOM_ACCESS_CEILING,
-                                            "unit": "L2 misses/s (TCC_MISS) vs independent random 32-byte reads/s of a "
-                                                    ">= 16 GiB table (profiles/r03_gather_tlb.txt)",
-                                            "frac": misses / (kernel_ms * 1e-3) / RANDOM_ACCESS_CEILING}
+                         # the kernel's L2 misses per second (random probes, short runs of text records, and the
+                         # sequential read stream together) beside what the part sustains with random 32-byte reads
+                         # alone: a ratio near 1 (the sequential share can take it past 1) says the memory system's
+                         # request rate, not its byte rate, is what is used up
+                         "random_access": ({"l2_misses_per_s": misses / (kernel_ms * 1e-3),
+                                            "random_gather_ceiling_per_s": RANDOM_ACCESS_CEILING,
+                                            "ratio": misses / (kernel_ms * 1e-3) / RANDOM_ACCESS_CEILING,
+                                            "source": "TCC_MISS of the counter passes; profiles/r03_gather_tlb.txt "
+                                                      "(3.8e10 random 32-byte reads/s over a 16-64 GiB table)"}
                                            if misses else None),
                          "kernel_build_id": kernel_build_id(),
                          "alg_achieved": alg_achieved, "alg_frac": alg_achieved / HBM_PEAK_GBS,
