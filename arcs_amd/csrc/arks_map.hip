@@ -2,6 +2,7 @@
 // (Arcs/Arcs.cpp:939-1014) for a batch, the pair rule of chromiumRead (:1264-1292) and the
 // (barcode, contig end) accumulation.  Reference behaviour restated, never its code.
 #include "arks_kernels.hpp"
+#include <cstddef>
 
 #include <cstdio>
 #include <cstdlib>
@@ -342,6 +343,7 @@ constexpr int kChunk = 48;       // reads handed out per grab of the work counte
                                  // finish, large enough for the counter (same-address atomics serialise at ~12 ns:
                                  // 24 reads per grab made the COUNTER the kernel's run time, 20 ms at C2)
 constexpr u32 kHnHeavy = 255, kHnOverflow = 254;
+constexpr int kRecFallback = -4; // window record of the medium kernel: "probe the fallback table" (between T6c and T6d)
 
 // Bit b of the result: none of the positions [b, b + k) of the 128-bit vector m3:m2:m1:m0 (m0 = positions
 // 0..31) is set, for b in [0, 32) and k in [32, 96].  Such a span always reaches the end of m0, so: b lies
@@ -1500,14 +1502,9 @@ map_reads_b_kernel(
 						const Key<KW> f = tile_window_key<KW>(S.cw, i, g);
 						const Key<KW> r = key_revcomp(f, g);
 						if (hn == kHnHeavy) {
-							Key<KW> c;
-							const bool lt = key_less(f, r);
-#pragma unroll
-							for (int x = 0; x < KW; ++x)
-								c.w[x] = lt ? f.w[x] : r.w[x];
-							if (key_eq(f, r)) // a palindrome lives in the fallback table under its damaged key
-								c = key_palindrome_quirk(f, g);
-							val = fallback_lookup<KW>(bx, c);
+							// an exact-key probe of the fallback table: not here, where every batch of 64 windows
+							// would wait for its own probes -- the windows are listed and probed together below
+							val = kRecFallback;
 						} else if (hn == kHnOverflow) {
 							{ // (the window's place in the batch's packed arrays: its read's, not the tile's)
 								const int jr = S.wread[i >> 5];
@@ -1526,6 +1523,81 @@ map_reads_b_kernel(
 						}
 					}
 					rec[i] = val;
+				}
+			}
+			ARKS_WAVE_SYNC();
+			// ---- T6d: the windows under heavy seeds: exact keys into the fallback table.  Their positions are
+			//      compacted (ballot + mbcnt) into the storage of the staged text, which is dead by now, and every
+			//      lane keeps TWO probes in flight per round trip (a repeat-rich draft sends ~70 windows of a read
+			//      here: eight dependent probe rounds per tile before, two or three now) -------------------------
+			{
+				unsigned short* const flist = reinterpret_cast<unsigned short*>(S.tcodes_f);
+				// (tcodes_f, tvis_f, tamb_f, town_f lie one behind the other: 2000 bytes for <= kTP positions)
+				static_assert(!FULL || offsetof(TileLds<FULL>, mm32_f) - offsetof(TileLds<FULL>, tcodes_f) >=
+				                           sizeof(unsigned short) * (size_t)kTP, "window list");
+				int nlist = 0;
+				for (int base = 0; base < n; base += 64) {
+					const int i = base + lane;
+					const bool need = i < n && rec[i] == kRecFallback;
+					const u64 nb = __ballot(need);
+					if (need)
+						flist[nlist + (int)mask_below(nb)] = (unsigned short)i;
+					nlist += __popcll(nb);
+				}
+				ARKS_WAVE_SYNC();
+				for (int base = 0; base < nlist; base += 128) {
+					int wi[2];
+					bool act[2];
+					Key<KW> c[2];
+					u64 sl[2];
+					int val[2] = { -1, -1 };
+#pragma unroll
+					for (int u = 0; u < 2; ++u) {
+						const int e = base + 64 * u + lane;
+						act[u] = e < nlist;
+						wi[u] = act[u] ? (int)flist[e] : 0;
+						const Key<KW> f = tile_window_key<KW>(S.cw, wi[u], g);
+						const Key<KW> r = key_revcomp(f, g);
+						const bool lt = key_less(f, r);
+#pragma unroll
+						for (int x = 0; x < KW; ++x)
+							c[u].w[x] = lt ? f.w[x] : r.w[x];
+						if (key_eq(f, r)) // a palindrome lives in the fallback table under its damaged key
+							c[u] = key_palindrome_quirk(f, g);
+						sl[u] = mulhi64(key_hash(c[u]), bx.fallback.cap);
+					}
+					while (__ballot(act[0] || act[1]) != 0) {
+						u64 w[2][kSlotWords];
+#pragma unroll
+						for (int u = 0; u < 2; ++u)
+							if (act[u]) {
+								const u64* slot = bx.fallback.slots + sl[u] * kSlotWords;
+#pragma unroll
+								for (int x = 0; x < kSlotWords; ++x)
+									w[u][x] = slot[x];
+							}
+						asm volatile("" : "+v"(w[0][0]), "+v"(w[1][0])); // both slots requested before either is looked at
+#pragma unroll
+						for (int u = 0; u < 2; ++u)
+							if (act[u]) {
+								const u32 st = (u32)w[u][3];
+								bool eq = true;
+#pragma unroll
+								for (int x = 0; x < KW; ++x)
+									eq = eq && w[u][x] == c[u].w[x];
+								if (st == kEmpty)
+									act[u] = false;
+								else if (eq) {
+									val[u] = (int)(st - 1u);
+									act[u] = false;
+								} else
+									sl[u] = (sl[u] + 1 == bx.fallback.cap) ? 0 : sl[u] + 1;
+							}
+					}
+#pragma unroll
+					for (int u = 0; u < 2; ++u)
+						if (base + 64 * u + lane < nlist)
+							rec[wi[u]] = val[u];
 				}
 			}
 			ARKS_WAVE_SYNC();
