@@ -533,18 +533,29 @@ bdilate_kernel(const u32* __restrict__ in, u64 total_words, int w, u32* __restri
 	out[word] = acc;
 }
 
-// text records of the seed index: what the hot kernel stages per text word, side by side
+// text records of the seed index: what the hot kernel stages per text word, side by side: 16 bytes = the word's codes,
+// its visited and its ambiguous bits.  The owner (contig end) of a word is not in the record: it changes only at the
+// borders of the ends, so a table of one u32 per 32 words (1024 bases; 5.5 MB at 3 Gbp: L2 / Infinity Cache
+// resident) answers for every block that lies inside one end, ~0 sends the few blocks with a border (or padding) in
+// them to word_owner.  (24-byte records with the owner inside cost the hot kernel a third load per staging slot and
+// every second read a 64-byte line more: 4.13 -> 3.89 ms per 20 M pairs by the loads alone, profiles/r03g_ab.txt.)
 __global__ void
 btextrec_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ visited, const u32* __restrict__ ambig,
-    const u32* __restrict__ word_owner, u64 alloc_words, u64* __restrict__ trec)
+    const u32* __restrict__ word_owner, u64 alloc_words, u64* __restrict__ trec, u32* __restrict__ owner_blk)
 {
 	const u64 word = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (word >= alloc_words)
 		return;
-	trec[3 * word + 0] = codes[word];
-	trec[3 * word + 1] = (u64)visited[word] | ((u64)ambig[word] << 32);
-	trec[3 * word + 2] = (u64)word_owner[word];
+	trec[2 * word + 0] = codes[word];
+	trec[2 * word + 1] = (u64)visited[word] | ((u64)ambig[word] << 32);
+	if ((word & 31) == 0) { // this thread's block of 32 words
+		const u32 o = word_owner[word];
+		bool same = true;
+		for (u64 x = 1; x < 32; ++x)
+			same = same && (word + x < alloc_words ? word_owner[word + x] : 0u) == o;
+		owner_blk[word >> 5] = same ? o : 0xFFFFFFFFu;
+	}
 }
 
 // registered m-mer positions per owner rank of a sharded seed table
@@ -1119,11 +1130,11 @@ launch_bowners(int mm, const u64* codes, const u32* is_min, u64 total_words, u32
 hipError_t
 launch_btextrec(
     const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner, u64 alloc_words, u64* trec,
-    hipStream_t st)
+    u32* owner_blk, hipStream_t st)
 {
 	if (alloc_words == 0)
 		return hipSuccess;
-	btextrec_kernel<<<blocks_for(alloc_words, 256), 256, 0, st>>>(codes, visited, ambig, word_owner, alloc_words, trec);
+	btextrec_kernel<<<blocks_for(alloc_words, 256), 256, 0, st>>>(codes, visited, ambig, word_owner, alloc_words, trec, owner_blk);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

@@ -997,12 +997,15 @@ index_build_impl(
 			idx->bxg = idx->bx;
 		if (dense) {
 			void* p = nullptr;
-			HIP_TRY(hipMalloc(&p, 3 * sizeof(u64) * alloc_words));
+			// 16-byte records, and behind them the owner per block of 32 words
+			HIP_TRY(hipMalloc(&p, 2 * sizeof(u64) * alloc_words + sizeof(u32) * (alloc_words / 32 + 1)));
 			idx->trec = static_cast<u64*>(p);
+			u32* const owner_blk = reinterpret_cast<u32*>(idx->trec + 2 * alloc_words);
 			// (word_owner is 0 in the padding, visited / ambig too: a diagonal that runs off the text matches nothing)
-			HIP_TRY(launch_btextrec(idx->codes, idx->visited, idx->ambig, idx->word_owner, alloc_words, idx->trec, st));
+			HIP_TRY(launch_btextrec(idx->codes, idx->visited, idx->ambig, idx->word_owner, alloc_words, idx->trec, owner_blk, st));
 			HIP_TRY(hipStreamSynchronize(st));
 			idx->bx.trec = idx->trec;
+			idx->bx.owner_blk = owner_blk;
 		}
 	}
 	*out = idx;
@@ -1140,7 +1143,7 @@ arks_index_device_bytes(const arks_index* idx)
 	}
 	if (idx->kind >= 1)
 		b += (int64_t)(idx->alloc_words * (sizeof(u64) + 3 * sizeof(u32))) + (int64_t)(idx->bx.mtab_cap * sizeof(u64)) +
-		     (idx->trec ? (int64_t)(idx->alloc_words * 3 * sizeof(u64)) : 0) +
+		     (idx->trec ? (int64_t)(idx->alloc_words * 2 * sizeof(u64) + (idx->alloc_words / 32 + 1) * sizeof(u32)) : 0) +
 		     (idx->mtab_gen ? (int64_t)(idx->bxg.mtab_cap * sizeof(u64)) : 0);
 	return b;
 }

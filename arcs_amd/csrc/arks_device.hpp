@@ -397,8 +397,10 @@ struct BIndexView
 	int w;       // minimizer window: k - m + 1
 	int enabled; // 0 => the plain hash table `TableView` is the index (small k)
 	int has_img; // the index holds regular keys that are quirk images (a palindromic query could hit them)
-	const u64* trec; // seed index: codes, visited | ambig << 32, owner of every text word side by side (3 u64 = 24 B
-	                 // per word): the hot kernel reads one record where the general kernels read four arrays
+	const u64* trec; // seed index: codes, visited | ambig << 32 of every text word side by side (2 u64 = 16 B per word):
+	                 // the hot kernel reads one record where the general kernels read three arrays
+	const u32* owner_blk; // seed index: contig end of the 32 text words [32 b, 32 b + 32), ~0 where they differ
+	                      // (a border of two ends, padding): word_owner then
 	int dense;   // 1: the table holds EVERY m-mer position inside a visited window ("seed index"): a query
 	             // window may be looked up through any m-mer it contains, so a read needs one fixed-position
 	             // seed per w windows and no minimizers at all; 0: minimizer positions only

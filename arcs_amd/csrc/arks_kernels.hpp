@@ -66,6 +66,7 @@ hipError_t launch_bowners(
     int mm, const u64* codes, const u32* is_min, u64 total_words, u32 n_own, u64* per_owner, hipStream_t st);
 hipError_t launch_btextrec(
     const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner, u64 alloc_words, u64* trec,
+    u32* owner_blk,
     hipStream_t st);
 hipError_t launch_bexport(
     int kw, const u64* codes, const u32* visited, const u32* ambig, const u32* word_owner,

@@ -2173,12 +2173,16 @@ map_reads_s_kernel(
 					const int j = S.sread[sl];
 					if (S.pdiag[j][d] >> 41) {
 						const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
-						const u64* rec = bx.trec + 3 * tw_idx; // codes | visited, ambig | owner: one 24-byte record
-						const u64 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-						S.tcodes[sl] = r0;
-						S.tvis[sl] = (u32)r1;
-						S.tamb[sl] = (u32)(r1 >> 32);
-						S.town[sl] = (u32)r2;
+						// codes | visited, ambig: one 16-byte record; the owner from the table of 32-word blocks (cache
+						// resident), from word_owner only for a block that holds a border of two ends
+						const ulonglong2 rec = *reinterpret_cast<const ulonglong2*>(bx.trec + 2 * tw_idx);
+						u32 own = bx.owner_blk[tw_idx >> 5];
+						if (own == 0xFFFFFFFFu)
+							own = bx.word_owner[tw_idx];
+						S.tcodes[sl] = rec.x;
+						S.tvis[sl] = (u32)rec.y;
+						S.tamb[sl] = (u32)(rec.y >> 32);
+						S.town[sl] = own;
 					}
 				}
 				if (lane < 8) // the spans of the last words read past the tile: no mismatch there

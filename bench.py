@@ -608,13 +608,13 @@ def main():
                                                                 ", the one read set dealt to the ranks in blocks"))},
             # `frac` = what the dominant kernel moves through HBM per second (rocprofv3 FETCH_SIZE + WRITE_SIZE per
             # launch / its mean duration by HIP events in THIS run) over the 8 TB/s peak -- a fraction by construction.
-            # The path's accesses are random 32-byte probes of a 46 GB table and 100-170-byte runs of text records,
+            # The path's accesses are random 32-byte probes of a 46 GB table and 80-110-byte runs of text records,
             # so what bounds it is the rate of independent HBM accesses (`random_access`), not the byte rate.
             # `alg_*` = SURVEY 8(d)'s algorithmic figure (a 15-byte key compare + a value per window): the locality
             # index does not move those bytes, so alg_frac may pass 1 -- it compares the path with "one key compare
             # per window at HBM speed" and is NOT a roofline fraction.
             "roofline": {"bound": "hbm",
-                         "bound_detail": "HBM random-access rate (32-byte seed-table probes + short runs of 24-byte "
+                         "bound_detail": "HBM random-access rate (32-byte seed-table probes + short runs of 16-byte "
                                          "text records), not byte bandwidth",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
