@@ -47,3 +47,16 @@ def test_bench_gpus_flag_starts_the_ranks(arks, gpu):
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak"
     assert weak["config"]["pairs_job"] == 800000
     assert weak["counters"]["windows"] > one["counters"]["windows"]
+
+
+@pytest.mark.gpu
+def test_bench_sharded_index_over_the_exchange(arks, gpu):
+    """`bench.py --sharded-index` with one process: the seed table in 3 local shards, the read set dealt to them,
+    every batch through arks_exchange -- the summed counters equal the replica run's on the same read set"""
+    one = _bench([])
+    sh = _bench(["--sharded-index", "--shards", "3"])
+    assert sh["n_gpus"] == 1 and sh["config"]["shards"] == 3 and sh["scaling"] == "strong"
+    assert sh["counters"] == one["counters"]
+    ex = sh["config"]["last_batch_of_rank0"]
+    assert ex["seeds"] > 0 and 0 < ex["sent"] < ex["seeds"] and ex["received"] > 0
+    assert max(sh["config"]["shard_bytes"]) > 0
