@@ -190,6 +190,8 @@ struct arks_exchange
 	u64* d_all = nullptr;    // world x world: [p * world + o] = seeds rank p asks of owner o
 	u64* h_totals = nullptr; // pinned: 1 + world, then world x world
 	arks_exchange_stats last{};
+	hipStream_t last_stream = nullptr; // the buffers are reused in the order of this stream
+	bool used = false;
 };
 
 namespace {
@@ -398,6 +400,12 @@ arks_map_reads_exchanged_device(
 	Rccl* rccl = x->comm ? Rccl::get() : nullptr;
 	LocalGroup* g = x->group;
 	int rc = ARKS_OK;
+	// the buffers of the last call (its map kernel may still be reading them) are reused in stream order: a call on
+	// another stream waits for the old one first
+	if (x->used && x->last_stream != st)
+		(void)hipStreamSynchronize(x->last_stream);
+	x->last_stream = st;
+	x->used = true;
 	std::vector<u64> sc((size_t)W), rcv((size_t)W), soff((size_t)W + 1), roff((size_t)W + 1);
 	u64 n_seeds = 0;
 	const long nb = seed_bucket_blocks((long)n_reads);
@@ -441,8 +449,8 @@ arks_map_reads_exchanged_device(
 			for (int o = 0; o < W; ++o)
 				x->h_totals[1 + W + p * W + o] = g->failed[(size_t)p] ? 0 : g->counts_host[(size_t)p][1 + o];
 		}
-		if (!g->barrier()) // everybody has read everybody's counts
-			return exchange_broken();
+		// (no second barrier: a rank overwrites its counts only in its NEXT call, which it enters behind the barriers
+		// below -- and those every rank reaches after it has read the counts)
 	} else if (W == 1)
 		x->h_totals[2] = x->h_totals[1];
 	if (rc != ARKS_OK && !g)
@@ -542,9 +550,9 @@ arks_map_reads_exchanged_device(
 			EX_TRY(hipMemcpyAsync(x->ans_back.as<u64>() + 2 * soff[(size_t)p], g->ans_out[(size_t)p] + 2 * off,
 			                      2 * sizeof(u64) * sc[(size_t)p], hipMemcpyDeviceToDevice, st));
 		}
-		EX_TRY(hipStreamSynchronize(st)); // I have read the others' answers ...
-		if (!g->barrier())                // ... and they mine: the buffers may be reused
-			return exchange_broken();
+		// (no wait here: the copies above are on this rank's stream; its next call -- on the same stream, see
+		// arks_hip.h -- synchronises that stream before it lets any other rank write the buffers they read from,
+		// so the map kernel below and the pair rule behind it overlap with the other ranks' next batch)
 	}
 	// ---- 6. the home finishes -------------------------------------------------------------------------------
 	if (rc == ARKS_OK && n_reads > 0) {

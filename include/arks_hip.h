@@ -333,7 +333,9 @@ int arks_exchange_last_stats(const arks_exchange* x, arks_exchange_stats* out);
  * counters as arks_map_reads_device against the whole index.  COLLECTIVE: every rank calls it, in the same order,
  * each with its own batch (n_reads may be 0).  On `stream`: seeds listed and bucketed by owner (three kernels),
  * all-to-all of the seeds (8 B), owner-side probe, all-to-all of the answers (16 B), map; one small
- * device-to-host copy (the per-owner counts) is the call's only wait for the device. */
+ * device-to-host copy (the per-owner counts) is the call's only wait for the device.  The calls of ONE exchange
+ * must all be made on the same stream (its buffers are reused from call to call in stream order); two exchanges
+ * on two streams may be in flight at the same time. */
 int arks_map_reads_exchanged_device(
     arks_exchange* x,
     const uint64_t* d_codes,
