@@ -58,25 +58,43 @@ def kernel_build_id():
 
 
 def pmc_traffic(workload):
-    """HBM bytes (and L2 misses) per launch of the dominant kernel from the committed rocprofv3 PMC summary of
-    this very workload (profiles/traffic_r*.json, written from separate --pmc passes by profiles/prof.sh).
-    Returns (summary, build_match): the summary taken on THIS kernel build when there is one; otherwise the
-    newest summary of the workload with build_match = False (reported as such: the counters of another build
-    are an estimate, never passed off as this build's); (None, False) when there is none at all."""
+    """HBM bytes (and L2 misses) per launch of the dominant kernel from the committed rocprofv3 PMC summaries
+    (profiles/traffic_r*.json, written from separate --pmc passes by profiles/prof.sh).
+    Returns (summary, build_match, scaled): the summary of this very workload taken on THIS kernel build when
+    there is one; otherwise the newest summary of the workload with build_match = False (reported as such: the
+    counters of another build are an estimate, never passed off as this build's).  A launch of another size over the
+    same draft and k (a rank's share under --gpus N) takes the per-pair figures of the full-size summary times its
+    pairs -- the kernel's traffic is per pair -- and says so (`scaled` = the pairs per launch it was scaled from);
+    (None, False, None) when there is nothing to go by."""
     bid = kernel_build_id()
-    best, stale = None, None
+    exact, stale, other = None, None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if d.get("workload") != workload:
-            continue
-        if d.get("kernel_build_id") == bid:
-            best = d
-        else:
-            stale = d
-    return (best, True) if best else (stale, False)
+        w = d.get("workload", {})
+        if w == workload:
+            if d.get("kernel_build_id") == bid:
+                exact = d
+            else:
+                stale = d
+        elif {k: v for k, v in w.items() if k != "pairs_per_launch"} == \
+                {k: v for k, v in workload.items() if k != "pairs_per_launch"} and w.get("pairs_per_launch"):
+            if other is None or d.get("kernel_build_id") == bid or other.get("kernel_build_id") != bid:
+                other = d
+    if exact:
+        return exact, True, None
+    if stale:
+        return stale, False, None
+    if other:
+        f = workload["pairs_per_launch"] / other["workload"]["pairs_per_launch"]
+        d = dict(other)
+        d["hbm_bytes_per_launch"] = other["hbm_bytes_per_launch"] * f
+        if other.get("TCC_MISS_per_launch"):
+            d["TCC_MISS_per_launch"] = other["TCC_MISS_per_launch"] * f
+        return d, other.get("kernel_build_id") == bid, other["workload"]["pairs_per_launch"]
+    return None, False, None
 
 
 # measured ceiling of independent random HBM accesses on this part (profiles/r03_gather_tlb.txt: 3.8e10 /s over a
@@ -582,7 +600,7 @@ def main():
         workload = {"draft_mbp": args.draft_mbp, "pairs_per_launch": wl.pairs_per_launch, "k": k}
         if args.repeats:
             workload["repeats"] = True
-        traffic, build_match = pmc_traffic(workload)
+        traffic, build_match, traffic_scaled = pmc_traffic(workload)
         hbm_gb = (traffic["hbm_bytes_per_launch"] / 1e9) if traffic else None
         achieved = (hbm_gb / (kernel_ms * 1e-3)) if traffic else None
         misses = traffic.get("TCC_MISS_per_launch") if traffic else None
@@ -623,6 +641,7 @@ def main():
                                          "profiled dispatches)",
                          "traffic_source": traffic["source"] if traffic else None,
                          "traffic_build_match": build_match,
+                         "traffic_scaled_from_pairs_per_launch": traffic_scaled,
                          # the kernel's L2 misses per second (random probes, short runs of text records, and the
                          # sequential read stream together) beside what the part sustains with random 32-byte reads
                          # alone: a ratio near 1 (the sequential share can take it past 1) says the memory system's
