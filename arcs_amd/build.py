@@ -11,11 +11,28 @@ HEADERS = [os.path.join(HERE, "csrc", f) for f in ("arks_device.hpp", "arks_kern
 OUT = os.path.join(HERE, "lib", "libarks_hip.so")
 
 
+STAMP = OUT + ".digest"          # digest of the sources the library was built from (travels with it)
+
+
+def _digest(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
+    """by content, not by time stamp: a copy of the tree (the GPU box gets one) must not look newer than the library
+    that came with it -- a rebuild there costs minutes of hipcc inside a test run"""
     if not os.path.exists(OUT):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+    try:
+        return open(STAMP).read().strip() != _digest(SOURCES + HEADERS)
+    except OSError:
+        t = os.path.getmtime(OUT)
+        return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
 def build(force=False, verbose=False):
@@ -29,6 +46,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_digest(SOURCES + HEADERS) + "\n")
     return OUT
 
 
@@ -39,9 +58,15 @@ HOST_OUT = os.path.join(HERE, "bin", "arcs")
 def build_host(force=False, verbose=False):
     """the `arcs --arks` front end (C++17 host program over the C ABI; needs zlib)"""
     build(force=False, verbose=verbose)
-    if not force and os.path.exists(HOST_OUT) and \
-            all(os.path.getmtime(p) <= os.path.getmtime(HOST_OUT) for p in HOST_SOURCES + [OUT]):
-        return HOST_OUT
+    host_stamp = HOST_OUT + ".digest"
+    host_digest = _digest(HOST_SOURCES + [os.path.join(ROOT, "include", "arks_hip.h"), STAMP])
+    if not force and os.path.exists(HOST_OUT) and os.path.exists(os.path.join(HERE, "bin", "long-to-linked-pe")):
+        try:
+            if open(host_stamp).read().strip() == host_digest:
+                return HOST_OUT
+        except OSError:
+            if all(os.path.getmtime(p) <= os.path.getmtime(HOST_OUT) for p in HOST_SOURCES + [OUT]):
+                return HOST_OUT
     os.makedirs(os.path.dirname(HOST_OUT), exist_ok=True)
     cxx = os.environ.get("CXX", "g++")
     cmd = [cxx, "-O2", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
@@ -58,6 +83,8 @@ def build_host(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd2), file=sys.stderr)
     subprocess.check_call(cmd2)
+    with open(host_stamp, "w") as f:
+        f.write(host_digest + "\n")
     return HOST_OUT
 
 
