@@ -478,9 +478,7 @@ arks_map_reads_exchanged_device(
 	EX_TRY(launch_seed_buckets(
 	    idx->bx.m, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, idx->k, idx->bx.w,
 	    (u32)W, x->cols.as<u32>(), x->d_totals, x->seed_off.as<long>(), x->slot.as<u32>(), x->send.as<u64>(), 1, st));
-	if (rc == ARKS_OK && sc[(size_t)me]) // my own seeds stay here
-		EX_TRY(hipMemcpyAsync(x->recv.as<u64>() + roff[(size_t)me], x->send.as<u64>() + soff[(size_t)me],
-		                      sizeof(u64) * sc[(size_t)me], hipMemcpyDeviceToDevice, st));
+	// (my own seeds stay where they are: they are answered straight from the send buffer into the answers' place, below)
 	if (rccl && W > 1 && rc == ARKS_OK) {
 		RCCL_TRY(rccl->GroupStart());
 		for (int p = 0; p < W; ++p) {
@@ -514,11 +512,14 @@ arks_map_reads_exchanged_device(
 		}
 	}
 	// ---- 4. the owner's answers -----------------------------------------------------------------------------
-	EX_TRY(launch_seeds_probe(idx->bx.m, idx->bx, x->recv.as<u64>(), (long)roff[(size_t)W], x->ans_out.as<u64>(), st));
+	// what the ranks in front of me asked, what the ranks behind me asked (my own part of the receive buffer lies between
+	// them, unused), and my own seeds from where they are to where their answers belong
+	EX_TRY(launch_seeds_probe(idx->bx.m, idx->bx, x->recv.as<u64>(), (long)roff[(size_t)me], x->ans_out.as<u64>(), st));
+	EX_TRY(launch_seeds_probe(idx->bx.m, idx->bx, x->recv.as<u64>() + roff[(size_t)me + 1],
+	                          (long)(roff[(size_t)W] - roff[(size_t)me + 1]), x->ans_out.as<u64>() + 2 * roff[(size_t)me + 1], st));
+	EX_TRY(launch_seeds_probe(idx->bx.m, idx->bx, x->send.as<u64>() + soff[(size_t)me], (long)sc[(size_t)me],
+	                          x->ans_back.as<u64>() + 2 * soff[(size_t)me], st));
 	// ---- 5. answers back ------------------------------------------------------------------------------------
-	if (rc == ARKS_OK && sc[(size_t)me])
-		EX_TRY(hipMemcpyAsync(x->ans_back.as<u64>() + 2 * soff[(size_t)me], x->ans_out.as<u64>() + 2 * roff[(size_t)me],
-		                      2 * sizeof(u64) * sc[(size_t)me], hipMemcpyDeviceToDevice, st));
 	if (rccl && W > 1 && rc == ARKS_OK) {
 		RCCL_TRY(rccl->GroupStart());
 		for (int p = 0; p < W; ++p) {

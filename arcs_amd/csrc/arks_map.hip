@@ -1991,9 +1991,14 @@ map_reads_s_kernel(
 			// ---- S1: words, metadata, seeds ----------------------------------------------------------
 			// (wave-uniform) does a read of the tile hold an invalid base?  nr <= 16 reads from cur on
 			const bool want_nm = ((nreads_mask >> cur) & ((1ull << nr) - 1ull)) != 0;
+			// REMOTE with slot numbers: lane = seed asks for its slot here, in the round trip of the tile's words --
+			// S2 then has one dependent load (the answer) where the fused kernel has its probe, not two
+			u32 slot_pref = ~0u;
 			{
 				u64 c_in = 0, c_pad = 0;
 				u32 m_in = 0, m_pad = 0;
+				if (REMOTE && seed_slot && lane < nh)
+					slot_pref = seed_slot[soff0 + (long)(gbase + lane)];
 				if (lane < tw) {
 					c_in = codes[base_w + (u64)lane];
 					if (want_nm)
@@ -2036,7 +2041,7 @@ map_reads_s_kernel(
 					S.redo = z;
 					S.redo2 = z;
 				}
-				asm volatile("" : "+v"(c_in), "+v"(m_in), "+v"(c_pad), "+v"(m_pad)); // all four loads in flight
+				asm volatile("" : "+v"(c_in), "+v"(m_in), "+v"(c_pad), "+v"(m_pad), "+v"(slot_pref)); // all loads in flight
 				if (lane < tw) {
 					S.cw[lane] = c_in;
 					if (want_nm)
@@ -2088,10 +2093,8 @@ map_reads_s_kernel(
 				if (!(has_n && tile_span_has_n(S.nm, q, MM))) {
 					if (REMOTE) {
 						long si = soff0 + (long)(gbase + lane);
-						if (seed_slot) {
-							const u32 sl = seed_slot[si];
-							si = sl == ~0u ? -1 : (long)sl;
-						}
+						if (seed_slot)
+							si = slot_pref == ~0u ? -1 : (long)slot_pref;
 						if (si >= 0) {
 							const u64* a = ans + 2 * si;
 							ent[0] = a[0], ent[1] = a[1];
