@@ -9,7 +9,7 @@
 //     device copies behind a host barrier -- what a single-GPU box can run: tests, bench.py --sharded-index at N = 1.
 // One call, arks_map_reads_exchanged_device, is the whole step for a batch of this rank's reads -- every rank calls it in
 // step (the exchange is collective):
-//   1. seeds listed and bucketed by owner on the device       launch_seed_buckets (count, scan, fill; arks_map.hip)
+//   1. seeds listed and bucketed by owner on the device       launch_seed_buckets (count, scan, fill; arks_shard.hip)
 //   2. counts to everybody (all-gather of world numbers)      one small device-to-host copy: the step's only host sync
 //   3. seeds to their owners (8 B each)                       all-to-all #1
 //   4. owners answer from their shard (16 B each)             seeds_probe_kernel
