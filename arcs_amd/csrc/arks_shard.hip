@@ -173,93 +173,56 @@ seed_bucket_fill_kernel(
     long n_blocks, const u32* __restrict__ cols, const u64* __restrict__ totals, long* __restrict__ seed_off,
     u32* __restrict__ slot, u64* __restrict__ send)
 {
-	// Slots are handed out IN ORDER: wave by wave, seed number by seed number, lane by lane (ballot + mbcnt), not by
-	// an atomic per seed -- the answers come back at the slots, and the map kernel reads the answers of a tile's seeds
-	// (16 reads = 16 neighbouring lanes of one wave here) from a few 64-byte lines per owner instead of one line per seed.
-	constexpr int kWaves = kBucketReads / 64;
+	// (slots within a block are handed out by an LDS atomic per seed, in no particular order.  Handing them out in
+	// order -- wave, seed number, lane: ballot + mbcnt -- so that a tile's answers lie in fewer lines was tried:
+	// the fill took 1.31 instead of 1.08 ms per 25 M pairs and the map kernel behind it the same 3.5 ms,
+	// profiles/r03p_sharded1_kernel_stats.csv against r03o's)
+	__shared__ u32 cnt[kMaxOwners + 1];
 	__shared__ u32 base[kMaxOwners + 1]; // [0]: first seed of the block (read-major); [1 + o]: first send slot of the block's seeds for owner o
-	__shared__ u32 wsum[kWaves];
-	__shared__ u32 wcnt[kWaves][kMaxOwners]; // seeds of wave v for owner o
-	__shared__ u32 run[kWaves][kMaxOwners];  // next slot of wave v for owner o
-	const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+	__shared__ u32 wsum[kBucketReads / 64];
 	if (threadIdx.x <= n_owners) {
+		cnt[threadIdx.x] = 0;
 		u64 b = cols[(long)threadIdx.x * n_blocks + blockIdx.x];
 		if (threadIdx.x >= 1)
 			for (u32 o = 0; o + 1 < threadIdx.x; ++o) // owners in front of this one in the send buffer
 				b += totals[1 + o];
 		base[threadIdx.x] = (u32)b;
 	}
-	for (u32 x = threadIdx.x; x < (u32)kWaves * n_owners; x += kBucketReads)
-		wcnt[x / n_owners][x % n_owners] = 0;
-	__syncthreads();
 	const long r = (long)blockIdx.x * kBucketReads + threadIdx.x;
 	u64 cm[kBucketInline];
 	u32 own[kBucketInline];
 	const int G = bucket_read_seeds<MM>(codes, nmask, word_off, lens, eval, r, n_reads, k, w, n_owners, cm, own, kBucketInline);
-	auto seed_of = [&](int gi, u64& c, u32& o) {
-		if (gi < kBucketInline)
-			c = cm[gi], o = own[gi];
-		else
-			bucket_one_seed<MM>(codes, nmask, word_off[r], (int)lens[r] - k + 1, w, gi, n_owners, c, o);
-	};
-	for (int gi = 0; gi < G; ++gi) { // this wave's seeds per owner
-		u64 c;
-		u32 o;
-		seed_of(gi, c, o);
-		if (o != ~0u)
-			atomicAdd(&wcnt[wave][o], 1u);
-	}
 	// read-major number of the read's first seed: exclusive scan of G over the block's threads
 	int incl = G;
 #pragma unroll
 	for (int d = 1; d < 64; d <<= 1) {
 		const int o = __shfl_up(incl, d);
-		incl += lane >= d ? o : 0;
+		incl += (int)(threadIdx.x & 63) >= d ? o : 0;
 	}
-	if (lane == 63)
-		wsum[wave] = (u32)incl;
+	if ((threadIdx.x & 63) == 63)
+		wsum[threadIdx.x >> 6] = (u32)incl;
 	__syncthreads();
-	for (u32 x = threadIdx.x; x < (u32)kWaves * n_owners; x += kBucketReads) {
-		const u32 v = x / n_owners, o = x % n_owners;
-		u32 b = base[1 + o];
-		for (u32 v2 = 0; v2 < v; ++v2)
-			b += wcnt[v2][o];
-		run[v][o] = b;
-	}
 	u32 before = 0;
-	for (int wv = 0; wv < wave; ++wv)
+	for (unsigned wv = 0; wv < (threadIdx.x >> 6); ++wv)
 		before += wsum[wv];
 	const long first = (long)base[0] + (long)before + (long)(incl - G);
 	if (r < n_reads)
 		seed_off[r] = first;
 	if (r == n_reads - 1)
 		seed_off[n_reads] = first + G;
-	__syncthreads();
-	for (int gi = 0; __ballot(gi < G) != 0; ++gi) {
-		const bool active = gi < G;
-		u64 c = ~0ull;
-		u32 o = ~0u;
-		if (active)
-			seed_of(gi, c, o);
+	for (int gi = 0; gi < G; ++gi) {
+		u64 c;
+		u32 o;
+		if (gi < kBucketInline)
+			c = cm[gi], o = own[gi];
+		else
+			bucket_one_seed<MM>(codes, nmask, word_off[r], (int)lens[r] - k + 1, w, gi, n_owners, c, o);
 		u32 sl = ~0u;
-		u64 todo = __ballot(active && o != ~0u);
-		while (todo) {
-			const int leader = __ffsll((long long)todo) - 1;
-			const u32 oo = (u32)__builtin_amdgcn_readlane((int)o, leader);
-			const u64 m = __ballot(active && o == oo);
-			if (active && o == oo)
-				sl = run[wave][oo] + mask_below(m);
-			ARKS_WAVE_SYNC();
-			if (lane == leader)
-				run[wave][oo] += (u32)__popcll(m);
-			ARKS_WAVE_SYNC();
-			todo &= ~m;
+		if (o != ~0u) {
+			sl = base[1 + o] + atomicAdd(&cnt[1 + o], 1u);
+			send[sl] = c;
 		}
-		if (active) {
-			if (sl != ~0u)
-				send[sl] = c;
-			slot[first + gi] = sl;
-		}
+		slot[first + gi] = sl;
 	}
 }
 
