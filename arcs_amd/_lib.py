@@ -61,6 +61,8 @@ SYMBOLS = {
     "arks_exchange_free": (_I, [_VP]),
     "arks_exchange_abort": (_I, [_VP]),
     "arks_exchange_last_stats": (_I, [_VP, _VP]),
+    "arks_exchange_submit": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
+    "arks_exchange_complete": (_I, [_VP]),
     "arks_map_reads_exchanged_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
     "arks_index_free": (_I, [_VP]),
     "arks_index_k": (_I, [_VP]),
@@ -84,6 +86,7 @@ SYMBOLS = {
     "arks_imap_set_pair_base": (_I, [_VP, C.c_uint64]),
     "arks_imap_export_ordered": (_I, [_VP, _VP, _VP]),
     "arks_debug_queue_counts": (_I, [_VP, _VP]),
+    "arks_exchange_debug_set_rccl": (_I, [_VP]),
     "arks_pair_gate_device": (_I, [_VP, _VP, _I64, _VP, _I, _VP]),
     "arks_gate_count_device": (_I, [_VP, _VP, _I64, _VP, _I, _VP]),
     "arks_pairs_device": (_I, [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _I, _VP]),

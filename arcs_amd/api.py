@@ -364,7 +364,7 @@ def map_reads_seeded(index, reads, j_index, seed_off, answers, eval_mask=None, s
 
 
 class ExchangeStats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("seeds", "sent", "received")]
+    _fields_ = [(n, C.c_uint64) for n in ("seeds", "sent", "received", "reruns")]
 
 
 class SeedExchange:
@@ -433,6 +433,24 @@ class SeedExchange:
             "arks_map_reads_exchanged_device")
         return out[:n]
 
+    def submit(self, reads, j_index, eval_mask=None, stats=None, out=None):
+        """arks_exchange_submit on the current torch stream (not collective): the batch's seeds bucketed by owner.
+        Returns the conreci tensor arks_exchange_complete fills (on the same stream); the caller keeps reads,
+        eval_mask and the result alive until then."""
+        torch = _torch()
+        n = reads.n_reads
+        if out is None:
+            out = torch.empty(max(n, 1), dtype=torch.int32, device=reads.codes.device)
+        check(lib().arks_exchange_submit(
+            self._h, reads.codes.data_ptr(), reads.nmask.data_ptr(), reads.word_off.data_ptr(), reads.lens.data_ptr(),
+            eval_mask.data_ptr() if eval_mask is not None else None, n, float(j_index), out.data_ptr(),
+            stats.data_ptr() if stats is not None else None, _stream_ptr(reads.device)), "arks_exchange_submit")
+        return out[:n]
+
+    def complete(self):
+        """arks_exchange_complete (COLLECTIVE): the oldest submitted batch is exchanged and mapped on its stream"""
+        check(lib().arks_exchange_complete(self._h), "arks_exchange_complete")
+
     def map_pairs(self, reads, j_index, pair_ok=None, barcode_id=None, imap=None, stored=None, stats=None):
         """chromiumRead's per-pair flow (Arcs.cpp:1264-1292) for this rank's read pairs: gate -> exchanged map ->
         pair rule + IndexMap update.  Returns (conreci, pair)."""
@@ -440,6 +458,57 @@ class SeedExchange:
         conreci = self.map_reads(reads, j_index, eval_mask=ev, stats=stats)
         pair = pairs_rule(conreci, reads, pair_ok, barcode_id, imap, stored)
         return conreci, pair
+
+    def map_pairs_pipelined(self, batches, j_index, streams, imap=None, stored=None, stats=None, n_calls=None,
+                            keep=True):
+        """The same flow over a list of batches (reads, pair_ok, barcode_id) with two of them in flight: batch n + 1 is
+        gated and submitted on streams[(n + 1) % 2] before batch n is completed, so its bucketing runs under batch n's
+        probes, transfers and map kernel, and the host never waits for counts.  COLLECTIVE: every rank makes
+        n_calls (default len(batches)) complete() calls -- a rank with fewer batches completes empty ones.  The pair
+        rule of all batches runs on streams[2] (the IndexMap is updated in one order).  Returns [(conreci, pair)]
+        (keep=False: nothing is kept, for timing runs)."""
+        torch = _torch()
+        dev = torch.device("cuda", self.index.device)
+        n_calls = len(batches) if n_calls is None else n_calls
+        empty = getattr(self, "_empty", None)
+        if empty is None:
+            empty = self._empty = PackedReads.from_arrays_device(
+                torch.zeros(0, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
+                torch.zeros(0, dtype=torch.int32, device=dev), device=self.index.device)
+        flight, res = [], []
+
+        def submit(i):
+            reads, ok, bid = batches[i] if i < len(batches) else (empty, None, None)
+            st = streams[i % 2]
+            with torch.cuda.stream(st):
+                ev = pair_gate(reads, ok)
+                conreci = self.submit(reads, j_index, eval_mask=ev, stats=stats)
+            flight.append((reads, ok, bid, ev, conreci, st))
+
+        def complete():
+            reads, ok, bid, ev, conreci, st = flight.pop(0)
+            self.complete()
+            done = torch.cuda.Event()
+            done.record(st)
+            streams[2].wait_event(done)
+            with torch.cuda.stream(streams[2]):
+                conreci.record_stream(streams[2])
+                ev.record_stream(streams[2])
+                pair = pairs_rule(conreci, reads, ok, bid, imap if bid is not None else None, stored) if reads.n_reads else None
+            # the batch's stream may not reuse ev / conreci before the pair rule has read them
+            tail = torch.cuda.Event()
+            tail.record(streams[2])
+            st.wait_event(tail)
+            if keep:
+                res.append((conreci, pair))
+
+        for i in range(n_calls):
+            submit(i)
+            if i >= 1:
+                complete()
+        if n_calls:
+            complete()
+        return res
 
 
 def map_votes_packed(index, reads, eval_mask=None, out=None):

@@ -59,6 +59,11 @@ def build_host(force=False, verbose=False):
     """the `arcs --arks` front end (C++17 host program over the C ABI; needs zlib)"""
     build(force=False, verbose=verbose)
     host_stamp = HOST_OUT + ".digest"
+    if not os.path.exists(STAMP):
+        # a library that needs_build() accepted by its time stamps (built by an older build.py, or a copied tree
+        # without the stamp): write the stamp it would have had
+        with open(STAMP, "w") as f:
+            f.write(_digest(SOURCES + HEADERS) + "\n")
     host_digest = _digest(HOST_SOURCES + [os.path.join(ROOT, "include", "arks_hip.h"), STAMP])
     if not force and os.path.exists(HOST_OUT) and os.path.exists(os.path.join(HERE, "bin", "long-to-linked-pe")):
         try:

@@ -1,24 +1,29 @@
 // arks_exchange.hpp -- the sharded seed table as product code (BASELINE configs[3]; included by arks_capi.hip).
 //
-// One arks_exchange per rank: the rank's shard of the seed table (arks_index_build_seed_shard), its device buffers,
-// and the transport that reaches the other ranks:
-//   * RCCL (one process per GPU, xGMI): ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the caller's stream --
-//     the library is opened on demand (dlopen: a process that never shards needs no RCCL, and a process that already
-//     carries one -- PyTorch bundles its own -- keeps that single copy);
-//   * local: the ranks are threads of ONE process (all shards on the visible device), buffers are handed over with
-//     device copies behind a host barrier -- what a single-GPU box can run: tests, bench.py --sharded-index at N = 1.
-// One call, arks_map_reads_exchanged_device, is the whole step for a batch of this rank's reads -- every rank calls it in
-// step (the exchange is collective):
-//   1. seeds listed and bucketed by owner on the device       launch_seed_buckets (count, scan, fill; arks_shard.hip)
-//   2. counts to everybody (all-gather of world numbers)      one small device-to-host copy: the step's only host sync
-//   3. seeds to their owners (8 B each)                       all-to-all #1
-//   4. owners answer from their shard (16 B each)             seeds_probe_kernel
-//   5. answers back, into send-buffer order                   all-to-all #2
-//   6. the home finishes                                      map_reads_s_kernel<REMOTE> reads ans[2 slot[seed]]
+// One arks_exchange per rank: the rank's shard of the seed table (arks_index_build_seed_shard), two sets of device
+// buffers (two batches in flight), and the transport that reaches the other ranks:
+//   * RCCL (one process per GPU, xGMI): ncclAllGather of the counts, ncclGroupStart / ncclSend / ncclRecv /
+//     ncclGroupEnd for the seeds and for the answers -- the library is opened on demand (dlopen: a process that never
+//     shards needs no RCCL, and a process that already carries one -- PyTorch bundles its own -- keeps that copy);
+//     every entry point is reached through one table of function pointers (arks_rccl_api), which a test replaces
+//     with threads-and-device-copies stand-ins, so that the code below runs with world > 1 on a one-GPU box;
+//   * direct: the ranks are threads of ONE process whose devices reach each other's memory (the same device, or
+//     peers over xGMI): nothing is copied at all -- the owner's probe kernel reads the askers' send buffers where
+//     they lie and writes its answers into the askers' answer buffers; host barriers and events order it.
+// A batch takes two calls (round 4; one until round 3, with a host wait in the middle of it):
+//   arks_exchange_submit    this rank alone: seeds listed and bucketed by owner in ONE launch (seed_bucket_kernel),
+//                           counts on their way to the host
+//   arks_exchange_complete  COLLECTIVE: counts to everybody, seeds to their owners (8 B each), owner-side probe
+//                           (16 B back each), answers home, map_reads_s_kernel<REMOTE> reads ans[2 slot[seed]]
+// With batch n + 1 submitted before batch n is completed (two streams), the host never waits for the device: the
+// counts of batch n have long arrived when complete(n) asks for them, and batch n + 1's bucketing and batch n's
+// probes, transfers and map kernel overlap.  arks_map_reads_exchanged_device = submit + complete (one batch at a time).
 // Replaces, for this path, what arcs_amd/dist.py did with torch sort / searchsorted / gather / index_put and two blocking
 // all_to_all_single calls ("what's weak" 10).  Reference seam: the reads are independent
 // (Arcs/Arcs.cpp:1169), the index is read-only while mapping (:969-971).
 #pragma once
+#include "arks_hip_debug.h"
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <dlfcn.h>
@@ -26,73 +31,57 @@
 namespace {
 
 // ---- RCCL, by name ------------------------------------------------------------------------------------------
-struct Rccl
-{
-	typedef struct { char internal[128]; } UniqueId;
-	typedef void* Comm;
-	void* h = nullptr;
-	int (*GetUniqueId)(UniqueId*) = nullptr;
-	int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
-	int (*CommDestroy)(Comm) = nullptr;
-	int (*GroupStart)() = nullptr;
-	int (*GroupEnd)() = nullptr;
-	int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
-	int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
-	int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
-	const char* (*GetErrorString)(int) = nullptr;
-	static constexpr int kUint64 = 5; // ncclUint64 (rccl.h: ncclInt8 0, Uint8 1, Int32 2, Uint32 3, Int64 4, Uint64 5)
+constexpr int kNcclUint8 = 1, kNcclUint64 = 5; // rccl.h: ncclInt8 0, Uint8 1, Int32 2, Uint32 3, Int64 4, Uint64 5
+static_assert(sizeof(arks_rccl_unique_id) == ARKS_EXCHANGE_ID_BYTES, "ncclUniqueId is 128 bytes");
 
-	static Rccl*
-	get()
-	{
-		static Rccl r;
-		static std::once_flag once;
-		std::call_once(once, [] {
-			const char* names[] = { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" };
-			for (const char* n : names) {
-				r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); // the copy the process already carries
-				if (r.h)
-					break;
-			}
-			for (size_t i = 0; !r.h && i < sizeof names / sizeof names[0]; ++i)
-				r.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-			if (!r.h)
-				return;
-#define ARKS_RCCL_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, name))
-			ARKS_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
-			ARKS_RCCL_SYM(CommInitRank, "ncclCommInitRank");
-			ARKS_RCCL_SYM(CommDestroy, "ncclCommDestroy");
-			ARKS_RCCL_SYM(GroupStart, "ncclGroupStart");
-			ARKS_RCCL_SYM(GroupEnd, "ncclGroupEnd");
-			ARKS_RCCL_SYM(Send, "ncclSend");
-			ARKS_RCCL_SYM(Recv, "ncclRecv");
-			ARKS_RCCL_SYM(AllGather, "ncclAllGather");
-			ARKS_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+std::atomic<const arks_rccl_api*> g_rccl_override{ nullptr };
+
+const arks_rccl_api*
+rccl_api()
+{
+	if (const arks_rccl_api* o = g_rccl_override.load(std::memory_order_acquire))
+		return o;
+	static arks_rccl_api r{};
+	static void* h = nullptr;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		const char* names[] = { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" };
+		for (const char* n : names) {
+			h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); // the copy the process already carries
+			if (h)
+				break;
+		}
+		for (size_t i = 0; !h && i < sizeof names / sizeof names[0]; ++i)
+			h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+		if (!h)
+			return;
+#define ARKS_RCCL_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name))
+		ARKS_RCCL_SYM(GetVersion, "ncclGetVersion");
+		ARKS_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+		ARKS_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+		ARKS_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+		ARKS_RCCL_SYM(CommAbort, "ncclCommAbort");
+		ARKS_RCCL_SYM(GroupStart, "ncclGroupStart");
+		ARKS_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+		ARKS_RCCL_SYM(Send, "ncclSend");
+		ARKS_RCCL_SYM(Recv, "ncclRecv");
+		ARKS_RCCL_SYM(AllGather, "ncclAllGather");
+		ARKS_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef ARKS_RCCL_SYM
-			if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv ||
-			    !r.AllGather || !r.GetErrorString)
-				r.h = nullptr;
-		});
-		return r.h ? &r : nullptr;
-	}
-};
-static_assert(sizeof(Rccl::UniqueId) == ARKS_EXCHANGE_ID_BYTES, "ncclUniqueId is 128 bytes");
+		if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv ||
+		    !r.AllGather || !r.GetErrorString)
+			h = nullptr; // (GetVersion and CommAbort are optional)
+	});
+	return h ? &r : nullptr;
+}
 
 int
 fail_rccl(int e, const char* what)
 {
-	Rccl* r = Rccl::get();
+	const arks_rccl_api* r = rccl_api();
 	g_last_error = std::string(what) + ": " + (r ? r->GetErrorString(e) : "RCCL not loaded");
 	return ARKS_ERR_HIP;
 }
-#define RCCL_TRY(expr)                                                                             \
-	do {                                                                                           \
-		int e_ = (expr);                                                                           \
-		if (e_ != 0) {                                                                             \
-			rc = fail_rccl(e_, #expr);                                                             \
-			goto done;                                                                             \
-		}                                                                                          \
-	} while (0)
 
 // ---- the ranks of one process -------------------------------------------------------------------------------
 struct LocalGroup
@@ -103,13 +92,18 @@ struct LocalGroup
 	int arrived = 0;
 	u64 generation = 0;
 	int members_alive = 0;
-	// what every rank shows the others between two barriers
-	std::vector<const u64*> counts_host; // 1 + world totals of the batch (pinned)
-	std::vector<const u64*> send;        // bucketed seeds
-	std::vector<const u64*> ans_out;     // answers to the seeds received
-	std::vector<int> failed;
-
 	bool aborted = false; // a rank left with an error (or never came): nobody waits for it again
+	// what a rank shows the others for the batch in buffer set s (written before a barrier, read behind it)
+	struct Shown
+	{
+		int status = 0, status2 = 0; // before the first / the second barrier of a batch
+		const u64* counts = nullptr; // pinned: fill[o] of the batch
+		u64 cap = 0;                 // region size of its send / answer buffers
+		const u64* send = nullptr;
+		u64* ans_back = nullptr;
+		hipEvent_t probed = nullptr; // its answers to everybody are written when this event has happened
+	};
+	std::vector<Shown> shown[2]; // [buffer set][rank]
 
 	// false: the group is broken (a rank failed in an earlier call, or did not arrive within ten minutes)
 	bool
@@ -147,7 +141,7 @@ struct GrowBuf
 	void* p = nullptr;
 	size_t cap = 0;
 	hipError_t
-	reserve(size_t bytes) // contents are not kept; the device is idle for this exchange when it grows
+	reserve(size_t bytes) // contents are not kept; hipFree waits for the device: nothing still reads the old block
 	{
 		if (bytes <= cap)
 			return hipSuccess;
@@ -155,7 +149,7 @@ struct GrowBuf
 			(void)hipFree(p);
 		p = nullptr;
 		cap = 0;
-		const size_t want = bytes + bytes / 4 + 4096;
+		const size_t want = bytes + bytes / 8 + 4096;
 		hipError_t e = hipMalloc(&p, want);
 		if (e == hipSuccess)
 			cap = want;
@@ -177,21 +171,47 @@ struct GrowBuf
 	}
 };
 
+// one batch in flight: its buffers and what complete() needs to know of it
+struct ExSet
+{
+	GrowBuf send, ans_back; // W regions of `cap` seeds (8 B) / answers (16 B), region o = what owner o is asked
+	GrowBuf slot, chunk_off;
+	GrowBuf recv, ans_out; // RCCL transport: what the others ask of me, and my answers, asker after asker
+	arks::SeedBucketCtl* d_ctl = nullptr;
+	arks::SeedBucketCtl* h_ctl = nullptr; // pinned
+	u64* d_gather = nullptr;              // RCCL: 1 + W of mine, then world x (1 + W) of everybody
+	u64* h_gather = nullptr;              // pinned, the same
+	hipEvent_t counted = nullptr, probed = nullptr;
+	hipStream_t st = nullptr;
+	bool used = false, pending = false;
+	int rc = ARKS_OK;
+	u64 cap = 0, slot_cap = 0;
+	// the batch
+	const u64* codes = nullptr;
+	const u32* nmask = nullptr;
+	const u64* word_off = nullptr;
+	const u32* lens = nullptr;
+	const uint8_t* eval = nullptr;
+	long n_reads = 0;
+	double j_index = 0;
+	int32_t* out = nullptr;
+	arks_map_stats* stats = nullptr;
+};
+
 } // namespace
 
 struct arks_exchange
 {
 	const arks_index* idx = nullptr;
 	int rank = 0, world = 1, device = 0;
-	Rccl::Comm comm = nullptr;   // RCCL transport
-	LocalGroup* group = nullptr; // local transport (shared by the ranks of the process)
-	GrowBuf cols, seed_off, slot, send, recv, ans_out, ans_back;
-	u64* d_totals = nullptr; // 1 + world
-	u64* d_all = nullptr;    // world x world: [p * world + o] = seeds rank p asks of owner o
-	u64* h_totals = nullptr; // pinned: 1 + world, then world x world
+	void* comm = nullptr;        // RCCL transport
+	LocalGroup* group = nullptr; // direct transport (shared by the ranks of the process)
+	ExSet set[2];
+	u64 submitted = 0, completed = 0;
+	// seeds per read the regions are sized for: per owner, and in all (raised when a batch does not fit)
+	double per_read_owner = 0, per_read_all = 3.3;
+	u64 reruns = 0;
 	arks_exchange_stats last{};
-	hipStream_t last_stream = nullptr; // the buffers are reused in the order of this stream
-	bool used = false;
 };
 
 namespace {
@@ -204,8 +224,7 @@ exchange_release(arks_exchange* x)
 	DeviceGuard guard(x->device);
 	(void)hipDeviceSynchronize();
 	if (x->comm) {
-		Rccl* r = Rccl::get();
-		if (r)
+		if (const arks_rccl_api* r = rccl_api())
 			(void)r->CommDestroy(x->comm);
 	}
 	if (x->group) {
@@ -217,14 +236,21 @@ exchange_release(arks_exchange* x)
 		if (last)
 			delete x->group;
 	}
-	x->cols.release(), x->seed_off.release(), x->slot.release(), x->send.release(), x->recv.release();
-	x->ans_out.release(), x->ans_back.release();
-	if (x->d_totals)
-		(void)hipFree(x->d_totals);
-	if (x->d_all)
-		(void)hipFree(x->d_all);
-	if (x->h_totals)
-		(void)hipHostFree(x->h_totals);
+	for (ExSet& s : x->set) {
+		s.send.release(), s.ans_back.release(), s.slot.release(), s.chunk_off.release(), s.recv.release(), s.ans_out.release();
+		if (s.d_ctl)
+			(void)hipFree(s.d_ctl);
+		if (s.h_ctl)
+			(void)hipHostFree(s.h_ctl);
+		if (s.d_gather)
+			(void)hipFree(s.d_gather);
+		if (s.h_gather)
+			(void)hipHostFree(s.h_gather);
+		if (s.counted)
+			(void)hipEventDestroy(s.counted);
+		if (s.probed)
+			(void)hipEventDestroy(s.probed);
+	}
 	delete x;
 }
 
@@ -246,14 +272,22 @@ exchange_new(arks_exchange** out, const arks_index* shard, int rank, int world)
 	if (!x)
 		return ARKS_ERR_OOM;
 	x->idx = shard, x->rank = rank, x->world = world, x->device = shard->device;
+	x->per_read_owner = 3.3 / world * 1.1;
 	DeviceGuard guard(x->device);
-	void* p = nullptr;
-	HIP_TRY(hipMalloc(&p, sizeof(u64) * (size_t)(1 + world)));
-	x->d_totals = static_cast<u64*>(p);
-	HIP_TRY(hipMalloc(&p, sizeof(u64) * (size_t)world * (size_t)world));
-	x->d_all = static_cast<u64*>(p);
-	HIP_TRY(hipHostMalloc(&p, sizeof(u64) * (size_t)(1 + world + world * world), hipHostMallocDefault));
-	x->h_totals = static_cast<u64*>(p);
+	const size_t gw = (size_t)(1 + world) * (size_t)(1 + world);
+	for (ExSet& s : x->set) {
+		void* p = nullptr;
+		HIP_TRY(hipMalloc(&p, sizeof(arks::SeedBucketCtl)));
+		s.d_ctl = static_cast<arks::SeedBucketCtl*>(p);
+		HIP_TRY(hipHostMalloc(&p, sizeof(arks::SeedBucketCtl), hipHostMallocDefault));
+		s.h_ctl = static_cast<arks::SeedBucketCtl*>(p);
+		HIP_TRY(hipMalloc(&p, sizeof(u64) * gw));
+		s.d_gather = static_cast<u64*>(p);
+		HIP_TRY(hipHostMalloc(&p, sizeof(u64) * gw, hipHostMallocDefault));
+		s.h_gather = static_cast<u64*>(p);
+		HIP_TRY(hipEventCreateWithFlags(&s.counted, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&s.probed, hipEventDisableTiming));
+	}
 	*out = x;
 	return ARKS_OK;
 done:
@@ -261,26 +295,107 @@ done:
 	return rc;
 }
 
+// RCCL's ncclUint64 is what this file believes it to be (and the transport moves whole buffers): a send to
+// oneself of a known pattern, checked byte for byte.  Runs once per communicator.
+int
+rccl_self_test(arks_exchange* x, const arks_rccl_api* r)
+{
+	int rc = ARKS_OK;
+	u64* d = nullptr;
+	u64 h[8] = { 0x0123456789ABCDEFull, 0xFEDCBA9876543210ull, 0x1111111111111111ull, ~0ull, 0, 0, 0, 0 };
+	hipStream_t st = nullptr;
+	int e = 0, e2 = 0;
+	HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof h));
+	HIP_TRY(hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice));
+	e = r->GroupStart();
+	if (e == 0) {
+		e = r->Send(d, 4, kNcclUint64, x->rank, x->comm, st);
+		if (e == 0)
+			e = r->Recv(d + 4, 4, kNcclUint64, x->rank, x->comm, st);
+		e2 = r->GroupEnd(); // (always: an open group would swallow every later call of this thread)
+		if (e == 0)
+			e = e2;
+	}
+	if (e != 0) {
+		rc = fail_rccl(e, "RCCL self test (send to self)");
+		goto done;
+	}
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+	if (std::memcmp(h, h + 4, 4 * sizeof(u64)) != 0) {
+		g_last_error = "RCCL self test: 4 x ncclUint64 did not move 32 bytes (data type numbering changed?)";
+		rc = ARKS_ERR_HIP;
+	}
+done:
+	if (d)
+		(void)hipFree(d);
+	if (st)
+		(void)hipStreamDestroy(st);
+	return rc;
+}
+
+// seeds (8 B, `unit` = 1) or answers (16 B, `unit` = 2) between all ranks: rank p gets cnt_to[p] items from
+// mine + off_to[p] and I get cnt_from[p] items from it at theirs + off_from[p] (offsets and counts in items).
+// The group is closed on every path; an error inside it aborts the communicator, so that the peers -- who may
+// already wait in their own group for what this rank will never send -- get an error instead of a hang.
+int
+rccl_all_to_all(
+    arks_exchange* x, const arks_rccl_api* r, const u64* mine, const u64* off_to, const u64* cnt_to, u64* theirs,
+    const u64* off_from, const u64* cnt_from, u64 unit, hipStream_t st, const char* what)
+{
+	int e = r->GroupStart();
+	if (e != 0)
+		return fail_rccl(e, what);
+	for (int p = 0; p < x->world && e == 0; ++p) {
+		if (p == x->rank)
+			continue;
+		if (cnt_to[p])
+			e = r->Send(mine + unit * off_to[p], unit * cnt_to[p], kNcclUint64, p, x->comm, st);
+		if (e == 0 && cnt_from[p])
+			e = r->Recv(theirs + unit * off_from[p], unit * cnt_from[p], kNcclUint64, p, x->comm, st);
+	}
+	const int e2 = r->GroupEnd();
+	if (e == 0)
+		e = e2;
+	if (e != 0) {
+		const int rc = fail_rccl(e, what);
+		if (r->CommAbort && x->comm) {
+			(void)r->CommAbort(x->comm);
+			x->comm = nullptr; // (aborting frees it)
+		}
+		return rc;
+	}
+	return ARKS_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int
+arks_exchange_debug_set_rccl(const arks_rccl_api* api)
+{
+	g_rccl_override.store(api, std::memory_order_release);
+	return ARKS_OK;
+}
 
 int
 arks_exchange_unique_id(unsigned char* out_id)
 {
 	if (!out_id)
 		return ARKS_ERR_BAD_ARG;
-	Rccl* r = Rccl::get();
+	const arks_rccl_api* r = rccl_api();
 	if (!r) {
 		g_last_error = "librccl.so.1 could not be opened";
 		return ARKS_ERR_HIP;
 	}
-	Rccl::UniqueId id;
-	int rc = ARKS_OK;
-	RCCL_TRY(r->GetUniqueId(&id));
+	arks_rccl_unique_id id;
+	const int e = r->GetUniqueId(&id);
+	if (e != 0)
+		return fail_rccl(e, "ncclGetUniqueId");
 	std::memcpy(out_id, id.internal, sizeof id.internal);
-done:
-	return rc;
+	return ARKS_OK;
 }
 
 int
@@ -293,7 +408,7 @@ arks_exchange_create(arks_exchange** out, const arks_index* shard, const unsigne
 	if (rc != ARKS_OK)
 		return rc;
 	if (world > 1 || unique_id) {
-		Rccl* r = Rccl::get();
+		const arks_rccl_api* r = rccl_api();
 		if (!r || !unique_id) {
 			g_last_error = !unique_id ? "world > 1 needs the unique id of rank 0 (arks_exchange_unique_id)"
 			                          : "librccl.so.1 could not be opened";
@@ -301,15 +416,21 @@ arks_exchange_create(arks_exchange** out, const arks_index* shard, const unsigne
 			return !unique_id ? ARKS_ERR_BAD_ARG : ARKS_ERR_HIP;
 		}
 		DeviceGuard guard(x->device);
-		Rccl::UniqueId id;
+		arks_rccl_unique_id id;
 		std::memcpy(id.internal, unique_id, sizeof id.internal);
-		RCCL_TRY(r->CommInitRank(&x->comm, world, id, rank));
+		const int e = r->CommInitRank(&x->comm, world, id, rank);
+		if (e != 0) {
+			x->comm = nullptr;
+			rc = fail_rccl(e, "ncclCommInitRank");
+		} else
+			rc = rccl_self_test(x, r);
+		if (rc != ARKS_OK) {
+			exchange_release(x);
+			return rc;
+		}
 	}
 	*out = x;
 	return ARKS_OK;
-done:
-	exchange_release(x);
-	return rc;
 }
 
 int
@@ -323,20 +444,35 @@ arks_exchange_create_local(arks_exchange** out, const arks_index* const* shards,
 	if (!g)
 		return ARKS_ERR_OOM;
 	g->world = world;
-	g->counts_host.assign((size_t)world, nullptr);
-	g->send.assign((size_t)world, nullptr);
-	g->ans_out.assign((size_t)world, nullptr);
-	g->failed.assign((size_t)world, 0);
+	g->shown[0].assign((size_t)world, LocalGroup::Shown());
+	g->shown[1].assign((size_t)world, LocalGroup::Shown());
 	int rc = ARKS_OK;
 	for (int r = 0; r < world && rc == ARKS_OK; ++r) {
 		rc = exchange_new(&out[r], shards[r], r, world);
 		if (rc == ARKS_OK) {
-			if (shards[r]->device != shards[0]->device)
-				rc = ARKS_ERR_BAD_ARG; // the ranks of one process share one device
 			out[r]->group = g;
 			g->members_alive++;
 		}
 	}
+	// the ranks' devices must reach each other's memory: the same device, or peers (xGMI) -- the owner's probe kernel
+	// reads the askers' buffers and writes into them
+	for (int a = 0; a < world && rc == ARKS_OK; ++a)
+		for (int b = 0; b < world && rc == ARKS_OK; ++b) {
+			const int da = shards[a]->device, db = shards[b]->device;
+			if (da == db)
+				continue;
+			int can = 0;
+			if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) {
+				g_last_error = "the devices of a local group must be able to access each other's memory";
+				rc = ARKS_ERR_BAD_ARG;
+				break;
+			}
+			DeviceGuard guard(da);
+			const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+			if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+				rc = fail_hip(e, "hipDeviceEnablePeerAccess");
+			(void)hipGetLastError();
+		}
 	if (rc != ARKS_OK) {
 		const bool any = g->members_alive > 0;
 		for (int r = 0; r < world; ++r) {
@@ -375,8 +511,43 @@ arks_exchange_last_stats(const arks_exchange* x, arks_exchange_stats* out)
 	return ARKS_OK;
 }
 
+} // extern "C"
+
+namespace {
+
+// the batch of set s bucketed with the current sizes (on its stream), counts on their way to the host
 int
-arks_map_reads_exchanged_device(
+exchange_bucket(arks_exchange* x, ExSet& s)
+{
+	const arks_index* idx = x->idx;
+	const int W = x->world;
+	int rc = ARKS_OK;
+	u64 cap = (u64)(x->per_read_owner * (double)s.n_reads) + 8192;
+	u64 slot_cap = (u64)(x->per_read_all * (double)s.n_reads) + 8192;
+	if (cap * (u64)W > 0xFFFFFFFEull || slot_cap > 0xFFFFFFFEull) {
+		g_last_error = "a batch of the exchange holds more than 2^32 seeds: split it";
+		return ARKS_ERR_BAD_ARG;
+	}
+	s.cap = cap, s.slot_cap = slot_cap;
+	HIP_TRY(s.send.reserve(sizeof(u64) * (size_t)cap * (size_t)W));
+	HIP_TRY(s.ans_back.reserve(2 * sizeof(u64) * (size_t)cap * (size_t)W));
+	HIP_TRY(s.slot.reserve(sizeof(u32) * (size_t)slot_cap));
+	HIP_TRY(s.chunk_off.reserve(sizeof(u32) * (size_t)(arks::seed_bucket_chunks(s.n_reads) + 1)));
+	HIP_TRY(arks::launch_seed_bucket(
+	    idx->bx.m, s.codes, s.nmask, s.word_off, s.lens, s.eval, s.n_reads, idx->k, idx->bx.w, (u32)W, cap, slot_cap, s.d_ctl,
+	    s.chunk_off.as<u32>(), s.slot.as<u32>(), s.send.as<u64>(), s.st));
+	HIP_TRY(hipMemcpyAsync(s.h_ctl, s.d_ctl, sizeof(arks::SeedBucketCtl), hipMemcpyDeviceToHost, s.st));
+	HIP_TRY(hipEventRecord(s.counted, s.st));
+done:
+	return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int
+arks_exchange_submit(
     arks_exchange* x,
     const uint64_t* d_codes,
     const uint32_t* d_nmask,
@@ -393,24 +564,48 @@ arks_map_reads_exchanged_device(
 		return ARKS_ERR_BAD_ARG;
 	if (n_reads > 0 && (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_out_conreci))
 		return ARKS_ERR_BAD_ARG;
-	const arks_index* idx = x->idx;
-	const int W = x->world, me = x->rank;
+	if (x->submitted - x->completed >= 2) {
+		g_last_error = "two batches are in flight already: arks_exchange_complete first";
+		return ARKS_ERR_BAD_ARG;
+	}
+	ExSet& s = x->set[x->submitted & 1];
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	DeviceGuard guard(x->device);
-	Rccl* rccl = x->comm ? Rccl::get() : nullptr;
+	// the buffers of the set's last batch (its map kernel may still be reading them) are reused in stream order: a
+	// batch on another stream waits for the old one first
+	if (s.used && s.st != st)
+		(void)hipStreamSynchronize(s.st);
+	s.st = st, s.used = true;
+	s.codes = reinterpret_cast<const u64*>(d_codes), s.nmask = d_nmask, s.word_off = reinterpret_cast<const u64*>(d_word_off);
+	s.lens = d_lens, s.eval = d_eval, s.n_reads = (long)n_reads, s.j_index = j_index, s.out = d_out_conreci, s.stats = d_stats;
+	s.rc = exchange_bucket(x, s);
+	// (a batch that failed here is completed all the same: the other ranks learn of it there, nobody waits in vain)
+	s.pending = true;
+	x->submitted++;
+	return s.rc;
+}
+
+int
+arks_exchange_complete(arks_exchange* x)
+{
+	if (!x)
+		return ARKS_ERR_BAD_ARG;
+	if (x->submitted == x->completed) {
+		g_last_error = "arks_exchange_complete: nothing was submitted";
+		return ARKS_ERR_BAD_ARG;
+	}
+	const int si = (int)(x->completed & 1);
+	ExSet& s = x->set[si];
+	x->completed++;
+	s.pending = false;
+	const arks_index* idx = x->idx;
+	const int W = x->world, me = x->rank;
+	hipStream_t st = s.st;
+	DeviceGuard guard(x->device);
+	const arks_rccl_api* rccl = x->comm ? rccl_api() : nullptr;
 	LocalGroup* g = x->group;
-	int rc = ARKS_OK;
-	// the buffers of the last call (its map kernel may still be reading them) are reused in stream order: a call on
-	// another stream waits for the old one first
-	if (x->used && x->last_stream != st)
-		(void)hipStreamSynchronize(x->last_stream);
-	x->last_stream = st;
-	x->used = true;
-	std::vector<u64> sc((size_t)W), rcv((size_t)W), soff((size_t)W + 1), roff((size_t)W + 1);
-	u64 n_seeds = 0;
-	const long nb = seed_bucket_blocks((long)n_reads);
-	const u64* all = x->h_totals + 1 + W; // [p * W + o]
-	// A local rank that fails must still meet the others at every barrier: errors are carried to the end.
+	int rc = s.rc;
+	// errors are carried to the end of the collective part: a rank that fails must still meet the others
 #define EX_TRY(expr)                                                                               \
 	do {                                                                                           \
 		if (rc == ARKS_OK) {                                                                       \
@@ -419,157 +614,230 @@ arks_map_reads_exchanged_device(
 				rc = fail_hip(e_, #expr);                                                          \
 		}                                                                                          \
 	} while (0)
-	// ---- 1. count + scan ------------------------------------------------------------------------------------
-	EX_TRY(x->cols.reserve(sizeof(u32) * (size_t)(1 + W) * (size_t)(nb > 0 ? nb : 1)));
-	EX_TRY(x->seed_off.reserve(sizeof(long) * ((size_t)n_reads + 1)));
-	EX_TRY(launch_seed_buckets(
-	    idx->bx.m, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, idx->k, idx->bx.w,
-	    (u32)W, x->cols.as<u32>(), x->d_totals, nullptr, nullptr, nullptr, 0, st));
-	// ---- 2. everybody's counts ------------------------------------------------------------------------------
-	EX_TRY(hipMemcpyAsync(x->h_totals, x->d_totals, sizeof(u64) * (size_t)(1 + W), hipMemcpyDeviceToHost, st));
-	if (rccl && W > 1) {
-		if (rc == ARKS_OK) {
-			int e = rccl->AllGather(x->d_totals + 1, x->d_all, (size_t)W, Rccl::kUint64, x->comm, st);
-			if (e != 0)
-				rc = fail_rccl(e, "ncclAllGather(seed counts)");
+	// ---- 1. my counts (they left the device with the submit; a batch that did not fit its regions is run again) ----
+	EX_TRY(hipEventSynchronize(s.counted));
+	for (int tries = 0; rc == ARKS_OK && s.h_ctl->overflow; ++tries) {
+		u64 mx = 0;
+		for (int o = 0; o < W; ++o)
+			mx = s.h_ctl->fill[o] > mx ? s.h_ctl->fill[o] : mx;
+		const double n = (double)(s.n_reads > 0 ? s.n_reads : 1);
+		if ((double)mx / n * 1.1 > x->per_read_owner)
+			x->per_read_owner = (double)mx / n * 1.1;
+		if ((double)s.h_ctl->seeds / n * 1.05 > x->per_read_all)
+			x->per_read_all = (double)s.h_ctl->seeds / n * 1.05;
+		x->reruns++;
+		if (tries == 2) {
+			g_last_error = "the exchange's regions overflowed three times in a row";
+			rc = ARKS_ERR_HIP;
+			break;
 		}
-		EX_TRY(hipMemcpyAsync(x->h_totals + 1 + W, x->d_all, sizeof(u64) * (size_t)W * (size_t)W, hipMemcpyDeviceToHost, st));
+		rc = exchange_bucket(x, s);
+		EX_TRY(hipEventSynchronize(s.counted));
 	}
-	EX_TRY(hipStreamSynchronize(st));
-	if (g) {
-		g->counts_host[(size_t)me] = x->h_totals;
-		g->failed[(size_t)me] = rc != ARKS_OK;
+	// ---- 2. everybody's counts and status: all[p * W + o] = seeds rank p asks of owner o -----------------------------
+	std::vector<u64> all((size_t)W * (size_t)W, 0), cap_of((size_t)W, 0);
+	int status = rc;
+	if (rccl && W > 1) {
+		// (1 + W) numbers per rank: status, counts.  Every rank holds the same matrix afterwards and decides alike.
+		u64* hg = s.h_gather;
+		hg[0] = (u64)(rc != ARKS_OK);
+		for (int o = 0; o < W; ++o)
+			hg[1 + o] = rc == ARKS_OK ? s.h_ctl->fill[o] : 0;
+		int e = 0;
+		hipError_t he = hipMemcpyAsync(s.d_gather, hg, sizeof(u64) * (size_t)(1 + W), hipMemcpyHostToDevice, st);
+		if (he == hipSuccess) {
+			e = rccl->AllGather(s.d_gather, s.d_gather + (1 + W), (size_t)(1 + W), kNcclUint64, x->comm, st);
+			if (e == 0)
+				he = hipMemcpyAsync(hg + (1 + W), s.d_gather + (1 + W), sizeof(u64) * (size_t)W * (size_t)(1 + W), hipMemcpyDeviceToHost, st);
+			if (e == 0 && he == hipSuccess)
+				he = hipStreamSynchronize(st);
+		}
+		if (e != 0 || he != hipSuccess) {
+			// nothing was agreed: the communicator is of no use any more (the peers' calls fail or time out)
+			rc = e != 0 ? fail_rccl(e, "ncclAllGather(seed counts)") : fail_hip(he, "seed counts");
+			if (rccl->CommAbort && x->comm) {
+				(void)rccl->CommAbort(x->comm);
+				x->comm = nullptr;
+			}
+			return rc;
+		}
+		for (int p = 0; p < W; ++p) {
+			const u64* row = hg + (size_t)(1 + W) * (size_t)(1 + p);
+			if (row[0] && status == ARKS_OK) {
+				g_last_error = "another rank of the exchange failed in this batch";
+				status = ARKS_ERR_HIP;
+			}
+			for (int o = 0; o < W; ++o)
+				all[(size_t)p * W + o] = row[1 + o];
+		}
+		if (status != ARKS_OK)
+			return status; // (every rank sees the same flags: all of them leave here, nobody waits)
+	} else if (g) {
+		LocalGroup::Shown& mine = g->shown[si][(size_t)me];
+		mine.status = rc;
+		mine.counts = s.h_ctl->fill;
+		mine.cap = s.cap;
+		mine.send = s.send.as<u64>();
+		mine.ans_back = s.ans_back.as<u64>();
+		mine.probed = s.probed;
 		if (!g->barrier())
 			return exchange_broken();
 		for (int p = 0; p < W; ++p) {
-			if (g->failed[(size_t)p] && rc == ARKS_OK) {
-				g_last_error = "another rank of the local group failed";
-				rc = ARKS_ERR_HIP;
+			const LocalGroup::Shown& sh = g->shown[si][(size_t)p];
+			if (sh.status != ARKS_OK && status == ARKS_OK) {
+				g_last_error = "another rank of the local group failed in this batch";
+				status = ARKS_ERR_HIP;
 			}
+			cap_of[(size_t)p] = sh.cap;
 			for (int o = 0; o < W; ++o)
-				x->h_totals[1 + W + p * W + o] = g->failed[(size_t)p] ? 0 : g->counts_host[(size_t)p][1 + o];
+				all[(size_t)p * W + o] = sh.status == ARKS_OK ? sh.counts[o] : 0;
 		}
-		// (no second barrier: a rank overwrites its counts only in its NEXT call, which it enters behind the barriers
-		// below -- and those every rank reaches after it has read the counts)
-	} else if (W == 1)
-		x->h_totals[2] = x->h_totals[1];
-	if (rc != ARKS_OK && !g)
-		return rc;
-	n_seeds = x->h_totals[0];
-	soff[0] = roff[0] = 0;
+		if (status != ARKS_OK) {
+			// every rank read the same flags behind the barrier; they all leave (a second barrier keeps a fast rank's
+			// next batch from rewriting what a slow one still reads)
+			(void)g->barrier();
+			g->abort();
+			return status;
+		}
+	} else {
+		if (rc != ARKS_OK)
+			return rc;
+		all[0] = s.h_ctl->fill[0];
+	}
+	// from here on rc == ARKS_OK on every rank
+	std::vector<u64> sc((size_t)W), rcv((size_t)W), soff((size_t)W), roff((size_t)W + 1);
+	roff[0] = 0;
 	for (int p = 0; p < W; ++p) {
 		sc[(size_t)p] = all[(size_t)me * W + p];  // what I ask of p
 		rcv[(size_t)p] = all[(size_t)p * W + me]; // what p asks of me
-		soff[(size_t)p + 1] = soff[(size_t)p] + sc[(size_t)p];
+		soff[(size_t)p] = (u64)p * s.cap;         // ... lies in region p of my send buffer
 		roff[(size_t)p + 1] = roff[(size_t)p] + rcv[(size_t)p];
 	}
 	{
-		const u64 S = soff[(size_t)W], R = roff[(size_t)W];
-		if (S > 0xFFFFFFFEull || n_seeds > 0xFFFFFFFEull)
-			rc = rc == ARKS_OK ? ARKS_ERR_BAD_ARG : rc; // slots are 32-bit: split the batch
-		EX_TRY(x->slot.reserve(sizeof(u32) * (size_t)(n_seeds + 1)));
-		EX_TRY(x->send.reserve(sizeof(u64) * (size_t)(S + 1)));
-		EX_TRY(x->ans_back.reserve(2 * sizeof(u64) * (size_t)(S + 1)));
-		EX_TRY(x->recv.reserve(sizeof(u64) * (size_t)(R + 1)));
-		EX_TRY(x->ans_out.reserve(2 * sizeof(u64) * (size_t)(R + 1)));
-		x->last.seeds = n_seeds, x->last.sent = S - sc[(size_t)me], x->last.received = R - rcv[(size_t)me];
+		u64 S = 0;
+		for (int p = 0; p < W; ++p)
+			S += sc[(size_t)p];
+		x->last.seeds = s.h_ctl->seeds, x->last.sent = S - sc[(size_t)me], x->last.received = roff[(size_t)W] - rcv[(size_t)me];
+		x->last.reruns = x->reruns;
 	}
-	// ---- 3. fill, seeds to their owners ---------------------------------------------------------------------
-	EX_TRY(launch_seed_buckets(
-	    idx->bx.m, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, idx->k, idx->bx.w,
-	    (u32)W, x->cols.as<u32>(), x->d_totals, x->seed_off.as<long>(), x->slot.as<u32>(), x->send.as<u64>(), 1, st));
-	// (my own seeds stay where they are: they are answered straight from the send buffer into the answers' place, below)
-	if (rccl && W > 1 && rc == ARKS_OK) {
-		RCCL_TRY(rccl->GroupStart());
-		for (int p = 0; p < W; ++p) {
-			if (p == me)
-				continue;
-			if (sc[(size_t)p])
-				RCCL_TRY(rccl->Send(x->send.as<u64>() + soff[(size_t)p], sc[(size_t)p], Rccl::kUint64, p, x->comm, st));
-			if (rcv[(size_t)p])
-				RCCL_TRY(rccl->Recv(x->recv.as<u64>() + roff[(size_t)p], rcv[(size_t)p], Rccl::kUint64, p, x->comm, st));
+	arks::ProbeSegs sg{};
+	if (rccl && W > 1) {
+		// ---- 3. seeds to their owners; 4. the owner's answers; 5. answers back -------------------------------------
+		const u64 R = roff[(size_t)W];
+		hipError_t he = s.recv.reserve(sizeof(u64) * (size_t)(R + 1));
+		if (he == hipSuccess)
+			he = s.ans_out.reserve(2 * sizeof(u64) * (size_t)(R + 1));
+		if (he != hipSuccess) {
+			// the others are on their way into the exchange: they must not wait for this rank
+			rc = fail_hip(he, "hipMalloc(exchange receive buffers)");
+			if (rccl->CommAbort && x->comm) {
+				(void)rccl->CommAbort(x->comm);
+				x->comm = nullptr;
+			}
+			return rc;
 		}
-		RCCL_TRY(rccl->GroupEnd());
+		rc = rccl_all_to_all(x, rccl, s.send.as<u64>(), soff.data(), sc.data(), s.recv.as<u64>(), roff.data(), rcv.data(), 1, st,
+		                     "seeds to their owners (ncclSend / ncclRecv)");
+		if (rc != ARKS_OK)
+			return rc;
+		// what the ranks in front of me and behind me asked (from the receive buffer), and my own seeds from where they
+		// are to where their answers belong
+		u64 run = 0;
+		for (int p = 0; p < W; ++p) {
+			if (!rcv[(size_t)p])
+				continue;
+			const int i = sg.n_segs++;
+			sg.src[i] = p == me ? s.send.as<u64>() + soff[(size_t)me] : s.recv.as<u64>() + roff[(size_t)p];
+			sg.dst[i] = p == me ? s.ans_back.as<u64>() + 2 * soff[(size_t)me] : s.ans_out.as<u64>() + 2 * roff[(size_t)p];
+			run += rcv[(size_t)p];
+			sg.end[i] = run;
+		}
+		EX_TRY(arks::launch_seeds_probe_segs(idx->bx.m, idx->bx, sg, st));
+		if (rc == ARKS_OK)
+			rc = rccl_all_to_all(x, rccl, s.ans_out.as<u64>(), roff.data(), rcv.data(), s.ans_back.as<u64>(), soff.data(), sc.data(),
+			                     2, st, "answers back (ncclSend / ncclRecv)");
+		else if (rccl->CommAbort && x->comm) {
+			(void)rccl->CommAbort(x->comm);
+			x->comm = nullptr;
+		}
+		if (rc != ARKS_OK)
+			return rc;
 	} else if (g) {
-		EX_TRY(hipStreamSynchronize(st)); // my send buffer is complete
-		g->send[(size_t)me] = x->send.as<u64>();
-		g->failed[(size_t)me] = rc != ARKS_OK;
-		if (!g->barrier())
+		// ---- 3-5. direct: I answer what everybody asks of me, reading the askers' send buffers (complete: every rank
+		// waited for its counts before the barrier) and writing into their answer buffers (free: their last map kernel
+		// on this set ran before their bucket kernel, in stream order) ------------------------------------------------
+		u64 run = 0;
+		for (int p = 0; p < W; ++p) {
+			if (!rcv[(size_t)p])
+				continue;
+			const LocalGroup::Shown& sh = g->shown[si][(size_t)p];
+			const int i = sg.n_segs++;
+			sg.src[i] = sh.send + (u64)me * sh.cap;
+			sg.dst[i] = sh.ans_back + 2 * (u64)me * sh.cap;
+			run += rcv[(size_t)p];
+			sg.end[i] = run;
+		}
+		EX_TRY(arks::launch_seeds_probe_segs(idx->bx.m, idx->bx, sg, st));
+		EX_TRY(hipEventRecord(s.probed, st));
+		g->shown[si][(size_t)me].status2 = rc;
+		if (!g->barrier()) // every owner's event is recorded (a wait for an event that was never recorded is no wait)
 			return exchange_broken();
 		for (int p = 0; p < W; ++p) {
-			if (g->failed[(size_t)p] && rc == ARKS_OK) {
-				g_last_error = "another rank of the local group failed";
+			const LocalGroup::Shown& sh = g->shown[si][(size_t)p];
+			if (sh.status2 != ARKS_OK && rc == ARKS_OK) {
+				g_last_error = "another rank of the local group failed in this batch";
 				rc = ARKS_ERR_HIP;
 			}
-			if (p == me || !rcv[(size_t)p] || rc != ARKS_OK)
-				continue;
-			// p's seeds for me start behind what p asks of the owners in front of me
-			u64 off = 0;
-			for (int o = 0; o < me; ++o)
-				off += all[(size_t)p * W + o];
-			EX_TRY(hipMemcpyAsync(x->recv.as<u64>() + roff[(size_t)p], g->send[(size_t)p] + off, sizeof(u64) * rcv[(size_t)p],
-			                      hipMemcpyDeviceToDevice, st));
+			if (p != me && sc[(size_t)p])
+				EX_TRY(hipStreamWaitEvent(st, sh.probed, 0)); // p's answers to me
 		}
+		// (the askers' buffers are read and written by other ranks' kernels until those events: a rank reuses a set only
+		// behind its own map kernel of that set, which waits for all of them)
+	} else {
+		sg.n_segs = sc[0] ? 1 : 0;
+		sg.src[0] = s.send.as<u64>();
+		sg.dst[0] = s.ans_back.as<u64>();
+		sg.end[0] = sc[0];
+		EX_TRY(arks::launch_seeds_probe_segs(idx->bx.m, idx->bx, sg, st));
 	}
-	// ---- 4. the owner's answers -----------------------------------------------------------------------------
-	// what the ranks in front of me asked, what the ranks behind me asked (my own part of the receive buffer lies between
-	// them, unused), and my own seeds from where they are to where their answers belong
-	EX_TRY(launch_seeds_probe(idx->bx.m, idx->bx, x->recv.as<u64>(), (long)roff[(size_t)me], x->ans_out.as<u64>(), st));
-	EX_TRY(launch_seeds_probe(idx->bx.m, idx->bx, x->recv.as<u64>() + roff[(size_t)me + 1],
-	                          (long)(roff[(size_t)W] - roff[(size_t)me + 1]), x->ans_out.as<u64>() + 2 * roff[(size_t)me + 1], st));
-	EX_TRY(launch_seeds_probe(idx->bx.m, idx->bx, x->send.as<u64>() + soff[(size_t)me], (long)sc[(size_t)me],
-	                          x->ans_back.as<u64>() + 2 * soff[(size_t)me], st));
-	// ---- 5. answers back ------------------------------------------------------------------------------------
-	if (rccl && W > 1 && rc == ARKS_OK) {
-		RCCL_TRY(rccl->GroupStart());
-		for (int p = 0; p < W; ++p) {
-			if (p == me)
-				continue;
-			if (rcv[(size_t)p])
-				RCCL_TRY(rccl->Send(x->ans_out.as<u64>() + 2 * roff[(size_t)p], 2 * rcv[(size_t)p], Rccl::kUint64, p, x->comm, st));
-			if (sc[(size_t)p])
-				RCCL_TRY(rccl->Recv(x->ans_back.as<u64>() + 2 * soff[(size_t)p], 2 * sc[(size_t)p], Rccl::kUint64, p, x->comm, st));
-		}
-		RCCL_TRY(rccl->GroupEnd());
-	} else if (g) {
-		EX_TRY(hipStreamSynchronize(st)); // my answers are complete (and I have read the others' seeds)
-		g->ans_out[(size_t)me] = x->ans_out.as<u64>();
-		g->failed[(size_t)me] = rc != ARKS_OK;
-		if (!g->barrier())
-			return exchange_broken();
-		for (int p = 0; p < W; ++p) {
-			if (g->failed[(size_t)p] && rc == ARKS_OK) {
-				g_last_error = "another rank of the local group failed";
-				rc = ARKS_ERR_HIP;
-			}
-			if (p == me || !sc[(size_t)p] || rc != ARKS_OK)
-				continue;
-			// my seeds lie in p's receive buffer behind those of the ranks in front of me
-			u64 off = 0;
-			for (int q = 0; q < me; ++q)
-				off += all[(size_t)q * W + p];
-			EX_TRY(hipMemcpyAsync(x->ans_back.as<u64>() + 2 * soff[(size_t)p], g->ans_out[(size_t)p] + 2 * off,
-			                      2 * sizeof(u64) * sc[(size_t)p], hipMemcpyDeviceToDevice, st));
-		}
-		// (no wait here: the copies above are on this rank's stream; its next call -- on the same stream, see
-		// arks_hip.h -- synchronises that stream before it lets any other rank write the buffers they read from,
-		// so the map kernel below and the pair rule behind it overlap with the other ranks' next batch)
-	}
-	// ---- 6. the home finishes -------------------------------------------------------------------------------
-	if (rc == ARKS_OK && n_reads > 0) {
+	// ---- 6. the home finishes -------------------------------------------------------------------------------------
+	if (rc == ARKS_OK && s.n_reads > 0) {
 		arks_index::QueueSet qs;
-		rc = ensure_queue(idx, stream, n_reads, &qs);
+		rc = ensure_queue(idx, st, s.n_reads, &qs);
 		if (rc == ARKS_OK)
 			EX_TRY(launch_map_reads_seeded(
-			    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, d_eval, (long)n_reads, j_index, idx->geom,
-			    idx->bx, idx->bxg, x->seed_off.as<long>(), x->ans_back.as<u64>(), d_out_conreci, reinterpret_cast<u64*>(d_stats),
-			    qs.queue, qs.queue_count, idx->n_cu, st, x->slot.as<u32>()));
+			    idx->kw, s.codes, s.nmask, s.word_off, s.lens, s.eval, s.n_reads, s.j_index, idx->geom, idx->bx, idx->bxg, nullptr,
+			    s.ans_back.as<u64>(), s.out, reinterpret_cast<u64*>(s.stats), qs.queue, qs.queue_count, idx->n_cu, st,
+			    s.slot.as<u32>(), s.chunk_off.as<u32>()));
 	}
-done:
 #undef EX_TRY
 	if (rc != ARKS_OK && g)
 		g->abort(); // this rank's caller will not call again: the others must not wait for it
 	return rc;
+}
+
+int
+arks_map_reads_exchanged_device(
+    arks_exchange* x,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream)
+{
+	if (x && x->submitted != x->completed) {
+		g_last_error = "a submitted batch is waiting for arks_exchange_complete";
+		return ARKS_ERR_BAD_ARG;
+	}
+	const int rc = arks_exchange_submit(x, d_codes, d_nmask, d_word_off, d_lens, d_eval, n_reads, j_index, d_out_conreci, d_stats, stream);
+	if (rc == ARKS_ERR_BAD_ARG && (!x || x->submitted == x->completed))
+		return rc; // nothing was submitted (bad arguments): nothing to complete
+	return arks_exchange_complete(x);
 }
 
 } // extern "C"

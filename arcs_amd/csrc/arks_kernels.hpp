@@ -39,11 +39,29 @@ hipError_t launch_map_reads_seeded(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval,
     long n_reads, double j_index, const KeyGeom& g, const BIndexView& bx, const BIndexView& bxg, const long* seed_off,
     const u64* ans, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st,
-    const u32* seed_slot = nullptr);
-long seed_bucket_blocks(long n_reads);
-hipError_t launch_seed_buckets(
+    const u32* seed_slot = nullptr, const u32* chunk_off = nullptr);
+// arks_exchange: a batch's seeds listed and bucketed by owner in one launch (arks_shard.hip)
+struct SeedBucketCtl
+{
+	u64 fill[64]; // seeds asked of owner o (goes on counting when a region is full)
+	u64 seeds;    // seeds of the batch, sent or not (the read-major numbering)
+	u64 overflow; // a block found no room: run the batch again with larger regions
+};
+long seed_bucket_chunks(long n_reads);
+hipError_t launch_seed_bucket(
     int mm, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval, long n_reads,
-    int k, int w, u32 n_owners, u32* cols, u64* totals, long* seed_off, u32* slot, u64* send, int phase, hipStream_t st);
+    int k, int w, u32 n_owners, u64 cap, u64 slot_cap, SeedBucketCtl* ctl, u32* chunk_off, u32* slot, u64* send,
+    hipStream_t st);
+// owner side of arks_exchange: the seeds of several askers answered in one launch; segment s holds n[s] seeds at
+// src[s], their answers (16 B each) go to dst[s]
+struct ProbeSegs
+{
+	int n_segs;
+	const u64* src[65];
+	u64* dst[65];
+	u64 end[65]; // inclusive prefix of the segments' lengths
+};
+hipError_t launch_seeds_probe_segs(int mm, const BIndexView& bx, const ProbeSegs& sg, hipStream_t st);
 hipError_t launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner, hipStream_t st);
 hipError_t launch_bmark(
     int kw, int mm, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,

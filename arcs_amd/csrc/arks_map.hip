@@ -47,6 +47,31 @@ mask_below(u64 m)
 }
 
 // value of lane l (wave-uniform l) as a scalar: stays in SGPRs, unlike the result of __shfl
+// inclusive prefix sum over the lanes of a wave by DPP (row shifts, then the row broadcasts of gfx9): no lane-index
+// registers -- the shuffle form keeps six of them alive as loop invariants of the chunk loop (spilled at 64 VGPRs)
+__device__ __forceinline__ int
+wave_incl_scan_i32(int v)
+{
+#define ARKS_SCAN_ADD(ctrl, rows) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rows, 0xF, true)
+	ARKS_SCAN_ADD(0x111, 0xF); // row_shr:1
+	ARKS_SCAN_ADD(0x112, 0xF); // row_shr:2
+	ARKS_SCAN_ADD(0x114, 0xF); // row_shr:4
+	ARKS_SCAN_ADD(0x118, 0xF); // row_shr:8
+	ARKS_SCAN_ADD(0x142, 0xA); // row_bcast:15 -> rows 1 and 3
+	ARKS_SCAN_ADD(0x143, 0xC); // row_bcast:31 -> rows 2 and 3
+#undef ARKS_SCAN_ADD
+	return v;
+}
+
+// the value of the next lane (0 for lane 63): wave_shl:1, a gfx9 DPP control -- no lane-index register
+__device__ __forceinline__ u64
+wave_next_u64(u64 v)
+{
+	const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x130, 0xF, 0xF, true);
+	const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x130, 0xF, 0xF, true);
+	return ((u64)hi << 32) | (u64)lo;
+}
+
 __device__ __forceinline__ u64
 lane_value_u64(u64 v, int l)
 {
@@ -1854,6 +1879,7 @@ struct SeedTileLds
 	u32 rmax[sTR][2];
 	u32 redo;  // reads for the slow queue
 	u32 redo2; // reads for the medium queue
+	u32 live;  // reads with a first-round seed that has entries (two-round S2)
 	u64 wstats[8];
 };
 
@@ -1883,8 +1909,9 @@ map_reads_s_kernel(
     u32* __restrict__ queue_count, // [0] slow length, [2] medium length; work counters behind (kWorkCtrOffset)
     const long* __restrict__ seed_off = nullptr, // REMOTE only
     const u64* __restrict__ ans = nullptr,       // REMOTE only
-    const u32* __restrict__ seed_slot = nullptr) // REMOTE only, may be NULL: the answer of seed s is ans[2 seed_slot[s]]
+    const u32* __restrict__ seed_slot = nullptr, // REMOTE only, may be NULL: the answer of seed s is ans[2 seed_slot[s]]
                                                  // (arks_exchange: answers lie in send-buffer order) instead of ans[2 s]
+    const u32* __restrict__ chunk_off = nullptr) // REMOTE only, instead of seed_off: first seed of chunk c0 / sChunk
 {
 	typedef typename Mmer<MM>::type mm_t;
 	__shared__ SeedTileLds S;
@@ -1892,6 +1919,20 @@ map_reads_s_kernel(
 	const int lane_id = threadIdx.x;
 	const int k = g.k, w = bx.w;
 	const u32 wrecip = (65536u + (u32)w - 1u) / (u32)w; // x / w == (x * wrecip) >> 16 for x < 65536 / w
+	// Two-round S2 (round 4): the seeds of a read are probed in two rounds.  Round 1 = its first seeds, as many as it
+	// takes for "none of them has an entry" to settle the vote: a seed without entries means that every window of
+	// its group is absent from the index (the property the whole kernel rests on), so the best contig can hold at
+	// most the windows of the groups behind, and when (those) / (all windows) cannot exceed j_index the read's
+	// result is 0 whatever the other seeds say (Arcs.cpp:1006-1010) -- they are not probed.  Half of a uniform read
+	// set lies outside the contig ends and pays one probe of two (128 bp, k = 60, j = 0.55), two of three (151 bp)
+	// instead of all of them.  Not with STATS (the counters want every window looked at), not for RAW votes
+	// (the count is the result) and not for REMOTE (the answers are there already).
+#ifdef ARKS_TWO_ROUND
+	constexpr bool kTwoRound = !STATS && !RAW && !REMOTE;
+#else
+	constexpr bool kTwoRound = false;
+#endif
+	const float jf = (float)j_index;
 	if (STATS && lane_id < 8)
 		S.wstats[lane_id] = 0;
 	u32* const work_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kWorkCtrOffset);
@@ -1940,24 +1981,23 @@ map_reads_s_kernel(
 					const uint8_t ev = eval[c0 + cl];
 					if (!ev)
 						rl = -1;
-					may_n = (ev & 2) == 0; // bit 1: known to hold ACGT only (arks_pair_gate_device from the read class)
+					// exactly ARKS_EVAL_ACGT_ONLY (3): evaluate, and the read is known to hold ACGT only -- what
+					// arks_pair_gate_device writes from the read class; any other nonzero value (1, 2, 0xFF ...) is a plain
+					// "evaluate" and the masks are fetched (arks_hip.h)
+					may_n = ev != 3;
 				}
 			}
 		}
 		// reads of the chunk that may hold an invalid base: only a tile with one of them fetches its N masks (a
 		// third of the read stream, and zero for > 98 % of the reads)
 		const u64 nreads_mask = __ballot(may_n);
-		const long soff0 = REMOTE ? seed_off[c0] : 0; // index of the chunk's first seed in `ans`
+		// index of the chunk's first seed in `ans` / `seed_slot`
+		const long soff0 = REMOTE ? (chunk_off ? (long)chunk_off[c0 / sChunk] : seed_off[c0]) : 0;
 		const int nwin_l = rl - k + 1;
 		const int G = nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
-		int gsum = G; // inclusive prefix over the lanes of the chunk
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const int o = __shfl_up(gsum, d);
-			gsum += lane_id >= d ? o : 0;
-		}
+		const int gsum = wave_incl_scan_i32(G); // inclusive prefix over the lanes of the chunk
 		const int gex = gsum - G; // seeds of the chunk's reads before this one
-		const u64 wo_next = __shfl_down(wo, 1);
+		const u64 wo_next = wave_next_u64(wo);
 		// reads beyond kSW words (512 bases) do not enter a tile: the per-read counters hold 10-bit fields
 		const u64 longmask = __ballot(lane_id < nchunk && wo_next - wo > (u64)kSW);
 		int cur = 0;
@@ -2018,15 +2058,25 @@ map_reads_s_kernel(
 					S.rlen[j] = rl;
 					if (lane == nxt - 1)
 						S.rstart[j + 1] = w1 * 32;
+					// (the three loops are kept rolled and scalar: unrolled or vectorised, their trip-count arithmetic -- per-chunk invariants of the
+					// tile loop -- is what went to scratch memory at 64 VGPRs)
+#pragma clang loop vectorize(disable) unroll(disable)
 					for (int x = w0; x < w1; ++x)
 						S.wmeta[x] = ((u32)j << 16) | (u32)rend;
+#pragma clang loop vectorize(disable) unroll(disable)
 					for (int x = w0; x <= w1; ++x) // one staging slot more than the read has words
 						S.sread[x + j] = (unsigned char)j;
 					const int hb = gex - gbase;
+#pragma clang loop vectorize(disable) unroll(disable)
 					for (int gi = 0; gi < G; ++gi) {
 						int q = (gi + 1) * w - 1;
 						q = q < nwin_l - 1 ? q : nwin_l - 1;
-						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)j << 12));
+						// bit 0: a second-round seed -- the groups in front of it cover enough of the read that, all of them
+						// absent, (windows left) / (all windows) > j_index is false.  The float test errs to the safe side
+						// (a margin of 1e-4 against a rounding error of 1e-7): a seed wrongly kept in round 1 costs a probe.
+						const u32 late =
+						    kTwoRound && gi > 0 && (float)(nwin_l - gi * w) * 1.0001f < jf * (float)nwin_l ? 1u : 0u;
+						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)j << 12) | late);
 					}
 					S.pdiag[j][0] = ~0ull;
 					S.pdiag[j][1] = ~0ull;
@@ -2040,6 +2090,8 @@ map_reads_s_kernel(
 					asm volatile("v_mov_b32 %0, 0" : "=v"(z));
 					S.redo = z;
 					S.redo2 = z;
+					if (kTwoRound)
+						S.live = z;
 				}
 				asm volatile("" : "+v"(c_in), "+v"(m_in), "+v"(c_pad), "+v"(m_pad), "+v"(slot_pref)); // all loads in flight
 				if (lane < tw) {
@@ -2082,31 +2134,47 @@ map_reads_s_kernel(
 			int jh = 0;
 			u64 dk0 = 0, dk1 = 0;
 			bool off = false;
-			if (lane < nh) {
-				const u32 hv = S.heads[lane];
-				const int q = (int)((hv >> 1) & 2047u);
-				jh = (int)(hv >> 12);
-				const mm_t mf = tile_mmer<MM>(S.cw, q), mr = mmer_rc<MM>(mf);
+			{
+				int q = 0;
+				bool late = false;
+				if (lane < nh) {
+					const u32 hv = S.heads[lane];
+					q = (int)((hv >> 1) & 2047u);
+					jh = (int)(hv >> 12);
+					late = kTwoRound && (hv & 1u);
+				}
 				u64 ent[2];
 				u32 cnt = 0;
-				// a seed that holds an invalid base has no entries: every window of its group holds that base too
-				if (!(has_n && tile_span_has_n(S.nm, q, MM))) {
-					if (REMOTE) {
-						long si = soff0 + (long)(gbase + lane);
-						if (seed_slot)
-							si = slot_pref == ~0u ? -1 : (long)slot_pref;
-						if (si >= 0) {
-							const u64* a = ans + 2 * si;
-							ent[0] = a[0], ent[1] = a[1];
-							cnt = seed_answer_count(ent[0], ent[1]);
-						}
-					} else
-						cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, ent);
+				u32 rstrand = 0;
+#pragma unroll
+				for (int rd = 0; rd < (kTwoRound ? 2 : 1); ++rd) {
+					// round 0: the first seeds of every read; round 1: the others, of the reads that are still open
+					const bool go = lane < nh && late == (rd == 1) && (rd == 0 || ((S.live >> jh) & 1u));
+					// a seed that holds an invalid base has no entries: every window of its group holds that base too
+					if (go && !(has_n && tile_span_has_n(S.nm, q, MM))) {
+						const mm_t mf = tile_mmer<MM>(S.cw, q), mr = mmer_rc<MM>(mf);
+						rstrand = mf < mr ? 1u : 0u;
+						if (REMOTE) {
+							long si = soff0 + (long)(gbase + lane);
+							if (seed_slot)
+								si = slot_pref == ~0u ? -1 : (long)slot_pref;
+							if (si >= 0) {
+								const u64* a = ans + 2 * si;
+								ent[0] = a[0], ent[1] = a[1];
+								cnt = seed_answer_count(ent[0], ent[1]);
+							}
+						} else
+							cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, ent);
+					}
+					if (kTwoRound && rd == 0) {
+						if (go && cnt)
+							atomicOr(&S.live, 1u << jh);
+						ARKS_WAVE_SYNC();
+					}
 				}
 				off = cnt == kHnHeavy || cnt == kHnOverflow;
 				if (cnt >= 1 && cnt <= 2) {
 					const int o = q - S.rstart[jh]; // offset of the seed in the read
-					const u32 rstrand = mf < mr ? 1u : 0u;
 					// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
 					const bool s0 = ((u32)(ent[0] >> 62) & 1u) == rstrand;
 					dk0 = (s0 ? (u64)(u32)ent[0] - (u64)o : (u64)(u32)ent[0] + (u64)(MM - 1 + o)) | ((u64)s0 << 40) |
@@ -2380,6 +2448,36 @@ seeds_probe_kernel(BIndexView bx, const u64* __restrict__ cm, long n, u64* __res
 	ans[2 * i + 1] = a1;
 }
 
+// the same for the seeds of several askers in one launch (arks_exchange): segment s = sg.src[s][0 .. n_s) -> sg.dst[s]
+template <int MM>
+__global__ void __launch_bounds__(256)
+seeds_probe_segs_kernel(BIndexView bx, ProbeSegs sg)
+{
+	typedef typename Mmer<MM>::type mm_t;
+	const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= sg.end[sg.n_segs - 1])
+		return;
+	int s = 0;
+	while (i >= sg.end[s]) // (a handful of segments: the askers of one owner)
+		++s;
+	const u64 j = i - (s ? sg.end[s - 1] : 0ull);
+	const u64 cm = sg.src[s][j];
+	u64 ent[2] = { 0, 0 };
+	u64 a0 = 0, a1 = 0;
+	if (cm != ~0ull) {
+		const u32 cnt = probe_minimizer_table<MM>(bx, (mm_t)cm, ent);
+		if (cnt == kHnOverflow)
+			a0 = kAnsOverflow;
+		else if (cnt == kHnHeavy)
+			a0 = kAnsHeavy;
+		else {
+			a0 = cnt >= 1 ? ent[0] : 0;
+			a1 = cnt >= 2 ? ent[1] : 0;
+		}
+	}
+	*reinterpret_cast<ulonglong2*>(sg.dst[s] + 2 * j) = make_ulonglong2(a0, a1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: pair gate and pair rule of chromiumRead.
 // ------------------------------------------------------------------------------------------------
@@ -2630,11 +2728,30 @@ launch_seeds_probe(int mm, const BIndexView& bx, const u64* cm, long n, u64* ans
 // bestContig for a batch whose seed probes were answered beforehand (sharded seed table): the hot kernel with
 // REMOTE answers, then the general kernels over the replicated minimizer table (bxg)
 hipError_t
+launch_seeds_probe_segs(int mm, const BIndexView& bx, const ProbeSegs& sg, hipStream_t st)
+{
+	if (sg.n_segs <= 0 || sg.n_segs > 65)
+		return sg.n_segs == 0 ? hipSuccess : hipErrorInvalidValue;
+	const u64 n = sg.end[sg.n_segs - 1];
+	if (n == 0)
+		return hipSuccess;
+	const unsigned b = (unsigned)((n + 255) / 256);
+	if (mm == kMShort)
+		seeds_probe_segs_kernel<kMShort><<<b, 256, 0, st>>>(bx, sg);
+	else
+		seeds_probe_segs_kernel<kMLong><<<b, 256, 0, st>>>(bx, sg);
+	ARKS_LAUNCH_CHECK();
+	return hipSuccess;
+}
+
+hipError_t
 launch_map_reads_seeded(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval,
     long n_reads, double j_index, const KeyGeom& g, const BIndexView& bx, const BIndexView& bxg, const long* seed_off,
-    const u64* ans, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st, const u32* seed_slot)
+    const u64* ans, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st, const u32* seed_slot,
+    const u32* chunk_off)
 {
+	static_assert(sChunk == 56, "arks_shard.hip (kBkChunk) numbers the seeds by chunks of the seed tile kernel");
 	if (n_reads <= 0)
 		return hipSuccess;
 	u64* const user_stats = stats;
@@ -2655,7 +2772,7 @@ launch_map_reads_seeded(
 	do {                                                                                           \
 		map_reads_s_kernel<KWV, ST, MMV, false, true><<<bh, 64, 0, st>>>(                          \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,        \
-		    queue + n_reads, queue_count, seed_off, ans, seed_slot);                               \
+		    queue + n_reads, queue_count, seed_off, ans, seed_slot, chunk_off);                    \
 		map_reads_b_kernel<KWV, ST, true, MMV, false, false><<<medium_blocks(bb), 64, 0, st>>>(    \
 		    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bxg, out, stats, queue,       \
 		    queue + n_reads, queue_count);                                                         \

@@ -31,16 +31,24 @@ mask_below(u64 m)
 }
 
 // ---- the sharded seed table, product path (arks_exchange): seeds listed AND bucketed by owner on the device ----
-// Three launches over blocks of kBucketReads reads, no library calls:
-//   count  per block: seeds of its reads (read-major numbering) and, per owner, the seeds that are sent
-//   scan   exclusive prefix over the blocks of every one of those columns (one workgroup per column)
-//   fill   d_seed_off[r] (read-major), and for every seed its slot in the send buffer -- the seeds of owner o
-//          lie together, blocks in order -- or ~0 for a seed that holds an invalid base (nobody is asked; the map
-//          kernel never looks at its answer); the canonical m-mer goes to send[slot]
-// A seed's answer comes back at the same slot, so the map kernel reads ans[2 * slot[s]] and no pass puts the
-// answers "back into seed order".
-constexpr int kBucketReads = 256; // reads per block = threads per block
+// ONE launch (round 4; rounds 2-3 counted, scanned and filled in three, with a host wait between the second and the
+// third): the send buffer is W regions of `cap` seeds, one per owner; a block of kBkReads reads counts its seeds per
+// owner in LDS, reserves its stretch of every region with one global atomic per owner (ctl->fill[o]) and a stretch
+// of the read-major seed numbering (ctl->seeds), and writes:
+//   send[o * cap + ...]     the canonical m-mers asked of owner o (the seeds of an owner lie together, no sort)
+//   slot[seed]              where seed `seed` went (its answer comes back at the same place), ~0 for a seed that
+//                           holds an invalid base (nobody is asked; the map kernel never looks at its answer)
+//   chunk_off[c]            number of the first seed of the map kernel's chunk c (sChunk = 56 reads): a block is a
+//                           whole number of chunks, and a chunk's seeds are numbered read by read
+// The counts reach the host with the batch's other results, one step behind the device (arks_exchange_complete);
+// nothing waits for them.  A block that does not fit sets ctl->overflow and writes nothing: the counters go on
+// counting, so the host knows what the batch needs and runs it again with larger regions (first batch of a shape).
 constexpr int kMaxOwners = 64;
+constexpr int kBkChunk = 56;                  // = sChunk of map_reads_s_kernel (arks_map.hip; checked at its launch)
+constexpr int kBkWaves = 16;
+constexpr int kBkChunksPerWave = 2;
+constexpr int kBkChunks = kBkWaves * kBkChunksPerWave; // 32 chunks = 1792 reads per block: ~28 k blocks per 50 M reads,
+constexpr int kBkReads = kBkChunks * kBkChunk;         // i.e. ~0.3 ms of same-address atomics per counter, in parallel
 
 template <int MM>
 __device__ __forceinline__ int
@@ -99,165 +107,148 @@ bucket_one_seed(
 
 constexpr int kBucketInline = 4; // seeds of a read kept in registers (a 10x pair has 2 + 3)
 
-// columns: [0] seeds of the block, [1 + o] seeds of the block that owner o is asked; cols[c * n_blocks + block]
-template <int MM>
-__global__ void __launch_bounds__(kBucketReads)
-seed_bucket_count_kernel(
-    const u64* __restrict__ codes, const u32* __restrict__ nmask, const u64* __restrict__ word_off,
-    const u32* __restrict__ lens, const uint8_t* __restrict__ eval, long n_reads, int k, int w, u32 n_owners,
-    long n_blocks, u32* __restrict__ cols)
+// inclusive prefix sum over the lanes of a wave by DPP (see arks_map.hip)
+__device__ __forceinline__ int
+bk_wave_incl_scan(int v)
 {
-	__shared__ u32 cnt[kMaxOwners + 1];
-	if (threadIdx.x <= n_owners)
+#define ARKS_SCAN_ADD(ctrl, rows) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rows, 0xF, true)
+	ARKS_SCAN_ADD(0x111, 0xF);
+	ARKS_SCAN_ADD(0x112, 0xF);
+	ARKS_SCAN_ADD(0x114, 0xF);
+	ARKS_SCAN_ADD(0x118, 0xF);
+	ARKS_SCAN_ADD(0x142, 0xA);
+	ARKS_SCAN_ADD(0x143, 0xC);
+#undef ARKS_SCAN_ADD
+	return v;
+}
+
+template <int MM>
+__global__ void __launch_bounds__(kBkWaves * 64)
+seed_bucket_kernel(
+    const u64* __restrict__ codes, const u32* __restrict__ nmask, const u64* __restrict__ word_off,
+    const u32* __restrict__ lens, const uint8_t* __restrict__ eval, long n_reads, int k, int w, u32 n_owners, u64 cap,
+    u64 slot_cap, SeedBucketCtl* __restrict__ ctl, u32* __restrict__ chunk_off, u32* __restrict__ slot,
+    u64* __restrict__ send)
+{
+	__shared__ u32 cnt[kMaxOwners];
+	__shared__ u32 base[kMaxOwners];
+	__shared__ u32 chunk_cnt[kBkChunks];
+	__shared__ u32 chunk_base[kBkChunks];
+	__shared__ u32 bad;
+	const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+	if (threadIdx.x < kMaxOwners)
 		cnt[threadIdx.x] = 0;
+	if (threadIdx.x == 0)
+		bad = 0;
 	__syncthreads();
-	const long r = (long)blockIdx.x * kBucketReads + threadIdx.x;
-	u64 cm[kBucketInline];
-	u32 own[kBucketInline];
-	const int G = bucket_read_seeds<MM>(codes, nmask, word_off, lens, eval, r, n_reads, k, w, n_owners, cm, own, kBucketInline);
-	if (G) {
-		atomicAdd(&cnt[0], (u32)G);
-		for (int gi = 0; gi < G; ++gi) {
+	u64 cm[kBkChunksPerWave][kBucketInline];
+	u32 own[kBkChunksPerWave][kBucketInline];
+	int G[kBkChunksPerWave], pre[kBkChunksPerWave];
+#pragma unroll
+	for (int it = 0; it < kBkChunksPerWave; ++it) {
+		const int ci = wave * kBkChunksPerWave + it;
+		const long r = ((long)blockIdx.x * kBkChunks + ci) * kBkChunk + lane;
+		G[it] = lane < kBkChunk
+		            ? bucket_read_seeds<MM>(codes, nmask, word_off, lens, eval, r, n_reads, k, w, n_owners, cm[it], own[it], kBucketInline)
+		            : 0;
+		const int incl = bk_wave_incl_scan(G[it]);
+		pre[it] = incl - G[it];
+		if (lane == 63)
+			chunk_cnt[ci] = (u32)incl;
+		for (int gi = 0; gi < G[it]; ++gi) {
 			u32 o;
 			if (gi < kBucketInline)
-				o = own[gi];
+				o = own[it][gi];
 			else {
 				u64 c;
 				bucket_one_seed<MM>(codes, nmask, word_off[r], (int)lens[r] - k + 1, w, gi, n_owners, c, o);
 			}
 			if (o != ~0u)
-				atomicAdd(&cnt[1 + o], 1u);
+				atomicAdd(&cnt[o], 1u);
 		}
 	}
 	__syncthreads();
-	if (threadIdx.x <= n_owners)
-		cols[(long)threadIdx.x * n_blocks + blockIdx.x] = cnt[threadIdx.x];
-}
-
-// exclusive prefix of every column over the blocks, in place (u32: a launch holds < 2^32 seeds); totals[c] = its sum.
-// One workgroup of 1024 threads per column: thread t sums its stretch, the stretch sums are scanned through LDS,
-// the stretch is rewritten.
-__global__ void __launch_bounds__(1024)
-seed_bucket_scan_kernel(long n_blocks, u32* __restrict__ cols, u64* __restrict__ totals)
-{
-	__shared__ u64 part[1024];
-	u32* col = cols + (long)blockIdx.x * n_blocks;
-	const long per = (n_blocks + 1023) / 1024;
-	const long lo = (long)threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
-	u64 sum = 0;
-	for (long i = lo; i < hi; ++i)
-		sum += col[i];
-	part[threadIdx.x] = sum;
-	__syncthreads();
-	for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
-		const u64 v = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
-		__syncthreads();
-		part[threadIdx.x] += v;
-		__syncthreads();
-	}
-	u64 run = part[threadIdx.x] - sum;
-	for (long i = lo; i < hi; ++i) {
-		const u32 v = col[i];
-		col[i] = (u32)run;
-		run += v;
-	}
-	if (threadIdx.x == 1023)
-		totals[blockIdx.x] = part[1023];
-}
-
-template <int MM>
-__global__ void __launch_bounds__(kBucketReads)
-seed_bucket_fill_kernel(
-    const u64* __restrict__ codes, const u32* __restrict__ nmask, const u64* __restrict__ word_off,
-    const u32* __restrict__ lens, const uint8_t* __restrict__ eval, long n_reads, int k, int w, u32 n_owners,
-    long n_blocks, const u32* __restrict__ cols, const u64* __restrict__ totals, long* __restrict__ seed_off,
-    u32* __restrict__ slot, u64* __restrict__ send)
-{
-	// (slots within a block are handed out by an LDS atomic per seed, in no particular order.  Handing them out in
-	// order -- wave, seed number, lane: ballot + mbcnt -- so that a tile's answers lie in fewer lines was tried:
-	// the fill took 1.31 instead of 1.08 ms per 25 M pairs and the map kernel behind it the same 3.5 ms,
-	// profiles/r03p_sharded1_kernel_stats.csv against r03o's)
-	__shared__ u32 cnt[kMaxOwners + 1];
-	__shared__ u32 base[kMaxOwners + 1]; // [0]: first seed of the block (read-major); [1 + o]: first send slot of the block's seeds for owner o
-	__shared__ u32 wsum[kBucketReads / 64];
-	if (threadIdx.x <= n_owners) {
-		cnt[threadIdx.x] = 0;
-		u64 b = cols[(long)threadIdx.x * n_blocks + blockIdx.x];
-		if (threadIdx.x >= 1)
-			for (u32 o = 0; o + 1 < threadIdx.x; ++o) // owners in front of this one in the send buffer
-				b += totals[1 + o];
+	// one stretch of every owner's region, one of the seed numbering: a global atomic each
+	if (threadIdx.x < n_owners) {
+		const u32 c = cnt[threadIdx.x];
+		u64 b = 0;
+		if (c) {
+			b = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->fill[threadIdx.x]), (unsigned long long)c);
+			if (b + c > cap)
+				bad = 1;
+		}
 		base[threadIdx.x] = (u32)b;
+		cnt[threadIdx.x] = 0; // handed out again below, seed by seed
 	}
-	const long r = (long)blockIdx.x * kBucketReads + threadIdx.x;
-	u64 cm[kBucketInline];
-	u32 own[kBucketInline];
-	const int G = bucket_read_seeds<MM>(codes, nmask, word_off, lens, eval, r, n_reads, k, w, n_owners, cm, own, kBucketInline);
-	// read-major number of the read's first seed: exclusive scan of G over the block's threads
-	int incl = G;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const int o = __shfl_up(incl, d);
-		incl += (int)(threadIdx.x & 63) >= d ? o : 0;
-	}
-	if ((threadIdx.x & 63) == 63)
-		wsum[threadIdx.x >> 6] = (u32)incl;
-	__syncthreads();
-	u32 before = 0;
-	for (unsigned wv = 0; wv < (threadIdx.x >> 6); ++wv)
-		before += wsum[wv];
-	const long first = (long)base[0] + (long)before + (long)(incl - G);
-	if (r < n_reads)
-		seed_off[r] = first;
-	if (r == n_reads - 1)
-		seed_off[n_reads] = first + G;
-	for (int gi = 0; gi < G; ++gi) {
-		u64 c;
-		u32 o;
-		if (gi < kBucketInline)
-			c = cm[gi], o = own[gi];
-		else
-			bucket_one_seed<MM>(codes, nmask, word_off[r], (int)lens[r] - k + 1, w, gi, n_owners, c, o);
-		u32 sl = ~0u;
-		if (o != ~0u) {
-			sl = base[1 + o] + atomicAdd(&cnt[1 + o], 1u);
-			send[sl] = c;
+	if (threadIdx.x == 64) {
+		u32 total = 0;
+		for (int c = 0; c < kBkChunks; ++c)
+			total += chunk_cnt[c];
+		const u64 sb = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->seeds), (unsigned long long)total);
+		if (sb + total > slot_cap)
+			bad = 1;
+		u32 run = (u32)sb;
+		for (int c = 0; c < kBkChunks; ++c) {
+			chunk_base[c] = run;
+			run += chunk_cnt[c];
 		}
-		slot[first + gi] = sl;
+	}
+	__syncthreads();
+	if (bad) { // the batch is run again with larger regions (the counters above say how large)
+		if (threadIdx.x == 0)
+			ctl->overflow = 1;
+		return;
+	}
+	if (threadIdx.x < kBkChunks) {
+		const long c = (long)blockIdx.x * kBkChunks + threadIdx.x;
+		if (c * kBkChunk < n_reads)
+			chunk_off[c] = chunk_base[threadIdx.x];
+	}
+#pragma unroll
+	for (int it = 0; it < kBkChunksPerWave; ++it) {
+		const int ci = wave * kBkChunksPerWave + it;
+		const long r = ((long)blockIdx.x * kBkChunks + ci) * kBkChunk + lane;
+		const u32 first = chunk_base[ci] + (u32)pre[it];
+		for (int gi = 0; gi < G[it]; ++gi) {
+			u64 c;
+			u32 o;
+			if (gi < kBucketInline)
+				c = cm[it][gi], o = own[it][gi];
+			else
+				bucket_one_seed<MM>(codes, nmask, word_off[r], (int)lens[r] - k + 1, w, gi, n_owners, c, o);
+			u32 sl = ~0u;
+			if (o != ~0u) {
+				sl = (u32)((u64)o * cap) + base[o] + atomicAdd(&cnt[o], 1u);
+				send[sl] = c;
+			}
+			slot[first + gi] = sl;
+		}
 	}
 }
 
-// seeds of a batch listed and bucketed by owner (see seed_bucket_count_kernel): cols = (1 + n_owners) * n_blocks u32 of
-// scratch, totals = 1 + n_owners u64 ([0] seeds of the batch, [1 + o] seeds owner o is asked)
 long
-seed_bucket_blocks(long n_reads)
+seed_bucket_chunks(long n_reads)
 {
-	return (n_reads + kBucketReads - 1) / kBucketReads;
+	return (n_reads + kBkChunk - 1) / kBkChunk;
 }
 
+// seeds of a batch listed and bucketed by owner; ctl is zeroed here.  cap * n_owners <= 0xFFFFFFFE (slots are 32-bit).
 hipError_t
-launch_seed_buckets(
+launch_seed_bucket(
     int mm, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval, long n_reads,
-    int k, int w, u32 n_owners, u32* cols, u64* totals, long* seed_off, u32* slot, u64* send, int phase, hipStream_t st)
+    int k, int w, u32 n_owners, u64 cap, u64 slot_cap, SeedBucketCtl* ctl, u32* chunk_off, u32* slot, u64* send,
+    hipStream_t st)
 {
-	if (n_owners < 1 || n_owners > (u32)kMaxOwners)
+	if (n_owners < 1 || n_owners > (u32)kMaxOwners || cap * (u64)n_owners > 0xFFFFFFFEull || slot_cap > 0xFFFFFFFEull)
 		return hipErrorInvalidValue;
-	const long nb = seed_bucket_blocks(n_reads);
-	if (phase == 0) { // count + scan: totals are valid when the stream gets here
-		if (n_reads <= 0)
-			return hipMemsetAsync(totals, 0, sizeof(u64) * (1 + n_owners), st);
-		if (mm == kMShort)
-			seed_bucket_count_kernel<kMShort><<<(unsigned)nb, kBucketReads, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, nb, cols);
-		else
-			seed_bucket_count_kernel<kMLong><<<(unsigned)nb, kBucketReads, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, nb, cols);
-		seed_bucket_scan_kernel<<<1 + n_owners, 1024, 0, st>>>(nb, cols, totals);
-	} else { // fill
-		if (n_reads <= 0)
-			return hipMemsetAsync(seed_off, 0, sizeof(long), st);
-		if (mm == kMShort)
-			seed_bucket_fill_kernel<kMShort><<<(unsigned)nb, kBucketReads, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, nb, cols, totals, seed_off, slot, send);
-		else
-			seed_bucket_fill_kernel<kMLong><<<(unsigned)nb, kBucketReads, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, nb, cols, totals, seed_off, slot, send);
-	}
+	hipError_t e = hipMemsetAsync(ctl, 0, sizeof(SeedBucketCtl), st);
+	if (e != hipSuccess || n_reads <= 0)
+		return e;
+	const unsigned nb = (unsigned)((n_reads + kBkReads - 1) / kBkReads);
+	if (mm == kMShort)
+		seed_bucket_kernel<kMShort><<<nb, kBkWaves * 64, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, cap, slot_cap, ctl, chunk_off, slot, send);
+	else
+		seed_bucket_kernel<kMLong><<<nb, kBkWaves * 64, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, cap, slot_cap, ctl, chunk_off, slot, send);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

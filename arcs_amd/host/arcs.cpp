@@ -22,6 +22,7 @@
 #include <getopt.h>
 #include <hip/hip_runtime_api.h>
 #include <signal.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -948,11 +949,13 @@ run_arks(const std::vector<std::string>& filenames)
 	bool all_open = true;
 	if (params.ranks > 1 && filenames.size() > 1)
 		for (const std::string& f : filenames) {
-			FILE* probe = f == "/dev/stdin" ? stdin : std::fopen(f.c_str(), "rb");
-			if (!probe)
+			// by stat / access, and only for regular files: opening and closing a FIFO here would block until its
+			// writer attaches and then take the only reader away from it (SIGPIPE before the read stage opens it)
+			struct stat sb;
+			if (::stat(f.c_str(), &sb) != 0)
 				all_open = false;
-			else if (probe != stdin)
-				std::fclose(probe);
+			else if (S_ISREG(sb.st_mode) && ::access(f.c_str(), R_OK) != 0)
+				all_open = false;
 		}
 	if (params.ranks > 1 && filenames.size() > 1 && all_open) {
 		g_world = (int)std::min<size_t>((size_t)params.ranks, filenames.size());

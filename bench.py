@@ -769,18 +769,20 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
     empty_ok = torch.zeros(0, dtype=torch.uint8, device=dev)
     imaps = [arcs_amd.ImapAccumulator(1 << 20, device=local) for _ in my_ranks]
     stats = [torch.zeros(8, dtype=torch.int64, device=dev) for _ in my_ranks]
-    streams = [torch.cuda.Stream(dev) for _ in my_ranks]
+    # three streams per rank: two batches in flight (submit n + 1 before complete n), the pair rule on the third
+    streams = [[torch.cuda.Stream(dev) for _ in range(3)] for _ in my_ranks]
 
     def rank_step(i, st):
-        with torch.cuda.stream(streams[i]):
-            for l in range(n_launch):
-                reads, ok, bid = per_rank[i][l] if l < len(per_rank[i]) else (empty, empty_ok, None)
-                if xs[i] is not None:
-                    xs[i].map_pairs(reads, j, pair_ok=ok, barcode_id=bid, imap=imaps[i] if bid is not None else None, stats=st)
-                else:
+        if xs[i] is not None:
+            xs[i].map_pairs_pipelined(per_rank[i], j, streams[i], imap=imaps[i], stats=st, n_calls=n_launch, keep=False)
+        else:
+            with torch.cuda.stream(streams[i][0]):
+                for l in range(n_launch):
+                    reads, ok, bid = per_rank[i][l] if l < len(per_rank[i]) else (empty, empty_ok, None)
                     adist.map_pairs_seed_sharded(shards[i], reads, j, pair_ok=ok, barcode_id=bid,
                                                  imap=imaps[i] if bid is not None else None, stats=st)
-            streams[i].synchronize()
+        for q in streams[i]:
+            q.synchronize()
 
     def step(with_stats=False):
         if n_local == 1:
@@ -837,7 +839,8 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
                        "k": k, "j": j, "shards": n_ranks, "launches_per_rank_and_step": n_launch,
                        "shard_bytes": [sh.device_bytes for sh in shards],
                        "transport": ("RCCL ncclSend/ncclRecv groups" if (world > 1 and use_exchange) else
-                                     "device copies between the local ranks of one process" if world == 1 else
+                                     "direct: the local ranks of one process read and write each other's buffers "
+                                     "(no copies); two batches in flight per rank" if world == 1 else
                                      "torch.distributed gloo through host memory (test transport)"),
                        "last_batch_of_rank0": ex,
                        "parallelism": f"seed table hash-sharded x{n_ranks}, reads dealt to the ranks in blocks, seeds "

@@ -299,43 +299,73 @@ int arks_map_reads_seeded_device(
     arks_map_stats* d_stats,
     void* stream);
 
-/* ---- the sharded seed table as one call per batch (the product path of BASELINE configs[3]) ---------------- */
+/* ---- the sharded seed table (the product path of BASELINE configs[3]) ------------------------------------- */
 
-/* One arks_exchange per rank: its shard of the seed table, device buffers for the seeds that travel, and the
- * transport to the other ranks -- RCCL (ncclSend / ncclRecv groups over xGMI, one process per GPU; librccl is
- * opened on demand) or, for the ranks of ONE process that share a device (tests, single-GPU runs), device copies
- * behind a host barrier.  The host program that starts the ranks (arcs --ranks N: forked processes and pipes;
- * bench.py: torch.distributed) carries the 128-byte id of rank 0 to the others, as an MPI or NCCL program does. */
+/* One arks_exchange per rank: its shard of the seed table, two sets of device buffers for the seeds that travel
+ * (two batches in flight), and the transport to the other ranks:
+ *   - RCCL (arks_exchange_create; one process per GPU): ncclAllGather of the per-owner counts, ncclSend / ncclRecv
+ *     groups over xGMI for the seeds and for the answers; librccl is opened on demand.  The host program that starts
+ *     the ranks (bench.py: torch.distributed) carries the 128-byte id of rank 0 to the others, as an MPI or NCCL
+ *     program does;
+ *   - direct (arks_exchange_create_local; the ranks are threads of ONE process): the devices of the ranks are the
+ *     same device or peers of each other (xGMI); nothing is copied -- the owner's probe kernel reads the askers'
+ *     buffers where they lie and writes its answers into theirs; host barriers and events order it.  What
+ *     `arcs --index-sharded` runs, and what a single-GPU box can test. */
 typedef struct arks_exchange arks_exchange;
 #define ARKS_EXCHANGE_ID_BYTES 128
 typedef struct
 {
-	uint64_t seeds;    /* seeds of the last batch of this rank */
+	uint64_t seeds;    /* seeds of the last completed batch of this rank */
 	uint64_t sent;     /* ... of which asked of other ranks (8 B out, 16 B back each) */
 	uint64_t received; /* seeds other ranks asked of this one */
+	uint64_t reruns;   /* batches so far that did not fit the send buffer's regions and were bucketed again, larger */
 } arks_exchange_stats;
 
 /* rank 0: a fresh id for arks_exchange_create on every rank (ncclGetUniqueId) */
 int arks_exchange_unique_id(unsigned char* out_id /* ARKS_EXCHANGE_ID_BYTES */);
-/* shard = arks_index_build_seed_shard(..., rank, world, device); unique_id may be NULL when world == 1 */
+/* shard = arks_index_build_seed_shard(..., rank, world, device); unique_id may be NULL when world == 1.  With a
+ * communicator, a send to oneself of a known pattern checks the data type numbering before anything travels. */
 int arks_exchange_create(arks_exchange** out, const arks_index* shard, const unsigned char* unique_id, int rank, int world);
-/* out[r] for r in [0, world): the ranks of one process (shards[r] = shard r, all on one device); each is driven by
- * its own host thread, arks_map_reads_exchanged_device blocks until all of them have called it */
+/* out[r] for r in [0, world): the ranks of one process (shards[r] = shard r, on one device or on devices with peer
+ * access to each other, which is enabled here); each rank is driven by its own host thread, and
+ * arks_exchange_complete blocks until all of them have called it */
 int arks_exchange_create_local(arks_exchange** out, const arks_index* const* shards, int world);
 int arks_exchange_free(arks_exchange* x);
 /* a local rank whose driver gives up (an error outside the library): the other ranks of its group get an error from
- * arks_map_reads_exchanged_device instead of waiting for it (a rank that is missing for ten minutes has the same
- * effect); no-op for an RCCL exchange, whose communicator has time-outs of its own */
+ * arks_exchange_complete instead of waiting for it (a rank that is missing for ten minutes has the same effect);
+ * no-op for an RCCL exchange (a rank that fails inside the library aborts its communicator itself) */
 int arks_exchange_abort(arks_exchange* x);
 int arks_exchange_last_stats(const arks_exchange* x, arks_exchange_stats* out);
 
-/* bestContig (Arcs/Arcs.cpp:939-1014) of this rank's reads against the sharded seed table: the same results and
- * counters as arks_map_reads_device against the whole index.  COLLECTIVE: every rank calls it, in the same order,
- * each with its own batch (n_reads may be 0).  On `stream`: seeds listed and bucketed by owner (three kernels),
- * all-to-all of the seeds (8 B), owner-side probe, all-to-all of the answers (16 B), map; one small
- * device-to-host copy (the per-owner counts) is the call's only wait for the device.  The calls of ONE exchange
- * must all be made on the same stream (its buffers are reused from call to call in stream order); two exchanges
- * on two streams may be in flight at the same time. */
+/* bestContig (Arcs/Arcs.cpp:939-1014) of this rank's reads against the sharded seed table, in two steps -- the
+ * same results and counters as arks_map_reads_device against the whole index (the reads are independent,
+ * Arcs.cpp:1169; the index is only read, :969-971):
+ *   arks_exchange_submit    NOT collective.  On `stream`: the batch's seeds listed and bucketed by owner (one
+ *                           kernel), the per-owner counts copied to the host.  At most two batches may be
+ *                           submitted and not yet completed; the arrays must stay valid until the batch's
+ *                           results have been consumed.
+ *   arks_exchange_complete  COLLECTIVE: every rank calls it, in the same order, for its oldest submitted batch
+ *                           (which may be empty).  Counts to everybody, the seeds to their owners (8 B each),
+ *                           owner-side probe, answers back (16 B each), map kernels -- all on the batch's stream;
+ *                           d_out_conreci / d_stats are complete when that stream gets there.
+ * Submitting batch n + 1 (on a second stream) before completing batch n keeps the device busy while the host
+ * waits for counts: they have long arrived.  A rank that fails (in either call) makes the same complete() fail on
+ * every rank; nobody is left waiting.  A buffer set is reused in the order of the stream it was last used on. */
+int arks_exchange_submit(
+    arks_exchange* x,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream);
+int arks_exchange_complete(arks_exchange* x);
+
+/* submit + complete for one batch at a time (COLLECTIVE; nothing else may be in flight) */
 int arks_map_reads_exchanged_device(
     arks_exchange* x,
     const uint64_t* d_codes,
@@ -404,9 +434,13 @@ int arks_imap_export_ordered(const arks_imap* m, uint32_t* h_triples, uint64_t* 
 
 /* The gate of chromiumRead, Arcs/Arcs.cpp:1264-1268: d_eval[2p], d_eval[2p+1] nonzero iff
  * pair_ok[p] && (class[2p] & 1) && (class[2p+1] & 1)  (goodmult is always true, :1267); a nonzero
- * d_eval[r] is 1 | (class[r] & 2): bit 1 = "read r holds ACGT only".  Any nonzero value means
- * "evaluate" to arks_map_reads_device; a caller's own array of 0 / 1 is as good (the N masks of
- * every read are fetched then). */
+ * d_eval[r] is 1 (ARKS_EVAL) or 3 (ARKS_EVAL_ACGT_ONLY: class bit 1, "read r holds ACGT only").
+ * The d_eval contract of every mapping entry point: 0 = not evaluated; ARKS_EVAL_ACGT_ONLY (exactly 3) =
+ * evaluate, and the caller VOUCHES that the read's N mask is all zero (the kernels do not fetch it); ANY
+ * other nonzero value (1, 2, 0xFF ...) = evaluate, nothing known about the bases.  A caller's own array
+ * must therefore not hold 3 unless it means it. */
+#define ARKS_EVAL 1
+#define ARKS_EVAL_ACGT_ONLY 3
 int arks_pair_gate_device(
     const uint8_t* d_pair_ok,
     const uint8_t* d_read_class,

@@ -17,6 +17,31 @@ extern "C" {
  * counters).  The reads the hot kernel of bestContig (Arcs/Arcs.cpp:939-1014) did not finish itself. */
 int arks_debug_queue_counts(const arks_index* idx, unsigned* out4);
 
+/* The RCCL entry points arks_exchange reaches (ncclSend / ncclRecv groups, ncclAllGather ...), with RCCL's own
+ * signatures.  By default the table is filled from librccl.so.1 (dlopen).  A test installs stand-ins -- threads of
+ * one process and device copies (tests/mock_rccl.cpp) -- and so runs the library's world > 1 code, which RCCL itself
+ * refuses to do on a box with one GPU (two ranks may not share a device). */
+typedef struct
+{
+	char internal[128];
+} arks_rccl_unique_id; /* = ncclUniqueId */
+typedef struct
+{
+	int (*GetVersion)(int*);                                               /* optional */
+	int (*GetUniqueId)(arks_rccl_unique_id*);
+	int (*CommInitRank)(void** comm, int world, arks_rccl_unique_id id, int rank);
+	int (*CommDestroy)(void* comm);
+	int (*CommAbort)(void* comm);                                          /* optional */
+	int (*GroupStart)(void);
+	int (*GroupEnd)(void);
+	int (*Send)(const void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
+	int (*Recv)(void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
+	int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, void* stream);
+	const char* (*GetErrorString)(int);
+} arks_rccl_api;
+/* api = NULL: librccl again.  The table must outlive every exchange made with it. */
+int arks_exchange_debug_set_rccl(const arks_rccl_api* api);
+
 #ifdef __cplusplus
 }
 #endif

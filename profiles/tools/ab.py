@@ -44,26 +44,32 @@ for name, path in variants:
     assert L.arks_index_build(C.byref(h), k, data.ctypes.data, offsets.ctypes.data, lens.ctypes.data, len(lens), 0, None) == 0
     codes = torch.zeros(total + 4, dtype=torch.int64, device=dev)
     nmask = torch.zeros(total + 4, dtype=torch.int32, device=dev)
-    assert L.arks_pack_reads_device(d_ascii.data_ptr(), batch["offsets"].data_ptr(), batch["lens"].data_ptr(), woff.data_ptr(), n, codes.data_ptr(), nmask.data_ptr(), None, 0, sp) == 0
+    rclass = torch.zeros(n, dtype=torch.uint8, device=dev)
+    assert L.arks_pack_reads_device(d_ascii.data_ptr(), batch["offsets"].data_ptr(), batch["lens"].data_ptr(), woff.data_ptr(), n, codes.data_ptr(), nmask.data_ptr(), rclass.data_ptr(), 0, sp) == 0
     out = torch.zeros(n, dtype=torch.int32, device=dev)
-    libs.append((name, L, h, codes, nmask, out))
+    ev = None
+    if os.environ.get("AB_EVAL"):          # the gate's eval array (0 / 1 / 3), as bench.py and the CLI map
+        L.arks_pair_gate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        ev = torch.zeros(n, dtype=torch.uint8, device=dev)
+        assert L.arks_pair_gate_device(batch["pair_ok"].data_ptr(), rclass.data_ptr(), n // 2, ev.data_ptr(), 0, sp) == 0
+    libs.append((name, L, h, codes, nmask, out, ev))
 torch.cuda.synchronize()
 d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
-def run(L, h, codes, nmask, out, name=""):
+def run(L, h, codes, nmask, out, ev=None, name=""):
     st = d_stats.data_ptr() if (os.environ.get("AB_STATS") or name.endswith("+stats")) else None
-    assert L.arks_map_reads_device(h, codes.data_ptr(), nmask.data_ptr(), woff.data_ptr(), batch["lens"].data_ptr(), None, n, j, out.data_ptr(), st, sp) == 0
-for (name, L, h, codes, nmask, out) in libs:
-    run(L, h, codes, nmask, out)
+    assert L.arks_map_reads_device(h, codes.data_ptr(), nmask.data_ptr(), woff.data_ptr(), batch["lens"].data_ptr(), ev.data_ptr() if ev is not None else None, n, j, out.data_ptr(), st, sp) == 0
+for (name, L, h, codes, nmask, out, ev) in libs:
+    run(L, h, codes, nmask, out, ev)
 torch.cuda.synchronize()
 ref = libs[0][5].clone()
 times = {name: [] for name, *_ in libs}
 for rnd in range(7):
-    for (name, L, h, codes, nmask, out) in libs:
+    for (name, L, h, codes, nmask, out, ev) in libs:
         a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-        a.record(); run(L, h, codes, nmask, out, name); b.record(); torch.cuda.synchronize()
+        a.record(); run(L, h, codes, nmask, out, ev, name); b.record(); torch.cuda.synchronize()
         times[name].append(a.elapsed_time(b))
 windows = int(torch.clamp(batch["lens"].to(torch.int64) - (k - 1), min=0).sum().item())
-for (name, L, h, codes, nmask, out) in libs:
+for (name, L, h, codes, nmask, out, ev) in libs:
     t = times[name]
     same = bool((out == ref).all().item())
     try:
