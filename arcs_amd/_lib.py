@@ -49,7 +49,7 @@ SYMBOLS = {
     "arks_index_build": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, C.POINTER(BuildStats)]),
     "arks_shard_of_ends": (_I, [_VP, _I64, _I, _VP]),
     "arks_index_build_shard": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I]),
-    "arks_index_build_seed_shard": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I]),
+    "arks_index_build_seed_shard": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I, C.POINTER(BuildStats)]),
     "arks_index_seed_ranks": (_I, [_VP]),
     "arks_seed_counts_device": (_I, [_VP, _VP, _VP, _I64, _VP, _VP]),
     "arks_seeds_fill_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
@@ -63,6 +63,7 @@ SYMBOLS = {
     "arks_exchange_last_stats": (_I, [_VP, _VP]),
     "arks_exchange_submit": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
     "arks_exchange_complete": (_I, [_VP]),
+    "arks_exchange_complete_group": (_I, [_VP, _I]),
     "arks_map_reads_exchanged_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
     "arks_index_free": (_I, [_VP]),
     "arks_index_k": (_I, [_VP]),

@@ -115,17 +115,19 @@ class ArksIndex:
         return cls(h, k, device, None)
 
     @classmethod
-    def build_seed_shard(cls, ends, k, rank, n_ranks, device=0):
+    def build_seed_shard(cls, ends, k, rank, n_ranks, device=0, want_stats=False):
         """arks_index_build_seed_shard: text, bitmaps and fallback table whole, the seed table's entries that
         rank `rank` of `n_ranks` owns (by a hash prefix of the m-mer), a replicated minimizer table for the
         general kernels; every rank is given the same list"""
         data, offsets, lens = _concat(ends)
         data = np.concatenate([data, np.zeros(1, np.uint8)])
         h = C.c_void_p()
+        st = BuildStats()
         rc = lib().arks_index_build_seed_shard(C.byref(h), k, data.ctypes.data, offsets.ctypes.data,
-                                               lens.ctypes.data, len(lens), rank, n_ranks, device)
+                                               lens.ctypes.data, len(lens), rank, n_ranks, device,
+                                               C.byref(st) if want_stats else None)
         check(rc, "arks_index_build_seed_shard")
-        return cls(h, k, device, None)
+        return cls(h, k, device, st.as_dict() if want_stats else None)
 
     @property
     def seed_ranks(self):
@@ -450,6 +452,12 @@ class SeedExchange:
     def complete(self):
         """arks_exchange_complete (COLLECTIVE): the oldest submitted batch is exchanged and mapped on its stream"""
         check(lib().arks_exchange_complete(self._h), "arks_exchange_complete")
+
+    @staticmethod
+    def complete_group(xs):
+        """arks_exchange_complete_group: every rank of a local group completed by this one thread"""
+        hs = (C.c_void_p * len(xs))(*[x._h for x in xs])
+        check(lib().arks_exchange_complete_group(hs, len(xs)), "arks_exchange_complete_group")
 
     def map_pairs(self, reads, j_index, pair_ok=None, barcode_id=None, imap=None, stored=None, stats=None):
         """chromiumRead's per-pair flow (Arcs.cpp:1264-1292) for this rank's read pairs: gate -> exchanged map ->

@@ -1067,11 +1067,12 @@ arks_index_build_seed_shard(
     int64_t n_ends,
     int rank,
     int n_ranks,
-    int device)
+    int device,
+    arks_build_stats* stats)
 {
 	if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
 		return ARKS_ERR_BAD_ARG;
-	const int rc = index_build_impl(out, k, h_bases, h_offsets, h_lens, n_ends, 0, 1, device, nullptr, rank, n_ranks);
+	const int rc = index_build_impl(out, k, h_bases, h_offsets, h_lens, n_ends, 0, 1, device, stats, rank, n_ranks);
 	if (rc == ARKS_OK && n_ranks > 1 && (*out)->kind != 2) { // k < 20: no seed table to shard
 		arks_index_free(*out);
 		*out = nullptr;

@@ -186,6 +186,7 @@ struct ExSet
 	bool used = false, pending = false;
 	int rc = ARKS_OK;
 	u64 cap = 0, slot_cap = 0;
+	std::vector<u64> all, sc, rcv, soff, roff; // the batch's counts: everybody's, and this rank's tables
 	// the batch
 	const u64* codes = nullptr;
 	const u32* nmask = nullptr;
@@ -585,27 +586,11 @@ arks_exchange_submit(
 	return s.rc;
 }
 
-int
-arks_exchange_complete(arks_exchange* x)
-{
-	if (!x)
-		return ARKS_ERR_BAD_ARG;
-	if (x->submitted == x->completed) {
-		g_last_error = "arks_exchange_complete: nothing was submitted";
-		return ARKS_ERR_BAD_ARG;
-	}
-	const int si = (int)(x->completed & 1);
-	ExSet& s = x->set[si];
-	x->completed++;
-	s.pending = false;
-	const arks_index* idx = x->idx;
-	const int W = x->world, me = x->rank;
-	hipStream_t st = s.st;
-	DeviceGuard guard(x->device);
-	const arks_rccl_api* rccl = x->comm ? rccl_api() : nullptr;
-	LocalGroup* g = x->group;
-	int rc = s.rc;
-	// errors are carried to the end of the collective part: a rank that fails must still meet the others
+} // extern "C"
+
+namespace {
+
+// errors are carried to the end of the collective part: a rank that fails must still meet the others
 #define EX_TRY(expr)                                                                               \
 	do {                                                                                           \
 		if (rc == ARKS_OK) {                                                                       \
@@ -614,7 +599,13 @@ arks_exchange_complete(arks_exchange* x)
 				rc = fail_hip(e_, #expr);                                                          \
 		}                                                                                          \
 	} while (0)
-	// ---- 1. my counts (they left the device with the submit; a batch that did not fit its regions is run again) ----
+
+// ---- 1. my counts (they left the device with the submit; a batch that did not fit its regions is run again) ----
+int
+ex_counts(arks_exchange* x, ExSet& s)
+{
+	const int W = x->world;
+	int rc = s.rc;
 	EX_TRY(hipEventSynchronize(s.counted));
 	for (int tries = 0; rc == ARKS_OK && s.h_ctl->overflow; ++tries) {
 		u64 mx = 0;
@@ -634,9 +625,182 @@ arks_exchange_complete(arks_exchange* x)
 		rc = exchange_bucket(x, s);
 		EX_TRY(hipEventSynchronize(s.counted));
 	}
+	return rc;
+}
+
+// what I ask of whom and who asks what of me, from all[p * W + o] = seeds rank p asks of owner o
+void
+ex_tables(arks_exchange* x, ExSet& s)
+{
+	const int W = x->world, me = x->rank;
+	s.sc.assign((size_t)W, 0), s.rcv.assign((size_t)W, 0), s.soff.assign((size_t)W, 0), s.roff.assign((size_t)W + 1, 0);
+	u64 S = 0;
+	for (int p = 0; p < W; ++p) {
+		s.sc[(size_t)p] = s.all[(size_t)me * W + p];  // what I ask of p
+		s.rcv[(size_t)p] = s.all[(size_t)p * W + me]; // what p asks of me
+		s.soff[(size_t)p] = (u64)p * s.cap;           // ... lies in region p of my send buffer
+		s.roff[(size_t)p + 1] = s.roff[(size_t)p] + s.rcv[(size_t)p];
+		S += s.sc[(size_t)p];
+	}
+	x->last.seeds = s.h_ctl->seeds, x->last.sent = S - s.sc[(size_t)me], x->last.received = s.roff[(size_t)W] - s.rcv[(size_t)me];
+	x->last.reruns = x->reruns;
+}
+
+// ---- 6. the home finishes: map_reads_s_kernel<REMOTE> + the general kernels -------------------------------------
+int
+ex_map(arks_exchange* x, ExSet& s)
+{
+	const arks_index* idx = x->idx;
+	int rc = ARKS_OK;
+	if (s.n_reads > 0) {
+		arks_index::QueueSet qs;
+		rc = ensure_queue(idx, s.st, s.n_reads, &qs);
+		if (rc == ARKS_OK)
+			EX_TRY(launch_map_reads_seeded(
+			    idx->kw, s.codes, s.nmask, s.word_off, s.lens, s.eval, s.n_reads, s.j_index, idx->geom, idx->bx, idx->bxg, nullptr,
+			    s.ans_back.as<u64>(), s.out, reinterpret_cast<u64*>(s.stats), qs.queue, qs.queue_count, idx->n_cu, s.st,
+			    s.slot.as<u32>(), s.chunk_off.as<u32>()));
+	}
+	return rc;
+}
+
+// ---- the direct transport, stage by stage (between the stages every rank of the group must have done the one before:
+//      a barrier when each rank has a thread of its own, a loop over the ranks when one thread drives them all) ------
+void
+direct_show(arks_exchange* x, int si, int rc) // after ex_counts
+{
+	ExSet& s = x->set[si];
+	LocalGroup::Shown& mine = x->group->shown[si][(size_t)x->rank];
+	mine.status = rc;
+	mine.counts = s.h_ctl->fill;
+	mine.cap = s.cap;
+	mine.send = s.send.as<u64>();
+	mine.ans_back = s.ans_back.as<u64>();
+	mine.probed = s.probed;
+}
+
+// everybody's counts; I answer what everybody asks of me, reading the askers' send buffers (complete: every rank
+// waited for its counts before it showed them) and writing into their answer buffers (free: their last map kernel on
+// this set ran before their bucket kernel, in stream order)
+int
+direct_probe(arks_exchange* x, int si)
+{
+	ExSet& s = x->set[si];
+	LocalGroup* g = x->group;
+	const int W = x->world, me = x->rank;
+	int rc = ARKS_OK;
+	s.all.assign((size_t)W * (size_t)W, 0);
+	for (int p = 0; p < W; ++p) {
+		const LocalGroup::Shown& sh = g->shown[si][(size_t)p];
+		if (sh.status != ARKS_OK) {
+			// every rank reads the same flags: they all leave here
+			if (p != me || g_last_error.empty())
+				g_last_error = "another rank of the local group failed in this batch";
+			return x->group->shown[si][(size_t)me].status != ARKS_OK ? x->group->shown[si][(size_t)me].status : ARKS_ERR_HIP;
+		}
+		for (int o = 0; o < W; ++o)
+			s.all[(size_t)p * W + o] = sh.counts[o];
+	}
+	ex_tables(x, s);
+	DeviceGuard guard(x->device);
+	arks::ProbeSegs sg{};
+	u64 run = 0;
+	for (int p = 0; p < W; ++p) {
+		if (!s.rcv[(size_t)p])
+			continue;
+		const LocalGroup::Shown& sh = g->shown[si][(size_t)p];
+		const int i = sg.n_segs++;
+		sg.src[i] = sh.send + (u64)me * sh.cap;
+		sg.dst[i] = sh.ans_back + 2 * (u64)me * sh.cap;
+		run += s.rcv[(size_t)p];
+		sg.end[i] = run;
+	}
+	EX_TRY(arks::launch_seeds_probe_segs(x->idx->bx.m, x->idx->bx, sg, s.st));
+	EX_TRY(hipEventRecord(s.probed, s.st));
+	g->shown[si][(size_t)me].status2 = rc;
+	return rc;
+}
+
+// every owner's event is recorded (a wait for an event that was never recorded is no wait): the answers are home when
+// the stream has passed them; then the map kernels.  (The askers' buffers are read and written by other ranks' kernels
+// until those events: a rank reuses a set only behind its own map kernel of that set, which waits for all of them.)
+int
+direct_finish(arks_exchange* x, int si, int rc)
+{
+	ExSet& s = x->set[si];
+	LocalGroup* g = x->group;
+	const int W = x->world, me = x->rank;
+	DeviceGuard guard(x->device);
+	for (int p = 0; p < W; ++p) {
+		const LocalGroup::Shown& sh = g->shown[si][(size_t)p];
+		if (sh.status2 != ARKS_OK && rc == ARKS_OK) {
+			g_last_error = "another rank of the local group failed in this batch";
+			rc = ARKS_ERR_HIP;
+		}
+		if (p != me && rc == ARKS_OK && s.sc[(size_t)p])
+			EX_TRY(hipStreamWaitEvent(s.st, sh.probed, 0)); // p's answers to me
+	}
+	if (rc == ARKS_OK)
+		rc = ex_map(x, s);
+	return rc;
+}
+
+// the oldest submitted batch of x, taken out of the queue
+int
+ex_take(arks_exchange* x, int* si)
+{
+	if (!x)
+		return ARKS_ERR_BAD_ARG;
+	if (x->submitted == x->completed) {
+		g_last_error = "arks_exchange_complete: nothing was submitted";
+		return ARKS_ERR_BAD_ARG;
+	}
+	*si = (int)(x->completed & 1);
+	x->completed++;
+	x->set[*si].pending = false;
+	return ARKS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int
+arks_exchange_complete(arks_exchange* x)
+{
+	int si = 0;
+	{
+		const int trc = ex_take(x, &si);
+		if (trc != ARKS_OK)
+			return trc;
+	}
+	ExSet& s = x->set[si];
+	const arks_index* idx = x->idx;
+	const int W = x->world, me = x->rank;
+	hipStream_t st = s.st;
+	DeviceGuard guard(x->device);
+	const arks_rccl_api* rccl = x->comm ? rccl_api() : nullptr;
+	LocalGroup* g = x->group;
+	int rc = ex_counts(x, s);
+	if (g) {
+		// ---- direct transport, a thread per rank: the stages with barriers between them ------------------------------
+		direct_show(x, si, rc);
+		if (!g->barrier())
+			return exchange_broken();
+		rc = direct_probe(x, si);
+		if (!g->barrier()) // (also keeps a fast rank's next batch from rewriting what a slow one still reads)
+			return exchange_broken();
+		bool agreed_failure = false;
+		for (int p = 0; p < W; ++p)
+			agreed_failure = agreed_failure || g->shown[si][(size_t)p].status != ARKS_OK;
+		if (!agreed_failure)
+			rc = direct_finish(x, si, rc);
+		if (rc != ARKS_OK)
+			g->abort(); // this rank's caller will not call again: the others must not wait for it
+		return rc;
+	}
 	// ---- 2. everybody's counts and status: all[p * W + o] = seeds rank p asks of owner o -----------------------------
-	std::vector<u64> all((size_t)W * (size_t)W, 0), cap_of((size_t)W, 0);
-	int status = rc;
+	s.all.assign((size_t)W * (size_t)W, 0);
 	if (rccl && W > 1) {
 		// (1 + W) numbers per rank: status, counts.  Every rank holds the same matrix afterwards and decides alike.
 		u64* hg = s.h_gather;
@@ -661,6 +825,7 @@ arks_exchange_complete(arks_exchange* x)
 			}
 			return rc;
 		}
+		int status = rc;
 		for (int p = 0; p < W; ++p) {
 			const u64* row = hg + (size_t)(1 + W) * (size_t)(1 + p);
 			if (row[0] && status == ARKS_OK) {
@@ -668,58 +833,18 @@ arks_exchange_complete(arks_exchange* x)
 				status = ARKS_ERR_HIP;
 			}
 			for (int o = 0; o < W; ++o)
-				all[(size_t)p * W + o] = row[1 + o];
+				s.all[(size_t)p * W + o] = row[1 + o];
 		}
 		if (status != ARKS_OK)
 			return status; // (every rank sees the same flags: all of them leave here, nobody waits)
-	} else if (g) {
-		LocalGroup::Shown& mine = g->shown[si][(size_t)me];
-		mine.status = rc;
-		mine.counts = s.h_ctl->fill;
-		mine.cap = s.cap;
-		mine.send = s.send.as<u64>();
-		mine.ans_back = s.ans_back.as<u64>();
-		mine.probed = s.probed;
-		if (!g->barrier())
-			return exchange_broken();
-		for (int p = 0; p < W; ++p) {
-			const LocalGroup::Shown& sh = g->shown[si][(size_t)p];
-			if (sh.status != ARKS_OK && status == ARKS_OK) {
-				g_last_error = "another rank of the local group failed in this batch";
-				status = ARKS_ERR_HIP;
-			}
-			cap_of[(size_t)p] = sh.cap;
-			for (int o = 0; o < W; ++o)
-				all[(size_t)p * W + o] = sh.status == ARKS_OK ? sh.counts[o] : 0;
-		}
-		if (status != ARKS_OK) {
-			// every rank read the same flags behind the barrier; they all leave (a second barrier keeps a fast rank's
-			// next batch from rewriting what a slow one still reads)
-			(void)g->barrier();
-			g->abort();
-			return status;
-		}
 	} else {
 		if (rc != ARKS_OK)
 			return rc;
-		all[0] = s.h_ctl->fill[0];
+		s.all[0] = s.h_ctl->fill[0];
 	}
 	// from here on rc == ARKS_OK on every rank
-	std::vector<u64> sc((size_t)W), rcv((size_t)W), soff((size_t)W), roff((size_t)W + 1);
-	roff[0] = 0;
-	for (int p = 0; p < W; ++p) {
-		sc[(size_t)p] = all[(size_t)me * W + p];  // what I ask of p
-		rcv[(size_t)p] = all[(size_t)p * W + me]; // what p asks of me
-		soff[(size_t)p] = (u64)p * s.cap;         // ... lies in region p of my send buffer
-		roff[(size_t)p + 1] = roff[(size_t)p] + rcv[(size_t)p];
-	}
-	{
-		u64 S = 0;
-		for (int p = 0; p < W; ++p)
-			S += sc[(size_t)p];
-		x->last.seeds = s.h_ctl->seeds, x->last.sent = S - sc[(size_t)me], x->last.received = roff[(size_t)W] - rcv[(size_t)me];
-		x->last.reruns = x->reruns;
-	}
+	ex_tables(x, s);
+	const std::vector<u64>&sc = s.sc, &rcv = s.rcv, &soff = s.soff, &roff = s.roff;
 	arks::ProbeSegs sg{};
 	if (rccl && W > 1) {
 		// ---- 3. seeds to their owners; 4. the owner's answers; 5. answers back -------------------------------------
@@ -762,37 +887,6 @@ arks_exchange_complete(arks_exchange* x)
 		}
 		if (rc != ARKS_OK)
 			return rc;
-	} else if (g) {
-		// ---- 3-5. direct: I answer what everybody asks of me, reading the askers' send buffers (complete: every rank
-		// waited for its counts before the barrier) and writing into their answer buffers (free: their last map kernel
-		// on this set ran before their bucket kernel, in stream order) ------------------------------------------------
-		u64 run = 0;
-		for (int p = 0; p < W; ++p) {
-			if (!rcv[(size_t)p])
-				continue;
-			const LocalGroup::Shown& sh = g->shown[si][(size_t)p];
-			const int i = sg.n_segs++;
-			sg.src[i] = sh.send + (u64)me * sh.cap;
-			sg.dst[i] = sh.ans_back + 2 * (u64)me * sh.cap;
-			run += rcv[(size_t)p];
-			sg.end[i] = run;
-		}
-		EX_TRY(arks::launch_seeds_probe_segs(idx->bx.m, idx->bx, sg, st));
-		EX_TRY(hipEventRecord(s.probed, st));
-		g->shown[si][(size_t)me].status2 = rc;
-		if (!g->barrier()) // every owner's event is recorded (a wait for an event that was never recorded is no wait)
-			return exchange_broken();
-		for (int p = 0; p < W; ++p) {
-			const LocalGroup::Shown& sh = g->shown[si][(size_t)p];
-			if (sh.status2 != ARKS_OK && rc == ARKS_OK) {
-				g_last_error = "another rank of the local group failed in this batch";
-				rc = ARKS_ERR_HIP;
-			}
-			if (p != me && sc[(size_t)p])
-				EX_TRY(hipStreamWaitEvent(st, sh.probed, 0)); // p's answers to me
-		}
-		// (the askers' buffers are read and written by other ranks' kernels until those events: a rank reuses a set only
-		// behind its own map kernel of that set, which waits for all of them)
 	} else {
 		sg.n_segs = sc[0] ? 1 : 0;
 		sg.src[0] = s.send.as<u64>();
@@ -800,21 +894,47 @@ arks_exchange_complete(arks_exchange* x)
 		sg.end[0] = sc[0];
 		EX_TRY(arks::launch_seeds_probe_segs(idx->bx.m, idx->bx, sg, st));
 	}
-	// ---- 6. the home finishes -------------------------------------------------------------------------------------
-	if (rc == ARKS_OK && s.n_reads > 0) {
-		arks_index::QueueSet qs;
-		rc = ensure_queue(idx, st, s.n_reads, &qs);
-		if (rc == ARKS_OK)
-			EX_TRY(launch_map_reads_seeded(
-			    idx->kw, s.codes, s.nmask, s.word_off, s.lens, s.eval, s.n_reads, s.j_index, idx->geom, idx->bx, idx->bxg, nullptr,
-			    s.ans_back.as<u64>(), s.out, reinterpret_cast<u64*>(s.stats), qs.queue, qs.queue_count, idx->n_cu, st,
-			    s.slot.as<u32>(), s.chunk_off.as<u32>()));
-	}
-#undef EX_TRY
-	if (rc != ARKS_OK && g)
-		g->abort(); // this rank's caller will not call again: the others must not wait for it
+	if (rc == ARKS_OK)
+		rc = ex_map(x, s);
 	return rc;
 }
+
+int
+arks_exchange_complete_group(arks_exchange* const* xs, int world)
+{
+	if (!xs || world < 1 || world > 64 || !xs[0] || !xs[0]->group || xs[0]->group->world != world)
+		return ARKS_ERR_BAD_ARG;
+	LocalGroup* g = xs[0]->group;
+	for (int r = 0; r < world; ++r)
+		if (!xs[r] || xs[r]->group != g || xs[r]->rank != r || xs[r]->submitted == xs[r]->completed) {
+			g_last_error = "arks_exchange_complete_group: the ranks of one local group, each with a submitted batch";
+			return ARKS_ERR_BAD_ARG;
+		}
+	{
+		std::lock_guard<std::mutex> lk(g->m);
+		if (g->aborted)
+			return exchange_broken();
+	}
+	std::vector<int> si((size_t)world, 0), rcs((size_t)world, ARKS_OK);
+	int rc = ARKS_OK;
+	for (int r = 0; r < world; ++r) {
+		(void)ex_take(xs[r], &si[(size_t)r]);
+		DeviceGuard guard(xs[r]->device);
+		direct_show(xs[r], si[(size_t)r], ex_counts(xs[r], xs[r]->set[si[(size_t)r]]));
+	}
+	for (int r = 0; r < world; ++r) {
+		rcs[(size_t)r] = direct_probe(xs[r], si[(size_t)r]);
+		rc = rc == ARKS_OK ? rcs[(size_t)r] : rc;
+	}
+	for (int r = 0; r < world && rc == ARKS_OK; ++r) {
+		rcs[(size_t)r] = direct_finish(xs[r], si[(size_t)r], rcs[(size_t)r]);
+		rc = rc == ARKS_OK ? rcs[(size_t)r] : rc;
+	}
+	if (rc != ARKS_OK)
+		g->abort();
+	return rc;
+}
+#undef EX_TRY
 
 int
 arks_map_reads_exchanged_device(

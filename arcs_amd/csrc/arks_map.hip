@@ -2163,8 +2163,14 @@ map_reads_s_kernel(
 								ent[0] = a[0], ent[1] = a[1];
 								cnt = seed_answer_count(ent[0], ent[1]);
 							}
-						} else
+						} else {
+#ifndef ARKS_CAL_NO_PROBE
 							cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, ent);
+#endif
+							// (ARKS_CAL_NO_PROBE: a calibration build, results wrong by design -- no probe, hence no diagonal and
+							// no text record: the kernel fetches its read stream and nothing else, a byte count that is known
+							// exactly; profiles/tools/fetch_calib.py holds rocprofv3's FETCH_SIZE against it)
+						}
 					}
 					if (kTwoRound && rd == 0) {
 						if (go && cnt)

@@ -45,10 +45,14 @@ mask_below(u64 m)
 // counting, so the host knows what the batch needs and runs it again with larger regions (first batch of a shape).
 constexpr int kMaxOwners = 64;
 constexpr int kBkChunk = 56;                  // = sChunk of map_reads_s_kernel (arks_map.hip; checked at its launch)
-constexpr int kBkWaves = 16;
+constexpr int kBkWaves = 8;
 constexpr int kBkChunksPerWave = 2;
-constexpr int kBkChunks = kBkWaves * kBkChunksPerWave; // 32 chunks = 1792 reads per block: ~28 k blocks per 50 M reads,
-constexpr int kBkReads = kBkChunks * kBkChunk;         // i.e. ~0.3 ms of same-address atomics per counter, in parallel
+constexpr int kBkChunks = kBkWaves * kBkChunksPerWave; // 16 chunks = 896 reads per block: ~56 k blocks per 50 M reads, i.e.
+constexpr int kBkReads = kBkChunks * kBkChunk;         // ~0.7 ms of same-address atomics per counter (in parallel); 512
+                                                       // threads at <= 64 VGPRs: four blocks per CU, so that the three
+                                                       // dependent round trips of a block (read, reserve, write) overlap
+                                                       // other blocks' (1024 threads at 83 VGPRs, one block per CU: 6.9 ms
+                                                       // per 25 M pairs instead of ~1, profiles/r04e_sharded1_kernel_stats.csv)
 
 template <int MM>
 __device__ __forceinline__ int
@@ -122,14 +126,26 @@ bk_wave_incl_scan(int v)
 	return v;
 }
 
+// seed gi of read r for the bucket kernel: canonical m-mer | owner << 56, ~0 = it holds an invalid base (not sent)
 template <int MM>
-__global__ void __launch_bounds__(kBkWaves * 64)
+__device__ __forceinline__ u64
+bucket_seed(const u64* __restrict__ codes, const u32* __restrict__ nmask, u64 wb, int nwin, int w, int gi, u32 n_owners)
+{
+	u64 c;
+	u32 o;
+	bucket_one_seed<MM>(codes, nmask, wb, nwin, w, gi, n_owners, c, o);
+	return o == ~0u ? ~0ull : (c | ((u64)o << 56));
+}
+
+template <int MM>
+__global__ void __launch_bounds__(kBkWaves * 64) __attribute__((amdgpu_waves_per_eu(8)))
 seed_bucket_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ nmask, const u64* __restrict__ word_off,
     const u32* __restrict__ lens, const uint8_t* __restrict__ eval, long n_reads, int k, int w, u32 n_owners, u64 cap,
     u64 slot_cap, SeedBucketCtl* __restrict__ ctl, u32* __restrict__ chunk_off, u32* __restrict__ slot,
     u64* __restrict__ send)
 {
+	static_assert(2 * MM <= 56, "the owner rides in the top byte of the m-mer");
 	__shared__ u32 cnt[kMaxOwners];
 	__shared__ u32 base[kMaxOwners];
 	__shared__ u32 chunk_cnt[kBkChunks];
@@ -141,30 +157,32 @@ seed_bucket_kernel(
 	if (threadIdx.x == 0)
 		bad = 0;
 	__syncthreads();
-	u64 cm[kBkChunksPerWave][kBucketInline];
-	u32 own[kBkChunksPerWave][kBucketInline];
-	int G[kBkChunksPerWave], pre[kBkChunksPerWave];
+	constexpr int kInline = 3; // seeds of a read kept in registers (a 10x pair has 2 + 3); others are made again
+	u64 sd[kBkChunksPerWave][kInline];
+	u64 wb[kBkChunksPerWave];
+	int G[kBkChunksPerWave], pre[kBkChunksPerWave], nwin[kBkChunksPerWave];
 #pragma unroll
 	for (int it = 0; it < kBkChunksPerWave; ++it) {
 		const int ci = wave * kBkChunksPerWave + it;
 		const long r = ((long)blockIdx.x * kBkChunks + ci) * kBkChunk + lane;
-		G[it] = lane < kBkChunk
-		            ? bucket_read_seeds<MM>(codes, nmask, word_off, lens, eval, r, n_reads, k, w, n_owners, cm[it], own[it], kBucketInline)
-		            : 0;
+		nwin[it] = 0, wb[it] = 0;
+		if (lane < kBkChunk && r < n_reads) {
+			nwin[it] = (eval && !eval[r]) ? 0 : (int)lens[r] - k + 1;
+			wb[it] = word_off[r];
+		}
+		G[it] = nwin[it] > 0 ? (nwin[it] + w - 1) / w : 0;
 		const int incl = bk_wave_incl_scan(G[it]);
 		pre[it] = incl - G[it];
 		if (lane == 63)
 			chunk_cnt[ci] = (u32)incl;
+#pragma unroll
+		for (int gi = 0; gi < kInline; ++gi)
+			sd[it][gi] = gi < G[it] ? bucket_seed<MM>(codes, nmask, wb[it], nwin[it], w, gi, n_owners) : ~0ull;
 		for (int gi = 0; gi < G[it]; ++gi) {
-			u32 o;
-			if (gi < kBucketInline)
-				o = own[it][gi];
-			else {
-				u64 c;
-				bucket_one_seed<MM>(codes, nmask, word_off[r], (int)lens[r] - k + 1, w, gi, n_owners, c, o);
-			}
-			if (o != ~0u)
-				atomicAdd(&cnt[o], 1u);
+			const u64 v = gi < kInline ? (gi == 0 ? sd[it][0] : gi == 1 ? sd[it][1] : sd[it][2])
+			                           : bucket_seed<MM>(codes, nmask, wb[it], nwin[it], w, gi, n_owners);
+			if (v != ~0ull)
+				atomicAdd(&cnt[(u32)(v >> 56)], 1u);
 		}
 	}
 	__syncthreads();
@@ -207,19 +225,15 @@ seed_bucket_kernel(
 #pragma unroll
 	for (int it = 0; it < kBkChunksPerWave; ++it) {
 		const int ci = wave * kBkChunksPerWave + it;
-		const long r = ((long)blockIdx.x * kBkChunks + ci) * kBkChunk + lane;
 		const u32 first = chunk_base[ci] + (u32)pre[it];
 		for (int gi = 0; gi < G[it]; ++gi) {
-			u64 c;
-			u32 o;
-			if (gi < kBucketInline)
-				c = cm[it][gi], o = own[it][gi];
-			else
-				bucket_one_seed<MM>(codes, nmask, word_off[r], (int)lens[r] - k + 1, w, gi, n_owners, c, o);
+			const u64 v = gi < kInline ? (gi == 0 ? sd[it][0] : gi == 1 ? sd[it][1] : sd[it][2])
+			                           : bucket_seed<MM>(codes, nmask, wb[it], nwin[it], w, gi, n_owners);
 			u32 sl = ~0u;
-			if (o != ~0u) {
+			if (v != ~0ull) {
+				const u32 o = (u32)(v >> 56);
 				sl = (u32)((u64)o * cap) + base[o] + atomicAdd(&cnt[o], 1u);
-				send[sl] = c;
+				send[sl] = v & ((1ull << 56) - 1ull);
 			}
 			slot[first + gi] = sl;
 		}

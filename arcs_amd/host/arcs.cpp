@@ -59,7 +59,11 @@ struct Params
 	long batch_pairs = 262144; // --batch-pairs (this build only): read pairs per GPU batch
 	int index_shards = 1;      // --index-shards (this build only): the contig k-mer index in N parts
 	int device = 0;             // --device (this build only)
-	int ranks = 1;              // --ranks (this build only): one process per GPU, read files dealt to the ranks
+	int ranks = 1;              // --ranks (this build only): N GPU ranks -- processes the read files are dealt to, and GPU
+	                            // lanes inside a process when there are fewer files than ranks
+	int index_sharded = 0;      // --index-sharded[=N] (this build only): the seed table hash-sharded over N ranks of this
+	                            // process (arks_exchange, BASELINE configs[3]); 0 = replicas
+	int lanes = 1;              // GPU lanes of THIS process (set by run_arks): device + 0 .. lanes - 1
 };
 
 Params params;
@@ -81,7 +85,8 @@ enum
 	OPT_BATCH_PAIRS,
 	OPT_DEVICE,
 	OPT_INDEX_SHARDS,
-	OPT_RANKS
+	OPT_RANKS,
+	OPT_INDEX_SHARDED
 };
 
 const char shortopts[] = "f:a:B:s:c:Dl:z:b:g:m:d:e:r:vt:u:j:k:P";
@@ -123,6 +128,7 @@ const struct option longopts[] = {
 	{ "device", required_argument, NULL, OPT_DEVICE },
 	{ "index-shards", required_argument, NULL, OPT_INDEX_SHARDS },
 	{ "ranks", required_argument, NULL, OPT_RANKS },
+	{ "index-sharded", optional_argument, NULL, OPT_INDEX_SHARDED },
 	{ NULL, 0, NULL, 0 }
 };
 
@@ -161,8 +167,11 @@ const char USAGE[] =
             "       --samples_tsv=FILE  write intra-contig distance/barcode samples to FILE\n"
             "       --batch-pairs=N   read pairs per GPU batch [262144]\n"
             "       --index-shards=N  build and map the contig k-mer index in N parts (very large drafts) [1]\n"
-            "       --ranks=N         N processes, one per GPU (device, device + 1, ...): the read files are dealt to\n"
-            "                         them, rank 0 merges the results; outputs as with one process [1]\n"
+            "       --ranks=N         N GPU ranks (device, device + 1, ...), an index replica each: with N or more read\n"
+            "                         files N processes the files are dealt to; with fewer files (one .fq.gz) the\n"
+            "                         batches of a file are dealt to the GPUs of its process; outputs as with one [1]\n"
+            "       --index-sharded[=N]  the index's seed table hash-sharded over N GPUs (default: --ranks, else all)\n"
+            "                         instead of replicated: a read's seeds are answered by the GPUs that own them\n"
             "       --device=N        GPU ordinal [0]\n";
 
 void
@@ -387,32 +396,65 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 		          << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_read0).count() << " ms\n";
 	if (params.verbose)
 		std::cerr << "Number of contigs:" << count << "\nSize of Contig Array:" << count * 2 + 1 << std::endl;
+	// lane-major: the indexes of lane 0 (every k; with --index-shards every part of a k together), then lane 1's ...
+	// A lane is a GPU of this process (--ranks with fewer files than ranks, --index-sharded).  Replica lanes that share a
+	// device share the index (tests on a one-GPU box); the build counters come from the first build of a k.
 	std::vector<arks_index*> idxs;
 	const int n_shards = std::max(1, params.index_shards);
+	const int n_lanes = std::max(1, params.lanes);
+	int ndev = 1;
+	(void)hipGetDeviceCount(&ndev);
+	std::vector<std::vector<arks_index*>> by_lane((size_t)n_lanes);
 	for (const int k : params.k_list) {
-		arks_index* idx = nullptr;
 		arks_build_stats st;
 		std::memset(&st, 0, sizeof st);
-		if (n_shards > 1) {
-			// --index-shards: N indexes of 1/N of the contigs each (a draft beyond one index's 2^32 text
-			// positions, or whose build scratch does not fit); the reads are mapped against each in turn
-			for (int s = 0; s < n_shards; ++s) {
-				const int rc = arks_index_build_shard(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(),
-				                                      s, n_shards, params.device);
+		for (int lane = 0; lane < n_lanes; ++lane) {
+			const int device = (params.device + lane) % std::max(1, ndev);
+			arks_index* idx = nullptr;
+			if (params.index_sharded > 0) {
+				// --index-sharded: lane = rank `lane` of the seed table's hash shards; text, bitmaps, fallback table whole
+				const int rc = arks_index_build_seed_shard(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(), lane,
+				                                           n_lanes, device, params.verbose && lane == 0 ? &st : nullptr);
 				if (rc != ARKS_OK)
-					die_arks(rc, "building a shard of the contig k-mer index");
-				idxs.push_back(idx);
+					die_arks(rc, "building a shard of the seed table");
+				by_lane[(size_t)lane].push_back(idx);
+				continue;
 			}
+			int same = -1; // an earlier lane on the same device: share its replica
+			for (int l2 = 0; l2 < lane && same < 0; ++l2)
+				if ((params.device + l2) % std::max(1, ndev) == device)
+					same = l2;
+			if (same >= 0) {
+				const size_t per_k = (size_t)n_shards, at = by_lane[(size_t)lane].size();
+				for (size_t x = 0; x < per_k; ++x)
+					by_lane[(size_t)lane].push_back(by_lane[(size_t)same][at + x]);
+				continue;
+			}
+			if (n_shards > 1) {
+				// --index-shards: N indexes of 1/N of the contigs each (a draft beyond one index's 2^32 text
+				// positions, or whose build scratch does not fit); the reads are mapped against each in turn
+				for (int sh = 0; sh < n_shards; ++sh) {
+					const int rc = arks_index_build_shard(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(),
+					                                      sh, n_shards, device);
+					if (rc != ARKS_OK)
+						die_arks(rc, "building a shard of the contig k-mer index");
+					by_lane[(size_t)lane].push_back(idx);
+				}
+				continue;
+			}
+			const int rc = arks_index_build(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(), device,
+			                                params.verbose && lane == 0 ? &st : nullptr);
+			if (rc != ARKS_OK)
+				die_arks(rc, "building the contig k-mer index");
+			by_lane[(size_t)lane].push_back(idx);
+		}
+		if (n_shards > 1) {
 			if (params.verbose)
 				appendf(log, "%s %u\n%s %u\n%s %u\n(index in %d shards: the k-mer counters are not collected)\n",
 				        "Total number of contigs in draft genome: ", (unsigned)total, "Total valid contigs: ", (unsigned)valid,
 				        "Total skipped contigs: ", (unsigned)skipped, n_shards);
 			continue;
 		}
-		const int rc = arks_index_build(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(), params.device,
-		                                params.verbose ? &st : nullptr);
-		if (rc != ARKS_OK)
-			die_arks(rc, "building the contig k-mer index");
 		if (params.verbose) {
 			if (params.k_list.size() > 1)
 				appendf(log, "k = %d:\n", k);
@@ -428,8 +470,10 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 			        "Number Times Kmers Removed (since duplicate in different contig): ", (unsigned)st.removed_dup,
 			        "Number of unique kmers (only one contig): ", (unsigned)st.unique);
 		}
-		idxs.push_back(idx);
 	}
+	for (const auto& v : by_lane)
+		idxs.insert(idxs.end(), v.begin(), v.end());
+	(void)hipSetDevice(params.device % std::max(1, ndev));
 	return idxs;
 }
 
@@ -441,72 +485,120 @@ struct DeviceSet
 	DevArray<uint8_t> d_ascii; // device-pack mode: the reads' bases as they are
 	DevArray<uint32_t> d_nmask, d_len, d_bid;
 	DevArray<uint8_t> d_class, d_ok, d_eval;
-	DevArray<int32_t> d_conreci;
+	std::vector<DevArray<int32_t>> d_conreci; // per k (a sharded exchange keeps every k's result until its round completes)
 	DevArray<uint64_t> d_votes, d_votes2; // --index-shards only
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;
 	PackedBatch* inflight = nullptr;
 };
 
-// The GPU end of the ingest pipeline: two device buffer sets on two streams, so that the copies of
-// one batch overlap the kernels of the previous one.  Counters are kept per input file.
-struct Mapper
+// The GPU end of the ingest pipeline.  A LANE is one GPU of this process (--ranks with fewer files than ranks,
+// --index-sharded: device, device + 1, ...; several lanes may share a device -- tests on a one-GPU box): its
+// indexes (a replica per k, or its shard of every k's seed table), an IndexMap accumulator per k, per-file
+// counters, and two device buffer sets on two streams, so that the copies of one batch overlap the kernels of the
+// previous one.  Replicas: batch t goes to lane t mod L.  Sharded seed table (arks_exchange): L batches make a
+// ROUND, one per lane; a round is submitted (upload, gate, seeds bucketed by owner) and the round before it completed
+// (arks_exchange_complete_group: every lane's seeds answered by their owners, map kernels) -- two rounds in flight.
+struct Lane
 {
+	int device = 0;
 	std::vector<arks_index*> idxs;  // n_k x n_shards, the shards of one k together
 	std::vector<arks_imap*> imaps;  // one per k
-	size_t n_shards, n_k;
+	std::vector<arks_exchange*> xs; // one per k (sharded seed table)
 	DeviceSet sets[2];
-	size_t turn = 0;
 	uint64_t* d_skipped = nullptr;     // [n_files]: skipped_invalidreadpair, counted on the device in device-pack mode
 	uint64_t* d_stored = nullptr;      // [n_k][n_files]
 	arks_map_stats* d_stats = nullptr; // [n_k][n_files]
-	size_t n_files;
+};
 
+struct Mapper
+{
+	std::vector<Lane> lanes;
+	size_t n_shards, n_k;
+	size_t turn = 0;
+	size_t n_files;
+	const bool sharded;
+	std::vector<PackedBatch*> round; // sharded: the batches of the round being collected
+	size_t rounds_submitted = 0, rounds_completed = 0;
 	std::vector<size_t> global_file; // position of this rank's files in the command line (pair numbering)
 
+	// idxs: lane-major, n_k x n_shards per lane
 	Mapper(const std::vector<arks_index*>& is, int64_t imap_capacity, size_t nfiles, const std::vector<size_t>& mine)
-	  : idxs(is)
+	  : lanes((size_t)std::max(1, params.lanes))
 	  , n_shards((size_t)std::max(1, params.index_shards))
-	  , n_k(is.size() / (size_t)std::max(1, params.index_shards))
+	  , n_k(params.k_list.size())
 	  , n_files(nfiles)
+	  , sharded(params.index_sharded > 0)
 	  , global_file(mine)
 	{
-		for (size_t ki = 0; ki < n_k; ++ki) {
-			arks_imap* im = nullptr;
-			const int rc = arks_imap_create(&im, imap_capacity, params.device);
-			if (rc != ARKS_OK)
-				die_arks(rc, "creating the IndexMap accumulator");
-			imaps.push_back(im);
-		}
-		const size_t nc = n_k * nfiles;
-		if (hipMalloc((void**)&d_stored, nc * sizeof(uint64_t)) != hipSuccess ||
-		    hipMalloc((void**)&d_skipped, nfiles * sizeof(uint64_t)) != hipSuccess ||
-		    hipMalloc((void**)&d_stats, nc * sizeof(arks_map_stats)) != hipSuccess) {
-			std::cerr << PROGRAM ": out of device memory\n";
-			exit(EXIT_FAILURE);
-		}
-		(void)hipMemset(d_stored, 0, nc * sizeof(uint64_t));
-		(void)hipMemset(d_skipped, 0, nfiles * sizeof(uint64_t));
-		(void)hipMemset(d_stats, 0, nc * sizeof(arks_map_stats));
-		for (auto& s : sets)
-			if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-			    hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
-				std::cerr << PROGRAM ": cannot create a HIP stream\n";
+		int ndev = 1;
+		(void)hipGetDeviceCount(&ndev);
+		const size_t per_lane = n_k * n_shards;
+		for (size_t l = 0; l < lanes.size(); ++l) {
+			Lane& ln = lanes[l];
+			ln.device = (params.device + (int)l) % std::max(1, ndev);
+			ln.idxs.assign(is.begin() + (long)(l * per_lane), is.begin() + (long)((l + 1) * per_lane));
+			(void)hipSetDevice(ln.device);
+			for (size_t ki = 0; ki < n_k; ++ki) {
+				arks_imap* im = nullptr;
+				const int rc = arks_imap_create(&im, imap_capacity, ln.device);
+				if (rc != ARKS_OK)
+					die_arks(rc, "creating the IndexMap accumulator");
+				ln.imaps.push_back(im);
+			}
+			const size_t nc = n_k * nfiles;
+			if (hipMalloc((void**)&ln.d_stored, nc * sizeof(uint64_t)) != hipSuccess ||
+			    hipMalloc((void**)&ln.d_skipped, nfiles * sizeof(uint64_t)) != hipSuccess ||
+			    hipMalloc((void**)&ln.d_stats, nc * sizeof(arks_map_stats)) != hipSuccess) {
+				std::cerr << PROGRAM ": out of device memory\n";
 				exit(EXIT_FAILURE);
 			}
+			(void)hipMemset(ln.d_stored, 0, nc * sizeof(uint64_t));
+			(void)hipMemset(ln.d_skipped, 0, nfiles * sizeof(uint64_t));
+			(void)hipMemset(ln.d_stats, 0, nc * sizeof(arks_map_stats));
+			for (auto& s : ln.sets) {
+				s.d_conreci.resize(n_k);
+				if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+				    hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+					std::cerr << PROGRAM ": cannot create a HIP stream\n";
+					exit(EXIT_FAILURE);
+				}
+			}
+		}
+		if (sharded) {
+			// one exchange group per k: lane l is rank l of each
+			for (size_t ki = 0; ki < n_k; ++ki) {
+				std::vector<arks_exchange*> xs(lanes.size(), nullptr);
+				std::vector<const arks_index*> shards;
+				for (Lane& ln : lanes)
+					shards.push_back(ln.idxs[ki]);
+				const int rc = arks_exchange_create_local(xs.data(), shards.data(), (int)lanes.size());
+				if (rc != ARKS_OK)
+					die_arks(rc, "setting up the exchange of the sharded seed table");
+				for (size_t l = 0; l < lanes.size(); ++l)
+					lanes[l].xs.push_back(xs[l]);
+			}
+		}
+		(void)hipSetDevice(lanes[0].device);
 	}
 
 	~Mapper()
 	{
-		for (auto& s : sets) {
-			if (s.done)
-				(void)hipEventDestroy(s.done);
-			if (s.stream)
-				(void)hipStreamDestroy(s.stream);
+		for (Lane& ln : lanes) {
+			(void)hipSetDevice(ln.device);
+			for (arks_exchange* x : ln.xs)
+				arks_exchange_free(x);
+			for (auto& s : ln.sets) {
+				if (s.done)
+					(void)hipEventDestroy(s.done);
+				if (s.stream)
+					(void)hipStreamDestroy(s.stream);
+			}
+			(void)hipFree(ln.d_stored);
+			(void)hipFree(ln.d_skipped);
+			(void)hipFree(ln.d_stats);
 		}
-		(void)hipFree(d_stored);
-		(void)hipFree(d_skipped);
-		(void)hipFree(d_stats);
+		(void)hipSetDevice(lanes[0].device);
 	}
 
 	// waits until the set's previous batch is through and gives its host buffers back
@@ -522,15 +614,10 @@ struct Mapper
 		s.inflight = nullptr;
 	}
 
-	int submit(PackedBatch* pb, IngestPipeline& pipe)
+	// the batch on its way to the device (set s of lane ln) and through the gate
+	int upload(Lane& ln, DeviceSet& s, PackedBatch* pb)
 	{
 		const int64_t n = pb->n_reads, np = pb->n_pairs;
-		if (n == 0) {
-			pipe.recycle(pb);
-			return ARKS_OK;
-		}
-		DeviceSet& s = sets[turn++ & 1];
-		retire(s, pipe);
 		const size_t words = pb->words;
 		s.d_codes.reserve(words);
 		s.d_nmask.reserve(words);
@@ -538,7 +625,8 @@ struct Mapper
 		s.d_len.reserve((size_t)n);
 		s.d_class.reserve((size_t)n);
 		s.d_eval.reserve((size_t)n);
-		s.d_conreci.reserve((size_t)n);
+		for (auto& c : s.d_conreci)
+			c.reserve((size_t)n);
 		s.d_ok.reserve((size_t)np);
 		s.d_bid.reserve((size_t)np);
 		auto up = [&](void* d, const void* h, size_t bytes) {
@@ -563,7 +651,7 @@ struct Mapper
 			    hipMemsetAsync(s.d_nmask.p, 0, words * sizeof(uint32_t), s.stream) != hipSuccess)
 				return ARKS_ERR_HIP;
 			rc = arks_pack_reads_device(s.d_ascii.p, s.d_aoff.p, s.d_len.p, s.d_woff.p, n, s.d_codes.p, s.d_nmask.p, s.d_class.p,
-			                            params.device, s.stream);
+			                            ln.device, s.stream);
 		} else {
 			up(s.d_codes.p, pb->codes, words * sizeof(uint64_t));
 			up(s.d_nmask.p, pb->nmask, words * sizeof(uint32_t));
@@ -572,36 +660,62 @@ struct Mapper
 		// (the copies above and the kernels below overlap the other set's: an index keeps one set of work
 		// queues per stream, and the IndexMap accumulator is updated with atomics)
 		if (rc == ARKS_OK)
-			rc = arks_pair_gate_device(s.d_ok.p, s.d_class.p, np, s.d_eval.p, params.device, s.stream);
+			rc = arks_pair_gate_device(s.d_ok.p, s.d_class.p, np, s.d_eval.p, ln.device, s.stream);
 		if (rc == ARKS_OK && pb->ascii)
-			rc = arks_gate_count_device(s.d_ok.p, s.d_eval.p, np, d_skipped + pb->file, params.device, s.stream);
+			rc = arks_gate_count_device(s.d_ok.p, s.d_eval.p, np, ln.d_skipped + pb->file, ln.device, s.stream);
+		return rc;
+	}
+
+	// pair rule + IndexMap update of k number ki for the batch of set s
+	int pairs(Lane& ln, DeviceSet& s, PackedBatch* pb, size_t ki)
+	{
+		const size_t slot = ki * n_files + (size_t)pb->file;
+		// pairs are numbered in input order (file, batch, pair): the order in which a single-threaded
+		// chromiumRead creates the IndexMap's barcodes (Arcs.cpp:1282-1285)
+		arks_imap_set_pair_base(ln.imaps[ki], ((uint64_t)global_file[(size_t)pb->file] << 48) | ((uint64_t)pb->seq << 24));
+		return arks_pairs_device(s.d_conreci[ki].p, s.d_ok.p, s.d_bid.p, pb->n_pairs, nullptr, ln.imaps[ki], ln.d_stored + slot,
+		                         ln.device, s.stream);
+	}
+
+	int submit(PackedBatch* pb, IngestPipeline& pipe)
+	{
+		if (pb->n_reads == 0) {
+			pipe.recycle(pb);
+			return ARKS_OK;
+		}
+		if (sharded) {
+			round.push_back(pb);
+			return round.size() == lanes.size() ? submit_round(pipe) : ARKS_OK;
+		}
+		const int64_t np = pb->n_pairs;
+		Lane& ln = lanes[turn % lanes.size()];
+		DeviceSet& s = ln.sets[(turn / lanes.size()) & 1];
+		turn++;
+		(void)hipSetDevice(ln.device);
+		retire(s, pipe);
+		int rc = upload(ln, s, pb);
 		if (n_shards > 1) {
-			s.d_votes.reserve((size_t)n);
-			s.d_votes2.reserve((size_t)n);
+			s.d_votes.reserve((size_t)pb->n_reads);
+			s.d_votes2.reserve((size_t)pb->n_reads);
 		}
 		for (size_t ki = 0; ki < n_k && rc == ARKS_OK; ++ki) { // the batch is resident: every k maps it
 			const size_t slot = ki * n_files + (size_t)pb->file;
 			if (n_shards > 1) {
 				// per shard the votes of bestContig's walk, folded with a maximum, then the j_index test
 				for (size_t sh = 0; sh < n_shards && rc == ARKS_OK; ++sh) {
-					rc = arks_map_votes_device(idxs[ki * n_shards + sh], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p,
+					rc = arks_map_votes_device(ln.idxs[ki * n_shards + sh], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p,
 					                           s.d_eval.p, 2 * np, sh ? s.d_votes2.p : s.d_votes.p, s.stream);
 					if (rc == ARKS_OK && sh)
-						rc = arks_votes_max_device(s.d_votes.p, s.d_votes2.p, 2 * np, params.device, s.stream);
+						rc = arks_votes_max_device(s.d_votes.p, s.d_votes2.p, 2 * np, ln.device, s.stream);
 				}
 				if (rc == ARKS_OK)
 					rc = arks_votes_resolve_device(s.d_votes.p, s.d_len.p, 2 * np, params.k_list[ki], params.j_index,
-					                               s.d_conreci.p, params.device, s.stream);
+					                               s.d_conreci[ki].p, ln.device, s.stream);
 			} else
-				rc = arks_map_reads_device(idxs[ki], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, 2 * np,
-				                           params.j_index, s.d_conreci.p, params.verbose ? d_stats + slot : nullptr, s.stream);
-			if (rc == ARKS_OK) {
-				// pairs are numbered in input order (file, batch, pair): the order in which a single-threaded
-				// chromiumRead creates the IndexMap's barcodes (Arcs.cpp:1282-1285)
-				arks_imap_set_pair_base(imaps[ki], ((uint64_t)global_file[(size_t)pb->file] << 48) | ((uint64_t)pb->seq << 24));
-				rc = arks_pairs_device(s.d_conreci.p, s.d_ok.p, s.d_bid.p, np, nullptr, imaps[ki], d_stored + slot,
-				                       params.device, s.stream);
-			}
+				rc = arks_map_reads_device(ln.idxs[ki], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, 2 * np,
+				                           params.j_index, s.d_conreci[ki].p, params.verbose ? ln.d_stats + slot : nullptr, s.stream);
+			if (rc == ARKS_OK)
+				rc = pairs(ln, s, pb, ki);
 		}
 		if (rc != ARKS_OK)
 			return rc;
@@ -611,10 +725,75 @@ struct Mapper
 		return ARKS_OK;
 	}
 
+	// ---- sharded seed table: a round = one batch per lane (the last round of the input may have fewer: the lanes
+	//      without one submit empty batches -- the exchange is collective) --------------------------------------------
+	int submit_round(IngestPipeline& pipe)
+	{
+		const size_t set = rounds_submitted & 1;
+		int rc = ARKS_OK;
+		for (size_t l = 0; l < lanes.size() && rc == ARKS_OK; ++l) {
+			Lane& ln = lanes[l];
+			DeviceSet& s = ln.sets[set];
+			(void)hipSetDevice(ln.device);
+			retire(s, pipe); // (the round before last, completed in the call before this one)
+			PackedBatch* pb = l < round.size() ? round[l] : nullptr;
+			if (pb)
+				rc = upload(ln, s, pb);
+			const int64_t n = pb ? 2 * pb->n_pairs : 0;
+			for (size_t ki = 0; ki < n_k && rc == ARKS_OK; ++ki)
+				rc = arks_exchange_submit(ln.xs[ki], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, n, params.j_index,
+				                          s.d_conreci[ki].p,
+				                          pb && params.verbose ? ln.d_stats + (ki * n_files + (size_t)pb->file) : nullptr, s.stream);
+			s.inflight = pb;
+		}
+		round.clear();
+		rounds_submitted++;
+		if (rc == ARKS_OK && rounds_submitted - rounds_completed == 2)
+			rc = complete_round();
+		return rc;
+	}
+
+	int complete_round()
+	{
+		const size_t set = rounds_completed & 1;
+		rounds_completed++;
+		int rc = ARKS_OK;
+		std::vector<arks_exchange*> xs(lanes.size());
+		for (size_t ki = 0; ki < n_k && rc == ARKS_OK; ++ki) {
+			for (size_t l = 0; l < lanes.size(); ++l)
+				xs[l] = lanes[l].xs[ki];
+			rc = arks_exchange_complete_group(xs.data(), (int)lanes.size());
+		}
+		for (size_t l = 0; l < lanes.size() && rc == ARKS_OK; ++l) {
+			Lane& ln = lanes[l];
+			DeviceSet& s = ln.sets[set];
+			(void)hipSetDevice(ln.device);
+			if (s.inflight)
+				for (size_t ki = 0; ki < n_k && rc == ARKS_OK; ++ki)
+					rc = pairs(ln, s, s.inflight, ki);
+			if (rc == ARKS_OK && hipEventRecord(s.done, s.stream) != hipSuccess)
+				rc = ARKS_ERR_HIP;
+		}
+		return rc;
+	}
+
 	void drain(IngestPipeline& pipe)
 	{
-		for (auto& s : sets)
-			retire(s, pipe);
+		if (sharded) {
+			int rc = ARKS_OK;
+			if (!round.empty())
+				rc = submit_round(pipe);
+			while (rc == ARKS_OK && rounds_completed < rounds_submitted)
+				rc = complete_round();
+			if (rc != ARKS_OK)
+				die_arks(rc, "mapping a read batch (sharded seed table)");
+		}
+		for (Lane& ln : lanes) {
+			(void)hipSetDevice(ln.device);
+			for (auto& s : ln.sets)
+				retire(s, pipe);
+		}
+		(void)hipSetDevice(lanes[0].device);
 	}
 };
 
@@ -694,6 +873,54 @@ PinnedPool g_pinned;
 // bounds the stage, and the pinned pool it needs is 2.4x the size.
 const bool g_device_pack = getenv("ARKS_DEVICE_PACK") != nullptr;
 
+// batches the consumer holds beyond the two of one lane: two per further lane, and the round being collected of a
+// sharded exchange
+unsigned
+extra_batch_buffers()
+{
+	const unsigned L = (unsigned)std::max(1, params.lanes);
+	return 2 * (L - 1) + (params.index_sharded > 0 ? L : 0);
+}
+
+// The IndexMap entries of several lanes -- each list sorted by (barcode id, conreci), as arks_imap_export_ordered
+// gives them -- into one: counts add up, the first stored pair of an entry is the earliest of the lanes'.
+void
+merge_lane_entries(
+    const std::vector<std::vector<uint32_t>>& lt, const std::vector<std::vector<uint64_t>>& lf, std::vector<uint32_t>& triples,
+    std::vector<uint64_t>& first)
+{
+	const size_t L = lt.size();
+	std::vector<size_t> cur(L, 0);
+	size_t total = 0;
+	for (size_t l = 0; l < L; ++l)
+		total += lf[l].size();
+	triples.clear(), first.clear();
+	triples.reserve(total * 3), first.reserve(total);
+	auto key = [&](size_t l) { return ((uint64_t)lt[l][3 * cur[l]] << 32) | (uint64_t)lt[l][3 * cur[l] + 1]; };
+	for (;;) {
+		bool any = false;
+		uint64_t best = 0;
+		for (size_t l = 0; l < L; ++l)
+			if (cur[l] < lf[l].size() && (!any || key(l) < best)) {
+				best = key(l);
+				any = true;
+			}
+		if (!any)
+			break;
+		uint64_t count = 0, fp = ~0ull;
+		for (size_t l = 0; l < L; ++l)
+			if (cur[l] < lf[l].size() && key(l) == best) {
+				count += lt[l][3 * cur[l] + 2];
+				fp = std::min(fp, lf[l][cur[l]]);
+				cur[l]++;
+			}
+		triples.push_back((uint32_t)(best >> 32));
+		triples.push_back((uint32_t)best);
+		triples.push_back((uint32_t)count);
+		first.push_back(fp);
+	}
+}
+
 // fused == true: no multiplicity file; the reads per barcode come back in the result (pre_counts) and
 // `redo` is set when the input needs the exact two-pass flow instead
 RankResult
@@ -713,7 +940,7 @@ map_files(
 	};
 	RankResult res;
 	res.files.resize(nf);
-	const size_t nk = idxs.size() / (size_t)std::max(1, params.index_shards);
+	const size_t nk = params.k_list.size();
 	res.triples.resize(nk);
 	res.first.resize(nk);
 	std::vector<std::unique_ptr<SeqReader>> readers;
@@ -740,6 +967,7 @@ map_files(
 		rdp.push_back(r.get());
 	IngestPipeline pipe(rdp, dict.get(), params.batch_pairs, params.verbose != 0, params.threads, pinned);
 	pipe.set_device_pack(g_device_pack);
+	pipe.add_buffers(extra_batch_buffers());
 	g_pinned.wait();
 	lap("open files, barcode dictionary, device buffers, pinned pool ready");
 	const int prc = pipe.run([&](PackedBatch* pb) {
@@ -770,8 +998,9 @@ map_files(
 		for (const PrepassInfo& pi : pipe.prepass())
 			if (pi.zero_len || pi.untagged_at.size() > (1u << 22)) {
 				res.redo = true; // rare input shapes: let the caller run the literal two passes
-				for (arks_imap* im : mapper.imaps)
-					arks_imap_free(im);
+				for (Lane& ln : mapper.lanes)
+					for (arks_imap* im : ln.imaps)
+						arks_imap_free(im);
 				return res;
 			}
 		DynamicDict& dyn = pipe.dynamic();
@@ -791,13 +1020,29 @@ map_files(
 		for (const std::string* s : dict->name)
 			res.names.push_back(*s);
 	}
-	std::vector<uint64_t> stored(nk * nm), skipped(nm, 0);
+	// counters: sums over the lanes; the IndexMap: the lanes' entries merged (same barcode ids: one dictionary)
+	std::vector<uint64_t> stored(nk * nm, 0), skipped(nm, 0);
 	std::vector<arks_map_stats> st(nk * nm);
-	(void)hipMemcpy(skipped.data(), mapper.d_skipped, nm * sizeof(uint64_t), hipMemcpyDeviceToHost);
+	std::memset(st.data(), 0, st.size() * sizeof(arks_map_stats));
+	for (Lane& ln : mapper.lanes) {
+		(void)hipSetDevice(ln.device);
+		std::vector<uint64_t> l_stored(nk * nm), l_skipped(nm, 0);
+		std::vector<arks_map_stats> l_st(nk * nm);
+		(void)hipMemcpy(l_skipped.data(), ln.d_skipped, nm * sizeof(uint64_t), hipMemcpyDeviceToHost);
+		(void)hipMemcpy(l_stored.data(), ln.d_stored, nk * nm * sizeof(uint64_t), hipMemcpyDeviceToHost);
+		(void)hipMemcpy(l_st.data(), ln.d_stats, nk * nm * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
+		for (size_t i = 0; i < nm; ++i)
+			skipped[i] += l_skipped[i];
+		for (size_t i = 0; i < nk * nm; ++i) {
+			stored[i] += l_stored[i];
+			const uint64_t* a = reinterpret_cast<const uint64_t*>(&l_st[i]);
+			uint64_t* acc = reinterpret_cast<uint64_t*>(&st[i]);
+			for (size_t w = 0; w < sizeof(arks_map_stats) / sizeof(uint64_t); ++w)
+				acc[w] += a[w];
+		}
+	}
 	for (size_t i = 0; i < mine.size(); ++i)
 		res.files[mine[i]].fc.skipped_invalid += skipped[i]; // (device-pack mode; 0 otherwise)
-	(void)hipMemcpy(stored.data(), mapper.d_stored, nk * nm * sizeof(uint64_t), hipMemcpyDeviceToHost);
-	(void)hipMemcpy(st.data(), mapper.d_stats, nk * nm * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
 	for (size_t i = 0; i < mine.size(); ++i) {
 		FileResult& fr = res.files[mine[i]];
 		fr.have = true;
@@ -807,18 +1052,30 @@ map_files(
 		}
 	}
 	for (size_t ki = 0; ki < nk; ++ki) {
-		const int64_t n = arks_imap_size(mapper.imaps[ki]);
-		if (n < 0)
-			die_arks((int)-n, "reading the IndexMap accumulator");
-		res.triples[ki].resize((size_t)n * 3 + 3);
-		res.first[ki].resize((size_t)n + 1);
-		const int rc = arks_imap_export_ordered(mapper.imaps[ki], res.triples[ki].data(), res.first[ki].data());
-		if (rc != ARKS_OK)
-			die_arks(rc, "exporting the IndexMap");
-		res.triples[ki].resize((size_t)n * 3);
-		res.first[ki].resize((size_t)n);
-		arks_imap_free(mapper.imaps[ki]);
+		std::vector<std::vector<uint32_t>> lt(mapper.lanes.size());
+		std::vector<std::vector<uint64_t>> lf(mapper.lanes.size());
+		for (size_t l = 0; l < mapper.lanes.size(); ++l) {
+			Lane& ln = mapper.lanes[l];
+			(void)hipSetDevice(ln.device);
+			const int64_t n = arks_imap_size(ln.imaps[ki]);
+			if (n < 0)
+				die_arks((int)-n, "reading the IndexMap accumulator");
+			lt[l].resize((size_t)n * 3 + 3);
+			lf[l].resize((size_t)n + 1);
+			const int rc = arks_imap_export_ordered(ln.imaps[ki], lt[l].data(), lf[l].data());
+			if (rc != ARKS_OK)
+				die_arks(rc, "exporting the IndexMap");
+			lt[l].resize((size_t)n * 3);
+			lf[l].resize((size_t)n);
+			arks_imap_free(ln.imaps[ki]);
+		}
+		if (mapper.lanes.size() == 1) {
+			res.triples[ki].swap(lt[0]);
+			res.first[ki].swap(lf[0]);
+		} else
+			merge_lane_entries(lt, lf, res.triples[ki], res.first[ki]);
 	}
+	(void)hipSetDevice(mapper.lanes[0].device);
 	lap("counters and IndexMap back to the host");
 	return res;
 }
@@ -946,7 +1203,18 @@ run_arks(const std::vector<std::string>& filenames)
 	// (a file that cannot be opened: no workers -- one process then writes the reference's log of the files in
 	// front of it and stops at it, Arcs.cpp:1158-1163, instead of a worker dying with its own message after
 	// rank 0 has mapped its whole share)
+	// With fewer files than ranks -- the pipeline's one reads.fq.gz (bin/arcs-make:290), /dev/stdin (:305) -- a process
+	// drives several GPUs: the batches of its files are dealt to its LANES (Mapper).  --index-sharded: one process,
+	// every rank a lane, the seed table hash-sharded over them instead of replicated.
 	bool all_open = true;
+	if (params.index_sharded != 0) {
+		if (params.index_sharded < 0) { // no number given: --ranks, else every visible GPU
+			int ndev = 1;
+			params.index_sharded = params.ranks > 1 ? params.ranks : (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 ? ndev : 1);
+		}
+		params.ranks = 1;
+		params.lanes = params.index_sharded;
+	}
 	if (params.ranks > 1 && filenames.size() > 1)
 		for (const std::string& f : filenames) {
 			// by stat / access, and only for regular files: opening and closing a FIFO here would block until its
@@ -991,9 +1259,18 @@ run_arks(const std::vector<std::string>& filenames)
 		exit(EXIT_FAILURE);
 	}
 	{
+		// the GPU ranks of the run dealt to the processes: rank r of g_world gets ranks / g_world of them (the first
+		// ranks % g_world one more) as its lanes, on the devices device + first lane ... (modulo the devices there are,
+		// so that a test can run several ranks on one GPU)
+		int first_lane = 0;
+		if (params.index_sharded == 0) {
+			const int n = std::max(1, params.ranks), p = std::max(1, g_world);
+			params.lanes = n / p + (g_rank < n % p ? 1 : 0);
+			first_lane = g_rank * (n / p) + std::min(g_rank, n % p);
+		}
 		int ndev = 0;
 		if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
-			params.device = (params.device + g_rank) % ndev;
+			params.device = (params.device + first_lane) % ndev;
 			(void)hipSetDevice(params.device);
 		}
 	}
@@ -1009,7 +1286,7 @@ run_arks(const std::vector<std::string>& filenames)
 			raw_estimate(params.batch_pairs, &bases, &reads);
 			slab = raw_slab_bytes(bases + bases / 8 + 64, reads + reads / 8 + 64);
 		}
-		g_pinned.prefill(IngestPipeline::buffers_for(params.threads, (unsigned)n_mine), slab);
+		g_pinned.prefill(IngestPipeline::buffers_for(params.threads, (unsigned)n_mine) + extra_batch_buffers(), slab);
 	}
 
 	std::vector<IndexMap> imaps;
@@ -1081,8 +1358,13 @@ run_arks(const std::vector<std::string>& filenames)
 		std::cerr << err << std::flush;
 	}
 	lap("read files -> IndexMap (ingest pipeline + GPU mapping)");
-	for (arks_index* idx : idxs)
-		arks_index_free(idx);
+	{
+		std::vector<arks_index*> uniq(idxs);
+		std::sort(uniq.begin(), uniq.end());
+		uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+		for (arks_index* idx : uniq) // (replica lanes on one device share an index)
+			arks_index_free(idx);
+	}
 	std::cout << "Cumulative memory usage: " << memory_usage() << std::endl;
 
 	for (size_t ki = 0; ki < params.k_list.size(); ++ki) {
@@ -1228,6 +1510,11 @@ main(int argc, char** argv)
 		case OPT_DEVICE: arg >> params.device; break;
 		case OPT_INDEX_SHARDS: arg >> params.index_shards; break;
 		case OPT_RANKS: arg >> params.ranks; break;
+		case OPT_INDEX_SHARDED:
+			params.index_sharded = -1; // (resolved in run_arks)
+			if (optarg != NULL)
+				arg >> params.index_sharded;
+			break;
 		case 'm': {
 			std::string first, second;
 			std::getline(arg, first, '-');
@@ -1297,6 +1584,14 @@ main(int argc, char** argv)
 	params.g.dist_est = params.dist_est;
 	if (params.index_shards < 1 || params.index_shards > 4096) {
 		std::cerr << PROGRAM ": --index-shards must be between 1 and 4096\n";
+		die = true;
+	}
+	if (params.index_sharded != 0 && (params.index_sharded < -1 || params.index_sharded > 64 || params.index_shards > 1)) {
+		std::cerr << PROGRAM ": --index-sharded takes 1 to 64 ranks and does not combine with --index-shards\n";
+		die = true;
+	}
+	if (params.ranks < 1 || params.ranks > 64) {
+		std::cerr << PROGRAM ": --ranks must be between 1 and 64\n";
 		die = true;
 	}
 	{ // -k: one value as in the reference, or a comma-separated list (this build only)

@@ -1524,6 +1524,9 @@ class IngestPipeline
 
 	// the batches carry the reads' bases instead of packed words: the caller packs (and classifies) on the device
 	void set_device_pack(bool on) { device_pack_ = on; }
+	// a consumer that keeps more than two batches in flight (several GPU lanes, a round of a sharded exchange being
+	// collected) needs as many more buffers, or the packers wait for buffers the consumer will not give back
+	void add_buffers(unsigned n) { n_buffers_ += n; }
 
 	DynamicDict& dynamic() { return dynamic_; }
 	const std::vector<PrepassInfo>& prepass() const { return prepass_; }

@@ -154,7 +154,8 @@ int arks_index_build_seed_shard(
     int64_t n_ends,
     int rank,
     int n_ranks,
-    int device);
+    int device,
+    arks_build_stats* stats /* may be NULL; the counters of the whole draft (the same on every rank) */);
 /* number of ranks the index's seed table is sharded over (1 = whole) */
 int arks_index_seed_ranks(const arks_index* idx);
 
@@ -364,6 +365,11 @@ int arks_exchange_submit(
     arks_map_stats* d_stats,
     void* stream);
 int arks_exchange_complete(arks_exchange* x);
+/* arks_exchange_complete for ALL ranks of a local group (arks_exchange_create_local) from ONE thread: xs[r] = rank r,
+ * each with a submitted batch; the stages of the ranks are interleaved in this call instead of meeting at barriers.
+ * What a host program with one consumer thread (arcs --index-sharded) calls; a group is driven either this way or
+ * by a thread per rank, not both at once. */
+int arks_exchange_complete_group(arks_exchange* const* xs, int world);
 
 /* submit + complete for one batch at a time (COLLECTIVE; nothing else may be in flight) */
 int arks_map_reads_exchanged_device(

@@ -69,6 +69,12 @@ for rnd in range(7):
         a.record(); run(L, h, codes, nmask, out, ev, name); b.record(); torch.cuda.synchronize()
         times[name].append(a.elapsed_time(b))
 windows = int(torch.clamp(batch["lens"].to(torch.int64) - (k - 1), min=0).sum().item())
+# the read stream of one launch, byte for byte (profiles/tools/fetch_calib.py: a build without probes fetches nothing else)
+_ev = libs[0][6]
+_n_eval = int((_ev != 0).sum().item()) if _ev is not None else n
+_may_n = int((_ev == 1).sum().item()) if _ev is not None else n
+print(f"stream_bytes codes={8 * total} nmask_if_all={4 * total} word_off={8 * (n + 1)} lens={4 * n} eval={n if _ev is not None else 0} "
+      f"out={4 * n} reads={n} evaluated={_n_eval} reads_whose_masks_may_be_fetched={_may_n}")
 for (name, L, h, codes, nmask, out, ev) in libs:
     t = times[name]
     same = bool((out == ref).all().item())

@@ -510,3 +510,84 @@ def test_arks_long_multi_k_at_scale(arks, gpu, oracle, tmp_path):
         assert f"Number of reads passing jaccard threshold: {want['stats']['reads_pass']}\n" in block
         n_edges += len(want["edges"])
     assert n_edges > 20, "long reads spanning contigs should link many ends"
+
+
+def _norm_log(text, basename):
+    import re
+    keep = []
+    for ln in text.split("\n"):
+        if ln.startswith(" pid ") or "Cumulative memory usage" in ln or re.search(r"\d\d:\d\d:\d\d \d{4}$", ln):
+            continue
+        keep.append(ln.replace("/" + basename, "/BASE"))
+    return "\n".join(keep)
+
+
+@pytest.mark.parametrize("kind", ["fq", "bgzf", "fq.gz"])
+def test_one_reads_file_many_gpus(arks, gpu, tmp_path, kind):
+    """What the pipeline passes is ONE reads file (bin/arcs-make:290).  --ranks N then deals the batches of that file to
+    N GPU lanes of the one process (an index replica each; here the lanes share the box's GPU), and --index-sharded=N
+    maps them against a seed table hash-sharded over the N lanes (arks_exchange, rounds of N batches, two rounds in
+    flight).  Log (-v counters included) and every output file are those of the one-GPU run, byte for byte; that
+    run is checked against the oracle flow in test_arcs_cli_end_to_end."""
+    from arcs_amd import build as b, synth
+    from test_host_ingest import write_bgzf
+    exe = b.build_host()
+    contigs = synth.make_draft(400_000, seed=77, lengths=(60000, 20000, 90000, 45000), small_frac=0.5)
+    cs = synth.contigs_to_strings(contigs)
+    fa = tmp_path / "draft.fa"
+    with open(fa, "w") as f:
+        for i, s in enumerate(cs):
+            f.write(f">{i + 1}\n{s}\n")
+    n_pairs = 9000
+    batch = synth.make_read_pairs(contigs, n_pairs, seed=78, mol_len=30000, pairs_per_mol=30, one_n_rate=0.03,
+                                  many_n_rate=0.01)
+    reads = synth.reads_to_strings(batch)
+    bid = batch["barcode_id"].numpy()
+    text = []
+    for p in range(n_pairs):
+        bc = "".join("ACGT"[(int(bid[p]) >> (2 * t)) & 3] for t in range(12)) + "-1"
+        n2 = f"other{p}" if p % 97 == 5 else f"read{p}"
+        for name, s in ((f"read{p}/1", reads[2 * p]), (n2 + "/2", reads[2 * p + 1])):
+            text.append(f"@{name} BX:Z:{bc}\n{s}\n+\n{'F' * len(s)}\n")
+    text = "".join(text).encode()
+    if kind == "fq":
+        fq = tmp_path / "reads.fq"
+        fq.write_bytes(text)
+    elif kind == "bgzf":
+        fq = tmp_path / "reads.fastq.gz"
+        write_bgzf(str(fq), text)
+    else:
+        fq = tmp_path / "reads.fq.gz"
+        with gzip.open(fq, "wb") as f:
+            f.write(text)
+
+    def run(tag, extra, k="60"):
+        args = [exe, "--arks", "-v", "-f", str(fa), "-c", "3", "-m", "8-10000", "-e", "30000", "-z", "500", "-j", "0.55",
+                "-k", k, "-t", "6", "-b", str(tmp_path / tag), "-P", "--batch-pairs", "700"] + extra + [str(fq)]
+        res = subprocess.run(args, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, (tag, res.stderr[-2000:])
+        return res
+    one = run("one", [])
+    assert "Stored read pairs: " in one.stdout and "Stored read pairs: 0\n" not in one.stdout
+    for tag, extra in (("r2", ["--ranks", "2"]), ("r3", ["--ranks", "3"]), ("s2", ["--index-sharded=2"]),
+                       ("s3", ["--index-sharded", "--ranks", "3"])):
+        res = run(tag, extra)
+        assert _norm_log(res.stdout, tag) == _norm_log(one.stdout, "one"), tag
+        for suffix in ("_original.gv", "_pair.tsv", "_main.tsv", ".dist.gv"):
+            assert open(str(tmp_path / tag) + suffix).read() == open(str(tmp_path / "one") + suffix).read(), (tag, suffix)
+    if kind == "fq":
+        # two k in one pass over a sharded seed table (an exchange group per k), and the pipe of arcs-make:305
+        base = run("k2", [], k="40,60")
+        res = run("k2s", ["--index-sharded=3"], k="40,60")
+        assert _norm_log(res.stdout, "k2s") == _norm_log(base.stdout, "k2")
+        for kk in (40, 60):
+            for suffix in ("_original.gv", "_main.tsv"):
+                a = [x for x in os.listdir(tmp_path) if x.startswith("k2s") and f"k{kk}" in x and x.endswith(suffix)]
+                assert len(a) == 1, (kk, suffix, a)
+                assert open(tmp_path / a[0]).read() == open(tmp_path / a[0].replace("k2s", "k2", 1)).read()
+        args = [exe, "--arks", "-f", str(fa), "-c", "3", "-m", "8-10000", "-k", "60", "-t", "4", "-b", str(tmp_path / "pipe"),
+                "--batch-pairs", "700", "--ranks", "3", "/dev/stdin"]
+        with open(fq, "rb") as src:
+            res = subprocess.run(args, stdin=src, capture_output=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert open(str(tmp_path / "pipe") + "_original.gv").read() == open(str(tmp_path / "one") + "_original.gv").read()

@@ -270,6 +270,47 @@ def test_local_ranks_against_the_oracle(arks, gpu, oracle, k, world):
         sh.close()
 
 
+def test_one_thread_drives_the_whole_group(arks, gpu, oracle):
+    """arks_exchange_complete_group: the ranks' stages interleaved by one caller (what arcs --index-sharded does), two
+    rounds in flight"""
+    import torch
+    k, world = 60, 3
+    cs = _draft(k, seed=515)
+    ends = arks.contig_ends(cs, 500, 3000)
+    ox = oracle.OracleIndex(k).build(ends)
+    reads = _reads(cs, ends, k, seed=516, n=1800)
+    shards = [arks.ArksIndex.build_seed_shard(ends, k, r, world, device=gpu) for r in range(world)]
+    xs = arks.SeedExchange.create_local(shards)
+    streams = [[torch.cuda.Stream() for _ in range(2)] for _ in range(world)]
+    empty = arks.PackedReads.from_ascii([], device=gpu)
+    rounds = [reads[0:500], reads[500:1300], reads[1300:1800]]
+    kept, outs = [], []
+    st = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(world)]
+    torch.cuda.synchronize()
+
+    def submit(i):
+        parts = _uneven_parts(rounds[i], world, i)
+        row = []
+        for r in range(world):
+            with torch.cuda.stream(streams[r][i % 2]):
+                b = arks.PackedReads.from_ascii(parts[r], device=gpu) if parts[r] else empty
+                row.append((b, xs[r].submit(b, 0.55, stats=st[r])))
+        kept.append(row)
+    for i in range(len(rounds)):
+        submit(i)
+        if i:
+            arks.SeedExchange.complete_group(xs)
+    arks.SeedExchange.complete_group(xs)
+    torch.cuda.synchronize()
+    ost = oracle.MapStats()
+    for i, row in enumerate(kept):
+        got = sum([c.cpu().tolist()[:b.n_reads] for b, c in row], [])
+        assert got == [ox.best_contig(r, 0.55, ost) for r in rounds[i]], i
+    assert dict(zip(STAT_NAMES, np.sum([x.cpu().numpy() for x in st], axis=0).tolist())) == ost.as_dict()
+    for x in xs:
+        x.close()
+
+
 def test_regions_grow_when_a_batch_does_not_fit(arks, gpu, oracle):
     """the regions of the send buffer are sized for 3.3 seeds per read; a batch of long reads (80 seeds each) overflows
     them, is bucketed again with what it needs, and the sizes stick for the next batch"""

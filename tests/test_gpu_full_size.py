@@ -1,6 +1,6 @@
-"""Full-size checks (BASELINE configs[1]: 50 Mbp draft + 20 M pairs is the bench; here a 10 Mbp /
-2 M-pair cut of the same generator keeps the suite short) through size-independent properties of
-the path, plus an oracle comparison on a slice."""
+"""Full-size checks through size-independent properties of the path and oracle comparisons: BASELINE configs[1] on a
+10 Mbp / 2 M-pair cut (properties) AND at its size -- 50 Mbp + 20 M pairs, the first 1.5 M pairs read for read against
+the oracle over the WHOLE draft --, configs[2-4] at 3 Gbp against sub-draft oracles."""
 import os
 
 import numpy as np
@@ -72,6 +72,65 @@ def test_properties_at_scale(arks, gpu, oracle):
 
 
 STAT_NAMES = ("total_valid", "bad", "found", "recorded", "dups", "reads_pass", "reads_fail", "windows")
+
+
+def test_configs1_at_its_size_against_the_whole_oracle(arks, gpu, oracle):
+    """BASELINE configs[1] as named: synthetic 50 Mbp draft + 20 M linked-read pairs, k = 60, j = 0.55, one MI355X.
+    The whole draft's oracle map (3e7 keys) fits the host, so no sub-draft argument is needed: all six build counters,
+    and conreci / pair result / all eight counters of the first 1.5 M pairs, are the oracle's; the 20 M pairs go
+    through in one launch with the properties of the path (pair rule, histogram) holding over all of them and the
+    first 1.5 M of that launch equal to the oracle as well (results do not depend on what else is in the batch)."""
+    import torch
+    from arcs_amd import synth
+    k, j = 60, 0.55
+    contigs = synth.make_draft(50_000_000, seed=synth.SEED)
+    cs = synth.contigs_to_strings(contigs)
+    ends = arks.contig_ends(cs)
+    ix = arks.ArksIndex.build(ends, k, device=gpu)
+    ox = oracle.OracleIndex(k).build(oracle.contig_ends(cs))
+    del cs, ends
+    assert {f: ix.build_stats[f] for f in ox.stats.as_dict()} == ox.stats.as_dict()
+    assert len(ix) == len(ox) > 25_000_000
+    threads = min(64, len(os.sched_getaffinity(0)))
+    n_all, n_chk = 20_000_000, 1_500_000
+    batch = synth.make_read_pairs(contigs, n_all, seed=synth.SEED + 1, device="cuda")
+    a = np.concatenate([batch["ascii"][: int(batch["offsets"][2 * n_chk].item())].cpu().numpy(), np.zeros(1, np.uint8)])
+    lens = batch["lens"][: 2 * n_chk].cpu().numpy().astype(np.uint32)
+    offs = batch["offsets"][: 2 * n_chk].cpu().numpy().astype(np.uint64)
+    ok = batch["pair_ok"][:n_chk].cpu().numpy()
+    want_c, want_p, want_st = ox.map_pairs(a, offs, lens, j, pair_ok=ok, threads=threads)
+    # the 1.5 M pairs alone, with the counters
+    head = arks.PackedReads.from_arrays_device(batch["ascii"][: int(batch["offsets"][2 * n_chk].item())],
+                                               batch["offsets"][: 2 * n_chk + 1], batch["lens"][: 2 * n_chk], device=gpu)
+    st = torch.zeros(8, dtype=torch.int64, device="cuda")
+    c, p = arks.map_pairs_packed(ix, head, j, pair_ok=batch["pair_ok"][:n_chk], stats=st)
+    torch.cuda.synchronize()
+    assert (c.cpu().numpy() == want_c).all() and (p.cpu().numpy() == want_p).all()
+    assert dict(zip(STAT_NAMES, st.cpu().tolist())) == {f: want_st[f] for f in STAT_NAMES}
+    del head
+    # all 20 M pairs in one launch
+    reads = arks.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=gpu)
+    stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+    stored = torch.zeros(1, dtype=torch.int64, device="cuda")
+    imap = arks.ImapAccumulator(1 << 20, device=gpu)
+    c, p = arks.map_pairs_packed(ix, reads, j, pair_ok=batch["pair_ok"], barcode_id=batch["barcode_id"], imap=imap,
+                                 stats=stats, stored=stored)
+    torch.cuda.synchronize()
+    c, p = c.cpu().numpy(), p.cpu().numpy()
+    assert (c[: 2 * n_chk] == want_c).all() and (p[:n_chk] == want_p).all()
+    s = dict(zip(STAT_NAMES, stats.cpu().tolist()))
+    assert s["windows"] == 3_220_000_000 - 161 * int((~(np.repeat(batch["pair_ok"].cpu().numpy().astype(bool), 2)
+                                                       & reads.read_class.cpu().numpy().astype(bool)[0::2].repeat(2)
+                                                       & reads.read_class.cpu().numpy().astype(bool)[1::2].repeat(2))).sum()) // 2
+    assert s["total_valid"] + s["bad"] == s["windows"] and s["found"] == s["recorded"] + s["dups"]
+    assert ((p != 0) == ((c[0::2] != 0) & (c[0::2] == c[1::2]))).all()
+    assert s["reads_pass"] == int((c != 0).sum()) and int(stored.item()) == int((p != 0).sum())
+    t = imap.triples()
+    key = batch["barcode_id"].cpu().numpy().astype(np.int64)[p != 0] * (1 << 32) + p[p != 0]
+    uk, cnt = np.unique(key, return_counts=True)
+    assert len(uk) == len(t) and (t[:, 0].astype(np.int64) * (1 << 32) + t[:, 1] == uk).all() and (t[:, 2] == cnt).all()
+    imap.close()
+    ix.close()
 
 
 def _ends_of(arks, contigs, end_length=30000):
