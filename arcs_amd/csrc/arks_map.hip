@@ -1881,6 +1881,12 @@ struct SeedTileLds
 	u32 redo2; // reads for the medium queue
 	u32 live;  // reads with a first-round seed that has entries (two-round S2)
 	u64 wstats[8];
+	// REMOTE without counters: the reads none of whose seeds has an entry are settled before the tiles are made, the
+	// others move up into their places
+	u64 wbase[sTR];            // tile word x of read j comes from codes[wbase[j] + x]
+	int sbase[sTR];            // tile seed h of read j is seed sbase[j] + h of the chunk
+	unsigned char rorig[sTR];  // read j of the tile is read c0 + rorig[j] of the batch
+	unsigned char perm[64];
 };
 
 #ifndef ARKS_SEED_WAVES
@@ -1933,6 +1939,13 @@ map_reads_s_kernel(
 	constexpr bool kTwoRound = false;
 #endif
 	const float jf = (float)j_index;
+	// REMOTE (the seeds' answers are there before the launch), no counters, no raw votes: a read none of whose seeds has
+	// an entry -- half of a uniform read set lies outside the contig ends -- has no window in the index: its result is 0,
+	// and it is settled per chunk, before the tiles are made; the tiles then hold the other reads only (half as many
+	// tiles).  Not when the index holds quirk images: a palindromic window's key is not its sequence's, the slow
+	// kernel decides those and finds them through the staged words (below).
+	constexpr bool kSkipDead = REMOTE && !STATS && !RAW;
+	const bool skip_dead = kSkipDead && !(bx.has_img && !(k & 1));
 	if (STATS && lane_id < 8)
 		S.wstats[lane_id] = 0;
 	u32* const work_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kWorkCtrOffset);
@@ -1990,43 +2003,95 @@ map_reads_s_kernel(
 		}
 		// reads of the chunk that may hold an invalid base: only a tile with one of them fetches its N masks (a
 		// third of the read stream, and zero for > 98 % of the reads)
-		const u64 nreads_mask = __ballot(may_n);
 		// index of the chunk's first seed in `ans` / `seed_slot`
 		const long soff0 = REMOTE ? (chunk_off ? (long)chunk_off[c0 / sChunk] : seed_off[c0]) : 0;
-		const int nwin_l = rl - k + 1;
-		const int G = nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
-		const int gsum = wave_incl_scan_i32(G); // inclusive prefix over the lanes of the chunk
-		const int gex = gsum - G; // seeds of the chunk's reads before this one
-		const u64 wo_next = wave_next_u64(wo);
+		int nwin_l = rl - k + 1;
+		int G = nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
+		int gex = wave_incl_scan_i32(G) - G; // seeds of the chunk's reads before this one
+		int wcnt = (int)(wave_next_u64(wo) - wo); // words of the read (garbage beyond the chunk: not looked at)
+		// pos: where the read starts in the word space the tiles are cut from -- the batch's packed words (wo), or, when
+		// reads are left out, the words of the reads that stay, closed up; wo stays the address of the read's first word
+		u64 pos = wo;
+		int gexo = gex;      // the read's first seed among the chunk's (answers are numbered with every read in place)
+		int rorig = lane_id; // the read this lane holds is read c0 + rorig
+		int nchunk_c = nchunk;
+		if (kSkipDead && skip_dead) {
+			bool keep = lane_id < nchunk && rl >= 0 && G > 0;
+			if (keep && G <= 3) {
+				// (three seeds at most: a 10x read has two or three; a read with more is kept unseen)
+				u64 a[3] = { 0, 0, 0 };
+				long si[3];
+#pragma unroll
+				for (int gi = 0; gi < 3; ++gi) {
+					si[gi] = -1;
+					if (gi < G) {
+						si[gi] = soff0 + (long)(gex + gi);
+						if (seed_slot) {
+							const u32 sl = seed_slot[si[gi]];
+							si[gi] = sl == ~0u ? -1 : (long)sl;
+						}
+					}
+				}
+#pragma unroll
+				for (int gi = 0; gi < 3; ++gi)
+					if (si[gi] >= 0)
+						a[gi] = ans[2 * si[gi]];
+				keep = (a[0] | a[1] | a[2]) != 0; // (an entry, or the "heavy" / "more than two" marks)
+			}
+			if (lane_id < nchunk && !keep)
+				put_none<RAW>(out_conreci, c0 + lane_id);
+			const u64 kept = __ballot(keep);
+			nchunk_c = __popcll((long long)kept);
+			if (keep)
+				S.perm[__builtin_amdgcn_mbcnt_hi((u32)(kept >> 32), __builtin_amdgcn_mbcnt_lo((u32)kept, 0u))] = (unsigned char)lane_id;
+			ARKS_WAVE_SYNC();
+			const bool have = lane_id < nchunk_c;
+			rorig = have ? (int)S.perm[lane_id] : 0;
+			const int sel = rorig << 2;
+			wo = ((u64)(u32)__builtin_amdgcn_ds_bpermute(sel, (int)(u32)(wo >> 32)) << 32) |
+			     (u64)(u32)__builtin_amdgcn_ds_bpermute(sel, (int)(u32)wo);
+			wcnt = have ? __builtin_amdgcn_ds_bpermute(sel, wcnt) : 0;
+			rl = have ? __builtin_amdgcn_ds_bpermute(sel, rl) : 0;
+			gexo = __builtin_amdgcn_ds_bpermute(sel, gex);
+			may_n = have && __builtin_amdgcn_ds_bpermute(sel, (int)may_n) != 0;
+			nwin_l = rl - k + 1;
+			G = have && nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
+			gex = wave_incl_scan_i32(G) - G;
+			pos = (u64)(u32)(wave_incl_scan_i32(wcnt) - wcnt); // (lane nchunk_c: the words of all of them)
+			ARKS_WAVE_SYNC(); // (S.perm is rewritten by the next chunk)
+		}
+		// reads of the chunk that may hold an invalid base: only a tile with one of them fetches its N masks (a
+		// third of the read stream, and zero for > 98 % of the reads)
+		const u64 nreads_mask = __ballot(may_n);
 		// reads beyond kSW words (512 bases) do not enter a tile: the per-read counters hold 10-bit fields
-		const u64 longmask = __ballot(lane_id < nchunk && wo_next - wo > (u64)kSW);
+		const u64 longmask = __ballot(lane_id < nchunk_c && wcnt > kSW);
 		int cur = 0;
-		while (cur < nchunk) {
+		while (cur < nchunk_c) {
 			int lane = lane_id;
 			asm volatile("" : "+v"(lane));
 			// ---- S0: tile = reads [cur, nxt) ---------------------------------------------------------
-			const u64 base_w = lane_value_u64(wo, cur);
+			const u64 base_w = lane_value_u64(pos, cur);
 			const int gbase = __builtin_amdgcn_readlane(gex, cur);
 			const u64 lm = longmask & (~0ull << cur);
 			const int limit = lm ? __ffsll((long long)lm) - 1 : 64; // the first long read from cur on
 			const u64 fit = __ballot(
-			    lane > cur && lane <= nchunk && lane <= limit && wo - base_w <= (u64)sTW && lane - cur <= sTR &&
+			    lane > cur && lane <= nchunk_c && lane <= limit && pos - base_w <= (u64)sTW && lane - cur <= sTR &&
 			    gex - gbase <= sNH);
 			if (fit == 0) { // a single read beyond the tile (or with more seeds than lanes): general kernels
 				if (lane == cur) {
 					if (rl < 0)
-						put_none<RAW>(out_conreci, c0 + cur);
-					else if (wo_next - wo <= (u64)kSW)
-						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)(c0 + cur);
+						put_none<RAW>(out_conreci, c0 + rorig);
+					else if (wcnt <= kSW)
+						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)(c0 + rorig);
 					else
-						queue[atomicAdd(queue_count, 1u)] = (u32)(c0 + cur);
+						queue[atomicAdd(queue_count, 1u)] = (u32)(c0 + rorig);
 				}
 				cur++;
 				continue;
 			}
 			const int nxt = 63 - __clzll((long long)fit);
 			const int nr = nxt - cur;
-			const int tw = (int)(lane_value_u64(wo, nxt) - base_w);
+			const int tw = (int)(lane_value_u64(pos, nxt) - base_w);
 			const int nh = __builtin_amdgcn_readlane(gex, nxt) - gbase;
 			// ---- S1: words, metadata, seeds ----------------------------------------------------------
 			// (wave-uniform) does a read of the tile hold an invalid base?  nr <= 16 reads from cur on
@@ -2037,21 +2102,31 @@ map_reads_s_kernel(
 			{
 				u64 c_in = 0, c_pad = 0;
 				u32 m_in = 0, m_pad = 0;
-				if (REMOTE && seed_slot && lane < nh)
-					slot_pref = seed_slot[soff0 + (long)(gbase + lane)];
-				if (lane < tw) {
-					c_in = codes[base_w + (u64)lane];
-					if (want_nm)
-						m_in = nmask[base_w + (u64)lane];
-				}
-				if (lane < 4) { // the windows of the last words read past the tile
-					c_pad = codes[base_w + (u64)(tw + lane)];
-					if (want_nm)
-						m_pad = nmask[base_w + (u64)(tw + lane)];
+				// (reads left out: the tile's words are not one stretch of the batch's -- the loads wait for the reads' lanes
+				// to say where each word comes from, below)
+				const bool gathered = kSkipDead && skip_dead;
+				if (!gathered) {
+					if (REMOTE && seed_slot && lane < nh)
+						slot_pref = seed_slot[soff0 + (long)(gbase + lane)];
+					if (lane < tw) {
+						c_in = codes[base_w + (u64)lane];
+						if (want_nm)
+							m_in = nmask[base_w + (u64)lane];
+					}
+					if (lane < 4) { // the windows of the last words read past the tile
+						c_pad = codes[base_w + (u64)(tw + lane)];
+						if (want_nm)
+							m_pad = nmask[base_w + (u64)(tw + lane)];
+					}
 				}
 				if (lane >= cur && lane < nxt) {
 					const int j = lane - cur;
-					const int w0 = (int)(wo - base_w), w1 = (int)(wo_next - base_w);
+					const int w0 = (int)(pos - base_w), w1 = w0 + wcnt;
+					if (kSkipDead) {
+						S.wbase[j] = wo - (u64)w0;
+						S.sbase[j] = gexo - (gex - gbase);
+						S.rorig[j] = (unsigned char)rorig;
+					}
 					const int rs = w0 * 32;
 					const int rend = rl > 0 ? rs + rl : 0;
 					S.rstart[j] = rs;
@@ -2092,6 +2167,23 @@ map_reads_s_kernel(
 					S.redo2 = z;
 					if (kTwoRound)
 						S.live = z;
+				}
+				if (gathered) {
+					ARKS_WAVE_SYNC();
+					if (REMOTE && seed_slot && lane < nh)
+						slot_pref = seed_slot[soff0 + (long)(S.sbase[S.heads[lane] >> 12] + lane)];
+					if (lane < tw) {
+						const u64 at = S.wbase[S.wmeta[lane] >> 16] + (u64)lane;
+						c_in = codes[at];
+						if (want_nm)
+							m_in = nmask[at];
+					}
+					if (lane < 4) { // (the words behind the tile's last read)
+						const u64 at = S.wbase[nr - 1] + (u64)(tw + lane);
+						c_pad = codes[at];
+						if (want_nm)
+							m_pad = nmask[at];
+					}
 				}
 				asm volatile("" : "+v"(c_in), "+v"(m_in), "+v"(c_pad), "+v"(m_pad), "+v"(slot_pref)); // all loads in flight
 				if (lane < tw) {
@@ -2155,7 +2247,7 @@ map_reads_s_kernel(
 						const mm_t mf = tile_mmer<MM>(S.cw, q), mr = mmer_rc<MM>(mf);
 						rstrand = mf < mr ? 1u : 0u;
 						if (REMOTE) {
-							long si = soff0 + (long)(gbase + lane);
+							long si = soff0 + (long)((kSkipDead && skip_dead ? S.sbase[jh] : gbase) + lane);
 							if (seed_slot)
 								si = slot_pref == ~0u ? -1 : (long)slot_pref;
 							if (si >= 0) {
@@ -2300,7 +2392,7 @@ map_reads_s_kernel(
 			u32 st_a = 0, st_b = 0, st_c = 0;
 			if (lane < nr) {
 				const int j = lane;
-				const long r = c0 + cur + j;
+				const long r = c0 + (kSkipDead && skip_dead ? (int)S.rorig[j] : cur + j);
 				const int L = S.rlen[j];
 				if (L < 0) {
 					put_none<RAW>(out_conreci, r);

@@ -91,6 +91,8 @@ def pmc_traffic(workload):
         f = workload["pairs_per_launch"] / other["workload"]["pairs_per_launch"]
         d = dict(other)
         d["hbm_bytes_per_launch"] = other["hbm_bytes_per_launch"] * f
+        if other.get("hbm_bytes_per_launch_uncalibrated"):
+            d["hbm_bytes_per_launch_uncalibrated"] = other["hbm_bytes_per_launch_uncalibrated"] * f
         if other.get("TCC_MISS_per_launch"):
             d["TCC_MISS_per_launch"] = other["TCC_MISS_per_launch"] * f
         return d, other.get("kernel_build_id") == bid, other["workload"]["pairs_per_launch"]
@@ -637,8 +639,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
                          "traffic": hbm_gb,
-                         "traffic_unit": "GB per launch (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE, mean over the "
-                                         "profiled dispatches)",
+                         "traffic_unit": "GB per launch (rocprofv3 PMC, mean over the profiled dispatches: read requests by "
+                                         "size -- 32/64/128 B x TCC_EA0_RDREQ_* -- + WRITE_SIZE; FETCH_SIZE alone counts "
+                                         "128-byte requests as 64, profiles/r04_fetch_calibration.json)",
+                         "traffic_calibration": traffic.get("traffic_calibration") if traffic else None,
+                         "traffic_uncalibrated": (traffic.get("hbm_bytes_per_launch_uncalibrated", 0) / 1e9 or None)
+                         if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
                          "traffic_build_match": build_match,
                          "traffic_scaled_from_pairs_per_launch": traffic_scaled,

@@ -90,7 +90,7 @@ def test_configs1_at_its_size_against_the_whole_oracle(arks, gpu, oracle):
     ox = oracle.OracleIndex(k).build(oracle.contig_ends(cs))
     del cs, ends
     assert {f: ix.build_stats[f] for f in ox.stats.as_dict()} == ox.stats.as_dict()
-    assert len(ix) == len(ox) > 25_000_000
+    assert len(ix) == len(ox) > 20_000_000
     threads = min(64, len(os.sched_getaffinity(0)))
     n_all, n_chk = 20_000_000, 1_500_000
     batch = synth.make_read_pairs(contigs, n_all, seed=synth.SEED + 1, device="cuda")
