@@ -537,7 +537,18 @@ and_window128(U128 v, int k)
 //      entries are written to `entries`; returns their number, kHnOverflow for more, kHnHeavy when the
 //      table holds the "heavy: ask the fallback table" marker.  Home slots and the capacity are multiples
 //      of 4 (mtab_home): every round trip reads one aligned group of four entries. -------------------
-template <int MM>
+#ifdef ARKS_PROBE16
+constexpr bool kProbe16Everywhere = true;
+#else
+constexpr bool kProbe16Everywhere = false;
+#endif
+// HALF16: two entries (16 bytes, one dwordx4) per round trip instead of the aligned group of four.  A random 16-byte
+// read costs the memory system less than a 32-byte one (profiles/r04j_gather_width2.txt: 4.9e10 against 3.9e10 per
+// second over a 32 GiB table), and at the table's load three probe sequences of four end within two slots; the others
+// find the second half of the group in the L2.  Pays where probing is ALL a kernel does (the owner-side
+// seeds_probe_segs_kernel of the sharded seed table); in the tile kernels, whose probes hide behind the other phases
+// of a tile, it is the same time within the noise (profiles/r04k_ab_probe16.txt; -DARKS_PROBE16 turns it on there).
+template <int MM, bool HALF16 = false>
 __device__ __forceinline__ u32
 probe_minimizer_table(const BIndexView& bx, typename Mmer<MM>::type cm, u64* entries)
 {
@@ -545,6 +556,37 @@ probe_minimizer_table(const BIndexView& bx, typename Mmer<MM>::type cm, u64* ent
 	u64 slot = mtab_home<MM>(cm, bx.mtab_cap);
 	u32 cnt = 0;
 	bool end = false;
+	while ((HALF16 || kProbe16Everywhere) && !end) {
+		const ulonglong2 h = *reinterpret_cast<const ulonglong2*>(bx.mtab + slot);
+		const u64 ev[2] = { h.x, h.y };
+#pragma unroll
+		for (int x = 0; x < 2; ++x) {
+			const u64 e = ev[x];
+			if (end)
+				continue;
+			if (!(e >> 63)) {
+				end = true;
+				continue;
+			}
+			if (((u32)(e >> 32) & kFpMask) != fp)
+				continue;
+			if ((u32)e == kHeavyPos) {
+				cnt = kHnHeavy;
+				end = true;
+				continue;
+			}
+			if (cnt == 0)
+				entries[0] = e;
+			if (cnt == 1)
+				entries[1] = e;
+			cnt = cnt < 2 ? cnt + 1 : kHnOverflow;
+			if (cnt == kHnOverflow)
+				end = true;
+		}
+		slot += 2;
+		if (slot >= bx.mtab_cap)
+			slot = 0;
+	}
 	while (!end) {
 		u64 ev[4];
 #pragma unroll
@@ -2344,7 +2386,13 @@ map_reads_s_kernel(
 						const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
 						// codes | visited, ambig: one 16-byte record; the owner from the table of 32-word blocks (cache
 						// resident), from word_owner only for a block that holds a border of two ends
+#ifdef ARKS_CAL_NO_TREC
+						// (a calibration build, results wrong by design: no text record is fetched -- FETCH_SIZE of the normal
+						// build minus this one's is what the records cost; profiles/tools/traffic_classes.py)
+						const ulonglong2 rec = make_ulonglong2(0ull, 0ull);
+#else
 						const ulonglong2 rec = *reinterpret_cast<const ulonglong2*>(bx.trec + 2 * tw_idx);
+#endif
 						u32 own = bx.owner_blk[tw_idx >> 5];
 						if (own == 0xFFFFFFFFu)
 							own = bx.word_owner[tw_idx];
@@ -2563,7 +2611,7 @@ seeds_probe_segs_kernel(BIndexView bx, ProbeSegs sg)
 	u64 ent[2] = { 0, 0 };
 	u64 a0 = 0, a1 = 0;
 	if (cm != ~0ull) {
-		const u32 cnt = probe_minimizer_table<MM>(bx, (mm_t)cm, ent);
+		const u32 cnt = probe_minimizer_table<MM, true>(bx, (mm_t)cm, ent);
 		if (cnt == kHnOverflow)
 			a0 = kAnsOverflow;
 		else if (cnt == kHnHeavy)

@@ -639,9 +639,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
                          "traffic": hbm_gb,
-                         "traffic_unit": "GB per launch (rocprofv3 PMC, mean over the profiled dispatches: read requests by "
-                                         "size -- 32/64/128 B x TCC_EA0_RDREQ_* -- + WRITE_SIZE; FETCH_SIZE alone counts "
-                                         "128-byte requests as 64, profiles/r04_fetch_calibration.json)",
+                         "traffic_unit": "GB per launch (rocprofv3 PMC, mean over the profiled dispatches: FETCH_SIZE x the "
+                                         "calibrated read factor + WRITE_SIZE; FETCH_SIZE counts a 128-byte request as 64)",
                          "traffic_calibration": traffic.get("traffic_calibration") if traffic else None,
                          "traffic_uncalibrated": (traffic.get("hbm_bytes_per_launch_uncalibrated", 0) / 1e9 or None)
                          if traffic else None,

@@ -8,7 +8,7 @@ PMC_ARGS=${PROF_PMC_ARGS:---steps 2 --warmup 0}
 mkdir -p gpurun_out /tmp/prof_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/kt -o kt -- python bench.py --no-cpu-baseline --no-extras "$@" > gpurun_out/${tag}_bench_under_rocprof.json 2>/tmp/prof_$tag/kt_err.log
 find /tmp/prof_$tag/kt -name '*kernel_stats.csv' -exec cp {} gpurun_out/${tag}_kernel_stats.csv \;
-for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-24)
   rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$tag/$n -o p -- python bench.py --no-cpu-baseline --no-extras "$@" $PMC_ARGS > /dev/null 2>/tmp/prof_$tag/${n}_err.log
   f=$(find /tmp/prof_$tag/$n -name '*counter_collection.csv' | head -1)

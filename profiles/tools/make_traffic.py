@@ -48,20 +48,17 @@ try:
     miss = mean_of(f"gpurun_out/{tag}_pmc_TCC_HIT_sum_TCC_MISS_sum.csv", "TCC_MISS_sum")
 except OSError:
     miss = None
-# read requests by size (one pass of four TCC counters): what the L2s asked of the fabric, byte for byte.  FETCH_SIZE
-# tallies every request at 64 bytes on gfx950 -- 128-byte requests (two adjacent lines: 8- and 16-byte-per-lane
-# streams, runs of text records) count half, as profiles/tools/fetch_calib.hip shows on known byte counts
-# (profiles/r04_fetch_calibration.json); 32-byte probes cost a 64-byte request each and are counted as such.
-rq = f"gpurun_out/{tag}_pmc_TCC_EA0_RDREQ_sum_TCC_EA.csv"
-by_size = None
+# FETCH_SIZE is 64 B x fabric read requests on gfx950, and a request for both sectors of a 128-byte L2 line is ONE
+# request: streams of >= 8 B per lane and half of the text-record runs are counted at half their bytes.  The
+# correction is per access class (profiles/tools/traffic_classes.py: three builds of the kernel under the counter,
+# factors from known byte counts in profiles/r04_fetch_calibration.json) and comes out as one factor for this
+# kernel on this workload's kind of reads.
+cal, factor = None, 1.0
 try:
-    r32, r64, r128, rall = (mean_of(rq, "TCC_EA0_RDREQ_32B_sum"), mean_of(rq, "TCC_EA0_RDREQ_64B_sum"),
-                            mean_of(rq, "TCC_EA0_RDREQ_128B_sum"), mean_of(rq, "TCC_EA0_RDREQ_sum"))
-    if r128 is not None and rall:
-        by_size = {"requests": rall, "requests_32B": r32 or 0.0, "requests_64B": r64 or 0.0, "requests_128B": r128,
-                   "read_bytes": 32.0 * (r32 or 0.0) + 64.0 * (r64 or 0.0) + 128.0 * r128}
-except OSError:
-    pass
+    cal = json.load(open(os.path.join("profiles", "r04_traffic_classes.json")))
+    factor = float(cal["read_factor_corrected_over_FETCH_SIZE"])
+except (OSError, KeyError, ValueError):
+    cal = None
 wk = {"draft_mbp": a.draft_mbp, "pairs_per_launch": min(a.chunk, a.pairs), "k": a.k}
 if a.repeats:
     wk["repeats"] = True
@@ -69,14 +66,15 @@ out = {"workload": wk,
        "kernel_build_id": bench.kernel_build_id(),
        "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
        "hbm_bytes_per_launch_uncalibrated": (f + w) * 1024.0,
-       "hbm_bytes_per_launch": ((by_size["read_bytes"] if by_size else f * 1024.0) + w * 1024.0),
-       "read_requests_by_size": by_size,
+       "hbm_bytes_per_launch": (f * factor + w) * 1024.0,
        "traffic_calibration": {
-           "source": "profiles/r04_fetch_calibration.json (profiles/tools/fetch_calib.hip + a build of the hot kernel without "
-                     "probes, known byte counts against rocprofv3)",
-           "reads": ("32 B x TCC_EA0_RDREQ_32B + 64 B x TCC_EA0_RDREQ_64B + 128 B x TCC_EA0_RDREQ_128B per launch"
-                     if by_size else "FETCH_SIZE x 1 (the by-size counters were not collected)"),
-           "FETCH_SIZE_over_read_bytes": (f * 1024.0 / by_size["read_bytes"]) if by_size else None,
+           "read_factor": factor,
+           "source": ("profiles/r04_traffic_classes.json (per-pair bytes by class: " +
+                      json.dumps({k: round(v, 1) for k, v in cal["per_pair_bytes_corrected"].items()}) +
+                      " corrected, " + json.dumps({k: round(v, 1) for k, v in cal["per_pair_bytes_counted"].items()}) +
+                      " as FETCH_SIZE counts them); class factors from profiles/r04_fetch_calibration.json, "
+                      "profiles/r04j_gather_width2.txt") if cal else "none found: FETCH_SIZE x 1",
+           "reads": "FETCH_SIZE x read_factor (the read stream at its known size, 32-byte probes x 1, runs of text records x 4/3)",
            "writes": "WRITE_SIZE x 1 (coalesced 4-byte stores: exact in the calibration)"},
        "TCC_MISS_per_launch": miss,
        "dispatches_profiled": dispatches_of(f"gpurun_out/{tag}_pmc_FETCH_SIZE.csv", "FETCH_SIZE"),
