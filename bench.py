@@ -134,6 +134,23 @@ def cpu_topology():
     return model, sockets
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cfs quota), None = no limit.
+    The GPU boxes of this pool show 256 logical CPUs and allow 16 (cpu.max 1600000 100000,
+    profiles/r04n_cpu_diag.txt): more busy threads than that are throttled, not run."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 # ---- workload ------------------------------------------------------------------------------------
 
 N_BLOCKS = 40          # the read set is generated in this many blocks (500 M pairs: 12.5 M each)
@@ -290,6 +307,10 @@ def cpu_baseline(wl, dev, local, log, sub_mbp=50.0):
     model, sockets = cpu_topology()
     sock = sorted(sockets)[0]
     cores = sockets[sock]
+    quota = cpu_quota()
+    if quota is not None and quota < len(cores):
+        # the container's CPU quota is what the "socket" leg can really use: that many threads, one per core
+        cores = cores[: max(1, int(quota))]
     saved = os.sched_getaffinity(0)
     os.sched_setaffinity(0, cores)             # OpenMP workers are created after this and inherit it
     try:
@@ -314,10 +335,11 @@ def cpu_baseline(wl, dev, local, log, sub_mbp=50.0):
     what = (f"{n_same} pairs ({st1['windows']} windows) of the workload's shape drawn from the first "
             f"{acc / 1e6:.0f} Mbp of the draft")
     out = {"value": st1["windows"] / dts_same, "unit": "k-mers/s", "cores": len(cores), "kind": "port",
-           "cpu_model": model, "sockets_visible": len(sockets),
+           "cpu_model": model, "sockets_visible": len(sockets), "cpu_quota_cpus": quota,
            "physical_cores_visible": sum(len(v) for v in sockets.values()),
            "sample": f"{what}, {dts_same:.2f}s (best of 3), OpenMP {len(cores)} threads pinned one per physical core "
-                     f"of socket {sock}; oracle index = the ends of those contigs ({len(ox)} keys, host RAM)",
+                     f"of socket {sock}" + (f" (the container's CPU quota is {quota:g} CPUs: as many threads as it can run)"
+                                            if quota is not None else "") + f"; oracle index = the ends of those contigs ({len(ox)} keys, host RAM)",
            "t1": {"value": st1["windows"] / dt1, "unit": "k-mers/s", "cores": 1,
                   "sample": f"the same {what}, {dt1:.1f}s"},
            "scaling_over_t1": (st1["windows"] / dts_same) / (st1["windows"] / dt1),
@@ -402,6 +424,9 @@ def end_to_end_files(wl, dev, log, sub_mbp=20.0, n_pairs=2_000_000, threads=16):
         # the CPU port
         model, sockets = cpu_topology()
         cores = sockets[sorted(sockets)[0]]
+        quota = cpu_quota()
+        if quota is not None and quota < len(cores):
+            cores = cores[: max(1, int(quota))]        # (what the container may really run at once)
         saved = os.sched_getaffinity(0)
         os.sched_setaffinity(0, cores)
         try:
