@@ -1986,7 +1986,17 @@ map_reads_s_kernel(
 	// and it is settled per chunk, before the tiles are made; the tiles then hold the other reads only (half as many
 	// tiles).  Not when the index holds quirk images: a palindromic window's key is not its sequence's, the slow
 	// kernel decides those and finds them through the staged words (below).
+	// Without REMOTE the same is done with probes of the kernel's own (ARKS_SKIP_DEAD_FUSED): per chunk, every read's
+	// FIRST seeds -- as many as it takes for "none of them has an entry" to settle the vote, the rule of the two-round
+	// S2 above: one of two for a 128-base read at k = 60 and j = 0.55, two of three for a 151-base one -- are made
+	// from the batch's words and probed; a read all of whose first seeds are absent is settled (result 0), the others
+	// go into tiles, where every seed is probed as before (the first ones a second time: cache hits).  An absent
+	// read costs its first probes and no tile; the dependent round trip is paid once per chunk, not per tile.
+#ifdef ARKS_SKIP_DEAD_FUSED
+	constexpr bool kSkipDead = !STATS && !RAW;
+#else
 	constexpr bool kSkipDead = REMOTE && !STATS && !RAW;
+#endif
 	const bool skip_dead = kSkipDead && !(bx.has_img && !(k & 1));
 	if (STATS && lane_id < 8)
 		S.wstats[lane_id] = 0;
@@ -2059,7 +2069,39 @@ map_reads_s_kernel(
 		int nchunk_c = nchunk;
 		if (kSkipDead && skip_dead) {
 			bool keep = lane_id < nchunk && rl >= 0 && G > 0;
-			if (keep && G <= 3) {
+			if (!REMOTE) {
+				if (keep) {
+					// g1 = the read's first-round seeds (see kTwoRound): with all of them absent the windows behind them cannot
+					// reach j_index (the float test errs to the safe side)
+					int g1 = 1;
+					while (g1 < G && !((float)(nwin_l - g1 * w) * 1.0001f < jf * (float)nwin_l))
+						++g1;
+					if (g1 <= 2) { // (more: the read is kept unseen)
+						bool any = false;
+#pragma unroll
+						for (int gi = 0; gi < 2; ++gi)
+							if (gi < g1) {
+								int q = (gi + 1) * w - 1;
+								q = q < nwin_l - 1 ? q : nwin_l - 1;
+								const u64 at = wo * 32ull + (u64)q;
+								bool has_n = false;
+								if (may_n) { // (a seed that holds an invalid base has no entries)
+									const u32* nm = nmask + (at >> 5);
+									const u64 two = ((u64)nm[0] << 32) | (u64)nm[1];
+									has_n = ((two << (at & 31)) >> (64 - MM)) != 0;
+								}
+								if (!has_n) {
+									const mm_t mf = mmer_fw<MM>(codes, at), mr = mmer_rc<MM>(mf);
+									u64 e2[2];
+									any = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, e2) != 0 || any;
+								}
+							}
+#ifndef ARKS_SKIP_DBG_KEEPALL
+						keep = any;
+#endif
+					}
+				}
+			} else if (keep && G <= 3) {
 				// (three seeds at most: a 10x read has two or three; a read with more is kept unseen)
 				u64 a[3] = { 0, 0, 0 };
 				long si[3];
@@ -2092,10 +2134,15 @@ map_reads_s_kernel(
 			const int sel = rorig << 2;
 			wo = ((u64)(u32)__builtin_amdgcn_ds_bpermute(sel, (int)(u32)(wo >> 32)) << 32) |
 			     (u64)(u32)__builtin_amdgcn_ds_bpermute(sel, (int)(u32)wo);
-			wcnt = have ? __builtin_amdgcn_ds_bpermute(sel, wcnt) : 0;
-			rl = have ? __builtin_amdgcn_ds_bpermute(sel, rl) : 0;
+			// (every lane takes part in every permute: a lane that is switched off hands out zeros, and the lanes behind the
+			// reads that stay are exactly the sources of the reads that move up)
+			const int p_wcnt = __builtin_amdgcn_ds_bpermute(sel, wcnt);
+			const int p_rl = __builtin_amdgcn_ds_bpermute(sel, rl);
+			const int p_mn = __builtin_amdgcn_ds_bpermute(sel, (int)may_n);
 			gexo = __builtin_amdgcn_ds_bpermute(sel, gex);
-			may_n = have && __builtin_amdgcn_ds_bpermute(sel, (int)may_n) != 0;
+			wcnt = have ? p_wcnt : 0;
+			rl = have ? p_rl : 0;
+			may_n = have && p_mn != 0;
 			nwin_l = rl - k + 1;
 			G = have && nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
 			gex = wave_incl_scan_i32(G) - G;

@@ -249,6 +249,12 @@ class Workload:
         elapsed = time.perf_counter() - t0
         launch_ms = [a.elapsed_time(b) for row in ev for a, b in row]
         st = dict(zip(STAT_NAMES, stats.cpu().tolist()))
+        # the timed passes run the kernels WITHOUT the -v counters (another instantiation, with shortcuts of its own); the
+        # IndexMap accumulated over warmup + 1 + steps identical passes: every count must be that many times the
+        # counters pass's -- i.e. a multiple -- and the counts must add up to passes x the stored pairs
+        passes = warmup + 1 + steps
+        t = self.imap.triples()
+        self.timed_path_parity = bool((t[:, 2] % passes == 0).all() and int(t[:, 2].sum()) == passes * int(stored.item()))
         return elapsed, launch_ms, st, int(stored.item())
 
 
@@ -690,6 +696,7 @@ def main():
                          "kernel_ms": kernel_ms, "launches_timed": len(launch_ms),
                          "kernel_ms_per_20M_pairs": kernel_ms * 20_000_000 / max(1, wl.pairs_per_launch)},
             "counters": st_job, "stored_pairs": stored_job,
+            "timed_path_parity": wl.timed_path_parity,   # (rank 0's: the passes without counters stored what the pass with them did)
         }
         if cpu_leg:
             cb, parity = cpu_baseline(wl, dev, local, log)
@@ -717,6 +724,7 @@ def main():
         print(json.dumps(out), flush=True)
         if cpu_leg:
             assert out["sample_parity"], "GPU results differ from the CPU oracle on the sample"
+            assert out["timed_path_parity"], "the timed passes (kernels without counters) stored other pairs than the counters pass"
         if "from_fq_gz" in out.get("end_to_end", {}):
             e2e = out["end_to_end"]["from_fq_gz"]
             assert e2e["gpu_cli"]["stored_pairs"] < 0 or e2e["same_stored_pairs"], \
@@ -851,6 +859,10 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
+    # the timed passes run the kernels without counters (dead reads settled per chunk: a path of its own): every
+    # IndexMap count must be a multiple of the number of identical passes
+    passes = args.warmup + 1 + args.steps
+    timed_parity = all(bool((im.triples()[:, 2] % passes == 0).all()) for im in imaps)
     st_job = dict(zip(STAT_NAMES, [int(x) for x in tot.tolist()]))
     windows = st_job["windows"]
     if rank == 0:
@@ -875,7 +887,7 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
                        "last_batch_of_rank0": ex,
                        "parallelism": f"seed table hash-sharded x{n_ranks}, reads dealt to the ranks in blocks, seeds "
                                       "routed to their owners and back (arks_exchange)"},
-            "counters": st_job,
+            "counters": st_job, "timed_path_parity": timed_parity,
             "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                          "traffic": None, "kernel": "whole step (bucket, exchange, probe, map_reads_s_kernel<REMOTE>, pair rule)",
                          "alg_achieved": windows * b_alg / (ms * 1e-3) / 1e9 / world,
@@ -884,6 +896,7 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
     for x in xs:
         if x is not None:
             x.close()
+    assert timed_parity, "the timed passes (kernels without counters) stored other pairs than the counters pass"
     if world > 1:
         dist.destroy_process_group()
 

@@ -67,6 +67,8 @@ while time.time() < t_end:
         bad = [i for i, (a, b) in enumerate(zip(got.tolist(), want)) if a != b]
         assert not bad, (seed - 1, k, j, bad[:5], [len(reads[i]) for i in bad[:5]])
         assert gst == st.as_dict(), (seed - 1, k, j, gst, st.as_dict())
+        # the kernels WITHOUT counters are instantiations of their own (shortcuts for reads without seed entries)
+        assert ix.map_reads(reads, j).tolist() == want, (seed - 1, k, j, "no counters")
     if os.environ.get("FUZZ_SHARDS"):      # the same reads through 2..5 index shards: votes, maximum, j_index test
         n_sh = int(rng.integers(2, 6))
         packed = arcs_amd.PackedReads.from_ascii(reads, device=0)
@@ -102,6 +104,25 @@ while time.time() < t_end:
             bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
             assert not bad, (seed - 1, k, j, n_sh, "seed shards", bad[:5])
             assert dict(zip(("total_valid", "bad", "found", "recorded", "dups", "reads_pass", "reads_fail", "windows"), stats.cpu().tolist())) == st.as_dict(), (seed - 1, k, j, n_sh)
+        if shards[0].kind == 2:
+            # the product path over the same shards: arks_exchange, the ranks of a local group driven by this one thread
+            # (submit per rank, arks_exchange_complete_group), the reads dealt unevenly, with and without counters
+            xs = arcs_amd.SeedExchange.create_local(shards)
+            cuts = sorted(int(x) for x in rng.integers(0, len(reads) + 1, size=n_sh - 1))
+            cuts = [0] + cuts + [len(reads)]
+            parts = [arcs_amd.PackedReads.from_ascii(reads[cuts[r]:cuts[r + 1]], device=0) for r in range(n_sh)]
+            jx = float(rng.choice([0.55, 0.0, 0.3]))
+            want = [ox.best_contig(r, jx) for r in reads]
+            for with_stats in (False, True):
+                sts = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(n_sh)]
+                outs = [xs[r].submit(parts[r], jx, stats=sts[r] if with_stats else None) for r in range(n_sh)]
+                arcs_amd.SeedExchange.complete_group(xs)
+                torch.cuda.synchronize()
+                got = sum([o.cpu().tolist()[:parts[r].n_reads] for r, o in enumerate(outs)], [])
+                bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+                assert not bad, (seed - 1, k, jx, n_sh, "exchange", with_stats, bad[:5])
+            for x in xs:
+                x.close()
         for sh in shards:
             sh.close()
     ix.close()

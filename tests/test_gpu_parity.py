@@ -303,3 +303,49 @@ def test_minimizer_length_variants(arks, gpu, oracle, golden_mini, monkeypatch, 
         assert got.tolist() == want, (k, j)
         assert gst == st.as_dict(), (k, j)
     ix.close()
+
+
+def test_reads_without_seed_entries_in_every_pattern(arks, gpu, oracle, index_layout):
+    """The seed tile kernel over a sharded seed table settles the reads none of whose seeds has an entry before it makes
+    its tiles and moves the others up into their places (a -DARKS_SKIP_DEAD_FUSED build of the library does the same
+    against a whole index).  Chunks of 56 reads with live and dead reads in every arrangement -- runs, alternations,
+    one dead read, dead pairs at either end, random -- with and without the -v counters, against the oracle."""
+    import torch
+    from arcs_amd import synth
+    k, j = 60, 0.55
+    contigs = synth.make_draft(600_000, seed=91, lengths=(20000, 50000, 100000, 30000))
+    cs = synth.contigs_to_strings(contigs)
+    ends = arks.contig_ends(cs)
+    ox = oracle.OracleIndex(k).build(oracle.contig_ends(cs))
+    rng = np.random.default_rng(3)
+
+    def live(n):
+        e = ends[int(rng.integers(0, len(ends)))]
+        a = int(rng.integers(0, len(e) - n))
+        return e[a:a + n]
+
+    def dead(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    pats = [lambda l: (l // 2) % 2 == 0, lambda l: (l // 2) % 2 == 1, lambda l: l >= 28, lambda l: l < 28, lambda l: l != 10,
+            lambda l: l >= 2, lambda l: l < 54, lambda l: l % 2 == 0, lambda l: True, lambda l: False,
+            lambda l: rng.random() < 0.5, lambda l: rng.random() < 0.9, lambda l: rng.random() < 0.1]
+    reads = []
+    for f in pats:
+        for l in range(56):
+            n = (128, 151, 75, 300)[l % 4] if f is pats[-3] else (128 if l % 2 == 0 else 151)
+            reads.append(live(n) if f(l) else dead(n))
+    reads = reads + reads[:31]                      # a last chunk that is not full
+    want = [ox.best_contig(r, j) for r in reads]
+    assert sum(1 for w in want if w) > len(reads) // 3
+    packed = arks.PackedReads.from_ascii(reads, device=gpu)
+    ix = arks.ArksIndex.build(ends, k, device=gpu)
+    st = torch.zeros(8, dtype=torch.int64, device="cuda")
+    assert arks.map_reads_packed(ix, packed, j).cpu().tolist() == want
+    assert arks.map_reads_packed(ix, packed, j, stats=st).cpu().tolist() == want
+    if index_layout != "seeds":
+        return                                      # (only the seed table is sharded)
+    sh = arks.ArksIndex.build_seed_shard(ends, k, 0, 1, device=gpu)
+    x = arks.SeedExchange.create_local([sh])[0]
+    assert x.map_reads(packed, j).cpu().tolist() == want
+    assert x.map_reads(packed, j, stats=st).cpu().tolist() == want
+    x.close()
