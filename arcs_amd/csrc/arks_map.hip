@@ -2077,25 +2077,63 @@ map_reads_s_kernel(
 					while (g1 < G && !((float)(nwin_l - g1 * w) * 1.0001f < jf * (float)nwin_l))
 						++g1;
 					if (g1 <= 2) { // (more: the read is kept unseen)
+						// both seeds' words in flight together, then both probes (an aligned group of four entries each):
+						// two round trips per chunk whatever the read's length
+						bool act[2] = { false, false };
+						u64 at[2] = { 0, 0 };
+						u64 w0[2], w1[2], nm2[2] = { 0, 0 };
+#pragma unroll
+						for (int gi = 0; gi < 2; ++gi) {
+							int q = (gi + 1) * w - 1;
+							q = q < nwin_l - 1 ? q : nwin_l - 1;
+							act[gi] = gi < g1;
+							at[gi] = wo * 32ull + (u64)q;
+							const u64* src = codes + (at[gi] >> 5);
+							w0[gi] = act[gi] ? src[0] : 0ull;
+							w1[gi] = act[gi] ? src[1] : 0ull;
+							if (act[gi] && may_n) { // (a seed that holds an invalid base has no entries)
+								const u32* nm = nmask + (at[gi] >> 5);
+								nm2[gi] = ((u64)nm[0] << 32) | (u64)nm[1];
+							}
+						}
+						mm_t cm[2];
+						u64 slot[2];
+						ulonglong2 h[2][2];
+#pragma unroll
+						for (int gi = 0; gi < 2; ++gi) {
+							const mm_t mf = (mm_t)(funnel_l(w0[gi], w1[gi], (int)(at[gi] & 31) * 2) >> (64 - 2 * MM)), mr = mmer_rc<MM>(mf);
+							cm[gi] = mf < mr ? mf : mr;
+							act[gi] = act[gi] && ((nm2[gi] << (at[gi] & 31)) >> (64 - MM)) == 0;
+							slot[gi] = mtab_home<MM>(cm[gi], bx.mtab_cap);
+							h[gi][0] = make_ulonglong2(0ull, 0ull), h[gi][1] = make_ulonglong2(0ull, 0ull);
+							if (act[gi]) {
+								h[gi][0] = *reinterpret_cast<const ulonglong2*>(bx.mtab + slot[gi]);
+								h[gi][1] = *reinterpret_cast<const ulonglong2*>(bx.mtab + slot[gi] + 2);
+							}
+						}
 						bool any = false;
 #pragma unroll
-						for (int gi = 0; gi < 2; ++gi)
-							if (gi < g1) {
-								int q = (gi + 1) * w - 1;
-								q = q < nwin_l - 1 ? q : nwin_l - 1;
-								const u64 at = wo * 32ull + (u64)q;
-								bool has_n = false;
-								if (may_n) { // (a seed that holds an invalid base has no entries)
-									const u32* nm = nmask + (at >> 5);
-									const u64 two = ((u64)nm[0] << 32) | (u64)nm[1];
-									has_n = ((two << (at & 31)) >> (64 - MM)) != 0;
-								}
-								if (!has_n) {
-									const mm_t mf = mmer_fw<MM>(codes, at), mr = mmer_rc<MM>(mf);
-									u64 e2[2];
-									any = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, e2) != 0 || any;
-								}
+						for (int gi = 0; gi < 2; ++gi) {
+							if (!act[gi])
+								continue;
+							const u32 fp = mmer_fp<MM>(cm[gi]);
+							const u64 e[4] = { h[gi][0].x, h[gi][0].y, h[gi][1].x, h[gi][1].y };
+							bool ended = false, hit = false;
+#pragma unroll
+							for (int x = 0; x < 4; ++x) {
+								if (ended)
+									continue;
+								if (!(e[x] >> 63))
+									ended = true; // an empty slot ends the probe sequence
+								else if (((u32)(e[x] >> 32) & kFpMask) == fp)
+									hit = ended = true; // an entry, or the "heavy" mark
 							}
+							if (!ended) { // (a full group without the m-mer: rare -- the whole sequence)
+								u64 e2[2];
+								hit = probe_minimizer_table<MM>(bx, cm[gi], e2) != 0;
+							}
+							any = any || hit;
+						}
 #ifndef ARKS_SKIP_DBG_KEEPALL
 						keep = any;
 #endif

@@ -68,6 +68,45 @@ struct RankResult
 	std::vector<std::vector<uint64_t>> first;
 };
 
+// The IndexMap entries of several lanes -- each list sorted by (barcode id, conreci), as arks_imap_export_ordered
+// gives them -- into one: counts add up, the first stored pair of an entry is the earliest of the lanes'.
+inline void
+merge_lane_entries(
+    const std::vector<std::vector<uint32_t>>& lt, const std::vector<std::vector<uint64_t>>& lf, std::vector<uint32_t>& triples,
+    std::vector<uint64_t>& first)
+{
+	const size_t L = lt.size();
+	std::vector<size_t> cur(L, 0);
+	size_t total = 0;
+	for (size_t l = 0; l < L; ++l)
+		total += lf[l].size();
+	triples.clear(), first.clear();
+	triples.reserve(total * 3), first.reserve(total);
+	auto key = [&](size_t l) { return ((uint64_t)lt[l][3 * cur[l]] << 32) | (uint64_t)lt[l][3 * cur[l] + 1]; };
+	for (;;) {
+		bool any = false;
+		uint64_t best = 0;
+		for (size_t l = 0; l < L; ++l)
+			if (cur[l] < lf[l].size() && (!any || key(l) < best)) {
+				best = key(l);
+				any = true;
+			}
+		if (!any)
+			break;
+		uint64_t count = 0, fp = ~0ull;
+		for (size_t l = 0; l < L; ++l)
+			if (cur[l] < lf[l].size() && key(l) == best) {
+				count += lt[l][3 * cur[l] + 2];
+				fp = std::min(fp, lf[l][cur[l]]);
+				cur[l]++;
+			}
+		triples.push_back((uint32_t)(best >> 32));
+		triples.push_back((uint32_t)best);
+		triples.push_back((uint32_t)count);
+		first.push_back(fp);
+	}
+}
+
 // rank results <-> a byte stream (the pipe between a worker rank and rank 0)
 struct ByteSink
 {

@@ -80,9 +80,61 @@ rank_result(const std::vector<FileScenario>& files, int rank, int world, size_t 
 	return r;
 }
 
+// `ranks_check lanes <seed>`: merge_lane_entries (the GPU lanes of one process: the same barcode ids, every lane's
+// entries sorted by key) against a fold through std::map
+static int
+check_lanes(unsigned seed)
+{
+	std::mt19937_64 rng(seed);
+	for (int round = 0; round < 200; ++round) {
+		const size_t L = 1 + rng() % 5;
+		std::vector<std::map<uint64_t, std::pair<uint32_t, uint64_t>>> lanes(L);
+		std::map<uint64_t, std::pair<uint64_t, uint64_t>> want;
+		const size_t n = rng() % 400;
+		for (size_t i = 0; i < n; ++i) {
+			const uint64_t key = ((uint64_t)(rng() % 40) << 32) | (uint64_t)(1 + rng() % 12);
+			const uint32_t cnt = 1 + (uint32_t)(rng() % 9);
+			const uint64_t first = rng() % 100000;
+			auto& e = lanes[rng() % L][key];
+			e.second = e.first ? std::min(e.second, first) : first;
+			e.first += cnt;
+			auto& w = want[key];
+			w.second = w.first ? std::min(w.second, first) : first;
+			w.first += cnt;
+		}
+		std::vector<std::vector<uint32_t>> lt(L);
+		std::vector<std::vector<uint64_t>> lf(L);
+		for (size_t l = 0; l < L; ++l)
+			for (const auto& kv : lanes[l]) {
+				lt[l].push_back((uint32_t)(kv.first >> 32)), lt[l].push_back((uint32_t)kv.first), lt[l].push_back(kv.second.first);
+				lf[l].push_back(kv.second.second);
+			}
+		std::vector<uint32_t> triples;
+		std::vector<uint64_t> first;
+		merge_lane_entries(lt, lf, triples, first);
+		if (first.size() != want.size() || triples.size() != 3 * want.size()) {
+			std::printf("lanes: size mismatch in round %d\n", round);
+			return 1;
+		}
+		size_t i = 0;
+		for (const auto& kv : want) {
+			if (triples[3 * i] != (uint32_t)(kv.first >> 32) || triples[3 * i + 1] != (uint32_t)kv.first ||
+			    triples[3 * i + 2] != (uint32_t)kv.second.first || first[i] != kv.second.second) {
+				std::printf("lanes: entry %zu differs in round %d\n", i, round);
+				return 1;
+			}
+			++i;
+		}
+	}
+	std::printf("lanes ok\n");
+	return 0;
+}
+
 int
 main(int argc, char** argv)
 {
+	if (argc == 3 && std::string(argv[1]) == "lanes")
+		return check_lanes((unsigned)std::atoi(argv[2]));
 	const int world = argc > 1 ? std::atoi(argv[1]) : 1;
 	const unsigned seed = argc > 2 ? (unsigned)std::atoi(argv[2]) : 1;
 	const bool fused = argc > 3 && std::atoi(argv[3]) != 0;

@@ -810,8 +810,15 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
     # three streams per rank: two batches in flight (submit n + 1 before complete n), the pair rule on the third
     streams = [[torch.cuda.Stream(dev) for _ in range(3)] for _ in my_ranks]
 
+    serial = os.environ.get("ARKS_BENCH_SHARDED_SERIAL") is not None   # (profiles: one batch at a time, nothing overlaps)
+
     def rank_step(i, st):
-        if xs[i] is not None:
+        if xs[i] is not None and serial:
+            with torch.cuda.stream(streams[i][0]):
+                for l in range(n_launch):
+                    reads, ok, bid = per_rank[i][l] if l < len(per_rank[i]) else (empty, empty_ok, None)
+                    xs[i].map_pairs(reads, j, pair_ok=ok, barcode_id=bid, imap=imaps[i] if bid is not None else None, stats=st)
+        elif xs[i] is not None:
             xs[i].map_pairs_pipelined(per_rank[i], j, streams[i], imap=imaps[i], stats=st, n_calls=n_launch, keep=False)
         else:
             with torch.cuda.stream(streams[i][0]):

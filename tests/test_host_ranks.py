@@ -65,3 +65,11 @@ def test_ranks_merge_like_one_process(ranks_check, seed, fused):
     # multiplicities of the fused mode are the per-file read counts summed; the log names every file once
     assert outs[0].stdout.count("Reading chrom reads") == (10 if fused else 5)
     assert "Stored read pairs: 0\n" in outs[0].stdout   # the empty file
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_lanes_of_one_process_merge_like_a_map(ranks_check, seed):
+    """merge_lane_entries (arcs --ranks N on one file, --index-sharded: the GPU lanes of one process share the barcode
+    ids; each lane's IndexMap entries come sorted by key): counts add, the first stored pair is the earliest"""
+    res = subprocess.run([ranks_check, "lanes", str(seed)], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0 and res.stdout.strip() == "lanes ok", res.stdout + res.stderr
