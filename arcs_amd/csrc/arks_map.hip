@@ -557,6 +557,8 @@ probe_minimizer_table(const BIndexView& bx, typename Mmer<MM>::type cm, u64* ent
 	u32 cnt = 0;
 	bool end = false;
 	while ((HALF16 || kProbe16Everywhere) && !end) {
+		// (a non-temporal load here -- 5.5e10 against 4.9e10 16-byte reads per second in the microbenchmark -- makes the
+		// second half of a group miss as well: 4.6 instead of 3.5 ms per 25 M pairs, profiles/r04x_probe_nt.txt)
 		const ulonglong2 h = *reinterpret_cast<const ulonglong2*>(bx.mtab + slot);
 		const u64 ev[2] = { h.x, h.y };
 #pragma unroll
