@@ -408,7 +408,7 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 	for (const int k : params.k_list) {
 		arks_build_stats st;
 		std::memset(&st, 0, sizeof st);
-		for (int lane = 0; lane < n_lanes; ++lane) {
+		const auto build_lane = [&](int lane) {
 			const int device = (params.device + lane) % std::max(1, ndev);
 			arks_index* idx = nullptr;
 			if (params.index_sharded > 0) {
@@ -418,7 +418,7 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 				if (rc != ARKS_OK)
 					die_arks(rc, "building a shard of the seed table");
 				by_lane[(size_t)lane].push_back(idx);
-				continue;
+				return;
 			}
 			int same = -1; // an earlier lane on the same device: share its replica
 			for (int l2 = 0; l2 < lane && same < 0; ++l2)
@@ -428,7 +428,7 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 				const size_t per_k = (size_t)n_shards, at = by_lane[(size_t)lane].size();
 				for (size_t x = 0; x < per_k; ++x)
 					by_lane[(size_t)lane].push_back(by_lane[(size_t)same][at + x]);
-				continue;
+				return;
 			}
 			if (n_shards > 1) {
 				// --index-shards: N indexes of 1/N of the contigs each (a draft beyond one index's 2^32 text
@@ -440,13 +440,31 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 						die_arks(rc, "building a shard of the contig k-mer index");
 					by_lane[(size_t)lane].push_back(idx);
 				}
-				continue;
+				return;
 			}
 			const int rc = arks_index_build(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(), device,
 			                                params.verbose && lane == 0 ? &st : nullptr);
 			if (rc != ARKS_OK)
 				die_arks(rc, "building the contig k-mer index");
 			by_lane[(size_t)lane].push_back(idx);
+		};
+		// the lanes of one device one after the other (its replicas are shared, its build scratch is one device's),
+		// the devices side by side: eight GPUs build their replicas or shards in the time of one
+		std::map<int, std::vector<int>> lanes_of_device;
+		for (int lane = 0; lane < n_lanes; ++lane)
+			lanes_of_device[(params.device + lane) % std::max(1, ndev)].push_back(lane);
+		if (lanes_of_device.size() == 1) {
+			for (int lane = 0; lane < n_lanes; ++lane)
+				build_lane(lane);
+		} else {
+			std::vector<std::thread> builders;
+			for (const auto& dl : lanes_of_device)
+				builders.emplace_back([&build_lane, &dl] {
+					for (const int lane : dl.second)
+						build_lane(lane);
+				});
+			for (std::thread& t : builders)
+				t.join();
 		}
 		if (n_shards > 1) {
 			if (params.verbose)
