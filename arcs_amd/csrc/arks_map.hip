@@ -2587,6 +2587,21 @@ map_reads_s_kernel(
 					// locus, the error-free ones are finished here instead of in the medium kernel.)
 					if (medium && nvalid > 0 && rec_a + amb_a + rec_b + amb_b == nvalid)
 						medium = false;
+					if (medium && !STATS && !RAW) {
+						// ... or the vote is settled by the windows that WERE found.  u windows are open; each could still turn
+						// out to belong to any contig end.  If the leader among the found ones passes j_index on its own and
+						// leads the other by more than u, it is the answer whatever the open windows hold (Arcs.cpp:998-1010:
+						// the count only grows, nobody can catch up or tie); if even leader + u does not pass, the answer is 0.
+						const int u = nvalid - (rec_a + amb_a + rec_b + amb_b);
+						int lead, other;
+						if (rec_a > 0 && rec_b > 0 && own_a == own_b)
+							lead = rec_a + rec_b, other = 0;
+						else
+							lead = rec_a > rec_b ? rec_a : rec_b, other = rec_a > rec_b ? rec_b : rec_a;
+						const double tot = (double)(L - k + 1);
+						if ((lead > other + u && (double)lead / tot > j_index) || !((double)(lead + u) / tot > j_index))
+							medium = false;
+					}
 					// matches on one diagonal that belong to different contig ends: general path
 					medium = medium || (rec_a && S.rmax[j][0] != own_a) || (rec_b && S.rmax[j][1] != own_b);
 					if (medium) {
