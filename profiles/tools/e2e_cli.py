@@ -56,7 +56,8 @@ for ext in (EXTS.split(",") if EXTS else (".fq", ".fq.gz", ".bgzf.fq.gz") if os.
     files = [f"{tmp}/r{fi}{ext}" for fi in range(NF)] * int(os.environ.get("E2E_REPEAT", 1))
     for t in [int(x) for x in os.environ.get('E2E_THREADS', '1,4,16').split(',')]:
         args = PREFIX + [exe, "--arks", "-f", f"{tmp}/draft.fa", "-u", f"{tmp}/mult.tsv", "-k", "60", "-j", "0.55", "-c", "5",
-                "-m", "50-10000", "-e", "30000", "-z", "500", "-t", str(t), "-b", f"{tmp}/out_{t}{ext.replace('.', '_')}"] + files
+                "-m", "50-10000", "-e", "30000", "-z", "500", "-t", str(t), "-b", f"{tmp}/out_{t}{ext.replace('.', '_')}"] + \
+            os.environ.get("E2E_ARGS", "").split() + files
         t1 = time.time()
         out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, ARKS_TIMING='1'))
         dt = time.time() - t1
