@@ -2203,8 +2203,11 @@ map_reads_s_kernel(
 						a[gi] = ans[2 * si[gi]];
 				keep = (a[0] | a[1] | a[2]) != 0; // (an entry, or the "heavy" / "more than two" marks)
 			}
-			if (lane_id < nchunk && !keep)
-				put_none<RAW>(out_conreci, c0 + lane_id);
+			if (lane_id < nchunk && !keep) {
+				int cl = lane_id; // (opaque: an address made of the lane number is otherwise formed once per kernel and kept)
+				asm volatile("" : "+v"(cl));
+				put_none<RAW>(out_conreci, c0 + cl);
+			}
 			const u64 kept = __ballot(keep);
 			nchunk_c = __popcll((long long)kept);
 			if (keep)
@@ -2249,12 +2252,15 @@ map_reads_s_kernel(
 			    gex - gbase <= sNH);
 			if (fit == 0) { // a single read beyond the tile (or with more seeds than lanes): general kernels
 				if (lane == cur) {
+					// (lane == cur: without reads left out the read's number is c0 + cur, a scalar -- written with the lane
+					// number it would be an address the compiler forms once per kernel and keeps, or spills)
+					const long r = c0 + (kSkipDead && skip_dead ? rorig : cur);
 					if (rl < 0)
-						put_none<RAW>(out_conreci, c0 + rorig);
+						put_none<RAW>(out_conreci, r);
 					else if (wcnt <= kSW)
-						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)(c0 + rorig);
+						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)r;
 					else
-						queue[atomicAdd(queue_count, 1u)] = (u32)(c0 + rorig);
+						queue[atomicAdd(queue_count, 1u)] = (u32)r;
 				}
 				cur++;
 				continue;
@@ -2508,27 +2514,51 @@ map_reads_s_kernel(
 			for (int d = 0; d < (any_b ? 2 : 1); ++d) {
 				// S4: lanes = staging slots (one round trip: text, visited, ambiguous, owner words)
 				const int ns = tw + nr;
-				for (int sl = lane; sl < ns; sl += 64) {
-					const int j = S.sread[sl];
-					if (S.pdiag[j][d] >> 41) {
-						const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
-						// codes | visited, ambig: one 16-byte record; the owner from the table of 32-word blocks (cache
-						// resident), from word_owner only for a block that holds a border of two ends
-#ifdef ARKS_CAL_NO_TREC
-						// (a calibration build, results wrong by design: no text record is fetched -- FETCH_SIZE of the normal
-						// build minus this one's is what the records cost; profiles/tools/traffic_classes.py)
-						const ulonglong2 rec = make_ulonglong2(0ull, 0ull);
-#else
-						const ulonglong2 rec = *reinterpret_cast<const ulonglong2*>(bx.trec + 2 * tw_idx);
+				// A tile of 10x reads has ~63 words + 14 reads = 77 staging slots: more than lanes.  As a loop (until round 4)
+				// the second batch of slots was loaded only after the first was stored -- a dependent round trip more per
+				// tile and diagonal, and the kernel's time is the sum of those: both batches are requested
+				// before either is used (-4.3 %, profiles/r05f_ab_s4.txt).  codes | visited, ambig: one 16-byte record; the
+				// owner from the table of 32-word blocks (cache resident), from word_owner only for a block that holds a
+				// border of two ends.  (ARKS_CAL_NO_TREC: a calibration build, results wrong by design -- no text record is
+				// fetched: FETCH_SIZE of the normal build minus this one's is what the records cost;
+				// profiles/tools/traffic_classes.py)
+				{
+					static_assert(sSlots <= 128, "two slots per lane");
+					ulonglong2 rec[2];
+					u32 own[2];
+					u32 twi[2]; // (text words: 2^32 positions / 32)
+					bool act[2];
+#pragma unroll
+					for (int u = 0; u < 2; ++u) {
+						const int sl = lane + 64 * u;
+						act[u] = sl < ns;
+						rec[u] = make_ulonglong2(0ull, 0ull);
+						own[u] = 0;
+						twi[u] = 0;
+						if (act[u]) {
+							const int j = S.sread[sl];
+							act[u] = (S.pdiag[j][d] >> 41) != 0;
+							twi[u] = S.tfirst[j][d] + (u32)(sl - ((S.rstart[j] >> 5) + j));
+						}
+						if (act[u]) {
+#ifndef ARKS_CAL_NO_TREC
+							rec[u] = *reinterpret_cast<const ulonglong2*>(bx.trec + 2 * (u64)twi[u]);
 #endif
-						u32 own = bx.owner_blk[tw_idx >> 5];
-						if (own == 0xFFFFFFFFu)
-							own = bx.word_owner[tw_idx];
-						S.tcodes[sl] = rec.x;
-						S.tvis[sl] = (u32)rec.y;
-						S.tamb[sl] = (u32)(rec.y >> 32);
-						S.town[sl] = own;
+							own[u] = bx.owner_blk[twi[u] >> 5];
+						}
 					}
+					asm volatile("" : "+v"(rec[0].x), "+v"(rec[1].x), "+v"(own[0]), "+v"(own[1])); // all four loads in flight
+#pragma unroll
+					for (int u = 0; u < 2; ++u)
+						if (act[u]) {
+							if (own[u] == 0xFFFFFFFFu)
+								own[u] = bx.word_owner[twi[u]];
+							const int sl = lane + 64 * u;
+							S.tcodes[sl] = rec[u].x;
+							S.tvis[sl] = (u32)rec[u].y;
+							S.tamb[sl] = (u32)(rec[u].y >> 32);
+							S.town[sl] = own[u];
+						}
 				}
 				if (lane < 8) // the spans of the last words read past the tile: no mismatch there
 					S.mm32[tw + lane] = 0u;
