@@ -2046,16 +2046,11 @@ map_reads_s_kernel(
 	u32* const work_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kWorkCtrOffset);
 	u32 ctr = blockIdx.x & (u32)(kCounters - 1), misses = 0;
 	bool first_grab = true;
-#ifdef ARKS_PREFETCH_GRAB
-	// the NEXT chunk's number is asked for while this chunk is worked on (lane 0 holds the counter's old value until the
-	// loop comes round): the atomic's round trip leaves the chain grab -> metadata -> words -> probes -> text that every
-	// chunk walks.  A wave's last prefetched grab is wasted (the counters only have to overshoot).
-	u32 pre = 0;
-	bool have_pre = false;
-#endif
 	for (;;) {
 		// ---- the next chunk: the first one is the wave's own (its block index), later ones come from the
-		//      interleaved counters (see map_reads_b_kernel) -------------------------------------------
+		//      interleaved counters (see map_reads_b_kernel).  (Asking for the NEXT chunk's number while this one is
+		//      worked on -- the atomic's round trip out of the chain -- was tried in round 4: no gain,
+		//      profiles/r06g_ab_grab_prefetch.txt) -------------------------------------------
 		long c0;
 		if (first_grab) {
 			c0 = (long)blockIdx.x * sChunk;
@@ -2064,12 +2059,6 @@ map_reads_s_kernel(
 				break;
 		} else {
 			u32 cnt = 0;
-#ifdef ARKS_PREFETCH_GRAB
-			if (have_pre) {
-				cnt = pre;
-				have_pre = false;
-			} else
-#endif
 			if (lane_id == 0)
 				cnt = atomicAdd(work_ctr + ctr * kCounterStride, 1u);
 			cnt = (u32)__builtin_amdgcn_readfirstlane((int)cnt);
@@ -2082,11 +2071,6 @@ map_reads_s_kernel(
 			}
 			misses = 0;
 		}
-#ifdef ARKS_PREFETCH_GRAB
-		if (lane_id == 0)
-			pre = atomicAdd(work_ctr + ctr * kCounterStride, 1u);
-		have_pre = true;
-#endif
 		const int nchunk = (int)((c0 + sChunk < n_reads ? c0 + sChunk : n_reads) - c0);
 		// lane l holds read c0 + l: first word, length (-1 = not evaluated), seeds; lane nchunk the end offset
 		u64 wo = 0;
@@ -2119,11 +2103,6 @@ map_reads_s_kernel(
 		// index of the chunk's first seed in `ans` / `seed_slot`
 		const long soff0 = REMOTE ? (chunk_off ? (long)chunk_off[c0 / sChunk] : seed_off[c0]) : 0;
 		int nwin_l = rl - k + 1;
-#ifdef ARKS_PREFETCH_GRAB
-		// (the counter's old value has come back with the chunk's metadata: from lane 0's register into a scalar, so
-		// that no vector register is held over the tile loop)
-		pre = (u32)__builtin_amdgcn_readfirstlane((int)pre);
-#endif
 		int G = nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
 		int gex = wave_incl_scan_i32(G) - G; // seeds of the chunk's reads before this one
 		int wcnt = (int)(wave_next_u64(wo) - wo); // words of the read (garbage beyond the chunk: not looked at)
