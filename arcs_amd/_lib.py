@@ -49,6 +49,7 @@ SYMBOLS = {
     "arks_index_build": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, C.POINTER(BuildStats)]),
     "arks_shard_of_ends": (_I, [_VP, _I64, _I, _VP]),
     "arks_index_build_shard": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I]),
+    "arks_index_build_shard_stats": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I, C.POINTER(BuildStats)]),
     "arks_index_build_seed_shard": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I, C.POINTER(BuildStats)]),
     "arks_index_seed_ranks": (_I, [_VP]),
     "arks_seed_counts_device": (_I, [_VP, _VP, _VP, _I64, _VP, _VP]),

@@ -103,16 +103,19 @@ class ArksIndex:
         return cls(h, k, device, st.as_dict() if want_stats else None)
 
     @classmethod
-    def build_shard(cls, ends, k, shard, n_shards, device=0):
-        """arks_index_build_shard: the k-mers of the ends that shard_of_ends gives to `shard`, keys
-        shared with any other end of the list read 0; every shard is given the same list"""
+    def build_shard(cls, ends, k, shard, n_shards, device=0, want_stats=False):
+        """arks_index_build_shard(_stats): the k-mers of the ends that shard_of_ends gives to `shard`, keys
+        shared with any other end of the list read 0; every shard is given the same list.  want_stats: the
+        shard's share of the build counters (their sums over the shards are arks_index_build's)"""
         data, offsets, lens = _concat(ends)
         data = np.concatenate([data, np.zeros(1, np.uint8)])
         h = C.c_void_p()
-        rc = lib().arks_index_build_shard(C.byref(h), k, data.ctypes.data, offsets.ctypes.data,
-                                          lens.ctypes.data, len(lens), shard, n_shards, device)
-        check(rc, "arks_index_build_shard")
-        return cls(h, k, device, None)
+        st = BuildStats()
+        rc = lib().arks_index_build_shard_stats(C.byref(h), k, data.ctypes.data, offsets.ctypes.data,
+                                                lens.ctypes.data, len(lens), shard, n_shards, device,
+                                                C.byref(st) if want_stats else None)
+        check(rc, "arks_index_build_shard_stats")
+        return cls(h, k, device, st.as_dict() if want_stats else None)
 
     @classmethod
     def build_seed_shard(cls, ends, k, rank, n_ranks, device=0, want_stats=False):

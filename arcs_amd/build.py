@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SOURCES = [os.path.join(HERE, "csrc", f) for f in ("arks_build.hip", "arks_map.hip", "arks_shard.hip", "arks_imap.hip", "arks_capi.hip")]
-HEADERS = [os.path.join(HERE, "csrc", f) for f in ("arks_device.hpp", "arks_kernels.hpp", "arks_exchange.hpp")] + \
+HEADERS = [os.path.join(HERE, "csrc", f) for f in ("arks_device.hpp", "arks_kernels.hpp", "arks_exchange.hpp", "arks_shard_stats.hpp")] + \
           [os.path.join(ROOT, "include", f) for f in ("arks_hip.h", "arks_hip_debug.h")]
 OUT = os.path.join(HERE, "lib", "libarks_hip.so")
 

@@ -11,6 +11,7 @@
 // (bestContig), :1264-1292 (pair rule), :366-389 (checkReadSequence),
 // Common/ReadsProcessor.cpp:376-535 (prepSeq).
 #include "arks_kernels.hpp"
+#include "arks_shard_stats.hpp"
 
 namespace arks {
 
@@ -294,7 +295,7 @@ insert_kernel(
 // One thread per visited window of the FOREIGN ends: a key found with an owner loses it; nothing is
 // inserted.  Runs after K2 has finished (no LOCKED states, keys and states are final), so plain
 // relaxed accesses suffice and the store is idempotent.
-template <int KW>
+template <int KW, bool MIN>
 __global__ void
 poison_kernel(
     const u64* __restrict__ codes,
@@ -302,6 +303,8 @@ poison_kernel(
     u64 total_words,
     KeyGeom g,
     TableView t,
+    const u32* __restrict__ word_end, // MIN: 1-based index into conreci of the end that owns a text word
+    const u32* __restrict__ conreci,  // MIN: the foreign ends' numbers in the whole list
     u64* __restrict__ counter) // += keys that lost their owner to another shard
 {
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,6 +329,8 @@ poison_kernel(
 			if (key_eq(sk, c)) {
 				if (st != 1u)
 					n_lost = __hip_atomic_exchange(state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u;
+				if (MIN) // the key's first holder is the shard of the smallest end over ALL shards (build_stats_kernel)
+					(void)__hip_atomic_fetch_min(state + 1, conreci[word_end[w] - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				break;
 			}
 			s = (s + 1 == t.cap) ? 0 : s + 1;
@@ -952,9 +957,49 @@ launch_poison(
 	const u64 n = total_words * 32;
 	const unsigned blocks = (unsigned)((n + 255) / 256);
 	if (kw == 2)
-		poison_kernel<2><<<blocks, 256, 0, st>>>(codes, visited, total_words, g, t, counter);
+		poison_kernel<2, false><<<blocks, 256, 0, st>>>(codes, visited, total_words, g, t, nullptr, nullptr, counter);
 	else
-		poison_kernel<3><<<blocks, 256, 0, st>>>(codes, visited, total_words, g, t, counter);
+		poison_kernel<3, false><<<blocks, 256, 0, st>>>(codes, visited, total_words, g, t, nullptr, nullptr, counter);
+	return hipGetLastError();
+}
+
+hipError_t
+launch_poison_min(
+    int kw, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView t,
+    const u32* word_end, const u32* conreci, u64* counter, hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	const unsigned blocks = blocks_for(total_words * 32ull, 256);
+	if (kw == 2)
+		poison_kernel<2, true><<<blocks, 256, 0, st>>>(codes, visited, total_words, g, t, word_end, conreci, counter);
+	else
+		poison_kernel<3, true><<<blocks, 256, 0, st>>>(codes, visited, total_words, g, t, word_end, conreci, counter);
+	return hipGetLastError();
+}
+
+// keys whose smallest end (over the shards: poison_kernel<MIN>) is an end of this shard
+__global__ void
+count_first_holder_kernel(TableView t, const u32* __restrict__ lens, u64* __restrict__ out)
+{
+	u64 acc = 0;
+	for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < t.cap; s += (u64)gridDim.x * blockDim.x) {
+		const u64 meta = t.slots[s * kSlotWords + 3];
+		if ((u32)meta != kEmpty)
+			acc += lens[(u32)(meta >> 32) - 1u] != 0u;
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		acc += __shfl_down(acc, off);
+	if ((threadIdx.x & 63) == 0 && acc)
+		atomicAdd(out, acc);
+}
+
+hipError_t
+launch_count_first_holder(TableView t, const u32* lens, u64* out, hipStream_t st)
+{
+	unsigned b = blocks_for(t.cap, 256);
+	b = b > 4096 ? 4096 : b;
+	count_first_holder_kernel<<<b, 256, 0, st>>>(t, lens, out);
 	return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 #include "arks_hip.h"
 #include "arks_hip_debug.h"
 #include "arks_kernels.hpp"
+#include "arks_shard_stats.hpp"
 
 // minimizer-table slots per entry: the map kernel's probe is a dependent HBM round trip per group of 4
 // entries, so what matters is how often a run needs a second one (measured at C2: 2 -> 4 slots per
@@ -578,22 +579,23 @@ static int
 poison_with_foreign_ends(
     const arks_index* idx, const char* h_bases, const uint64_t* h_offsets, const uint32_t* h_lens,
     int64_t n_ends, int shard, const std::vector<int32_t>& shard_of, TableView full, u64* d_counter,
-    hipStream_t st)
+    bool first_holder, hipStream_t st)
 {
 	int rc = ARKS_OK;
 	const uint64_t kChunkBases = 1ull << 28;
 	const int kBackPad = 16;
 	std::vector<uint64_t> woff, offs, src;
-	std::vector<uint32_t> lens;
-	DevBuf d_ascii, d_offs, d_lens, d_woff, d_codes, d_nmask, d_visited, d_scratch;
+	std::vector<uint32_t> lens, conreci;
+	DevBuf d_ascii, d_offs, d_lens, d_woff, d_codes, d_nmask, d_visited, d_scratch, d_wend, d_conreci;
 	HIP_TRY(d_scratch.alloc(sizeof(u64) * 8));
 	for (int64_t e = 0; e < n_ends;) {
-		woff.clear(), offs.clear(), src.clear(), lens.clear();
+		woff.clear(), offs.clear(), src.clear(), lens.clear(), conreci.clear();
 		uint64_t acc = kFrontPadWords, bacc = 0;
 		for (; e < n_ends && (bacc == 0 || bacc + h_lens[e] <= kChunkBases); ++e) {
 			if (shard_of[(size_t)e] == shard || h_lens[e] == 0)
 				continue;
 			woff.push_back(acc), offs.push_back(bacc), src.push_back(h_offsets[e]), lens.push_back(h_lens[e]);
+			conreci.push_back((uint32_t)e + 1u);
 			acc += ((uint64_t)h_lens[e] + 31) / 32;
 			bacc += h_lens[e];
 		}
@@ -632,8 +634,18 @@ poison_with_foreign_ends(
 		HIP_TRY(launch_visit(
 		    d_nmask.as<u32>(), d_woff.as<u64>(), d_lens.as<u32>(), (long)n, idx->k, d_visited.as<u32>(),
 		    d_scratch.as<u64>(), st));
-		HIP_TRY(launch_poison(
-		    idx->kw, d_codes.as<u64>(), d_visited.as<u32>(), text_words, idx->geom, full, d_counter, st));
+		if (first_holder) {
+			// counters wanted: the key also learns the smallest foreign end that holds it (arks_shard_stats.hpp)
+			HIP_TRY(d_wend.alloc(sizeof(u32) * alloc_words));
+			HIP_TRY(d_conreci.alloc(sizeof(u32) * n));
+			HIP_TRY(hipMemcpy(d_conreci.p, conreci.data(), sizeof(u32) * n, hipMemcpyHostToDevice));
+			HIP_TRY(launch_word_owner(d_woff.as<u64>(), (long)n, alloc_words, d_wend.as<u32>(), st));
+			HIP_TRY(launch_poison_min(
+			    idx->kw, d_codes.as<u64>(), d_visited.as<u32>(), text_words, idx->geom, full, d_wend.as<u32>(),
+			    d_conreci.as<u32>(), d_counter, st));
+		} else
+			HIP_TRY(launch_poison(
+			    idx->kw, d_codes.as<u64>(), d_visited.as<u32>(), text_words, idx->geom, full, d_counter, st));
 		HIP_TRY(hipStreamSynchronize(st)); // the buffers are reused (or freed) next
 	}
 done:
@@ -698,7 +710,7 @@ index_build_impl(
 	uint64_t total_bases = 0;
 	DevBuf d_ascii, d_offs, d_lens, d_woff, d_nmask, d_counters, d_full;
 	DevBuf d_ismin, d_ispal, d_isimg, d_heavy, d_ckeys, d_ccnts, d_wown;
-	u64 text_words = 0, alloc_words = 0, counters[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	u64 text_words = 0, alloc_words = 0, counters[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	u64 visited_total = 0, n_min = 0, n_pal = 0, n_fb = 0, ccap = 0, mcap = 0;
 	TableView full{ nullptr, 0 };
 	int mm = kMShort, w = 0;
@@ -799,7 +811,7 @@ index_build_impl(
 	ARKS_TRACE_STEP("launch_insert");
 	if (n_shards > 1) {
 		rc = poison_with_foreign_ends(
-		    idx, h_bases, h_offsets, h_all_lens, n_ends, shard, shard_of, full, d_counters.as<u64>() + 7, st);
+		    idx, h_bases, h_offsets, h_all_lens, n_ends, shard, shard_of, full, d_counters.as<u64>() + 7, stats != nullptr, st);
 		if (rc != ARKS_OK)
 			goto done;
 		ARKS_TRACE_STEP("foreign ends");
@@ -808,6 +820,8 @@ index_build_impl(
 		HIP_TRY(launch_build_stats(
 		    idx->kw, idx->codes, idx->visited, d_woff.as<u64>(), (long)n_ends, text_words, idx->geom,
 		    full, d_counters.as<u64>(), st));
+	if (stats && n_shards > 1)
+		HIP_TRY(launch_count_first_holder(full, d_lens.as<u32>(), d_counters.as<u64>() + 8, st));
 	ARKS_TRACE_STEP("launch_build_stats");
 	HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -819,6 +833,16 @@ index_build_impl(
 		stats->total_kmers = visited_total;
 		stats->null_kmers = counters[0];
 		stats->short_ends = counters[1];
+		if (n_shards > 1) {
+			// this shard's share (include/arks_hip.h: the sums over the shards are the counters of the one map):
+			// a key is recorded by the shard that holds the smallest end that visited it, the other ends' visits
+			// are collisions wherever they are
+			int64_t foreign = 0;
+			for (int64_t e = 0; e < n_ends; ++e)
+				foreign += shard_of[(size_t)e] != shard;
+			stats->short_ends = counters[1] - (u64)foreign; // (the foreign ends were visited as empty strings)
+			counters[2] = counters[8];
+		}
 		stats->recorded = counters[2];
 		stats->collisions = visited_total - counters[2];
 		stats->removed_dup = visited_total - counters[4];
@@ -1055,6 +1079,22 @@ arks_index_build_shard(
     int device)
 {
 	return index_build_impl(out, k, h_bases, h_offsets, h_lens, n_ends, shard, n_shards, device, nullptr);
+}
+
+int
+arks_index_build_shard_stats(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int shard,
+    int n_shards,
+    int device,
+    arks_build_stats* stats)
+{
+	return index_build_impl(out, k, h_bases, h_offsets, h_lens, n_ends, shard, n_shards, device, stats);
 }
 
 int

@@ -433,12 +433,18 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 			if (n_shards > 1) {
 				// --index-shards: N indexes of 1/N of the contigs each (a draft beyond one index's 2^32 text
 				// positions, or whose build scratch does not fit); the reads are mapped against each in turn
+				// -v: every part reports its share of the counters, the sums are the one map's (include/arks_hip.h)
 				for (int sh = 0; sh < n_shards; ++sh) {
-					const int rc = arks_index_build_shard(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(),
-					                                      sh, n_shards, device);
+					arks_build_stats part;
+					std::memset(&part, 0, sizeof part);
+					const int rc = arks_index_build_shard_stats(&idx, k, bases.data(), off.data(), len.data(), (int64_t)len.size(),
+					                                            sh, n_shards, device, params.verbose && lane == 0 ? &part : nullptr);
 					if (rc != ARKS_OK)
 						die_arks(rc, "building a shard of the contig k-mer index");
 					by_lane[(size_t)lane].push_back(idx);
+					st.total_kmers += part.total_kmers, st.null_kmers += part.null_kmers, st.short_ends += part.short_ends;
+					st.recorded += part.recorded, st.collisions += part.collisions, st.removed_dup += part.removed_dup;
+					st.unique += part.unique;
 				}
 				return;
 			}
@@ -465,13 +471,6 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 				});
 			for (std::thread& t : builders)
 				t.join();
-		}
-		if (n_shards > 1) {
-			if (params.verbose)
-				appendf(log, "%s %u\n%s %u\n%s %u\n(index in %d shards: the k-mer counters are not collected)\n",
-				        "Total number of contigs in draft genome: ", (unsigned)total, "Total valid contigs: ", (unsigned)valid,
-				        "Total skipped contigs: ", (unsigned)skipped, n_shards);
-			continue;
 		}
 		if (params.verbose) {
 			if (params.k_list.size() > 1)

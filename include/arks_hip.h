@@ -131,6 +131,24 @@ int arks_index_build_shard(
     int shard,
     int n_shards,
     int device);
+/* The same with the counters of getContigKmers (Arcs/Arcs.cpp:1093-1107) -- this shard's SHARE of them: the sums
+ * over the shards are exactly what arks_index_build reports for the whole list.  total_kmers, null_kmers and
+ * short_ends are those of the shard's own ends; a key that several shards hold is `recorded` by the shard that
+ * holds the smallest end of the list that visited it (the one the serial loop of :884-927 meets first), and every
+ * other visit is a collision in the shard of its end; removed_dup counts, as in the one map, the visits after the
+ * first end's; unique counts the keys no other end of the list holds.  The streaming of the foreign ends carries
+ * the end numbers for this (an atomic minimum per shared key); stats == NULL is arks_index_build_shard. */
+int arks_index_build_shard_stats(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int shard,
+    int n_shards,
+    int device,
+    arks_build_stats* stats);
 
 /* The north star's sharded configuration (BASELINE configs[3]): the SEED TABLE of the seed index -- 32 B per
  * text position, 43 GB for a 3 Gbp draft, everything else of the index is ~2 GB -- split over the ranks
@@ -247,8 +265,10 @@ int arks_map_reads_device(
  * finishes the call.  Same rule per index and stream as arks_map_reads_device.
  * No arks_map_stats here (documented omission): total_valid / bad / windows are the same in every shard,
  * recorded adds up over shards, but a key shared by two shards reads 0 -- found, duplicate -- in BOTH, so
- * found and dups of the whole map are not the sums of the shards' and would need a per-key "first holder"
- * mark that the build does not keep; `arcs --index-shards` prints that the counters are not collected. */
+ * found and dups of the whole map are not the sums of the shards' and would need the per-key "first holder"
+ * mark at map time: arks_index_build_shard_stats derives it for the BUILD counters, the index does not keep it
+ * (a bit per text position for the map kernels); `arcs --index-shards` prints that the counters of the read
+ * stage are not collected. */
 int arks_map_votes_device(
     const arks_index* idx,
     const uint64_t* d_codes,

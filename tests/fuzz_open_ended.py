@@ -73,11 +73,16 @@ while time.time() < t_end:
         n_sh = int(rng.integers(2, 6))
         packed = arcs_amd.PackedReads.from_ascii(reads, device=0)
         votes = None
+        share = {}
         for sidx in range(n_sh):
-            sh = arcs_amd.ArksIndex.build_shard(ends, k, sidx, n_sh, device=0)
+            sh = arcs_amd.ArksIndex.build_shard(ends, k, sidx, n_sh, device=0, want_stats=True)
+            for f, v in sh.build_stats.items():
+                share[f] = share.get(f, 0) + v
             v = arcs_amd.map_votes_packed(sh, packed).clone()
             votes = v if votes is None else arcs_amd.max_votes(votes, v)
             torch.cuda.synchronize(); sh.close()
+        # the shards' shares of the build counters add up to the serial loop's over all the ends
+        assert {f: share[f] for f in ox.stats.as_dict()} == ox.stats.as_dict(), (seed - 1, k, n_sh, "build counters")
         assert torch.equal(votes, arcs_amd.map_votes_packed(ix, packed)), (seed - 1, k, n_sh, "votes")
         for j in (0.55, 0.0):
             got = arcs_amd.resolve_votes(votes, packed, k, j).cpu().tolist()

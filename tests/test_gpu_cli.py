@@ -234,7 +234,14 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
     for suffix in ("_original.gv", "_pair.tsv", "_main.tsv"):
         assert open(str(tmp_path / "sharded") + suffix).read() == open(base + suffix).read(), suffix
     assert f"Stored read pairs: {stored}\n" in res4.stdout
-    assert "(index in 3 shards: the k-mer counters are not collected)" in res4.stdout
+    # -v: the counters of the index build are collected over the parts (arks_index_build_shard_stats) and read as in
+    # the run with one index; those of the read stage are not (include/arks_hip.h: arks_map_votes_device)
+    build_lines = [ln for ln in res.stdout.split("\n") if ln.startswith(("Total number of Kmers", "Number Null Kmers",
+                   "Number Kmers Recorded", "Number Kmer Collisions", "Number Times Kmers Removed", "Number of unique kmers"))]
+    assert len(build_lines) == 6
+    for ln in build_lines:
+        assert ln + "\n" in res4.stdout, ln
+    assert "(index in 3 shards: the k-mer counters of the read stage are not collected)" in res4.stdout
     # ---- -D: distance estimates (dist_est.hpp) on the same run: d= / maxd= on the edges, --dist_tsv,
     #      --samples_tsv, d= of the ABySS graph ------------------------------------------------------------
     args5 = list(args)

@@ -69,7 +69,17 @@ def test_shards_equal_whole_index(arks, gpu, oracle, k, n_shards):
     ok, ov = ox.dump()
     whole = {bytes(kk): int(v) for kk, v in zip(ok, ov)}
     ix = arks.ArksIndex.build(ends, k, device=gpu)
-    shards = [arks.ArksIndex.build_shard(ends, k, s, n_shards, device=gpu) for s in range(n_shards)]
+    shards = [arks.ArksIndex.build_shard(ends, k, s, n_shards, device=gpu, want_stats=True) for s in range(n_shards)]
+
+    # (0) the counters of getContigKmers (Arcs.cpp:1093-1107): every shard reports its share, the sums are the
+    #     whole map's -- the oracle's serial loop over all the ends -- counter by counter
+    want_stats = ox.stats.as_dict()
+    assert {f: ix.build_stats[f] for f in want_stats} == want_stats
+    assert {f: sum(sh.build_stats[f] for sh in shards) for f in want_stats} == want_stats, (k, n_shards)
+    assert sum(sh.build_stats["collisions"] > 0 for sh in shards) >= 2 and want_stats["removed_dup"] > 100
+    plain = arks.ArksIndex.build_shard(ends, k, 0, n_shards, device=gpu)      # without counters: the same table
+    assert plain.build_stats is None and index_digest(*plain.export()) == index_digest(*shards[0].export())
+    plain.close()
 
     # (1) content: the keys its own ends visit, with the values of the whole map
     n_zeroed = 0
