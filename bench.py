@@ -876,6 +876,17 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
         b_alg = alg_bytes_per_window(k, 279, 161)
         ms = 1e3 * elapsed / args.steps
         ex = xs[0].last_stats() if xs[0] is not None else None
+        # HBM bytes of one step, every kernel of it summed (profiles/prof_sharded.sh: separate --pmc passes over this
+        # very command on one GPU); with several GPUs the step's bytes divide over them like its time does
+        traffic = None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_sharded_r*.json"))):
+            try:
+                d = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            if d.get("workload") == {"draft_mbp": args.draft_mbp, "pairs": args.pairs, "k": k, "shards": n_ranks, "n_gpus": 1}:
+                traffic = d
+        step_gb = traffic["hbm_bytes_per_step_uncalibrated"] / 1e9 if traffic else None
         print(json.dumps({
             "metric": METRIC, "value": windows * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -895,8 +906,17 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
                        "parallelism": f"seed table hash-sharded x{n_ranks}, reads dealt to the ranks in blocks, seeds "
                                       "routed to their owners and back (arks_exchange)"},
             "counters": st_job, "timed_path_parity": timed_parity,
-            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                         "traffic": None, "kernel": "whole step (bucket, exchange, probe, map_reads_s_kernel<REMOTE>, pair rule)",
+            "roofline": {"bound": "hbm", "achieved": (step_gb / world / (ms * 1e-3)) if traffic else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (step_gb / world / (ms * 1e-3) / HBM_PEAK_GBS) if traffic else None,
+                         "traffic": (step_gb / world) if traffic else None,
+                         "traffic_unit": "GB per GPU and step (rocprofv3 PMC, FETCH_SIZE x 1 + WRITE_SIZE summed over every "
+                                         "kernel of the step: a lower bound, whole-line requests of the streams count half)",
+                         "traffic_source": traffic["source"] if traffic else None,
+                         "traffic_build_match": (traffic["kernel_build_id"] == kernel_build_id()) if traffic else None,
+                         "traffic_by_kernel_GB": ({kn: round(v["fetch"] + v["write"], 2)
+                                                   for kn, v in traffic["per_kernel_GB_per_step"].items()} if traffic else None),
+                         "kernel": "whole step (bucket, exchange, probe, map_reads_s_kernel<REMOTE>, pair rule)",
                          "alg_achieved": windows * b_alg / (ms * 1e-3) / 1e9 / world,
                          "alg_frac": windows * b_alg / (ms * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
                          "alg_bytes_per_window": b_alg}}), flush=True)
