@@ -80,6 +80,7 @@ SYMBOLS = {
     "arks_map_votes_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP]),
     "arks_votes_max_device": (_I, [_VP, _VP, _I64, _I, _VP]),
     "arks_votes_resolve_device": (_I, [_VP, _VP, _I64, _I, _D, _VP, _I, _VP]),
+    "arks_votes_count_device": (_I, [_VP, _VP, _VP, _I64, _I, _D, _VP, _I, _VP]),
     "arks_map_reads": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _VP, C.POINTER(MapStats)]),
     "arks_imap_create": (_I, [C.POINTER(_VP), _I64, _I]),
     "arks_imap_free": (_I, [_VP]),

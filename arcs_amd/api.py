@@ -556,6 +556,14 @@ def resolve_votes(votes, reads, k, j_index, out=None):
     return out[:n]
 
 
+def count_votes(votes, reads, k, j_index, stats, eval_mask=None):
+    """arks_votes_count_device: reads_pass / reads_fail of folded votes added to the int64[8] device tensor `stats`"""
+    check(lib().arks_votes_count_device(votes.data_ptr(), reads.lens.data_ptr(),
+                                        eval_mask.data_ptr() if eval_mask is not None else None, reads.n_reads, int(k),
+                                        float(j_index), stats.data_ptr(), reads.device, _stream_ptr(reads.device)),
+          "arks_votes_count_device")
+
+
 def pair_gate(reads, pair_ok=None):
     """arks_pair_gate_device -> uint8[2 * n_pairs]"""
     torch = _torch()

@@ -994,6 +994,99 @@ count_first_holder_kernel(TableView t, const u32* __restrict__ lens, u64* __rest
 		atomicAdd(out, acc);
 }
 
+// K2q: a key that ends of several shards visit stays in ONE shard's index -- that of the smallest end of the list
+// that visited it (the slot's smallest-end field after poison_kernel<MIN>).  The other shards take their visits of
+// it back: the key reads 0 wherever it is (shared between ends), so no vote changes, and with it in one place only
+// the read stage's found / duplicate counters of the shards add up to the one map's (Arcs.cpp:975-982).
+template <int KW>
+__global__ void
+drop_later_holders_kernel(
+    const u64* __restrict__ codes, u32* __restrict__ visited, const u32* __restrict__ lens, u64 total_words,
+    KeyGeom g, TableView t, u64* __restrict__ counter) // += visits taken back
+{
+	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 w = pos >> 5;
+	bool active = w < total_words;
+	if (active)
+		active = (visited[w] >> (31 - (pos & 31))) & 1u;
+	u32 drop = 0;
+	if (active) {
+		const Key<KW> c = reference_key(window_key_at<KW>(codes, pos, g), g);
+		u64 s = mulhi64(key_hash(c), t.cap);
+		for (;;) {
+			const u64* slot = t.slots + s * kSlotWords;
+			const u64 meta = slot[3];
+			if ((u32)meta == kEmpty)
+				break; // cannot happen for a visited window
+			if (key_eq(slot_key<KW>(slot), c)) {
+				drop = lens[(u32)(meta >> 32) - 1u] == 0u;
+				break;
+			}
+			s = (s + 1 == t.cap) ? 0 : s + 1;
+		}
+		if (drop) // (a bit is read and cleared by its own thread only)
+			atomicAnd(visited + w, ~(1u << (31 - (pos & 31))));
+	}
+	const u64 b = __ballot(drop);
+	if ((threadIdx.x & 63) == 0 && b)
+		atomicAdd(counter, (u64)__popcll(b));
+}
+
+// ... and where the table itself is the index (no text: k < 20, ARKS_INDEX_KIND=hash), the first holders' slots are
+// re-inserted into a table of their own (distinct keys: a free slot is claimed, nothing is compared)
+template <int KW>
+__global__ void
+keep_first_holders_kernel(TableView from, const u32* __restrict__ lens, TableView to)
+{
+	for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < from.cap; s += (u64)gridDim.x * blockDim.x) {
+		const u64* slot = from.slots + s * kSlotWords;
+		const u64 meta = slot[3];
+		if ((u32)meta == kEmpty || lens[(u32)(meta >> 32) - 1u] == 0u)
+			continue;
+		const Key<KW> c = slot_key<KW>(slot);
+		u64 d = mulhi64(key_hash(c), to.cap);
+		for (;;) {
+			u64* dst = to.slots + d * kSlotWords;
+			u32* state = reinterpret_cast<u32*>(dst + 3);
+			if (atomicCAS(state, kEmpty, (u32)meta) == kEmpty) {
+#pragma unroll
+				for (int j = 0; j < KW; ++j)
+					dst[j] = c.w[j];
+				state[1] = (u32)(meta >> 32);
+				break;
+			}
+			d = (d + 1 == to.cap) ? 0 : d + 1;
+		}
+	}
+}
+
+hipError_t
+launch_drop_later_holders(
+    int kw, const u64* codes, u32* visited, const u32* lens, u64 total_words, const KeyGeom& g, TableView t, u64* counter,
+    hipStream_t st)
+{
+	if (total_words == 0)
+		return hipSuccess;
+	const unsigned b = blocks_for(total_words * 32ull, 256);
+	if (kw == 2)
+		drop_later_holders_kernel<2><<<b, 256, 0, st>>>(codes, visited, lens, total_words, g, t, counter);
+	else
+		drop_later_holders_kernel<3><<<b, 256, 0, st>>>(codes, visited, lens, total_words, g, t, counter);
+	return hipGetLastError();
+}
+
+hipError_t
+launch_keep_first_holders(int kw, TableView from, const u32* lens, TableView to, hipStream_t st)
+{
+	unsigned b = blocks_for(from.cap, 256);
+	b = b > 4096 ? 4096 : b;
+	if (kw == 2)
+		keep_first_holders_kernel<2><<<b, 256, 0, st>>>(from, lens, to);
+	else
+		keep_first_holders_kernel<3><<<b, 256, 0, st>>>(from, lens, to);
+	return hipGetLastError();
+}
+
 hipError_t
 launch_count_first_holder(TableView t, const u32* lens, u64* out, hipStream_t st)
 {

@@ -811,7 +811,7 @@ index_build_impl(
 	ARKS_TRACE_STEP("launch_insert");
 	if (n_shards > 1) {
 		rc = poison_with_foreign_ends(
-		    idx, h_bases, h_offsets, h_all_lens, n_ends, shard, shard_of, full, d_counters.as<u64>() + 7, stats != nullptr, st);
+		    idx, h_bases, h_offsets, h_all_lens, n_ends, shard, shard_of, full, d_counters.as<u64>() + 7, true, st);
 		if (rc != ARKS_OK)
 			goto done;
 		ARKS_TRACE_STEP("foreign ends");
@@ -820,7 +820,7 @@ index_build_impl(
 		HIP_TRY(launch_build_stats(
 		    idx->kw, idx->codes, idx->visited, d_woff.as<u64>(), (long)n_ends, text_words, idx->geom,
 		    full, d_counters.as<u64>(), st));
-	if (stats && n_shards > 1)
+	if (n_shards > 1)
 		HIP_TRY(launch_count_first_holder(full, d_lens.as<u32>(), d_counters.as<u64>() + 8, st));
 	ARKS_TRACE_STEP("launch_build_stats");
 	HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
@@ -847,6 +847,39 @@ index_build_impl(
 		stats->collisions = visited_total - counters[2];
 		stats->removed_dup = visited_total - counters[4];
 		stats->unique = counters[5];
+	}
+	if (n_shards > 1) {
+		// FIRST HOLDERS ONLY: a key that ends of other shards visit too is kept by the shard of the smallest end of
+		// the list that visited it (the slot's smallest-end field, lowered by the foreign ends that streamed through);
+		// the other shards take their visits of it back.  It reads 0 wherever it is, so no vote changes; with it in
+		// one shard only, the found / duplicate counters of the read stage add up over the shards (arks_hip.h).
+		HIP_TRY(hipMemsetAsync(d_counters.as<u64>() + 6, 0, sizeof(u64), st));
+		HIP_TRY(launch_drop_later_holders(
+		    idx->kw, idx->codes, idx->visited, d_lens.as<u32>(), text_words, idx->geom, full, d_counters.as<u64>() + 9, st));
+		HIP_TRY(launch_popcount(idx->visited, text_words, d_counters.as<u64>() + 6, st));
+		HIP_TRY(hipMemcpyAsync(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if (counters[6] + counters[9] != visited_total) {
+			g_last_error = "first holders: the visits kept and taken back do not add up";
+			rc = ARKS_ERR_HIP;
+			goto done;
+		}
+		visited_total = counters[6];
+		idx->n_visited = (int64_t)visited_total;
+		idx->n_keys = (int64_t)counters[8];
+		ARKS_TRACE_STEP("first holders");
+		if (!locality) {
+			// the table is the index: the first holders' slots move to a table of their own
+			TableView kept{ nullptr, std::max<u64>(1024, counters[8] * 2 + 64) };
+			DevBuf d_kept;
+			HIP_TRY(d_kept.alloc(kept.cap * kSlotWords * sizeof(u64)));
+			kept.slots = d_kept.as<u64>();
+			HIP_TRY(hipMemsetAsync(kept.slots, 0, kept.cap * kSlotWords * sizeof(u64), st));
+			HIP_TRY(launch_keep_first_holders(idx->kw, full, d_lens.as<u32>(), kept, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			std::swap(d_full.p, d_kept.p); // (d_kept frees the old table)
+			full = kept;
+		}
 	}
 
 	if (!locality) {
@@ -1514,6 +1547,37 @@ arks_votes_resolve_device(
 	DeviceGuard guard(device);
 	HIP_TRY(launch_resolve_votes(
 	    (const u64*)d_votes, d_lens, (long)n_reads, k, j_index, d_out_conreci, static_cast<hipStream_t>(stream)));
+done:
+	return rc;
+}
+
+int
+arks_votes_count_device(
+    const uint64_t* d_votes,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    int k,
+    double j_index,
+    arks_map_stats* d_stats,
+    int device,
+    void* stream)
+{
+	if (n_reads < 0 || !d_stats || (n_reads > 0 && (!d_votes || !d_lens)))
+		return ARKS_ERR_BAD_ARG;
+	static_assert(offsetof(arks_map_stats, reads_pass) == 5 * sizeof(uint64_t) &&
+	                  offsetof(arks_map_stats, reads_fail) == 6 * sizeof(uint64_t),
+	              "votes_count_kernel adds to words 5 and 6");
+	int rc = check_k(k);
+	if (rc != ARKS_OK)
+		return rc;
+	rc = require_device(device);
+	if (rc != ARKS_OK)
+		return rc;
+	DeviceGuard guard(device);
+	HIP_TRY(launch_votes_count(
+	    (const u64*)d_votes, d_lens, d_eval, (long)n_reads, k, j_index, reinterpret_cast<u64*>(d_stats),
+	    static_cast<hipStream_t>(stream)));
 done:
 	return rc;
 }

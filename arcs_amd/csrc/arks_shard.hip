@@ -4,6 +4,7 @@
 // bench.py's kernel_build_id is a digest of those.)
 #include "arks_device.hpp"
 #include "arks_kernels.hpp"
+#include "arks_shard_stats.hpp"
 #include <cstddef>
 #include <cstdint>
 
@@ -265,6 +266,45 @@ launch_seed_bucket(
 		seed_bucket_kernel<kMLong><<<nb, kBkWaves * 64, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, cap, slot_cap, ctl, chunk_off, slot, send);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
+}
+
+// bestContig's last step (Arcs/Arcs.cpp:1006-1013) as counters, for votes folded over the shards of a contig-sharded
+// index: stats[5] (reads_pass) += reads with count / total > j_index, stats[6] (reads_fail) += the others -- of the
+// reads bestContig is called for (eval != 0); the same arithmetic as resolve_votes_kernel
+__global__ void
+votes_count_kernel(
+    const u64* __restrict__ votes, const u32* __restrict__ lens, const uint8_t* __restrict__ eval, long n_reads, int k,
+    double j_index, u64* __restrict__ stats)
+{
+	const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	bool called = r < n_reads;
+	if (called && eval)
+		called = eval[r] != 0;
+	bool pass = false;
+	if (called) {
+		const int best_cnt = (int)(votes[r] >> 32);
+		const int nwin = (int)lens[r] - k + 1;
+		const int total = nwin > 0 ? nwin : 0;
+		const double maxj = best_cnt > 0 ? (double)best_cnt / (double)total : 0.0;
+		pass = maxj > j_index;
+	}
+	const u64 bp = __ballot(called && pass), bf = __ballot(called && !pass);
+	if ((threadIdx.x & 63) == 0) {
+		if (bp)
+			atomicAdd(stats + 5, (u64)__popcll(bp));
+		if (bf)
+			atomicAdd(stats + 6, (u64)__popcll(bf));
+	}
+}
+
+hipError_t
+launch_votes_count(
+    const u64* votes, const u32* lens, const uint8_t* eval, long n_reads, int k, double j_index, u64* stats, hipStream_t st)
+{
+	if (n_reads <= 0)
+		return hipSuccess;
+	votes_count_kernel<<<(unsigned)((n_reads + 255) / 256), 256, 0, st>>>(votes, lens, eval, n_reads, k, j_index, stats);
+	return hipGetLastError();
 }
 
 } // namespace arks

@@ -504,6 +504,7 @@ struct DeviceSet
 	DevArray<uint8_t> d_class, d_ok, d_eval;
 	std::vector<DevArray<int32_t>> d_conreci; // per k (a sharded exchange keeps every k's result until its round completes)
 	DevArray<uint64_t> d_votes, d_votes2; // --index-shards only
+	DevArray<int32_t> d_scratch;          // --index-shards -v: the counters' pass writes its per-shard results here
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;
 	PackedBatch* inflight = nullptr;
@@ -526,6 +527,11 @@ struct Lane
 	uint64_t* d_skipped = nullptr;     // [n_files]: skipped_invalidreadpair, counted on the device in device-pack mode
 	uint64_t* d_stored = nullptr;      // [n_k][n_files]
 	arks_map_stats* d_stats = nullptr; // [n_k][n_files]
+	// --index-shards -v: d_stats takes the first part's counters (total_valid, bad, windows are the same in every
+	// part), d_stats_rest the other parts' (found, recorded, dups add up: every key is in one part),
+	// d_stats_votes reads_pass / reads_fail of the folded votes
+	arks_map_stats* d_stats_rest = nullptr;
+	arks_map_stats* d_stats_votes = nullptr;
 };
 
 struct Mapper
@@ -566,13 +572,17 @@ struct Mapper
 			const size_t nc = n_k * nfiles;
 			if (hipMalloc((void**)&ln.d_stored, nc * sizeof(uint64_t)) != hipSuccess ||
 			    hipMalloc((void**)&ln.d_skipped, nfiles * sizeof(uint64_t)) != hipSuccess ||
-			    hipMalloc((void**)&ln.d_stats, nc * sizeof(arks_map_stats)) != hipSuccess) {
+			    hipMalloc((void**)&ln.d_stats, nc * sizeof(arks_map_stats)) != hipSuccess ||
+			    hipMalloc((void**)&ln.d_stats_rest, nc * sizeof(arks_map_stats)) != hipSuccess ||
+			    hipMalloc((void**)&ln.d_stats_votes, nc * sizeof(arks_map_stats)) != hipSuccess) {
 				std::cerr << PROGRAM ": out of device memory\n";
 				exit(EXIT_FAILURE);
 			}
 			(void)hipMemset(ln.d_stored, 0, nc * sizeof(uint64_t));
 			(void)hipMemset(ln.d_skipped, 0, nfiles * sizeof(uint64_t));
 			(void)hipMemset(ln.d_stats, 0, nc * sizeof(arks_map_stats));
+			(void)hipMemset(ln.d_stats_rest, 0, nc * sizeof(arks_map_stats));
+			(void)hipMemset(ln.d_stats_votes, 0, nc * sizeof(arks_map_stats));
 			for (auto& s : ln.sets) {
 				s.d_conreci.resize(n_k);
 				if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -614,6 +624,8 @@ struct Mapper
 			(void)hipFree(ln.d_stored);
 			(void)hipFree(ln.d_skipped);
 			(void)hipFree(ln.d_stats);
+			(void)hipFree(ln.d_stats_rest);
+			(void)hipFree(ln.d_stats_votes);
 		}
 		(void)hipSetDevice(lanes[0].device);
 	}
@@ -728,6 +740,19 @@ struct Mapper
 				if (rc == ARKS_OK)
 					rc = arks_votes_resolve_device(s.d_votes.p, s.d_len.p, 2 * np, params.k_list[ki], params.j_index,
 					                               s.d_conreci[ki].p, ln.device, s.stream);
+				if (params.verbose) {
+					// the k-mer counters of the log (Arcs.cpp:1329-1340): a second pass per part with the counters'
+					// kernels -- every key is in ONE part (its first holder, arks_index_build_shard), so found,
+					// recorded and duplicates add up over the parts -- and the j_index test counted on the folded votes
+					s.d_scratch.reserve((size_t)pb->n_reads);
+					for (size_t sh = 0; sh < n_shards && rc == ARKS_OK; ++sh)
+						rc = arks_map_reads_device(ln.idxs[ki * n_shards + sh], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p,
+						                           s.d_eval.p, 2 * np, params.j_index, s.d_scratch.p,
+						                           (sh ? ln.d_stats_rest : ln.d_stats) + slot, s.stream);
+					if (rc == ARKS_OK)
+						rc = arks_votes_count_device(s.d_votes.p, s.d_len.p, s.d_eval.p, 2 * np, params.k_list[ki], params.j_index,
+						                             ln.d_stats_votes + slot, ln.device, s.stream);
+				}
 			} else
 				rc = arks_map_reads_device(ln.idxs[ki], s.d_codes.p, s.d_nmask.p, s.d_woff.p, s.d_len.p, s.d_eval.p, 2 * np,
 				                           params.j_index, s.d_conreci[ki].p, params.verbose ? ln.d_stats + slot : nullptr, s.stream);
@@ -1009,6 +1034,15 @@ map_files(
 		(void)hipMemcpy(l_skipped.data(), ln.d_skipped, nm * sizeof(uint64_t), hipMemcpyDeviceToHost);
 		(void)hipMemcpy(l_stored.data(), ln.d_stored, nk * nm * sizeof(uint64_t), hipMemcpyDeviceToHost);
 		(void)hipMemcpy(l_st.data(), ln.d_stats, nk * nm * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
+		if (params.index_shards > 1) {
+			std::vector<arks_map_stats> rest(nk * nm), votes(nk * nm);
+			(void)hipMemcpy(rest.data(), ln.d_stats_rest, nk * nm * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
+			(void)hipMemcpy(votes.data(), ln.d_stats_votes, nk * nm * sizeof(arks_map_stats), hipMemcpyDeviceToHost);
+			for (size_t i = 0; i < nk * nm; ++i) {
+				l_st[i].found += rest[i].found, l_st[i].recorded += rest[i].recorded, l_st[i].dups += rest[i].dups;
+				l_st[i].reads_pass = votes[i].reads_pass, l_st[i].reads_fail = votes[i].reads_fail;
+			}
+		}
 		for (size_t i = 0; i < nm; ++i)
 			skipped[i] += l_skipped[i];
 		for (size_t i = 0; i < nk * nm; ++i) {

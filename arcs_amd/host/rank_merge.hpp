@@ -350,18 +350,13 @@ merge_results(
 			       "%u\nSkipped reads pairs without a good contig: %u\n",
 			       (unsigned)stored, (unsigned)mc.skipped_invalid, (unsigned)mc.skipped_unpaired,
 			       (unsigned)(mc.gated - stored));
-			if (params.index_shards > 1)
-				// a key shared by ends of two shards reads 0 in both: the per-window counters of the shards
-				// do not add up to the reference's, so they are not collected (include/arks_hip.h)
-				appendf(out, "(index in %d shards: the k-mer counters of the read stage are not collected)\n",
-				        params.index_shards);
-			else
-				appendf(out, "Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
-				       "%u\nNumber of kmers recorded in Ktrack: %u\nNumber of kmers found in ContigKmap but "
-				       "duplicate: %u\nNumber of reads passing jaccard threshold: %u\nNumber of reads failing "
-				       "jaccard threshold: %u\n",
-				       (unsigned)c.total_valid, (unsigned)c.bad, (unsigned)c.found, (unsigned)c.recorded,
-				       (unsigned)c.dups, (unsigned)c.reads_pass, (unsigned)c.reads_fail);
+			// (--index-shards: the parts' counters folded by the read stage, arcs.cpp)
+			appendf(out, "Total valid kmers: %u\nNumber invalid kmers: %u\nNumber of kmers found in ContigKmap: "
+			       "%u\nNumber of kmers recorded in Ktrack: %u\nNumber of kmers found in ContigKmap but "
+			       "duplicate: %u\nNumber of reads passing jaccard threshold: %u\nNumber of reads failing "
+			       "jaccard threshold: %u\n",
+			       (unsigned)c.total_valid, (unsigned)c.bad, (unsigned)c.found, (unsigned)c.recorded,
+			       (unsigned)c.dups, (unsigned)c.reads_pass, (unsigned)c.reads_fail);
 			if (mc.emptybarcode > 0)
 				appendf(out, "WARNING:: Your chromium read file has %d readpairs that have an empty barcode.",
 				       (int)mc.emptybarcode);

@@ -115,11 +115,16 @@ int arks_index_build(
  * k-mers of the ends that arks_shard_of_ends assigns to it (a contig's head and tail together; contigs
  * dealt in list order to the shard with the fewest bases so far); every rank passes the SAME end list,
  * conreci numbering is that of the whole list.
- * A key that also occurs in an end of another shard reads 0 in this shard, as it does in the one map of
+ * A key that also occurs in an end of another shard reads 0, as it does in the one map of
  * Arcs/Arcs.cpp:903-920: the foreign ends are streamed through the shard's table once while it is
  * built (no exchange between ranks).  Every conreci therefore lives in exactly one shard, and the
  * winner of bestContig's walk (Arcs.cpp:998-1004) over the whole map is the maximum over shards of the
- * per-shard winners -- see arks_map_votes_device.  n_shards == 1 is arks_index_build. */
+ * per-shard winners -- see arks_map_votes_device.  Such a shared key is KEPT by one shard only (round 4): its
+ * first holder, the shard of the smallest end of the list that visited it -- the end the serial loop of
+ * :884-927 meets first (the streaming carries the end numbers: an atomic minimum per shared key); the other
+ * shards take their visits of it back.  No vote changes (the key reads 0 wherever it is), and every key of the
+ * one map is in exactly one shard: the counters of the build and of the read stage add up over the shards.
+ * n_shards == 1 is arks_index_build. */
 int arks_shard_of_ends(const uint32_t* h_lens, int64_t n_ends, int n_shards, int32_t* h_shard);
 int arks_index_build_shard(
     arks_index** out,
@@ -136,8 +141,7 @@ int arks_index_build_shard(
  * short_ends are those of the shard's own ends; a key that several shards hold is `recorded` by the shard that
  * holds the smallest end of the list that visited it (the one the serial loop of :884-927 meets first), and every
  * other visit is a collision in the shard of its end; removed_dup counts, as in the one map, the visits after the
- * first end's; unique counts the keys no other end of the list holds.  The streaming of the foreign ends carries
- * the end numbers for this (an atomic minimum per shared key); stats == NULL is arks_index_build_shard. */
+ * first end's; unique counts the keys no other end of the list holds.  stats == NULL is arks_index_build_shard. */
 int arks_index_build_shard_stats(
     arks_index** out,
     int k,
@@ -263,12 +267,11 @@ int arks_map_reads_device(
  * (:1000, strict <).  That maximum is the only data-path exchange of the sharded configuration (one
  * 8-byte all-reduce(MAX) per read; reads are replicated to every shard), arks_votes_resolve_device
  * finishes the call.  Same rule per index and stream as arks_map_reads_device.
- * No arks_map_stats here (documented omission): total_valid / bad / windows are the same in every shard,
- * recorded adds up over shards, but a key shared by two shards reads 0 -- found, duplicate -- in BOTH, so
- * found and dups of the whole map are not the sums of the shards' and would need the per-key "first holder"
- * mark at map time: arks_index_build_shard_stats derives it for the BUILD counters, the index does not keep it
- * (a bit per text position for the map kernels); `arcs --index-shards` prints that the counters of the read
- * stage are not collected. */
+ * No arks_map_stats here; the counters of the whole map (Arcs.cpp:1329-1340) come from arks_map_reads_device on
+ * every shard -- a shard's index keeps a shared key only if the shard is the key's first holder
+ * (arks_index_build_shard), so found, recorded and dups ADD UP over the shards, and total_valid, bad and windows are
+ * the same in every shard (take one) -- and from arks_votes_count_device on the folded votes (reads_pass,
+ * reads_fail).  `arcs --index-shards -v` does that: a second map pass per shard, for the verbose log only. */
 int arks_map_votes_device(
     const arks_index* idx,
     const uint64_t* d_codes,
@@ -418,6 +421,19 @@ int arks_votes_resolve_device(
     int k,
     double j_index,
     int32_t* d_out_conreci,
+    int device,
+    void* stream);
+
+/* The same test as counters (Arcs.cpp:1006-1013), for the reads bestContig is called for (d_eval[r] != 0; NULL = all):
+ * d_stats->reads_pass += reads with count / total > j_index, d_stats->reads_fail += the others. */
+int arks_votes_count_device(
+    const uint64_t* d_votes,
+    const uint32_t* d_lens,
+    const uint8_t* d_eval,
+    int64_t n_reads,
+    int k,
+    double j_index,
+    arks_map_stats* d_stats,
     int device,
     void* stream);
 

@@ -74,21 +74,35 @@ while time.time() < t_end:
         packed = arcs_amd.PackedReads.from_ascii(reads, device=0)
         votes = None
         share = {}
+        parts = []
         for sidx in range(n_sh):
             sh = arcs_amd.ArksIndex.build_shard(ends, k, sidx, n_sh, device=0, want_stats=True)
             for f, v in sh.build_stats.items():
                 share[f] = share.get(f, 0) + v
             v = arcs_amd.map_votes_packed(sh, packed).clone()
             votes = v if votes is None else arcs_amd.max_votes(votes, v)
+            t = torch.zeros(8, dtype=torch.int64, device="cuda")     # the read stage's counters of this shard
+            arcs_amd.map_reads_packed(sh, packed, 0.55, stats=t)
+            parts.append(t.cpu().tolist())
             torch.cuda.synchronize(); sh.close()
         # the shards' shares of the build counters add up to the serial loop's over all the ends
         assert {f: share[f] for f in ox.stats.as_dict()} == ox.stats.as_dict(), (seed - 1, k, n_sh, "build counters")
         assert torch.equal(votes, arcs_amd.map_votes_packed(ix, packed)), (seed - 1, k, n_sh, "votes")
         for j in (0.55, 0.0):
             got = arcs_amd.resolve_votes(votes, packed, k, j).cpu().tolist()
-            want = [ox.best_contig(r, j) for r in reads]
+            st2 = oracle.MapStats()
+            want = [ox.best_contig(r, j, st2) for r in reads]
             bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
             assert not bad, (seed - 1, k, j, n_sh, "sharded", bad[:5])
+            # every key is in one shard (its first holder): found, recorded, duplicates add up; the other window
+            # counters are the same in every shard; the j_index test is counted on the folded votes
+            folded = torch.zeros(8, dtype=torch.int64, device="cuda")
+            arcs_amd.count_votes(votes, packed, k, j, folded)
+            g = folded.cpu().tolist()
+            g[2:5] = [sum(p[i] for p in parts) for i in (2, 3, 4)]
+            g[0], g[1], g[7] = parts[0][0], parts[0][1], parts[0][7]
+            assert all(p[0] == g[0] and p[1] == g[1] and p[7] == g[7] for p in parts), (seed - 1, k, n_sh, "window counters")
+            assert dict(zip(st2.as_dict(), g)) == st2.as_dict(), (seed - 1, k, j, n_sh, "read-stage counters", g, st2.as_dict())
     if os.environ.get("FUZZ_SEED_SHARDS"):  # the seed table in 2..4 shards, every seed answered by its owner
         n_sh = int(rng.integers(2, 5))
         packed = arcs_amd.PackedReads.from_ascii(reads, device=0)

@@ -234,14 +234,17 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
     for suffix in ("_original.gv", "_pair.tsv", "_main.tsv"):
         assert open(str(tmp_path / "sharded") + suffix).read() == open(base + suffix).read(), suffix
     assert f"Stored read pairs: {stored}\n" in res4.stdout
-    # -v: the counters of the index build are collected over the parts (arks_index_build_shard_stats) and read as in
-    # the run with one index; those of the read stage are not (include/arks_hip.h: arks_map_votes_device)
-    build_lines = [ln for ln in res.stdout.split("\n") if ln.startswith(("Total number of Kmers", "Number Null Kmers",
-                   "Number Kmers Recorded", "Number Kmer Collisions", "Number Times Kmers Removed", "Number of unique kmers"))]
-    assert len(build_lines) == 6
-    for ln in build_lines:
+    # -v: the counters of the index build and of the read stage are collected over the parts (every key is in one
+    # part: its first holder, arks_index_build_shard) and read as in the run with one index -- the whole log does
+    counter_lines = [ln for ln in res.stdout.split("\n") if ln.startswith(("Total number of Kmers", "Number Null Kmers",
+                     "Number Kmers Recorded", "Number Kmer Collisions", "Number Times Kmers Removed", "Number of unique kmers",
+                     "Total valid kmers", "Number invalid kmers", "Number of kmers found", "Number of kmers recorded",
+                     "Number of reads passing", "Number of reads failing"))]
+    assert len(counter_lines) == 13
+    for ln in counter_lines:
         assert ln + "\n" in res4.stdout, ln
-    assert "(index in 3 shards: the k-mer counters of the read stage are not collected)" in res4.stdout
+    assert "not collected" not in res4.stdout
+    assert _norm(res4.stdout, "sharded", "counts4") == _norm(res.stdout, "out", "counts")
     # ---- -D: distance estimates (dist_est.hpp) on the same run: d= / maxd= on the edges, --dist_tsv,
     #      --samples_tsv, d= of the ABySS graph ------------------------------------------------------------
     args5 = list(args)

@@ -81,23 +81,36 @@ def test_shards_equal_whole_index(arks, gpu, oracle, k, n_shards):
     assert plain.build_stats is None and index_digest(*plain.export()) == index_digest(*shards[0].export())
     plain.close()
 
-    # (1) content: the keys its own ends visit, with the values of the whole map
-    n_zeroed = 0
+    # (1) content: of the keys its own ends visit, with the values of the whole map, those the shard is the FIRST
+    #     HOLDER of -- the smallest end of the list that visits the key is one of its own; every key of the whole map
+    #     is in exactly one shard
+    n_zeroed = n_left = 0
     owner = arks.shard_of_ends([len(e) for e in ends], n_shards)
     assert all(owner[i] == owner[i + 1] for i in range(0, len(ends), 2))      # head and tail together
     load = np.bincount(owner, weights=[len(e) for e in ends], minlength=n_shards)
     assert load.max() - load.min() <= 2 * max(len(e) for e in ends)           # balanced to within one contig
+    first_end = {}
+    for e, end in enumerate(ends):
+        for kk in oracle.OracleIndex(k).build([end]).dump()[0]:
+            first_end.setdefault(bytes(kk), e)
+    assert set(first_end) == set(whole)
+    held = 0
     for s, sh in enumerate(shards):
         own = [e if owner[i] == s else "" for i, e in enumerate(ends)]
         oxs = oracle.OracleIndex(k).build(own)
         keys, local_vals = oxs.dump()
         want_vals = np.array([whole[bytes(kk)] for kk in keys], dtype=np.int32)
         n_zeroed += int(np.count_nonzero((want_vals == 0) & (local_vals != 0)))
+        first = np.array([owner[first_end[bytes(kk)]] == s for kk in keys], dtype=bool)
+        n_left += int(np.count_nonzero(~first))
+        assert not np.any(want_vals[~first])                                  # only keys that read 0 are given up
         gk, gv = sh.export()
-        assert len(sh) == len(keys)
-        assert index_digest(gk, gv) == index_digest(keys, want_vals), (k, n_shards, s)
+        assert len(sh) == int(np.count_nonzero(first))
+        assert index_digest(gk, gv) == index_digest(keys[first], want_vals[first]), (k, n_shards, s)
         assert sh.kind == ix.kind
-    assert n_zeroed > 100        # the draft does have keys shared between shards
+        held += len(sh)
+    assert n_zeroed > 100 and n_left > 50        # the draft does have keys shared between shards
+    assert held == len(whole)
 
     # (2) mapping: max of the shard votes == the whole index == the oracle
     reads = _reads(cs, ends, k, 900 + k)
@@ -118,6 +131,36 @@ def test_shards_equal_whole_index(arks, gpu, oracle, k, n_shards):
         assert plain == want, (k, j)
         assert got == want, (k, n_shards, j)
     assert len({c for c in want if c}) > 8
+
+    # (3) the counters of the read stage (Arcs.cpp:1329-1340) over the shards: found, recorded and dups add up (every
+    #     key is in one shard), total_valid / bad / windows are the same in every shard, reads_pass / reads_fail come
+    #     from the folded votes -- equal to the whole index's and to the oracle's serial loop
+    for j in (0.55, 0.0):
+        st = oracle.MapStats()
+        for i, r in enumerate(reads):
+            if evh[i]:
+                ox.best_contig(r, j, st)
+        want_st = st.as_dict()
+        whole_st = torch.zeros(8, dtype=torch.int64, device="cuda")
+        arks.map_reads_packed(ix, packed, j, eval_mask=ev, stats=whole_st)
+        names = list(want_st)
+        assert dict(zip(names, whole_st.cpu().tolist())) == want_st, (k, j)
+        parts = []
+        for sh in shards:
+            t = torch.zeros(8, dtype=torch.int64, device="cuda")
+            arks.map_reads_packed(sh, packed, j, eval_mask=ev, stats=t)
+            parts.append(dict(zip(names, t.cpu().tolist())))
+        folded = torch.zeros(8, dtype=torch.int64, device="cuda")
+        arks.count_votes(votes, packed, k, j, folded, eval_mask=ev)
+        got_st = dict(zip(names, folded.cpu().tolist()))
+        assert got_st["reads_pass"] + got_st["reads_fail"] == int(evh.sum())
+        for f in ("found", "recorded", "dups"):
+            got_st[f] = sum(p[f] for p in parts)
+        for f in ("total_valid", "bad", "windows"):
+            assert len({p[f] for p in parts}) == 1
+            got_st[f] = parts[0][f]
+        assert got_st == want_st, (k, n_shards, j)
+        assert want_st["dups"] > 0
     for sh in shards:
         sh.close()
     ix.close()
@@ -142,6 +185,21 @@ def test_hash_layout_shards(arks, gpu, oracle, monkeypatch):
     for j in (0.55, 0.0):
         got = arks.resolve_votes(votes, packed, k, j).cpu().tolist()
         assert got == [ox.best_contig(r, j) for r in reads], j
+    # first holders only: the tables of the shards hold every key of the whole map once, and the found / recorded /
+    # duplicate counters of the read stage add up
+    assert sum(len(sh) for sh in shards) == len(ox)
+    st = oracle.MapStats()
+    for r in reads:
+        ox.best_contig(r, 0.55, st)
+    got = {"found": 0, "recorded": 0, "dups": 0}
+    for sh in shards:
+        t = torch.zeros(8, dtype=torch.int64, device="cuda")
+        arks.map_reads_packed(sh, packed, 0.55, stats=t)
+        part = dict(zip(st.as_dict(), t.cpu().tolist()))
+        for f in got:
+            got[f] += part[f]
+        assert part["total_valid"] == st.total_valid and part["bad"] == st.bad
+    assert got == {f: st.as_dict()[f] for f in got} and st.dups > 0
 
 
 def _one_rank_case():
