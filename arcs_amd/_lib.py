@@ -98,6 +98,9 @@ SYMBOLS = {
 _lib = None
 
 
+ABI_VERSION = 2          # include/arks_hip.h ARKS_ABI_VERSION
+
+
 def lib_path():
     return _PATH
 
@@ -123,6 +126,11 @@ def lib():
             fn = getattr(L, name)  # AttributeError when the ABI and the header disagree
             fn.restype = res
             fn.argtypes = args
+        v = L.arks_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f"{_PATH} reports ABI version {v}, this package is written against {ABI_VERSION}"
+                               + (" (a calibration build: results wrong by design)" if v < 0 else "")
+                               + ": rebuild with `python -m arcs_amd.build --force`")
         _lib = L
     return _lib
 

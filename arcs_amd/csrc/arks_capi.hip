@@ -223,7 +223,11 @@ extern "C" {
 int
 arks_abi_version(void)
 {
+#ifdef ARKS_CALIBRATION_BUILD
+	return -ARKS_ABI_VERSION; /* results wrong by design: no product caller accepts this library */
+#else
 	return ARKS_ABI_VERSION;
+#endif
 }
 
 const char*

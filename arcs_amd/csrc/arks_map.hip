@@ -537,17 +537,12 @@ and_window128(U128 v, int k)
 //      entries are written to `entries`; returns their number, kHnOverflow for more, kHnHeavy when the
 //      table holds the "heavy: ask the fallback table" marker.  Home slots and the capacity are multiples
 //      of 4 (mtab_home): every round trip reads one aligned group of four entries. -------------------
-#ifdef ARKS_PROBE16
-constexpr bool kProbe16Everywhere = true;
-#else
-constexpr bool kProbe16Everywhere = false;
-#endif
 // HALF16: two entries (16 bytes, one dwordx4) per round trip instead of the aligned group of four.  A random 16-byte
 // read costs the memory system less than a 32-byte one (profiles/r04j_gather_width2.txt: 4.9e10 against 3.9e10 per
 // second over a 32 GiB table), and at the table's load three probe sequences of four end within two slots; the others
 // find the second half of the group in the L2.  Pays where probing is ALL a kernel does (the owner-side
-// seeds_probe_segs_kernel of the sharded seed table); in the tile kernels, whose probes hide behind the other phases
-// of a tile, it is the same time within the noise (profiles/r04k_ab_probe16.txt; -DARKS_PROBE16 turns it on there).
+// seeds_probe_segs_kernel of the sharded seed table); in the tile kernels it was the same time within the noise
+// (profiles/r04k_ab_probe16.txt) and is not used there.
 template <int MM, bool HALF16 = false>
 __device__ __forceinline__ u32
 probe_minimizer_table(const BIndexView& bx, typename Mmer<MM>::type cm, u64* entries)
@@ -556,7 +551,7 @@ probe_minimizer_table(const BIndexView& bx, typename Mmer<MM>::type cm, u64* ent
 	u64 slot = mtab_home<MM>(cm, bx.mtab_cap);
 	u32 cnt = 0;
 	bool end = false;
-	while ((HALF16 || kProbe16Everywhere) && !end) {
+	while (HALF16 && !end) {
 		// (a non-temporal load here -- 5.5e10 against 4.9e10 16-byte reads per second in the microbenchmark -- makes the
 		// second half of a group miss as well: 4.6 instead of 3.5 ms per 25 M pairs, profiles/r04x_probe_nt.txt)
 		const ulonglong2 h = *reinterpret_cast<const ulonglong2*>(bx.mtab + slot);
@@ -875,7 +870,7 @@ map_reads_b_kernel(
 	for (int x = lane_id; x < 96; x += 64)
 		S.a[kTP + x] = 0xFFFFFFFFu;
 #ifdef ARKS_PROFILE_SECTIONS
-	unsigned long long sec_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long sec_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -1964,7 +1959,6 @@ struct SeedTileLds
 	u32 rmax[sTR][2];
 	u32 redo;  // reads for the slow queue
 	u32 redo2; // reads for the medium queue
-	u32 live;  // reads with a first-round seed that has entries (two-round S2)
 	u64 wstats[8];
 	// REMOTE without counters: the reads none of whose seeds has an entry are settled before the tiles are made, the
 	// others move up into their places
@@ -2010,35 +2004,37 @@ map_reads_s_kernel(
 	const int lane_id = threadIdx.x;
 	const int k = g.k, w = bx.w;
 	const u32 wrecip = (65536u + (u32)w - 1u) / (u32)w; // x / w == (x * wrecip) >> 16 for x < 65536 / w
-	// Two-round S2 (round 4): the seeds of a read are probed in two rounds.  Round 1 = its first seeds, as many as it
-	// takes for "none of them has an entry" to settle the vote: a seed without entries means that every window of
-	// its group is absent from the index (the property the whole kernel rests on), so the best contig can hold at
-	// most the windows of the groups behind, and when (those) / (all windows) cannot exceed j_index the read's
-	// result is 0 whatever the other seeds say (Arcs.cpp:1006-1010) -- they are not probed.  Half of a uniform read
-	// set lies outside the contig ends and pays one probe of two (128 bp, k = 60, j = 0.55), two of three (151 bp)
-	// instead of all of them.  Not with STATS (the counters want every window looked at), not for RAW votes
-	// (the count is the result) and not for REMOTE (the answers are there already).
-#ifdef ARKS_TWO_ROUND
-	constexpr bool kTwoRound = !STATS && !RAW && !REMOTE;
-#else
-	constexpr bool kTwoRound = false;
-#endif
 	const float jf = (float)j_index;
-	// REMOTE (the seeds' answers are there before the launch), no counters, no raw votes: a read none of whose seeds has
-	// an entry -- half of a uniform read set lies outside the contig ends -- has no window in the index: its result is 0,
-	// and it is settled per chunk, before the tiles are made; the tiles then hold the other reads only (half as many
-	// tiles).  Not when the index holds quirk images: a palindromic window's key is not its sequence's, the slow
-	// kernel decides those and finds them through the staged words (below).
-	// Without REMOTE the same is done with probes of the kernel's own (ARKS_SKIP_DEAD_FUSED): per chunk, every read's
-	// FIRST seeds -- as many as it takes for "none of them has an entry" to settle the vote, the rule of the two-round
-	// S2 above: one of two for a 128-base read at k = 60 and j = 0.55, two of three for a 151-base one -- are made
-	// from the batch's words and probed; a read all of whose first seeds are absent is settled (result 0), the others
-	// go into tiles, where every seed is probed as before (the first ones a second time: cache hits).  An absent
-	// read costs its first probes and no tile; the dependent round trip is paid once per chunk, not per tile.
-#ifdef ARKS_SKIP_DEAD_FUSED
-	constexpr bool kSkipDead = !STATS && !RAW;
-#else
+	// No counters, no raw votes: a read none of whose seeds has an entry -- half of a uniform read set lies outside the
+	// contig ends -- has no window in the index: its result is 0, and it is settled per chunk, before the tiles are made;
+	// the tiles then hold the other reads only (half as many tiles).  Not when the index holds quirk images: a
+	// palindromic window's key is not its sequence's, the slow kernel decides those and finds them through the staged
+	// words (below).
+	// REMOTE: the seeds' answers are there before the launch.  Otherwise the kernel probes, per chunk, every read's FIRST
+	// seeds -- as many as it takes for "none of them has an entry" to settle the vote: a seed without entries means that
+	// every window of its group is absent from the index (the property the whole kernel rests on), so the best contig
+	// can hold at most the windows of the groups behind, and when (those) / (all windows) cannot exceed j_index the
+	// read's result is 0 whatever the other seeds say (Arcs.cpp:1006-1010): one of two seeds for a 128-base read at
+	// k = 60 and j = 0.55, two of three for a 151-base one -- made from the batch's words; a read all of whose first
+	// seeds are absent is settled, the others go into tiles, where every seed is probed as before (the first ones a
+	// second time: cache hits).  An absent read costs its first probes and no tile; the dependent round trip is paid
+	// once per chunk, not per tile (round 4: -4.7 % as a build option, profiles/r04s_ab_skip_dead_fused.txt; the
+	// default since round 5).  Tried and dropped: the same two rounds PER TILE (21 % fewer probes, +1.5 % time,
+	// profiles/r04c_ab_two_round.txt), and -- round 5 -- every seed of a chunk probed once from words staged in LDS with
+	// the answers parked there, tiles of one round trip (text) each: 8-12 KB of LDS per wave leave 3-5 waves per SIMD
+	// and the launch takes 5.1-6.0 ms against 3.6 (profiles/r09a_ab_chunk_probe.txt: the kernel's time is round trips
+	// x waves, and LDS is what buys waves).
+#if defined(ARKS_CAL_NO_PROBE) || defined(ARKS_CAL_NO_TREC)
+#ifndef ARKS_CALIBRATION_BUILD
+#error "ARKS_CAL_NO_PROBE / ARKS_CAL_NO_TREC are calibration builds (results wrong by design): pass -DARKS_CALIBRATION_BUILD too"
+#endif
+#endif
+#ifdef ARKS_CAL_NO_PROBE
+	// (calibration build: no probe anywhere, hence no diagonal and no text record -- every read goes through the tiles and
+	// the kernel fetches its read stream and nothing else, a byte count that is known exactly; profiles/tools/fetch_calib.py)
 	constexpr bool kSkipDead = REMOTE && !STATS && !RAW;
+#else
+	constexpr bool kSkipDead = !STATS && !RAW;
 #endif
 	const bool skip_dead = kSkipDead && !(bx.has_img && !(k & 1));
 	if (STATS && lane_id < 8)
@@ -2046,6 +2042,10 @@ map_reads_s_kernel(
 	u32* const work_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kWorkCtrOffset);
 	u32 ctr = blockIdx.x & (u32)(kCounters - 1), misses = 0;
 	bool first_grab = true;
+#ifdef ARKS_PROFILE_SECTIONS
+	unsigned long long sec_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();
+#endif
 	for (;;) {
 		// ---- the next chunk: the first one is the wave's own (its block index), later ones come from the
 		//      interleaved counters (see map_reads_b_kernel).  (Asking for the NEXT chunk's number while this one is
@@ -2100,6 +2100,7 @@ map_reads_s_kernel(
 		}
 		// reads of the chunk that may hold an invalid base: only a tile with one of them fetches its N masks (a
 		// third of the read stream, and zero for > 98 % of the reads)
+		ARKS_SEC(0);
 		// index of the chunk's first seed in `ans` / `seed_slot`
 		const long soff0 = REMOTE ? (chunk_off ? (long)chunk_off[c0 / sChunk] : seed_off[c0]) : 0;
 		int nwin_l = rl - k + 1;
@@ -2116,8 +2117,8 @@ map_reads_s_kernel(
 			bool keep = lane_id < nchunk && rl >= 0 && G > 0;
 			if (!REMOTE) {
 				if (keep) {
-					// g1 = the read's first-round seeds (see kTwoRound): with all of them absent the windows behind them cannot
-					// reach j_index (the float test errs to the safe side)
+					// g1 = the read's first seeds: with all of them absent the windows behind them cannot reach j_index (the
+					// float test errs to the safe side: a margin of 1e-4 against a rounding error of 1e-7)
 					int g1 = 1;
 					while (g1 < G && !((float)(nwin_l - g1 * w) * 1.0001f < jf * (float)nwin_l))
 						++g1;
@@ -2179,9 +2180,7 @@ map_reads_s_kernel(
 							}
 							any = any || hit;
 						}
-#ifndef ARKS_SKIP_DBG_KEEPALL
 						keep = any;
-#endif
 					}
 				}
 			} else if (keep && G <= 3) {
@@ -2237,6 +2236,7 @@ map_reads_s_kernel(
 		}
 		// reads of the chunk that may hold an invalid base: only a tile with one of them fetches its N masks (a
 		// third of the read stream, and zero for > 98 % of the reads)
+		ARKS_SEC(5);
 		const u64 nreads_mask = __ballot(may_n);
 		// reads beyond kSW words (512 bases) do not enter a tile: the per-read counters hold 10-bit fields
 		const u64 longmask = __ballot(lane_id < nchunk_c && wcnt > kSW);
@@ -2271,6 +2271,7 @@ map_reads_s_kernel(
 			const int nr = nxt - cur;
 			const int tw = (int)(lane_value_u64(pos, nxt) - base_w);
 			const int nh = __builtin_amdgcn_readlane(gex, nxt) - gbase;
+			ARKS_SEC(6);
 			// ---- S1: words, metadata, seeds ----------------------------------------------------------
 			// (wave-uniform) does a read of the tile hold an invalid base?  nr <= 16 reads from cur on
 			const bool want_nm = ((nreads_mask >> cur) & ((1ull << nr) - 1ull)) != 0;
@@ -2324,12 +2325,7 @@ map_reads_s_kernel(
 					for (int gi = 0; gi < G; ++gi) {
 						int q = (gi + 1) * w - 1;
 						q = q < nwin_l - 1 ? q : nwin_l - 1;
-						// bit 0: a second-round seed -- the groups in front of it cover enough of the read that, all of them
-						// absent, (windows left) / (all windows) > j_index is false.  The float test errs to the safe side
-						// (a margin of 1e-4 against a rounding error of 1e-7): a seed wrongly kept in round 1 costs a probe.
-						const u32 late =
-						    kTwoRound && gi > 0 && (float)(nwin_l - gi * w) * 1.0001f < jf * (float)nwin_l ? 1u : 0u;
-						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)j << 12) | late);
+						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)j << 12));
 					}
 					S.pdiag[j][0] = ~0ull;
 					S.pdiag[j][1] = ~0ull;
@@ -2343,8 +2339,6 @@ map_reads_s_kernel(
 					asm volatile("v_mov_b32 %0, 0" : "=v"(z));
 					S.redo = z;
 					S.redo2 = z;
-					if (kTwoRound)
-						S.live = z;
 				}
 				if (gathered) {
 					ARKS_WAVE_SYNC();
@@ -2400,52 +2394,38 @@ map_reads_s_kernel(
 					}
 				}
 			}
+			ARKS_SEC(7);
 			// ---- S2: lanes = seeds: probe, proposals (0 = none) of up to two diagonals -------------------
 			int jh = 0;
 			u64 dk0 = 0, dk1 = 0;
 			bool off = false;
 			{
 				int q = 0;
-				bool late = false;
 				if (lane < nh) {
 					const u32 hv = S.heads[lane];
 					q = (int)((hv >> 1) & 2047u);
 					jh = (int)(hv >> 12);
-					late = kTwoRound && (hv & 1u);
 				}
 				u64 ent[2];
 				u32 cnt = 0;
 				u32 rstrand = 0;
-#pragma unroll
-				for (int rd = 0; rd < (kTwoRound ? 2 : 1); ++rd) {
-					// round 0: the first seeds of every read; round 1: the others, of the reads that are still open
-					const bool go = lane < nh && late == (rd == 1) && (rd == 0 || ((S.live >> jh) & 1u));
-					// a seed that holds an invalid base has no entries: every window of its group holds that base too
-					if (go && !(has_n && tile_span_has_n(S.nm, q, MM))) {
-						const mm_t mf = tile_mmer<MM>(S.cw, q), mr = mmer_rc<MM>(mf);
-						rstrand = mf < mr ? 1u : 0u;
-						if (REMOTE) {
-							long si = soff0 + (long)((kSkipDead && skip_dead ? S.sbase[jh] : gbase) + lane);
-							if (seed_slot)
-								si = slot_pref == ~0u ? -1 : (long)slot_pref;
-							if (si >= 0) {
-								const u64* a = ans + 2 * si;
-								ent[0] = a[0], ent[1] = a[1];
-								cnt = seed_answer_count(ent[0], ent[1]);
-							}
-						} else {
-#ifndef ARKS_CAL_NO_PROBE
-							cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, ent);
-#endif
-							// (ARKS_CAL_NO_PROBE: a calibration build, results wrong by design -- no probe, hence no diagonal and
-							// no text record: the kernel fetches its read stream and nothing else, a byte count that is known
-							// exactly; profiles/tools/fetch_calib.py holds rocprofv3's FETCH_SIZE against it)
+				// a seed that holds an invalid base has no entries: every window of its group holds that base too
+				if (lane < nh && !(has_n && tile_span_has_n(S.nm, q, MM))) {
+					const mm_t mf = tile_mmer<MM>(S.cw, q), mr = mmer_rc<MM>(mf);
+					rstrand = mf < mr ? 1u : 0u;
+					if (REMOTE) {
+						long si = soff0 + (long)((kSkipDead && skip_dead ? S.sbase[jh] : gbase) + lane);
+						if (seed_slot)
+							si = slot_pref == ~0u ? -1 : (long)slot_pref;
+						if (si >= 0) {
+							const u64* a = ans + 2 * si;
+							ent[0] = a[0], ent[1] = a[1];
+							cnt = seed_answer_count(ent[0], ent[1]);
 						}
-					}
-					if (kTwoRound && rd == 0) {
-						if (go && cnt)
-							atomicOr(&S.live, 1u << jh);
-						ARKS_WAVE_SYNC();
+					} else {
+#ifndef ARKS_CAL_NO_PROBE
+						cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, ent);
+#endif
 					}
 				}
 				off = cnt == kHnHeavy || cnt == kHnOverflow;
@@ -2503,6 +2483,7 @@ map_reads_s_kernel(
 			}
 			const bool any_b = __ballot(has_b) != 0;
 			ARKS_WAVE_SYNC();
+			ARKS_SEC(8);
 			// ---- S4 / S5 per diagonal: A for every tile, B only for a tile that has one ---------------------
 			u32 ok_a = 0; // the word's windows matched on diagonal A (a window matched on both counts once, on A)
 			int jw = 0;
@@ -2562,6 +2543,7 @@ map_reads_s_kernel(
 							S.town[sl] = own[u];
 						}
 				}
+				ARKS_SEC(9);
 				if (lane < 8) // the spans of the last words read past the tile: no mismatch there
 					S.mm32[tw + lane] = 0u;
 				ARKS_WAVE_SYNC();
@@ -2594,6 +2576,7 @@ map_reads_s_kernel(
 				}
 				ARKS_WAVE_SYNC(); // the staging storage is rewritten by the next diagonal
 			}
+			ARKS_SEC(10);
 			// ---- S6: lane = read: at most two distinct positive values (one per diagonal): the vote of
 			//      Arcs.cpp:998-1004 is a compare ------------------------------------------------------------
 			const u32 redo_mask = S.redo, redo2_mask = S.redo2;
@@ -2681,9 +2664,15 @@ map_reads_s_kernel(
 				}
 			}
 			ARKS_WAVE_SYNC();
+			ARKS_SEC(11);
 			cur = nxt;
 		}
 	}
+#ifdef ARKS_PROFILE_SECTIONS
+	if (!STATS && !RAW && lane_id == 0)
+		for (int x = 0; x < 12; ++x)
+			atomicAdd(&g_sec_cycles[x], sec_acc[x]);
+#endif
 	if (STATS) {
 		ARKS_WAVE_SYNC();
 		if (lane_id == 0) {

@@ -1266,6 +1266,12 @@ run_arks(const std::vector<std::string>& filenames)
 			g_workers.push_back(Worker{ pid, fds[0] });
 		}
 	}
+	if (arks_abi_version() != ARKS_ABI_VERSION) {
+		// (arks_abi_version makes no HIP call: safe in front of the forks' first device use)
+		std::cerr << PROGRAM ": error: libarks_hip reports ABI version " << arks_abi_version() << ", this program was built against "
+		          << ARKS_ABI_VERSION << (arks_abi_version() < 0 ? " (a calibration build of the library: results wrong by design)" : "") << ".\n";
+		exit(EXIT_FAILURE);
+	}
 	if (arks_device_count() < 1) {
 		std::cerr << PROGRAM ": error: no gfx950 (MI355X) device is visible; this build has no CPU path.\n";
 		exit(EXIT_FAILURE);

@@ -37,7 +37,12 @@
 extern "C" {
 #endif
 
-#define ARKS_ABI_VERSION 1
+/* 2 (round 5): arks_index_build_seed_shard took a trailing `arks_build_stats*` and arks_exchange_stats grew `reruns`
+ * in round 4 without a new number; callers check arks_abi_version() == ARKS_ABI_VERSION at load (arcs_amd/_lib.py,
+ * arcs_amd/host/arcs.cpp) so that a caller built against another header fails there, not in a wild write.  A
+ * calibration build of the library (-DARKS_CALIBRATION_BUILD: kernels with a memory phase taken out, results wrong by
+ * design, profiles/tools/) reports the NEGATIVE number and is refused by both. */
+#define ARKS_ABI_VERSION 2
 
 /* status codes */
 #define ARKS_OK 0

@@ -82,4 +82,12 @@ for (name, L, h, codes, nmask, out, ev) in libs:
         qc = (C.c_uint * 4)(); L.arks_debug_queue_counts.argtypes = [C.c_void_p, C.c_void_p]; L.arks_debug_queue_counts(h, qc); print("   queues: slow", qc[0], "medium", qc[2], "of", n, "reads")
     except AttributeError:
         pass
+    try:
+        sec = (C.c_ulonglong * 16)(); L.arks_debug_section_cycles.argtypes = [C.c_void_p]; L.arks_debug_section_cycles(sec)
+        tot = sum(sec[:12]) or 1
+        print("   sections (share of the hot kernel's wave cycles):", " ".join(f"{i}:{100.0 * sec[i] / tot:.1f}" for i in range(12)), f"total {tot:.3e}")
+    except AttributeError:
+        pass
+    dig = int((out.to(torch.int64) * (torch.arange(n, device=dev, dtype=torch.int64) % 1000003 + 1)).sum().item())
+    print(f"{name:14s} digest {dig} nonzero {int((out != 0).sum().item())}")
     print(f"{name:14s} median {statistics.median(t):7.3f} ms  min {min(t):7.3f}  -> {windows / (statistics.median(t) * 1e-3) / 1e9:6.2f} G k-mers/s  same_as_first={same}")

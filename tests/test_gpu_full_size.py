@@ -106,6 +106,10 @@ def test_configs1_at_its_size_against_the_whole_oracle(arks, gpu, oracle):
     c, p = arks.map_pairs_packed(ix, head, j, pair_ok=batch["pair_ok"][:n_chk], stats=st)
     torch.cuda.synchronize()
     assert (c.cpu().numpy() == want_c).all() and (p.cpu().numpy() == want_p).all()
+    # (the instantiation without counters: what `arcs` runs without -v and what bench.py times)
+    c, p = arks.map_pairs_packed(ix, head, j, pair_ok=batch["pair_ok"][:n_chk])
+    torch.cuda.synchronize()
+    assert (c.cpu().numpy() == want_c).all() and (p.cpu().numpy() == want_p).all()
     assert dict(zip(STAT_NAMES, st.cpu().tolist())) == {f: want_st[f] for f in STAT_NAMES}
     del head
     # all 20 M pairs in one launch
@@ -219,6 +223,11 @@ def test_human_scale_draft(arks, gpu, oracle):
     assert (conreci.cpu().numpy() == want_c).all()
     assert (pair.cpu().numpy() == want_p).all()
     assert dict(zip(STAT_NAMES, stats.cpu().tolist())) == {f: want_st[f] for f in STAT_NAMES}
+    # (the instantiation without counters: what `arcs` runs without -v and what bench.py times)
+    c2, p2 = arks.map_pairs_packed(ix, reads, j, pair_ok=batch["pair_ok"])
+    torch.cuda.synchronize()
+    assert (c2.cpu().numpy() == want_c).all() and (p2.cpu().numpy() == want_p).all()
+    del c2, p2
     sel = (want_p != 0) & (ok != 0)
     key = batch["barcode_id"].cpu().numpy().astype(np.int64)[sel] * (1 << 32) + want_p[sel]
     uk, cnt = np.unique(key, return_counts=True)
@@ -371,6 +380,10 @@ def test_arks_long_human_scale_multi_k(arks, gpu, oracle):
         assert (conreci.cpu().numpy() == want_c).all(), k
         assert (pair.cpu().numpy() == want_p).all(), k
         assert dict(zip(STAT_NAMES, stats.cpu().tolist())) == {f: want_st[f] for f in STAT_NAMES}, k
+        # (the instantiation without counters: what `arcs` runs without -v and what bench.py times)
+        conreci, pair = arks.map_pairs_packed(ix, reads, j, pair_ok=batch["pair_ok"])
+        torch.cuda.synchronize()
+        assert (conreci.cpu().numpy() == want_c).all() and (pair.cpu().numpy() == want_p).all(), (k, "no counters")
         passed += int((want_p != 0).sum())
         del ox
     assert passed > n_pairs          # most pairs name an end at every k with j = 0.05
@@ -434,6 +447,11 @@ def test_seed_table_in_eight_shards_human_scale(arks, gpu, oracle):
     assert (conreci.cpu().numpy() == want_c).all()
     assert (pair.cpu().numpy() == want_p).all()
     assert dict(zip(STAT_NAMES, stats.cpu().tolist())) == {f: want_st[f] for f in STAT_NAMES}
+    # (the instantiation without counters: what `arcs` runs without -v and what bench.py times)
+    c2 = arks.api.map_reads_seeded(home, reads, j, seed_off, answers, eval_mask=ev)
+    torch.cuda.synchronize()
+    assert (c2.cpu().numpy() == want_c).all()
+    del c2
     sel = (want_p != 0) & (ok != 0)
     key = batch["barcode_id"].cpu().numpy().astype(np.int64)[sel] * (1 << 32) + want_p[sel]
     uk, cnt = np.unique(key, return_counts=True)

@@ -8,6 +8,8 @@ also went through 2..5 index shards (FUZZ_SHARDS=1): votes, maximum, j_index tes
 import numpy as np
 import pytest
 
+from util import map_reads_both_ways
+
 pytestmark = [pytest.mark.gpu]
 
 COMP = str.maketrans("ACGTacgtNn", "TGCAtgcaNn")
@@ -64,7 +66,7 @@ def test_fuzz_vs_oracle(arks, gpu, oracle, first_seed, index_layout, monkeypatch
         for j in (0.55, 0.0, float(rng.random())):
             st = oracle.MapStats()
             want = [ox.best_contig(r, j, st) for r in reads]
-            got, gst = ix.map_reads(reads, j, want_stats=True)
+            got, gst = map_reads_both_ways(ix, reads, j)
             bad = [i for i, (a, b) in enumerate(zip(got.tolist(), want)) if a != b]
             assert not bad, (seed - 1, k, j, bad[:5], [len(reads[i]) for i in bad[:5]])
             assert gst == st.as_dict(), (seed - 1, k, j, gst, st.as_dict())

@@ -3,7 +3,7 @@ fixtures.  Bit-exact: keys, values, per-read contig ends, pair results, counters
 import numpy as np
 import pytest
 
-from util import index_digest, oracle_pairs
+from util import index_digest, map_reads_both_ways, oracle_pairs
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("index_layout")]
 
@@ -93,7 +93,7 @@ def test_random_draft_and_reads_vs_oracle(arks, gpu, oracle, k):
     for j in (0.55, 0.05, 0.0, -1.0):
         st = oracle.MapStats()
         want = [ox.best_contig(r, j, st) for r in reads]
-        got, gst = ix.map_reads(reads, j, want_stats=True)
+        got, gst = map_reads_both_ways(ix, reads, j)
         assert got.tolist() == want, (k, j)
         assert gst == st.as_dict(), (k, j)
     ix.close()
@@ -217,7 +217,7 @@ def test_locality_index_exceptions(arks, gpu, oracle):
         for j in (0.0, 0.3, 0.55):
             st = oracle.MapStats()
             want = [ox.best_contig(r, j, st) for r in reads]
-            got, gst = ix.map_reads(reads, j, want_stats=True)
+            got, gst = map_reads_both_ways(ix, reads, j)
             assert got.tolist() == want, (k, j)
             assert gst == st.as_dict(), (k, j)
         ix.close()
@@ -252,7 +252,7 @@ def test_reads_across_adjacent_text_sequences(arks, gpu, oracle):
         for j in (0.0, 0.2, 0.55):
             st = oracle.MapStats()
             want = [ox.best_contig(r, j, st) for r in reads]
-            got, gst = ix.map_reads(reads, j, want_stats=True)
+            got, gst = map_reads_both_ways(ix, reads, j)
             assert got.tolist() == want, (k, j)
             assert gst == st.as_dict(), (k, j)
         ix.close()
@@ -270,7 +270,7 @@ def test_hash_kind_still_exact(arks, gpu, oracle, golden_mini, monkeypatch):
     ox = oracle.OracleIndex(60).build(ends)
     st = oracle.MapStats()
     want = [ox.best_contig(r, 0.55, st) for r in reads]
-    got, gst = ix.map_reads(reads, 0.55, want_stats=True)
+    got, gst = map_reads_both_ways(ix, reads, 0.55)
     assert got.tolist() == want and gst == st.as_dict()
     ix.close()
 
@@ -299,7 +299,7 @@ def test_minimizer_length_variants(arks, gpu, oracle, golden_mini, monkeypatch, 
     for j in (0.05, 0.55):
         st = oracle.MapStats()
         want = [ox.best_contig(r, j, st) for r in allreads]
-        got, gst = ix.map_reads(allreads, j, want_stats=True)
+        got, gst = map_reads_both_ways(ix, allreads, j)
         assert got.tolist() == want, (k, j)
         assert gst == st.as_dict(), (k, j)
     ix.close()

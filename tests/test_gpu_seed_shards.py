@@ -51,6 +51,8 @@ def test_answers_of_the_owners_give_the_whole_index(arks, gpu, oracle, k, n_rank
         want = [ox.best_contig(r, j, st) for r in reads]
         assert got.cpu().tolist() == want, j
         assert dict(zip(STAT_NAMES, stats.cpu().tolist())) == st.as_dict()
+        # (the instantiation without counters: what `arcs` runs without -v and what bench.py times)
+        assert arks.api.map_reads_seeded(home, packed, j, seed_off, answers).cpu().tolist() == want, j
         assert arks.map_reads_packed(whole, packed, j).cpu().tolist() == want
     with pytest.raises(arks.ArksError):                   # a shard cannot answer the plain call
         arks.map_reads_packed(home, packed, 0.5)
@@ -154,6 +156,7 @@ def _rccl_worker(port):
     ox = O.OracleIndex(60).build(ends)
     st = O.MapStats()
     assert got == [ox.best_contig(r, 0.55, st) for r in reads]
+    assert adist.map_reads_seed_sharded(sh, packed, 0.55).cpu().tolist() == got      # (the instantiation without counters: what `arcs` runs without -v and what bench.py times)
     assert dict(zip(STAT_NAMES, stats.cpu().tolist())) == st.as_dict()
     dist.destroy_process_group()
     print("rccl exchange ok")

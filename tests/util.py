@@ -85,3 +85,15 @@ def expected_cli_outputs(oracle_mod, G, names, cs, recs, mult, k, j, P, threads=
             "main.tsv": G.tsv_text(imap, pmap, mult, P), "imap": imap, "pmap": pmap, "ids": ids, "edges": edges,
             "dead": dead, "lengths": lengths, "stats": st, "pair": pair, "pair_ok": pair_ok,
             "build_stats": ox.stats.as_dict()}
+
+
+def map_reads_both_ways(ix, reads, j):
+    """ix.map_reads with the -v counters AND without: two instantiations of every map kernel -- the one without
+    counters is what `arcs` runs by default and what bench.py times, and it has shortcuts of its own (absent reads
+    settled per chunk, flagged reads finished in place when the found windows settle the vote).  Every oracle
+    comparison of per-read results goes through both.  Returns (conreci, counters)."""
+    got, gst = ix.map_reads(reads, j, want_stats=True)
+    plain = ix.map_reads(reads, j)
+    bad = [i for i, (a, b) in enumerate(zip(plain.tolist(), got.tolist())) if a != b]
+    assert not bad, ("the kernels without counters differ from the ones with", j, bad[:5], [len(reads[i]) for i in bad[:5]])
+    return got, gst
