@@ -63,6 +63,7 @@ SYMBOLS = {
     "arks_exchange_abort": (_I, [_VP]),
     "arks_exchange_last_stats": (_I, [_VP, _VP]),
     "arks_exchange_submit": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
+    "arks_exchange_submit_pairs": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP, _VP]),
     "arks_exchange_complete": (_I, [_VP]),
     "arks_exchange_complete_group": (_I, [_VP, _I]),
     "arks_map_reads_exchanged_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
@@ -70,6 +71,7 @@ SYMBOLS = {
     "arks_index_k": (_I, [_VP]),
     "arks_index_size": (_I64, [_VP]),
     "arks_index_device_bytes": (_I64, [_VP]),
+    "arks_index_fallback_size": (_I, [_VP, _VP]),
     "arks_index_kind": (_I, [_VP]),
     "arks_index_export": (_I, [_VP, _VP, _VP]),
     "arks_end_cutoff": (_I, [_I, _I, _I, C.POINTER(_I)]),

@@ -164,6 +164,13 @@ class ArksIndex:
     def device_bytes(self):
         return lib().arks_index_device_bytes(self._h)
 
+    @property
+    def fallback_size(self):
+        """(keys, bytes) of the exact table of the keys the text cannot answer (windows under heavy seeds, palindromes)"""
+        out = (C.c_int64 * 2)()
+        check(lib().arks_index_fallback_size(self._h, out), "arks_index_fallback_size")
+        return int(out[0]), int(out[1])
+
     def export(self):
         """(keys uint8[n, key_bytes] in the reference's byte order, vals int32[n])"""
         n = len(self)
@@ -452,6 +459,21 @@ class SeedExchange:
             stats.data_ptr() if stats is not None else None, _stream_ptr(reads.device)), "arks_exchange_submit")
         return out[:n]
 
+    def submit_pairs(self, reads, j_index, pair_ok=None, stats=None, out=None):
+        """arks_exchange_submit_pairs: submit with the pair gate folded into the bucketing kernel (reads 2p, 2p + 1 are
+        mates).  Returns (conreci, eval): both filled on the stream -- eval by this call, conreci by complete()."""
+        torch = _torch()
+        n = reads.n_reads
+        if out is None:
+            out = torch.empty(max(n, 1), dtype=torch.int32, device=reads.codes.device)
+        ev = torch.empty(max(n, 1), dtype=torch.uint8, device=reads.codes.device)
+        check(lib().arks_exchange_submit_pairs(
+            self._h, reads.codes.data_ptr(), reads.nmask.data_ptr(), reads.word_off.data_ptr(), reads.lens.data_ptr(),
+            reads.read_class.data_ptr(), pair_ok.data_ptr() if pair_ok is not None else None, n, float(j_index),
+            ev.data_ptr(), out.data_ptr(), stats.data_ptr() if stats is not None else None, _stream_ptr(reads.device)),
+            "arks_exchange_submit_pairs")
+        return out[:n], ev[:n]
+
     def complete(self):
         """arks_exchange_complete (COLLECTIVE): the oldest submitted batch is exchanged and mapped on its stream"""
         check(lib().arks_exchange_complete(self._h), "arks_exchange_complete")
@@ -471,13 +493,14 @@ class SeedExchange:
         return conreci, pair
 
     def map_pairs_pipelined(self, batches, j_index, streams, imap=None, stored=None, stats=None, n_calls=None,
-                            keep=True):
+                            keep=True, fold_gate=True):
         """The same flow over a list of batches (reads, pair_ok, barcode_id) with two of them in flight: batch n + 1 is
         gated and submitted on streams[(n + 1) % 2] before batch n is completed, so its bucketing runs under batch n's
         probes, transfers and map kernel, and the host never waits for counts.  COLLECTIVE: every rank makes
         n_calls (default len(batches)) complete() calls -- a rank with fewer batches completes empty ones.  The pair
         rule of all batches runs on streams[2] (the IndexMap is updated in one order).  Returns [(conreci, pair)]
-        (keep=False: nothing is kept, for timing runs)."""
+        (keep=False: nothing is kept, for timing runs).  fold_gate: the pair gate computed by the bucketing kernel
+        (arks_exchange_submit_pairs) instead of a launch of its own."""
         torch = _torch()
         dev = torch.device("cuda", self.index.device)
         n_calls = len(batches) if n_calls is None else n_calls
@@ -492,8 +515,11 @@ class SeedExchange:
             reads, ok, bid = batches[i] if i < len(batches) else (empty, None, None)
             st = streams[i % 2]
             with torch.cuda.stream(st):
-                ev = pair_gate(reads, ok)
-                conreci = self.submit(reads, j_index, eval_mask=ev, stats=stats)
+                if fold_gate and reads.n_reads:
+                    conreci, ev = self.submit_pairs(reads, j_index, pair_ok=ok, stats=stats)
+                else:
+                    ev = pair_gate(reads, ok)
+                    conreci = self.submit(reads, j_index, eval_mask=ev, stats=stats)
             flight.append((reads, ok, bid, ev, conreci, st))
 
         def complete():

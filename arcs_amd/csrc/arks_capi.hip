@@ -1233,6 +1233,16 @@ arks_index_kind(const arks_index* idx)
 }
 
 int
+arks_index_fallback_size(const arks_index* idx, int64_t out[2])
+{
+	if (!idx || !out)
+		return ARKS_ERR_BAD_ARG;
+	out[0] = idx->kind >= 1 ? idx->n_fallback : 0;
+	out[1] = idx->kind >= 1 ? (int64_t)(idx->table.cap * kSlotWords * sizeof(u64)) : 0;
+	return ARKS_OK;
+}
+
+int
 arks_index_export(const arks_index* idx, unsigned char* h_keys, int32_t* h_vals)
 {
 	if (!idx || !h_keys || !h_vals)
@@ -1739,8 +1749,28 @@ imap_reserve(arks_imap* m, u64 incoming)
 	m->bound = n;
 	if ((n + 8 * incoming) * 2 <= m->v.cap) // room for at least eight more launches of this size
 		return ARKS_OK;
+	// Room for eight more launches where the device has it (an exact count is a device-wide wait: the fewer the better),
+	// for four, two or just this one where it does not: a table takes 20 bytes per slot, and with launches of 10^7-10^8
+	// pairs "eight launches" is 5-40 GB per accumulator -- eight local ranks on one device (bench.py --sharded-index,
+	// arcs --index-sharded) ran out of memory over it in round 5.  No more than an eighth of what is free now.
+	u64 ahead = 8;
+	{
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+			free_b = 0, (void)hipGetLastError();
+		auto slots_for = [&](u64 a) {
+			u64 sl = m->v.cap;
+			while ((n + a * incoming) * 2 > sl)
+				sl *= 2;
+			return sl;
+		};
+		while (ahead > 1 && slots_for(ahead) * 20ull > (u64)free_b / 8)
+			ahead /= 2;
+		if ((n + ahead * incoming) * 2 <= m->v.cap)
+			return ARKS_OK;
+	}
 	u64 slots = m->v.cap;
-	while ((n + 8 * incoming) * 2 > slots)
+	while ((n + ahead * incoming) * 2 > slots)
 		slots *= 2;
 	ImapView to;
 	rc = imap_alloc(to, slots);

@@ -97,7 +97,7 @@ struct LocalGroup
 	struct Shown
 	{
 		int status = 0, status2 = 0; // before the first / the second barrier of a batch
-		const u64* counts = nullptr; // pinned: fill[o] of the batch
+		const u64* counts = nullptr; // the batch's seeds per owner (ExSet::counts)
 		u64 cap = 0;                 // region size of its send / answer buffers
 		const u64* send = nullptr;
 		u64* ans_back = nullptr;
@@ -186,6 +186,16 @@ struct ExSet
 	bool used = false, pending = false;
 	int rc = ARKS_OK;
 	u64 cap = 0, slot_cap = 0;
+	u64 cap_floor = 0, slot_floor = 0; // set while a batch that did not fit is run again
+	arks::SeedBucketBase base{};   // where d_ctl's counters stood before this batch's launch (they only count up)
+	u64 launches = 0;              // bucket launches on d_ctl so far (SeedBucketBase::seq of the next one - 1)
+	u64 counts[64] = { 0 };        // the batch's seeds per owner, and ...
+	u64 n_seeds = 0;               // ... in all (differences of the counters; valid after ex_counts)
+	arks_index::QueueSet qs{};     // the map kernels' queues and scratch on this batch's stream (scratch zeroed by the bucket launch)
+	bool scratch_zeroed = false;
+	const uint8_t* read_class = nullptr; // arks_exchange_submit_pairs: the gate is computed by the bucket kernel ...
+	const uint8_t* pair_ok = nullptr;
+	uint8_t* eval_out = nullptr;         // ... and written here (the map kernels read it)
 	std::vector<u64> all, sc, rcv, soff, roff; // the batch's counts: everybody's, and this rank's tables
 	// the batch
 	const u64* codes = nullptr;
@@ -210,7 +220,10 @@ struct arks_exchange
 	ExSet set[2];
 	u64 submitted = 0, completed = 0;
 	// seeds per read the regions are sized for: per owner, and in all (raised when a batch does not fit)
-	double per_read_owner = 0, per_read_all = 3.3;
+	// (first guess: a 10x read pair has 2 + 3 seeds at k = 60; a batch of another shape does not fit, says what it needs,
+	// and is bucketed again -- once per shape; 3.3 until round 4: 30 % of the buffers of a 10x batch were never used)
+	double per_read_owner = 0, per_read_all = 2.65;
+	long largest_batch = 0;
 	u64 reruns = 0;
 	arks_exchange_stats last{};
 };
@@ -273,13 +286,14 @@ exchange_new(arks_exchange** out, const arks_index* shard, int rank, int world)
 	if (!x)
 		return ARKS_ERR_OOM;
 	x->idx = shard, x->rank = rank, x->world = world, x->device = shard->device;
-	x->per_read_owner = 3.3 / world * 1.1;
+	x->per_read_owner = 2.65 / world * 1.06;
 	DeviceGuard guard(x->device);
 	const size_t gw = (size_t)(1 + world) * (size_t)(1 + world);
 	for (ExSet& s : x->set) {
 		void* p = nullptr;
 		HIP_TRY(hipMalloc(&p, sizeof(arks::SeedBucketCtl)));
 		s.d_ctl = static_cast<arks::SeedBucketCtl*>(p);
+		HIP_TRY(hipMemset(s.d_ctl, 0, sizeof(arks::SeedBucketCtl))); // once: the counters only count up from here
 		HIP_TRY(hipHostMalloc(&p, sizeof(arks::SeedBucketCtl), hipHostMallocDefault));
 		s.h_ctl = static_cast<arks::SeedBucketCtl*>(p);
 		HIP_TRY(hipMalloc(&p, sizeof(u64) * gw));
@@ -525,6 +539,10 @@ exchange_bucket(arks_exchange* x, ExSet& s)
 	int rc = ARKS_OK;
 	u64 cap = (u64)(x->per_read_owner * (double)s.n_reads) + 8192;
 	u64 slot_cap = (u64)(x->per_read_all * (double)s.n_reads) + 8192;
+	cap = cap < s.cap_floor ? s.cap_floor : cap;           // (a batch that is run again: what its counters asked for)
+	slot_cap = slot_cap < s.slot_floor ? s.slot_floor : slot_cap;
+	if ((long)s.n_reads > x->largest_batch)
+		x->largest_batch = (long)s.n_reads;
 	if (cap * (u64)W > 0xFFFFFFFEull || slot_cap > 0xFFFFFFFEull) {
 		g_last_error = "a batch of the exchange holds more than 2^32 seeds: split it";
 		return ARKS_ERR_BAD_ARG;
@@ -534,13 +552,71 @@ exchange_bucket(arks_exchange* x, ExSet& s)
 	HIP_TRY(s.ans_back.reserve(2 * sizeof(u64) * (size_t)cap * (size_t)W));
 	HIP_TRY(s.slot.reserve(sizeof(u32) * (size_t)slot_cap));
 	HIP_TRY(s.chunk_off.reserve(sizeof(u32) * (size_t)(arks::seed_bucket_chunks(s.n_reads) + 1)));
-	HIP_TRY(arks::launch_seed_bucket(
-	    idx->bx.m, s.codes, s.nmask, s.word_off, s.lens, s.eval, s.n_reads, idx->k, idx->bx.w, (u32)W, cap, slot_cap, s.d_ctl,
-	    s.chunk_off.as<u32>(), s.slot.as<u32>(), s.send.as<u64>(), s.st));
+	// the map kernels' queues of this stream: made (or grown) here, so that the bucket launch can zero their scratch
+	// block on the side -- one launch less per batch
+	s.scratch_zeroed = false;
+	if (s.n_reads > 0) {
+		rc = ensure_queue(idx, s.st, s.n_reads, &s.qs);
+		if (rc != ARKS_OK)
+			goto done;
+		s.scratch_zeroed = true;
+	}
+	{
+		// the counters stand where the set's last launch left them: h_ctl holds that (the launch before this one on
+		// this set is complete -- its counts were waited for in ex_counts, or this is the set's first)
+		for (int o = 0; o < 64; ++o)
+			s.base.fill[o] = s.launches ? s.h_ctl->fill[o * arks::kCtlStride] : 0;
+		s.base.seeds = s.launches ? s.h_ctl->seeds[0] : 0;
+		s.base.seq = ++s.launches;
+		arks::SeedBucketGate gate;
+		gate.read_class = s.read_class, gate.pair_ok = s.pair_ok, gate.eval_out = s.eval_out;
+		HIP_TRY(arks::launch_seed_bucket(
+		    idx->bx.m, s.codes, s.nmask, s.word_off, s.lens, s.eval, s.n_reads, idx->k, idx->bx.w, (u32)W, cap, slot_cap, s.d_ctl,
+		    s.base, gate, s.scratch_zeroed ? s.qs.queue_count : nullptr, (int)(kMapScratchBytes / sizeof(u32)),
+		    s.chunk_off.as<u32>(), s.slot.as<u32>(), s.send.as<u64>(), s.st));
+	}
 	HIP_TRY(hipMemcpyAsync(s.h_ctl, s.d_ctl, sizeof(arks::SeedBucketCtl), hipMemcpyDeviceToHost, s.st));
 	HIP_TRY(hipEventRecord(s.counted, s.st));
 done:
 	return rc;
+}
+
+} // namespace
+
+namespace {
+
+int
+exchange_submit(
+    arks_exchange* x, const uint64_t* d_codes, const uint32_t* d_nmask, const uint64_t* d_word_off, const uint32_t* d_lens,
+    const uint8_t* d_eval, const uint8_t* d_read_class, const uint8_t* d_pair_ok, uint8_t* d_eval_out, int64_t n_reads,
+    double j_index, int32_t* d_out_conreci, arks_map_stats* d_stats, void* stream)
+{
+	if (!x || n_reads < 0 || n_reads > 0xFFFFFFFFll)
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads > 0 && (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_out_conreci))
+		return ARKS_ERR_BAD_ARG;
+	if (d_read_class && n_reads > 0 && (!d_eval_out || (n_reads & 1)))
+		return ARKS_ERR_BAD_ARG; // (the gate is a rule over PAIRS: reads 2p, 2p + 1)
+	if (x->submitted - x->completed >= 2) {
+		g_last_error = "two batches are in flight already: arks_exchange_complete first";
+		return ARKS_ERR_BAD_ARG;
+	}
+	ExSet& s = x->set[x->submitted & 1];
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	DeviceGuard guard(x->device);
+	// the buffers of the set's last batch (its map kernel may still be reading them) are reused in stream order: a
+	// batch on another stream waits for the old one first
+	if (s.used && s.st != st)
+		(void)hipStreamSynchronize(s.st);
+	s.st = st, s.used = true;
+	s.codes = reinterpret_cast<const u64*>(d_codes), s.nmask = d_nmask, s.word_off = reinterpret_cast<const u64*>(d_word_off);
+	s.lens = d_lens, s.eval = d_eval, s.n_reads = (long)n_reads, s.j_index = j_index, s.out = d_out_conreci, s.stats = d_stats;
+	s.read_class = n_reads > 0 ? d_read_class : nullptr, s.pair_ok = d_pair_ok, s.eval_out = d_eval_out;
+	s.rc = exchange_bucket(x, s);
+	// (a batch that failed here is completed all the same: the other ranks learn of it there, nobody waits in vain)
+	s.pending = true;
+	x->submitted++;
+	return s.rc;
 }
 
 } // namespace
@@ -561,29 +637,30 @@ arks_exchange_submit(
     arks_map_stats* d_stats,
     void* stream)
 {
-	if (!x || n_reads < 0 || n_reads > 0xFFFFFFFFll)
+	return exchange_submit(x, d_codes, d_nmask, d_word_off, d_lens, d_eval, nullptr, nullptr, nullptr, n_reads, j_index, d_out_conreci,
+	                       d_stats, stream);
+}
+
+int
+arks_exchange_submit_pairs(
+    arks_exchange* x,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_read_class,
+    const uint8_t* d_pair_ok,
+    int64_t n_reads,
+    double j_index,
+    uint8_t* d_eval_out,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream)
+{
+	if (!d_read_class && n_reads > 0)
 		return ARKS_ERR_BAD_ARG;
-	if (n_reads > 0 && (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_out_conreci))
-		return ARKS_ERR_BAD_ARG;
-	if (x->submitted - x->completed >= 2) {
-		g_last_error = "two batches are in flight already: arks_exchange_complete first";
-		return ARKS_ERR_BAD_ARG;
-	}
-	ExSet& s = x->set[x->submitted & 1];
-	hipStream_t st = static_cast<hipStream_t>(stream);
-	DeviceGuard guard(x->device);
-	// the buffers of the set's last batch (its map kernel may still be reading them) are reused in stream order: a
-	// batch on another stream waits for the old one first
-	if (s.used && s.st != st)
-		(void)hipStreamSynchronize(s.st);
-	s.st = st, s.used = true;
-	s.codes = reinterpret_cast<const u64*>(d_codes), s.nmask = d_nmask, s.word_off = reinterpret_cast<const u64*>(d_word_off);
-	s.lens = d_lens, s.eval = d_eval, s.n_reads = (long)n_reads, s.j_index = j_index, s.out = d_out_conreci, s.stats = d_stats;
-	s.rc = exchange_bucket(x, s);
-	// (a batch that failed here is completed all the same: the other ranks learn of it there, nobody waits in vain)
-	s.pending = true;
-	x->submitted++;
-	return s.rc;
+	return exchange_submit(x, d_codes, d_nmask, d_word_off, d_lens, nullptr, d_read_class, d_pair_ok, d_eval_out, n_reads, j_index,
+	                       d_out_conreci, d_stats, stream);
 }
 
 } // extern "C"
@@ -607,15 +684,28 @@ ex_counts(arks_exchange* x, ExSet& s)
 	const int W = x->world;
 	int rc = s.rc;
 	EX_TRY(hipEventSynchronize(s.counted));
-	for (int tries = 0; rc == ARKS_OK && s.h_ctl->overflow; ++tries) {
+	auto take = [&] { // the batch's counts: what the counters moved by
+		for (int o = 0; o < 64; ++o)
+			s.counts[o] = o < W ? s.h_ctl->fill[o * arks::kCtlStride] - s.base.fill[o] : 0;
+		s.n_seeds = s.h_ctl->seeds[0] - s.base.seeds;
+	};
+	if (rc == ARKS_OK)
+		take();
+	for (int tries = 0; rc == ARKS_OK && s.h_ctl->overflow[0] == s.base.seq; ++tries) {
+		// the regions are sized from what THIS batch needs (its absolute counts, + 10 %), and the sizes for later batches
+		// follow the seeds per read of the batch that did not fit -- of a full-size batch only: a small batch of long
+		// reads must not blow up the regions of every batch behind it
 		u64 mx = 0;
 		for (int o = 0; o < W; ++o)
-			mx = s.h_ctl->fill[o] > mx ? s.h_ctl->fill[o] : mx;
+			mx = s.counts[o] > mx ? s.counts[o] : mx;
 		const double n = (double)(s.n_reads > 0 ? s.n_reads : 1);
-		if ((double)mx / n * 1.1 > x->per_read_owner)
-			x->per_read_owner = (double)mx / n * 1.1;
-		if ((double)s.h_ctl->seeds / n * 1.05 > x->per_read_all)
-			x->per_read_all = (double)s.h_ctl->seeds / n * 1.05;
+		s.cap_floor = mx + mx / 10 + 8192, s.slot_floor = s.n_seeds + s.n_seeds / 20 + 8192;
+		if (s.n_reads >= x->largest_batch / 2) {
+			if ((double)mx / n * 1.1 > x->per_read_owner)
+				x->per_read_owner = (double)mx / n * 1.1;
+			if ((double)s.n_seeds / n * 1.05 > x->per_read_all)
+				x->per_read_all = (double)s.n_seeds / n * 1.05;
+		}
 		x->reruns++;
 		if (tries == 2) {
 			g_last_error = "the exchange's regions overflowed three times in a row";
@@ -624,7 +714,10 @@ ex_counts(arks_exchange* x, ExSet& s)
 		}
 		rc = exchange_bucket(x, s);
 		EX_TRY(hipEventSynchronize(s.counted));
+		if (rc == ARKS_OK)
+			take();
 	}
+	s.cap_floor = s.slot_floor = 0;
 	return rc;
 }
 
@@ -642,7 +735,7 @@ ex_tables(arks_exchange* x, ExSet& s)
 		s.roff[(size_t)p + 1] = s.roff[(size_t)p] + s.rcv[(size_t)p];
 		S += s.sc[(size_t)p];
 	}
-	x->last.seeds = s.h_ctl->seeds, x->last.sent = S - s.sc[(size_t)me], x->last.received = s.roff[(size_t)W] - s.rcv[(size_t)me];
+	x->last.seeds = s.n_seeds, x->last.sent = S - s.sc[(size_t)me], x->last.received = s.roff[(size_t)W] - s.rcv[(size_t)me];
 	x->last.reruns = x->reruns;
 }
 
@@ -653,13 +746,12 @@ ex_map(arks_exchange* x, ExSet& s)
 	const arks_index* idx = x->idx;
 	int rc = ARKS_OK;
 	if (s.n_reads > 0) {
-		arks_index::QueueSet qs;
-		rc = ensure_queue(idx, s.st, s.n_reads, &qs);
-		if (rc == ARKS_OK)
-			EX_TRY(launch_map_reads_seeded(
-			    idx->kw, s.codes, s.nmask, s.word_off, s.lens, s.eval, s.n_reads, s.j_index, idx->geom, idx->bx, idx->bxg, nullptr,
-			    s.ans_back.as<u64>(), s.out, reinterpret_cast<u64*>(s.stats), qs.queue, qs.queue_count, idx->n_cu, s.st,
-			    s.slot.as<u32>(), s.chunk_off.as<u32>()));
+		// (the queues were made at submit; their scratch block was zeroed by the bucket launch, in front of this one on
+		// the stream.  With the gate folded in, the map kernels read the eval the bucket kernel wrote.)
+		EX_TRY(launch_map_reads_seeded(
+		    idx->kw, s.codes, s.nmask, s.word_off, s.lens, s.read_class ? s.eval_out : s.eval, s.n_reads, s.j_index, idx->geom, idx->bx,
+		    idx->bxg, nullptr, s.ans_back.as<u64>(), s.out, reinterpret_cast<u64*>(s.stats), s.qs.queue, s.qs.queue_count, idx->n_cu,
+		    s.st, s.slot.as<u32>(), s.chunk_off.as<u32>(), s.scratch_zeroed));
 	}
 	return rc;
 }
@@ -672,7 +764,7 @@ direct_show(arks_exchange* x, int si, int rc) // after ex_counts
 	ExSet& s = x->set[si];
 	LocalGroup::Shown& mine = x->group->shown[si][(size_t)x->rank];
 	mine.status = rc;
-	mine.counts = s.h_ctl->fill;
+	mine.counts = s.counts;
 	mine.cap = s.cap;
 	mine.send = s.send.as<u64>();
 	mine.ans_back = s.ans_back.as<u64>();
@@ -715,7 +807,7 @@ direct_probe(arks_exchange* x, int si)
 		run += s.rcv[(size_t)p];
 		sg.end[i] = run;
 	}
-	EX_TRY(arks::launch_seeds_probe_segs(x->idx->bx.m, x->idx->bx, sg, s.st));
+	EX_TRY(arks::launch_seeds_probe_segs(x->idx->bx.m, x->idx->bx, sg, s.st, x->idx->n_cu));
 	EX_TRY(hipEventRecord(s.probed, s.st));
 	g->shown[si][(size_t)me].status2 = rc;
 	return rc;
@@ -806,7 +898,7 @@ arks_exchange_complete(arks_exchange* x)
 		u64* hg = s.h_gather;
 		hg[0] = (u64)(rc != ARKS_OK);
 		for (int o = 0; o < W; ++o)
-			hg[1 + o] = rc == ARKS_OK ? s.h_ctl->fill[o] : 0;
+			hg[1 + o] = rc == ARKS_OK ? s.counts[o] : 0;
 		int e = 0;
 		hipError_t he = hipMemcpyAsync(s.d_gather, hg, sizeof(u64) * (size_t)(1 + W), hipMemcpyHostToDevice, st);
 		if (he == hipSuccess) {
@@ -840,7 +932,7 @@ arks_exchange_complete(arks_exchange* x)
 	} else {
 		if (rc != ARKS_OK)
 			return rc;
-		s.all[0] = s.h_ctl->fill[0];
+		s.all[0] = s.counts[0];
 	}
 	// from here on rc == ARKS_OK on every rank
 	ex_tables(x, s);
@@ -877,7 +969,7 @@ arks_exchange_complete(arks_exchange* x)
 			run += rcv[(size_t)p];
 			sg.end[i] = run;
 		}
-		EX_TRY(arks::launch_seeds_probe_segs(idx->bx.m, idx->bx, sg, st));
+		EX_TRY(arks::launch_seeds_probe_segs(idx->bx.m, idx->bx, sg, st, idx->n_cu));
 		if (rc == ARKS_OK)
 			rc = rccl_all_to_all(x, rccl, s.ans_out.as<u64>(), roff.data(), rcv.data(), s.ans_back.as<u64>(), soff.data(), sc.data(),
 			                     2, st, "answers back (ncclSend / ncclRecv)");
@@ -892,7 +984,7 @@ arks_exchange_complete(arks_exchange* x)
 		sg.src[0] = s.send.as<u64>();
 		sg.dst[0] = s.ans_back.as<u64>();
 		sg.end[0] = sc[0];
-		EX_TRY(arks::launch_seeds_probe_segs(idx->bx.m, idx->bx, sg, st));
+		EX_TRY(arks::launch_seeds_probe_segs(idx->bx.m, idx->bx, sg, st, idx->n_cu));
 	}
 	if (rc == ARKS_OK)
 		rc = ex_map(x, s);

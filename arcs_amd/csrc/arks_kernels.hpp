@@ -39,19 +39,43 @@ hipError_t launch_map_reads_seeded(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval,
     long n_reads, double j_index, const KeyGeom& g, const BIndexView& bx, const BIndexView& bxg, const long* seed_off,
     const u64* ans, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st,
-    const u32* seed_slot = nullptr, const u32* chunk_off = nullptr);
+    const u32* seed_slot = nullptr, const u32* chunk_off = nullptr, bool scratch_zeroed = false);
 // arks_exchange: a batch's seeds listed and bucketed by owner in one launch (arks_shard.hip)
+// The counters of seed_bucket_kernel.  They are never zeroed (round 5: a memset per batch was a launch of its own on
+// a stream that has ~10 of them per batch): they only count up, the launch is told where they stood (SeedBucketBase:
+// the host knows, the set's previous batch is complete when the next is submitted) and works with the differences.
+// One counter per 128-byte line: thousands of blocks add to each of them, and atomics on one line queue up behind each
+// other whatever their addresses.
+constexpr int kCtlStride = 16; // u64 words between two counters
 struct SeedBucketCtl
 {
-	u64 fill[64]; // seeds asked of owner o (goes on counting when a region is full)
-	u64 seeds;    // seeds of the batch, sent or not (the read-major numbering)
-	u64 overflow; // a block found no room: run the batch again with larger regions
+	u64 fill[64 * kCtlStride]; // [o * kCtlStride]: seeds asked of owner o so far (goes on counting when a region is full)
+	u64 seeds[kCtlStride];     // [0]: seeds so far, sent or not (the read-major numbering)
+	u64 overflow[kCtlStride];  // [0]: number (SeedBucketBase::seq) of the last launch in which a block found no room:
+	                           // that batch is run again with larger regions
+};
+struct SeedBucketBase
+{
+	u64 fill[64];
+	u64 seeds;
+	u64 seq; // > 0, another one for every launch on this ctl
+};
+// the pair gate of chromiumRead (checkReadSequence of both mates and the barcode test, Arcs.cpp:1264-1292) folded into
+// the bucket kernel: eval is computed from the read classes and pair_ok (arks_pair_gate_device's rule) and written to
+// eval_out for the map kernels, instead of being read
+struct SeedBucketGate
+{
+	const uint8_t* read_class = nullptr; // != NULL: compute; reads 2p, 2p+1 are mates
+	const uint8_t* pair_ok = nullptr;    // may be NULL
+	uint8_t* eval_out = nullptr;
 };
 long seed_bucket_chunks(long n_reads);
+// zero_words / n_zero: a block of words the launch zeroes on the side (the map kernels' scratch of the same stream:
+// saves that launch's memset); may be NULL
 hipError_t launch_seed_bucket(
     int mm, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval, long n_reads,
-    int k, int w, u32 n_owners, u64 cap, u64 slot_cap, SeedBucketCtl* ctl, u32* chunk_off, u32* slot, u64* send,
-    hipStream_t st);
+    int k, int w, u32 n_owners, u64 cap, u64 slot_cap, SeedBucketCtl* ctl, const SeedBucketBase& base,
+    const SeedBucketGate& gate, u32* zero_words, int n_zero, u32* chunk_off, u32* slot, u64* send, hipStream_t st);
 // owner side of arks_exchange: the seeds of several askers answered in one launch; segment s holds n[s] seeds at
 // src[s], their answers (16 B each) go to dst[s]
 struct ProbeSegs
@@ -61,7 +85,7 @@ struct ProbeSegs
 	u64* dst[65];
 	u64 end[65]; // inclusive prefix of the segments' lengths
 };
-hipError_t launch_seeds_probe_segs(int mm, const BIndexView& bx, const ProbeSegs& sg, hipStream_t st);
+hipError_t launch_seeds_probe_segs(int mm, const BIndexView& bx, const ProbeSegs& sg, hipStream_t st, int n_cu = 256);
 hipError_t launch_word_owner(const u64* word_off, long n_ends, u64 total_words, u32* owner, hipStream_t st);
 hipError_t launch_bmark(
     int kw, int mm, const u64* codes, const u32* visited, u64 total_words, const KeyGeom& g, TableView full,

@@ -2764,7 +2764,10 @@ seeds_probe_kernel(BIndexView bx, const u64* __restrict__ cm, long n, u64* __res
 	ans[2 * i + 1] = a1;
 }
 
-// the same for the seeds of several askers in one launch (arks_exchange): segment s = sg.src[s][0 .. n_s) -> sg.dst[s]
+// the same for the seeds of several askers in one launch (arks_exchange): segment s = sg.src[s][0 .. n_s) -> sg.dst[s].
+// (Round 5 tried it as a persistent grid of 8 / 16 / 32 waves per CU with four seeds per thread in flight, so that the
+// askers' latency-bound map kernels keep their wave slots beside it: 163-165 ms per pass against 155 -- the step's time
+// is the SUM of its kernels' times alone, whoever shares the device with whom; profiles/r09f_sharded_isolated.txt.)
 template <int MM>
 __global__ void __launch_bounds__(256)
 seeds_probe_segs_kernel(BIndexView bx, ProbeSegs sg)
@@ -3044,13 +3047,14 @@ launch_seeds_probe(int mm, const BIndexView& bx, const u64* cm, long n, u64* ans
 // bestContig for a batch whose seed probes were answered beforehand (sharded seed table): the hot kernel with
 // REMOTE answers, then the general kernels over the replicated minimizer table (bxg)
 hipError_t
-launch_seeds_probe_segs(int mm, const BIndexView& bx, const ProbeSegs& sg, hipStream_t st)
+launch_seeds_probe_segs(int mm, const BIndexView& bx, const ProbeSegs& sg, hipStream_t st, int n_cu)
 {
 	if (sg.n_segs <= 0 || sg.n_segs > 65)
 		return sg.n_segs == 0 ? hipSuccess : hipErrorInvalidValue;
 	const u64 n = sg.end[sg.n_segs - 1];
 	if (n == 0)
 		return hipSuccess;
+	(void)n_cu;
 	const unsigned b = (unsigned)((n + 255) / 256);
 	if (mm == kMShort)
 		seeds_probe_segs_kernel<kMShort><<<b, 256, 0, st>>>(bx, sg);
@@ -3065,7 +3069,7 @@ launch_map_reads_seeded(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval,
     long n_reads, double j_index, const KeyGeom& g, const BIndexView& bx, const BIndexView& bxg, const long* seed_off,
     const u64* ans, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st, const u32* seed_slot,
-    const u32* chunk_off)
+    const u32* chunk_off, bool scratch_zeroed)
 {
 	static_assert(sChunk == 56, "arks_shard.hip (kBkChunk) numbers the seeds by chunks of the seed tile kernel");
 	if (n_reads <= 0)
@@ -3073,7 +3077,8 @@ launch_map_reads_seeded(
 	u64* const user_stats = stats;
 	if (stats)
 		stats = reinterpret_cast<u64*>(reinterpret_cast<char*>(queue_count) + 64);
-	hipError_t e = hipMemsetAsync(queue_count, 0, kMapScratchBytes, st);
+	// (scratch_zeroed: the caller's previous kernel on this stream zeroed the block -- arks_exchange's bucket kernel)
+	hipError_t e = scratch_zeroed ? hipSuccess : hipMemsetAsync(queue_count, 0, kMapScratchBytes, st);
 	if (e != hipSuccess)
 		return e;
 	const u64 cus = (u64)(n_cu > 0 ? n_cu : 256);

@@ -42,8 +42,11 @@ mask_below(u64 m)
 //   chunk_off[c]            number of the first seed of the map kernel's chunk c (sChunk = 56 reads): a block is a
 //                           whole number of chunks, and a chunk's seeds are numbered read by read
 // The counts reach the host with the batch's other results, one step behind the device (arks_exchange_complete);
-// nothing waits for them.  A block that does not fit sets ctl->overflow and writes nothing: the counters go on
+// nothing waits for them.  A block that does not fit marks ctl->overflow and writes nothing: the counters go on
 // counting, so the host knows what the batch needs and runs it again with larger regions (first batch of a shape).
+// Round 5: the counters only count up and the launch is told where they stood (no memset per batch); the pair gate
+// can be computed here instead of read (SeedBucketGate); block 0 zeroes the map kernels' scratch on the side; the N
+// masks of reads the gate knows to hold ACGT only are not fetched.
 constexpr int kMaxOwners = 64;
 constexpr int kBkChunk = 56;                  // = sChunk of map_reads_s_kernel (arks_map.hip; checked at its launch)
 constexpr int kBkWaves = 8;
@@ -93,14 +96,19 @@ template <int MM>
 __device__ __forceinline__ void
 bucket_one_seed(
     const u64* __restrict__ codes, const u32* __restrict__ nmask, u64 wb, int nwin, int w, int gi, u32 n_owners, u64& cm,
-    u32& own)
+    u32& own, bool may_n = true)
 {
 	typedef typename Mmer<MM>::type mm_t;
 	int q = (gi + 1) * w - 1;
 	q = q < nwin - 1 ? q : nwin - 1;
 	const u64 pos = wb * 32ull + (u64)q;
-	const u32* nm = nmask + (pos >> 5);
-	const u64 two = ((u64)nm[0] << 32) | (u64)nm[1];
+	// (may_n = false: the pair gate knows the read to hold ACGT only -- eval == ARKS_EVAL_ACGT_ONLY --, its N masks, a
+	// third of the read stream and zero for > 98 % of the reads, are not fetched; the map kernels do the same)
+	u64 two = 0;
+	if (may_n) {
+		const u32* nm = nmask + (pos >> 5);
+		two = ((u64)nm[0] << 32) | (u64)nm[1];
+	}
 	cm = ~0ull;
 	own = ~0u;
 	if (((two << (pos & 31)) >> (64 - MM)) == 0) {
@@ -130,11 +138,11 @@ bk_wave_incl_scan(int v)
 // seed gi of read r for the bucket kernel: canonical m-mer | owner << 56, ~0 = it holds an invalid base (not sent)
 template <int MM>
 __device__ __forceinline__ u64
-bucket_seed(const u64* __restrict__ codes, const u32* __restrict__ nmask, u64 wb, int nwin, int w, int gi, u32 n_owners)
+bucket_seed(const u64* __restrict__ codes, const u32* __restrict__ nmask, u64 wb, int nwin, int w, int gi, u32 n_owners, bool may_n)
 {
 	u64 c;
 	u32 o;
-	bucket_one_seed<MM>(codes, nmask, wb, nwin, w, gi, n_owners, c, o);
+	bucket_one_seed<MM>(codes, nmask, wb, nwin, w, gi, n_owners, c, o, may_n);
 	return o == ~0u ? ~0ull : (c | ((u64)o << 56));
 }
 
@@ -143,8 +151,8 @@ __global__ void __launch_bounds__(kBkWaves * 64) __attribute__((amdgpu_waves_per
 seed_bucket_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ nmask, const u64* __restrict__ word_off,
     const u32* __restrict__ lens, const uint8_t* __restrict__ eval, long n_reads, int k, int w, u32 n_owners, u64 cap,
-    u64 slot_cap, SeedBucketCtl* __restrict__ ctl, u32* __restrict__ chunk_off, u32* __restrict__ slot,
-    u64* __restrict__ send)
+    u64 slot_cap, SeedBucketCtl* __restrict__ ctl, SeedBucketBase cb, SeedBucketGate gate, u32* __restrict__ zero_words,
+    int n_zero, u32* __restrict__ chunk_off, u32* __restrict__ slot, u64* __restrict__ send)
 {
 	static_assert(2 * MM <= 56, "the owner rides in the top byte of the m-mer");
 	__shared__ u32 cnt[kMaxOwners];
@@ -157,18 +165,33 @@ seed_bucket_kernel(
 		cnt[threadIdx.x] = 0;
 	if (threadIdx.x == 0)
 		bad = 0;
+	if (blockIdx.x == 0 && zero_words)
+		for (int x = (int)threadIdx.x; x < n_zero; x += kBkWaves * 64)
+			zero_words[x] = 0u;
 	__syncthreads();
 	constexpr int kInline = 3; // seeds of a read kept in registers (a 10x pair has 2 + 3); others are made again
 	u64 sd[kBkChunksPerWave][kInline];
 	u64 wb[kBkChunksPerWave];
 	int G[kBkChunksPerWave], pre[kBkChunksPerWave], nwin[kBkChunksPerWave];
+	bool mn[kBkChunksPerWave];
 #pragma unroll
 	for (int it = 0; it < kBkChunksPerWave; ++it) {
 		const int ci = wave * kBkChunksPerWave + it;
 		const long r = ((long)blockIdx.x * kBkChunks + ci) * kBkChunk + lane;
-		nwin[it] = 0, wb[it] = 0;
+		nwin[it] = 0, wb[it] = 0, mn[it] = true;
 		if (lane < kBkChunk && r < n_reads) {
-			nwin[it] = (eval && !eval[r]) ? 0 : (int)lens[r] - k + 1;
+			uint8_t ev = 1;
+			if (gate.read_class) {
+				// arks_pair_gate_device's rule: both mates pass checkReadSequence (class bit 0) and the pair's barcode
+				// test; bit 1 of the class = the read holds ACGT only
+				const uint8_t c0 = gate.read_class[r], c1 = gate.read_class[r ^ 1];
+				const bool e = (gate.pair_ok ? gate.pair_ok[r >> 1] != 0 : true) && (c0 & 1) && (c1 & 1);
+				ev = e ? (uint8_t)(1 | (c0 & 2)) : (uint8_t)0;
+				gate.eval_out[r] = ev;
+			} else if (eval)
+				ev = eval[r];
+			nwin[it] = !ev ? 0 : (int)lens[r] - k + 1;
+			mn[it] = ev != 3; // (exactly ARKS_EVAL_ACGT_ONLY: include/arks_hip.h)
 			wb[it] = word_off[r];
 		}
 		G[it] = nwin[it] > 0 ? (nwin[it] + w - 1) / w : 0;
@@ -178,10 +201,10 @@ seed_bucket_kernel(
 			chunk_cnt[ci] = (u32)incl;
 #pragma unroll
 		for (int gi = 0; gi < kInline; ++gi)
-			sd[it][gi] = gi < G[it] ? bucket_seed<MM>(codes, nmask, wb[it], nwin[it], w, gi, n_owners) : ~0ull;
+			sd[it][gi] = gi < G[it] ? bucket_seed<MM>(codes, nmask, wb[it], nwin[it], w, gi, n_owners, mn[it]) : ~0ull;
 		for (int gi = 0; gi < G[it]; ++gi) {
 			const u64 v = gi < kInline ? (gi == 0 ? sd[it][0] : gi == 1 ? sd[it][1] : sd[it][2])
-			                           : bucket_seed<MM>(codes, nmask, wb[it], nwin[it], w, gi, n_owners);
+			                           : bucket_seed<MM>(codes, nmask, wb[it], nwin[it], w, gi, n_owners, mn[it]);
 			if (v != ~0ull)
 				atomicAdd(&cnt[(u32)(v >> 56)], 1u);
 		}
@@ -192,7 +215,8 @@ seed_bucket_kernel(
 		const u32 c = cnt[threadIdx.x];
 		u64 b = 0;
 		if (c) {
-			b = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->fill[threadIdx.x]), (unsigned long long)c);
+			b = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->fill[threadIdx.x * kCtlStride]), (unsigned long long)c) -
+			    cb.fill[threadIdx.x];
 			if (b + c > cap)
 				bad = 1;
 		}
@@ -203,7 +227,7 @@ seed_bucket_kernel(
 		u32 total = 0;
 		for (int c = 0; c < kBkChunks; ++c)
 			total += chunk_cnt[c];
-		const u64 sb = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->seeds), (unsigned long long)total);
+		const u64 sb = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->seeds[0]), (unsigned long long)total) - cb.seeds;
 		if (sb + total > slot_cap)
 			bad = 1;
 		u32 run = (u32)sb;
@@ -215,7 +239,7 @@ seed_bucket_kernel(
 	__syncthreads();
 	if (bad) { // the batch is run again with larger regions (the counters above say how large)
 		if (threadIdx.x == 0)
-			ctl->overflow = 1;
+			ctl->overflow[0] = cb.seq; // (every block that writes it writes the same number)
 		return;
 	}
 	if (threadIdx.x < kBkChunks) {
@@ -229,7 +253,7 @@ seed_bucket_kernel(
 		const u32 first = chunk_base[ci] + (u32)pre[it];
 		for (int gi = 0; gi < G[it]; ++gi) {
 			const u64 v = gi < kInline ? (gi == 0 ? sd[it][0] : gi == 1 ? sd[it][1] : sd[it][2])
-			                           : bucket_seed<MM>(codes, nmask, wb[it], nwin[it], w, gi, n_owners);
+			                           : bucket_seed<MM>(codes, nmask, wb[it], nwin[it], w, gi, n_owners, mn[it]);
 			u32 sl = ~0u;
 			if (v != ~0ull) {
 				const u32 o = (u32)(v >> 56);
@@ -247,23 +271,26 @@ seed_bucket_chunks(long n_reads)
 	return (n_reads + kBkChunk - 1) / kBkChunk;
 }
 
-// seeds of a batch listed and bucketed by owner; ctl is zeroed here.  cap * n_owners <= 0xFFFFFFFE (slots are 32-bit).
+// seeds of a batch listed and bucketed by owner; ctl's counters stand at `base` (zero after creation) and count on.
+// cap * n_owners <= 0xFFFFFFFE (slots are 32-bit).  A batch without reads still makes one (empty) launch when there is
+// scratch to zero.
 hipError_t
 launch_seed_bucket(
     int mm, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval, long n_reads,
-    int k, int w, u32 n_owners, u64 cap, u64 slot_cap, SeedBucketCtl* ctl, u32* chunk_off, u32* slot, u64* send,
-    hipStream_t st)
+    int k, int w, u32 n_owners, u64 cap, u64 slot_cap, SeedBucketCtl* ctl, const SeedBucketBase& base,
+    const SeedBucketGate& gate, u32* zero_words, int n_zero, u32* chunk_off, u32* slot, u64* send, hipStream_t st)
 {
 	if (n_owners < 1 || n_owners > (u32)kMaxOwners || cap * (u64)n_owners > 0xFFFFFFFEull || slot_cap > 0xFFFFFFFEull)
 		return hipErrorInvalidValue;
-	hipError_t e = hipMemsetAsync(ctl, 0, sizeof(SeedBucketCtl), st);
-	if (e != hipSuccess || n_reads <= 0)
-		return e;
-	const unsigned nb = (unsigned)((n_reads + kBkReads - 1) / kBkReads);
+	if (gate.read_class && (!gate.eval_out || (n_reads & 1)))
+		return hipErrorInvalidValue;
+	if (n_reads <= 0 && !zero_words)
+		return hipSuccess;
+	const unsigned nb = n_reads > 0 ? (unsigned)((n_reads + kBkReads - 1) / kBkReads) : 1u;
 	if (mm == kMShort)
-		seed_bucket_kernel<kMShort><<<nb, kBkWaves * 64, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, cap, slot_cap, ctl, chunk_off, slot, send);
+		seed_bucket_kernel<kMShort><<<nb, kBkWaves * 64, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, cap, slot_cap, ctl, base, gate, zero_words, n_zero, chunk_off, slot, send);
 	else
-		seed_bucket_kernel<kMLong><<<nb, kBkWaves * 64, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, cap, slot_cap, ctl, chunk_off, slot, send);
+		seed_bucket_kernel<kMLong><<<nb, kBkWaves * 64, 0, st>>>(codes, nmask, word_off, lens, eval, n_reads, k, w, n_owners, cap, slot_cap, ctl, base, gate, zero_words, n_zero, chunk_off, slot, send);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

@@ -67,6 +67,75 @@ def plant_repeats(contigs, seed, scale=1.0, sites=None, alu_copies=100_000, l1_c
             sites.append((j, p, p + L))
 
 
+def plant_human_like(contigs, seed, scale=1.0, sites=None, sine_frac=0.105, line_frac=0.10,
+                     sine_copies=35_000, line_copies=2_500, sat_arrays=100):
+    """A human-like repeat SPECTRUM planted in place into `contigs` (hg38 is ~10 % Alu in 1.2 M
+    copies and ~17 % L1; `plant_repeats` above is 1.3 % of the draft).  Families, not one element: what a read sees
+    is the copy number and divergence WITHIN a family, so a family has a fixed size and the NUMBER of families
+    scales with the draft (`scale` = draft size / 3 Gbp) -- a 100 Mbp draft (one family of each class) shows a read
+    the same multiplicities as the 3 Gbp one (30 of each), which is what lets a small whole-draft oracle stand
+    for the big draft's repeat handling.
+      * SINE-like: families of `sine_copies` copies of a 300-bp subfamily consensus (a master consensus changed at
+        2-8 % of its bases, as AluJ / S / Y are), every copy 5-20 % diverged from its subfamily consensus:
+        sine_frac of the draft (3 Gbp: 30 families, 1.05 M copies, 315 Mbp);
+      * LINE-like: families of `line_copies` copies of a 6-kbp subfamily consensus, 3-15 % diverged, 70 % of them
+        5'-truncated to 0.5-6 kbp: line_frac of the draft (3 Gbp: 30 families, 75 k copies, ~300 Mbp);
+      * the satellite arrays of plant_repeats.
+    Young copies (5-8 %) share most 21-mers AND many 60-mers with their siblings (heavy seeds, value-0 keys), old
+    ones (15-20 %) neither.  `sites` (a list) receives (contig, start, end) of every copy."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x48554D41))
+    big = np.array([j for j, c in enumerate(contigs) if len(c) >= 12000], dtype=np.int64)
+    if len(big) == 0:
+        return
+    total = sum(len(c) for c in contigs)
+
+    def mutate_rows(cons, n, dlo, dhi):
+        d = rng.uniform(dlo, dhi, size=(n, 1))
+        out = np.broadcast_to(cons, (n, len(cons))).copy()
+        hit = rng.random(out.shape) < d
+        out[hit] = _ACGT[rng.integers(0, 4, size=int(hit.sum()), dtype=np.uint8)]
+        return out
+
+    def place(block, lens=None):
+        n = len(block)
+        cj = big[rng.integers(0, len(big), size=n)]
+        width = block.shape[1]
+        u = rng.random(n)
+        for i in range(n):
+            L = int(lens[i]) if lens is not None else width
+            c = contigs[int(cj[i])]
+            p = int(u[i] * (len(c) - L))
+            c[p:p + L] = block[i][width - L:]
+            if sites is not None:
+                sites.append((int(cj[i]), p, p + L))
+
+    def family_class(master_len, copies, frac, dlo, dhi, trunc):
+        n_fam = max(1, int(round(frac * total / (copies * master_len * (0.3 + 0.7 * 0.54 if trunc else 1.0)))))
+        master = _ACGT[rng.integers(0, 4, size=master_len, dtype=np.uint8)]
+        for _ in range(n_fam):
+            sub = mutate_rows(master, 1, 0.02, 0.08)[0]
+            for lo in range(0, copies, 5000):
+                n = min(5000, copies - lo)
+                lens = None
+                if trunc:
+                    lens = np.where(rng.random(n) < 0.7, rng.integers(500, master_len, size=n), master_len)
+                place(mutate_rows(sub, n, dlo, dhi), lens)
+        return n_fam
+
+    n_sine = family_class(300, sine_copies, sine_frac, 0.05, 0.20, False)
+    n_line = family_class(6000, line_copies, line_frac, 0.03, 0.15, True)
+    mono = _ACGT[rng.integers(0, 4, size=171, dtype=np.uint8)]
+    for _ in range(max(1, int(sat_arrays * scale))):
+        j = int(big[rng.integers(0, len(big))])
+        c = contigs[j]
+        L = int(min(rng.integers(20000, 60000), len(c) - 200))
+        p = int(rng.integers(0, len(c) - L))
+        c[p:p + L] = mutate_rows(mono, L // 171 + 1, 0.01, 0.04).reshape(-1)[:L]
+        if sites is not None:
+            sites.append((j, p, p + L))
+    return n_sine, n_line
+
+
 def sites_to_runs(contigs, sites):
     """(contig, start, end) -> int64[n, 2] intervals of the concatenated draft (what sub_draft_index takes)"""
     lens = np.fromiter((len(c) for c in contigs), dtype=np.int64, count=len(contigs))
@@ -83,8 +152,8 @@ def make_draft(total_bp, seed=SEED, lengths=(20000, 50000, 100000, 230000), smal
     """list of uint8 ASCII arrays (contigs, FASTA order).  dup_events (a list) receives the
     (source contig, destination contig) of every copied segment, so that a caller can find the
     contigs that share k-mers with a given set (closed_contig_set).  repeats=True plants human-like
-    repeat families (plant_repeats; copy numbers scaled by total_bp / 3 Gbp) before the other quirks
-    are injected; repeat_sites (a list) receives their (contig, start, end)."""
+    repeat families (plant_repeats; copy numbers scaled by total_bp / 3 Gbp; repeats="human": the human-like
+    spectrum of plant_human_like, ~20 % of the draft) before the other quirks are injected; repeat_sites (a list) receives their (contig, start, end)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     contigs = []
     acc = 0
@@ -97,7 +166,9 @@ def make_draft(total_bp, seed=SEED, lengths=(20000, 50000, 100000, 230000), smal
         i += 1
         if rng.random() < small_frac:  # a contig shorter than -z 500: skipped by the index
             contigs.append(_ACGT[rng.integers(0, 4, size=int(rng.integers(50, 499)), dtype=np.uint8)])
-    if repeats:
+    if repeats == "human":
+        plant_human_like(contigs, seed, scale=total_bp / 3e9, sites=repeat_sites)
+    elif repeats:
         plant_repeats(contigs, seed, scale=total_bp / 3e9, sites=repeat_sites)
     if inject:
         big = [j for j, c in enumerate(contigs) if len(c) >= 12000]

@@ -192,6 +192,7 @@ class Workload:
         log(f"draft: {len(contigs)} contigs, {sum(map(len, contigs))} bp, {len(ends)} ends in {time.time() - t0:.1f}s")
         t0 = time.time()
         self.index = arcs_amd.ArksIndex.build(ends, k, device=local, want_stats=want_stats)
+        self.index_build_s = time.time() - t0
         del ends
         log(f"index: {len(self.index)} keys, {self.index.device_bytes / 2**30:.2f} GiB, built in "
             f"{time.time() - t0:.1f}s {self.index.build_stats}")
@@ -380,6 +381,75 @@ def repeats_key(args, k, j, dev, local, log, barrier):
                                              f"{'identical' if same else 'DIFFERENT'}"}
 
 
+def human_like_key(args, k, j, dev, local, log, barrier):
+    """Secondary key `configs2_human_like`: the 3 Gbp draft with a human-like repeat SPECTRUM --
+    synth.plant_human_like: ~10 % SINE-like (families of 35 k copies of a 300-bp element, 5-20 % diverged) + ~10 %
+    LINE-like (families of 2.5 k copies of a 6-kbp element, 3-15 %, most truncated) + satellite arrays -- and 100 M
+    read pairs in one launch: k-mers/s, the reads the hot kernel leaves to the general kernels, the bytes of the exact
+    table behind heavy seeds, the index build time.  Sample parity: the families have a FIXED size and their number
+    scales with the draft, so a 100 Mbp draft of the same generator (one family of each class) shows a read the same
+    multiplicities; 1 M pairs drawn from ALL of it, the GPU against the oracle over the WHOLE small draft (a sub-draft
+    oracle of the 3 Gbp one would have to hold the windows around 1.1 M copies: 0.7 G keys)."""
+    from oracle import pyoracle as O
+    pairs = min(args.pairs, 100_000_000)
+    wl = Workload(args.draft_mbp, pairs, pairs, k, j, dev, local, log, want_stats=False, repeats="human")
+    steps = max(2, args.steps // 2)
+    el, l_ms, st, _ = wl.timed(steps, 1, barrier)
+    q = arcs_amd.queue_counts(wl.index)
+    fb_keys, fb_bytes = wl.index.fallback_size
+    out = {"workload": f"synthetic {args.draft_mbp:g} Mbp draft with a human-like repeat spectrum ({len(wl.repeat_sites)} "
+                       f"copies, {sum(e - b for _, b, e in wl.repeat_sites) / 1e6:.0f} Mbp = "
+                       f"{100.0 * sum(e - b for _, b, e in wl.repeat_sites) / (args.draft_mbp * 1e6):.1f} % of the draft) + "
+                       f"{pairs} linked-read pairs in one launch, k={k} j={j}",
+           "value": st["windows"] * steps / el, "unit": "k-mers/s", "kernel_ms": float(np.mean(l_ms)),
+           "kernel_ms_per_20M_pairs": float(np.mean(l_ms)) * 20_000_000 / max(1, pairs),
+           "reads_left_to_general_kernels": {"medium": q[1], "slow": q[0], "of": 2 * pairs},
+           "index_keys": len(wl.index), "index_bytes": wl.index.device_bytes, "index_build_s": wl.index_build_s,
+           "fallback_keys": fb_keys, "fallback_bytes": fb_bytes, "timed_path_parity": wl.timed_path_parity}
+    del wl
+    torch.cuda.empty_cache()
+    # the small draft of the same generator against the whole oracle
+    small_mbp, n_pairs = 100.0, 1_000_000
+    contigs = synth.make_draft(int(small_mbp * 1e6), seed=synth.SEED, repeats="human")
+    ends = []
+    for c in contigs:
+        cut = arcs_amd.end_cutoff(len(c))
+        if cut is not None:
+            ends.append(c[:cut].tobytes())
+            ends.append(c[len(c) - cut:].tobytes())
+    ix = arcs_amd.ArksIndex.build(ends, k, device=local, want_stats=False)
+    O.build_oracle()
+    t0 = time.time()
+    ox = O.OracleIndex(k).build(ends)
+    t_ox = time.time() - t0
+    del ends
+    genome = torch.from_numpy(np.concatenate(contigs)).to(dev)
+    batch = synth.make_read_pairs(genome, n_pairs, seed=synth.SEED + 780, device=dev)
+    a = np.concatenate([batch["ascii"].cpu().numpy(), np.zeros(1, np.uint8)])
+    lens = batch["lens"].cpu().numpy().astype(np.uint32)
+    offs = batch["offsets"].cpu().numpy().astype(np.uint64)
+    ok = batch["pair_ok"].cpu().numpy()
+    t0 = time.time()
+    c, p_, sto = ox.map_pairs(a, offs[: 2 * n_pairs], lens, j, pair_ok=ok, threads=min(64, os.cpu_count() or 1))
+    dt = time.time() - t0
+    reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
+    got_c, got_p = arcs_amd.map_pairs_packed(ix, reads, j, pair_ok=batch["pair_ok"])
+    stc = torch.zeros(8, dtype=torch.int64, device=dev)
+    got_c2, got_p2 = arcs_amd.map_pairs_packed(ix, reads, j, pair_ok=batch["pair_ok"], stats=stc)
+    torch.cuda.synchronize(dev)
+    same = bool((got_c.cpu().numpy() == c).all() and (got_p.cpu().numpy() == p_).all()
+                and (got_c2.cpu().numpy() == c).all() and (got_p2.cpu().numpy() == p_).all()
+                and dict(zip(STAT_NAMES, stc.cpu().tolist())) == {f: sto[f] for f in STAT_NAMES})
+    qs = arcs_amd.queue_counts(ix)
+    out["sample_parity"] = same
+    out["sample"] = (f"{n_pairs} pairs drawn from a {small_mbp:g} Mbp draft of the same generator ({len(contigs)} contigs; "
+                     f"one family of each class, the same copies per family), oracle over the WHOLE draft ({len(ox)} keys, "
+                     f"built in {t_ox:.1f}s, mapped in {dt:.1f}s): per-read results, pair results (with and without "
+                     f"counters) and the eight counters {'identical' if same else 'DIFFERENT'}; "
+                     f"{int((c != 0).sum())} reads with a contig end; medium queue {qs[1]}, slow {qs[0]} of {2 * n_pairs}")
+    return out
+
+
 def end_to_end_files(wl, dev, log, sub_mbp=20.0, n_pairs=2_000_000, threads=16):
     """SURVEY 8(d), "additionally end-to-end from .fq.gz": ONE gzipped interleaved FASTQ of n_pairs read pairs drawn
     from the first sub_mbp of the draft (+ that sub-draft as FASTA and a barcode multiplicity file), mapped
@@ -555,6 +625,8 @@ def main():
                     help="N > 1: every rank maps its own --pairs read pairs (per-GPU work fixed) instead of a share "
                          "of the one read set (the default: strong scaling on the fixed workload)")
     ap.add_argument("--strong", action="store_true", help="(the default; kept for older command lines)")
+    ap.add_argument("--human-like", action="store_true",
+                    help="only the configs2_human_like key (the draft with a human-like repeat spectrum): for profiles")
     ap.add_argument("--repeats", action="store_true",
                     help="the headline workload on the draft with planted repeat families (what the configs2_repeats "
                          "key runs at 100 M pairs): for profiles")
@@ -602,6 +674,9 @@ def main():
     if args.sharded_index:
         return sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier)
 
+    if args.human_like:
+        print(json.dumps({"configs2_human_like": human_like_key(args, k, j, dev, local, log, barrier)}), flush=True)
+        return
     weak = args.weak and world > 1
     n_blocks = len(read_blocks(args.pairs))
     blocks = None if weak else blocks_of_rank(n_blocks, rank, world)
@@ -717,6 +792,8 @@ def main():
             del c2
             torch.cuda.empty_cache()
             out["configs2_repeats"] = repeats_key(args, k, j, dev, local, log, barrier)
+            torch.cuda.empty_cache()
+            out["configs2_human_like"] = human_like_key(args, k, j, dev, local, log, barrier)
             out["configs1"] = {"workload": "synthetic 50 Mbp draft + 20000000 linked-read pairs, k=60 j=0.55",
                                "value": s2["windows"] * args.steps / e2, "unit": "k-mers/s",
                                "kernel_ms": float(np.mean(l2)),
@@ -731,6 +808,8 @@ def main():
                 "CLI and CPU port store different numbers of pairs"
         if "configs2_repeats" in out:
             assert out["configs2_repeats"]["sample_parity"], "repeat-rich draft: GPU results differ from the CPU oracle"
+        if "configs2_human_like" in out:
+            assert out["configs2_human_like"]["sample_parity"], "human-like draft: GPU results differ from the CPU oracle"
     if world > 1:
         dist.destroy_process_group()
 
@@ -749,7 +828,8 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
     k, j = args.k, args.j
     n_local = max(1, args.shards) if world == 1 else 1
     if n_local > 1:
-        args.chunk = min(args.chunk, 12_500_000)      # the exchange buffers of all local ranks live on the one device
+        # the exchange buffers of all local ranks live on the one device (~155 B per pair and rank for two batches in flight)
+        args.chunk = min(args.chunk, int(os.environ.get("ARKS_BENCH_SHARDED_CHUNK", 12_500_000)))
     n_ranks = world * n_local
     contigs = synth.make_draft(int(args.draft_mbp * 1e6), seed=synth.SEED)
     ends = []
@@ -852,8 +932,15 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
 
     del genome
     torch.cuda.empty_cache()         # the exchange buffers are the library's own allocations
+
+    def mem(what):
+        free, total = torch.cuda.mem_get_info(dev)
+        log(f"device memory {what}: {(total - free) / 2**30:.1f} of {total / 2**30:.1f} GiB in use "
+            f"(torch holds {torch.cuda.memory_reserved(dev) / 2**30:.1f})")
+    mem("with the shards and the reads resident")
     for _ in range(args.warmup):
         step()
+    mem("after the first pass (exchange buffers, queues)")
     step(True)
     barrier()
     t0 = time.perf_counter()

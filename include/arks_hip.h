@@ -192,6 +192,10 @@ int arks_index_k(const arks_index* idx);
 int64_t arks_index_size(const arks_index* idx);
 /* device bytes held by the index */
 int64_t arks_index_device_bytes(const arks_index* idx);
+/* locality indexes: keys the text cannot answer and the exact table holds instead -- palindromes, windows under a heavy
+ * seed (an m-mer of a repeat family), quirk images -- and that table's bytes (part of arks_index_device_bytes); what a
+ * repeat-rich draft costs shows here.  out[0] = keys, out[1] = bytes; zeros for the plain hash table (kind 0). */
+int arks_index_fallback_size(const arks_index* idx, int64_t out[2]);
 /* layout of the index: 0 = exact open-addressed hash table of packed keys (k < 20, or when the
  * environment says ARKS_INDEX_KIND=hash); 1 = locality index over MINIMIZERS (packed contig-end text +
  * table of the minimizer positions + exact fallback table; ARKS_INDEX_KIND=minimizer); 2 = locality
@@ -389,6 +393,25 @@ int arks_exchange_submit(
     const uint8_t* d_eval,
     int64_t n_reads,
     double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream);
+/* arks_exchange_submit for a batch of PAIRS (reads 2p, 2p + 1 are mates; n_reads even) with the pair gate of
+ * chromiumRead folded in: what arks_pair_gate_device would write from d_read_class (arks_pack_reads_device / the host
+ * packer) and d_pair_ok (may be NULL) is computed by the bucketing kernel itself -- one launch and one pass over an
+ * array less per batch -- and written to d_eval_out (n_reads bytes), which the map kernels of arks_exchange_complete
+ * read and the caller may use afterwards (arks_gate_count_device, ...). */
+int arks_exchange_submit_pairs(
+    arks_exchange* x,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_read_class,
+    const uint8_t* d_pair_ok,
+    int64_t n_reads,
+    double j_index,
+    uint8_t* d_eval_out,
     int32_t* d_out_conreci,
     arks_map_stats* d_stats,
     void* stream);

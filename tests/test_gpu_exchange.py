@@ -231,6 +231,17 @@ def test_two_batches_in_flight(arks, gpu, oracle, mock_rccl, transport, world):
             for q in streams:
                 q.synchronize()
             out = [o for o in out if o[1] is not None]
+            # the same batches through the other two paths: the kernels WITHOUT counters (what `arcs` runs without -v
+            # and bench.py times: absent reads settled per chunk), once with the pair gate folded into the bucketing
+            # kernel (arks_exchange_submit_pairs) and once with the gate as a launch of its own (arks_exchange_submit)
+            for fold in (True, False):
+                again = xs[r].map_pairs_pipelined(batches, 0.55, streams, n_calls=n_calls, fold_gate=fold)
+                for q in streams:
+                    q.synchronize()
+                again = [o for o in again if o[1] is not None]
+                assert len(again) == len(out)
+                for (c1, p1), (c2, p2) in zip(out, again):
+                    assert torch.equal(c1, c2) and torch.equal(p1, p2), ("no counters", fold)
             res[r] = (np.concatenate([o[0].cpu().numpy() for o in out]), np.concatenate([o[1].cpu().numpy() for o in out]),
                       st.cpu().numpy(), imap.triples())
         except Exception as e:           # noqa: BLE001
