@@ -10,7 +10,8 @@ from arcs_amd.api import _concat
 variants = [a.split("=", 1) for a in sys.argv[1:]]
 k, j = 60, 0.55
 NP = int(os.environ.get("AB_PAIRS", 4_000_000))
-contigs = synth.make_draft(int(float(os.environ.get('AB_DRAFT_MBP', 50)) * 1e6), seed=synth.SEED)
+contigs = synth.make_draft(int(float(os.environ.get('AB_DRAFT_MBP', 50)) * 1e6), seed=synth.SEED,
+                           repeats={"": False, "human": "human", "1": True}[os.environ.get("AB_REPEATS", "")])
 cs = synth.contigs_to_strings(contigs)
 ends = arcs_amd.contig_ends(cs) if False else None
 # contig ends without touching the default lib
@@ -86,6 +87,13 @@ for (name, L, h, codes, nmask, out, ev) in libs:
         sec = (C.c_ulonglong * 16)(); L.arks_debug_section_cycles.argtypes = [C.c_void_p]; L.arks_debug_section_cycles(sec)
         tot = sum(sec[:12]) or 1
         print("   sections (share of the hot kernel's wave cycles):", " ".join(f"{i}:{100.0 * sec[i] / tot:.1f}" for i in range(12)), f"total {tot:.3e}")
+    except AttributeError:
+        pass
+    try:
+        ad = (C.c_ulonglong * 8)(); L.arks_debug_alt_round.argtypes = [C.c_void_p]; L.arks_debug_alt_round(ad)
+        print("   alt round (all launches of this process): candidates", ad[0], "finished", ad[1], "| words > 4 differing bases", ad[2],
+              "list full", ad[3], "seed with entries", ad[4], "seed heavy / > 2 entries", ad[5], "open window without anchor (words)", ad[6],
+              "candidates without diagonal A", ad[7])
     except AttributeError:
         pass
     dig = int((out.to(torch.int64) * (torch.arange(n, device=dev, dtype=torch.int64) % 1000003 + 1)).sum().item())
