@@ -376,7 +376,7 @@ def map_reads_seeded(index, reads, j_index, seed_off, answers, eval_mask=None, s
 
 
 class ExchangeStats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("seeds", "sent", "received", "reruns")]
+    _fields_ = [(n, C.c_uint64) for n in ("seeds", "sent", "received", "reruns", "stream_syncs")]
 
 
 class SeedExchange:

@@ -182,6 +182,8 @@ struct ExSet
 	u64* d_gather = nullptr;              // RCCL: 1 + W of mine, then world x (1 + W) of everybody
 	u64* h_gather = nullptr;              // pinned, the same
 	hipEvent_t counted = nullptr, probed = nullptr;
+	bool gathered = false; // RCCL: the counts all-gather of this batch was enqueued at submit (behind `counted`'s copy)
+	bool status_sent = false; // ... and carried this rank's failure (the peers know; nobody waits for it)
 	hipStream_t st = nullptr;
 	bool used = false, pending = false;
 	int rc = ARKS_OK;
@@ -222,6 +224,7 @@ struct arks_exchange
 	// seeds per read the regions are sized for: per owner, and in all (raised when a batch does not fit)
 	// (first guess: a 10x read pair has 2 + 3 seeds at k = 60; a batch of another shape does not fit, says what it needs,
 	// and is bucketed again -- once per shape; 3.3 until round 4: 30 % of the buffers of a 10x batch were never used)
+	u64 stream_syncs = 0; // hipStreamSynchronize calls made by complete() (arks_exchange_stats)
 	double per_read_owner = 0, per_read_all = 2.65;
 	long largest_batch = 0;
 	u64 reruns = 0;
@@ -384,6 +387,69 @@ rccl_all_to_all(
 	return ARKS_OK;
 }
 
+// a kernel on device da reads a buffer that lives on device db and writes into another one there; db's stream waits for
+// da's event and copies the result home: the direct transport's path, once, with a known answer
+int
+peer_path_check(int da, int db)
+{
+	constexpr int kN = 4096;
+	int rc = ARKS_OK;
+	u64 *src = nullptr, *dst = nullptr;
+	hipStream_t sa = nullptr, sb = nullptr;
+	hipEvent_t written = nullptr;
+	std::vector<u64> h((size_t)kN), back((size_t)kN, 0);
+	const u64 salt = 0x9E3779B97F4A7C15ull ^ ((u64)da << 32) ^ (u64)db;
+	for (int i = 0; i < kN; ++i)
+		h[(size_t)i] = 0x0123456789ABCDEFull * (u64)(i + 1);
+	{
+		DeviceGuard gb(db);
+		HIP_TRY(hipMalloc(reinterpret_cast<void**>(&src), sizeof(u64) * kN));
+		HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dst), sizeof(u64) * kN));
+		HIP_TRY(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+		HIP_TRY(hipMemcpy(src, h.data(), sizeof(u64) * kN, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemset(dst, 0, sizeof(u64) * kN));
+		HIP_TRY(hipDeviceSynchronize());
+	}
+	{
+		DeviceGuard ga(da);
+		HIP_TRY(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&written, hipEventDisableTiming));
+		HIP_TRY(arks::launch_peer_pattern(src, dst, kN, salt, sa)); // (reads and writes device db's memory)
+		HIP_TRY(hipEventRecord(written, sa));
+	}
+	{
+		DeviceGuard gb(db);
+		HIP_TRY(hipStreamWaitEvent(sb, written, 0));
+		HIP_TRY(hipMemcpyAsync(back.data(), dst, sizeof(u64) * kN, hipMemcpyDeviceToHost, sb));
+		HIP_TRY(hipStreamSynchronize(sb));
+	}
+	for (int i = 0; i < kN && rc == ARKS_OK; ++i)
+		if (back[(size_t)i] != (h[(size_t)i] ^ salt ^ (u64)i)) {
+			g_last_error = "local group: a kernel on device " + std::to_string(da) + " does not reach the memory of device " +
+			               std::to_string(db) + " (word " + std::to_string(i) + " of the check pattern came back wrong): peer access is "
+			               "enabled but does not deliver";
+			rc = ARKS_ERR_HIP;
+		}
+done:
+	{
+		DeviceGuard ga(da);
+		if (sa)
+			(void)hipStreamSynchronize(sa), (void)hipStreamDestroy(sa);
+		if (written)
+			(void)hipEventDestroy(written);
+	}
+	{
+		DeviceGuard gb(db);
+		if (sb)
+			(void)hipStreamDestroy(sb);
+		if (src)
+			(void)hipFree(src);
+		if (dst)
+			(void)hipFree(dst);
+	}
+	return rc;
+}
+
 } // namespace
 
 extern "C" {
@@ -488,6 +554,25 @@ arks_exchange_create_local(arks_exchange** out, const arks_index* const* shards,
 				rc = fail_hip(e, "hipDeviceEnablePeerAccess");
 			(void)hipGetLastError();
 		}
+	// ... and do, before the first batch: the very path of a batch -- a kernel of device a reads a buffer of device b and
+	// writes into another, b's stream waits for a's event and reads the result -- run once per ordered pair of devices
+	// (once on itself where all ranks share one device) and checked word for word.  A peer mapping that is enabled but
+	// does not deliver (IOMMU, a missing xGMI link, HSA_ENABLE_IPC_MODE_LEGACY left on) fails HERE, with a message,
+	// not as wrong votes three stages later.
+	if (rc == ARKS_OK) {
+		std::vector<std::pair<int, int>> done_pairs;
+		for (int a = 0; a < world && rc == ARKS_OK; ++a)
+			for (int b = 0; b < world && rc == ARKS_OK; ++b) {
+				const int da = shards[a]->device, db = shards[b]->device;
+				bool seen = false;
+				for (const auto& pr : done_pairs)
+					seen = seen || (pr.first == da && pr.second == db);
+				if (seen || (da == db && !done_pairs.empty()))
+					continue;
+				done_pairs.emplace_back(da, db);
+				rc = peer_path_check(da, db);
+			}
+	}
 	if (rc != ARKS_OK) {
 		const bool any = g->members_alive > 0;
 		for (int r = 0; r < world; ++r) {
@@ -614,6 +699,34 @@ exchange_submit(
 	s.read_class = n_reads > 0 ? d_read_class : nullptr, s.pair_ok = d_pair_ok, s.eval_out = d_eval_out;
 	s.rc = exchange_bucket(x, s);
 	// (a batch that failed here is completed all the same: the other ranks learn of it there, nobody waits in vain)
+	s.gathered = false;
+	if (x->comm && x->world > 1) {
+		// RCCL transport: the all-gather of (status, counts) rides on the batch's stream behind the bucket kernel -- from
+		// the counters on the device, no host round trip -- and its result comes home with an event; complete() finds it
+		// there.  (A batch that is bucketed again because a region was too small keeps its counts: the counters count on
+		// when a block finds no room.)  A rank whose submit failed contributes its status: everybody decides alike.
+		const arks_rccl_api* rccl = rccl_api();
+		const int W = x->world;
+		s.status_sent = s.rc != ARKS_OK;
+		hipError_t he = arks::launch_gather_prep(s.d_ctl, s.base, (u64)(s.rc != ARKS_OK), W, s.d_gather, s.st);
+		int e = 0;
+		if (he == hipSuccess && rccl)
+			e = rccl->AllGather(s.d_gather, s.d_gather + (1 + W), (size_t)(1 + W), kNcclUint64, x->comm, s.st);
+		if (he == hipSuccess && e == 0)
+			he = hipMemcpyAsync(s.h_gather + (1 + W), s.d_gather + (1 + W), sizeof(u64) * (size_t)W * (size_t)(1 + W), hipMemcpyDeviceToHost, s.st);
+		if (he == hipSuccess && e == 0)
+			he = hipEventRecord(s.counted, s.st); // (behind the ctl copy AND the gathered matrix: one wait in complete())
+		if (!rccl || e != 0 || he != hipSuccess) {
+			// nothing can be agreed any more: the communicator is of no use (the peers' calls fail or time out)
+			const int rc2 = !rccl ? ARKS_ERR_HIP : (e != 0 ? fail_rccl(e, "ncclAllGather(seed counts)") : fail_hip(he, "seed counts"));
+			if (rccl && rccl->CommAbort && x->comm) {
+				(void)rccl->CommAbort(x->comm);
+				x->comm = nullptr;
+			}
+			s.rc = s.rc != ARKS_OK ? s.rc : rc2;
+		} else
+			s.gathered = true;
+	}
 	s.pending = true;
 	x->submitted++;
 	return s.rc;
@@ -737,6 +850,7 @@ ex_tables(arks_exchange* x, ExSet& s)
 	}
 	x->last.seeds = s.n_seeds, x->last.sent = S - s.sc[(size_t)me], x->last.received = s.roff[(size_t)W] - s.rcv[(size_t)me];
 	x->last.reruns = x->reruns;
+	x->last.stream_syncs = x->stream_syncs;
 }
 
 // ---- 6. the home finishes: map_reads_s_kernel<REMOTE> + the general kernels -------------------------------------
@@ -894,24 +1008,22 @@ arks_exchange_complete(arks_exchange* x)
 	// ---- 2. everybody's counts and status: all[p * W + o] = seeds rank p asks of owner o -----------------------------
 	s.all.assign((size_t)W * (size_t)W, 0);
 	if (rccl && W > 1) {
-		// (1 + W) numbers per rank: status, counts.  Every rank holds the same matrix afterwards and decides alike.
+		// (1 + W) numbers per rank: status, counts -- gathered on the batch's stream since the submit (round 5: complete()
+		// used to enqueue the all-gather itself and wait for the stream, a host stall per batch); every rank holds the
+		// same matrix and decides alike.  ex_counts has waited for the event behind the matrix.
 		u64* hg = s.h_gather;
-		hg[0] = (u64)(rc != ARKS_OK);
-		for (int o = 0; o < W; ++o)
-			hg[1 + o] = rc == ARKS_OK ? s.counts[o] : 0;
-		int e = 0;
-		hipError_t he = hipMemcpyAsync(s.d_gather, hg, sizeof(u64) * (size_t)(1 + W), hipMemcpyHostToDevice, st);
-		if (he == hipSuccess) {
-			e = rccl->AllGather(s.d_gather, s.d_gather + (1 + W), (size_t)(1 + W), kNcclUint64, x->comm, st);
-			if (e == 0)
-				he = hipMemcpyAsync(hg + (1 + W), s.d_gather + (1 + W), sizeof(u64) * (size_t)W * (size_t)(1 + W), hipMemcpyDeviceToHost, st);
-			if (e == 0 && he == hipSuccess)
-				he = hipStreamSynchronize(st);
+		if (!s.gathered) {
+			if (rc == ARKS_OK) {
+				g_last_error = "the counts of this batch were never gathered (its submit failed)";
+				rc = ARKS_ERR_HIP;
+			}
+			return rc;
 		}
-		if (e != 0 || he != hipSuccess) {
-			// nothing was agreed: the communicator is of no use any more (the peers' calls fail or time out)
-			rc = e != 0 ? fail_rccl(e, "ncclAllGather(seed counts)") : fail_hip(he, "seed counts");
-			if (rccl->CommAbort && x->comm) {
+		if (rc != ARKS_OK) {
+			// a failure the all-gather carried (the submit's): every rank reads it and leaves, nobody waits.  One that came
+			// after it -- a region that overflowed three times, a HIP error: the peers believe this rank fine and are on
+			// their way into the exchange -- aborts the communicator, so that they get an error instead of a hang.
+			if (!s.status_sent && rccl->CommAbort && x->comm) {
 				(void)rccl->CommAbort(x->comm);
 				x->comm = nullptr;
 			}

@@ -70,6 +70,11 @@ struct SeedBucketGate
 	uint8_t* eval_out = nullptr;
 };
 long seed_bucket_chunks(long n_reads);
+// out[0] = status, out[1 + o] = the batch's seeds for owner o (0 with a status): what a rank contributes to the counts
+// all-gather of the RCCL transport, made on the device behind the bucket launch
+hipError_t launch_gather_prep(const SeedBucketCtl* ctl, const SeedBucketBase& base, u64 status, int n_owners, u64* out, hipStream_t st);
+// dst[i] = src[i] ^ salt ^ i (arks_exchange_create_local's check of the path between two devices)
+hipError_t launch_peer_pattern(const u64* src, u64* dst, int n, u64 salt, hipStream_t st);
 // zero_words / n_zero: a block of words the launch zeroes on the side (the map kernels' scratch of the same stream:
 // saves that launch's memset); may be NULL
 hipError_t launch_seed_bucket(

@@ -265,6 +265,38 @@ seed_bucket_kernel(
 	}
 }
 
+__global__ void
+gather_prep_kernel(const SeedBucketCtl* __restrict__ ctl, SeedBucketBase cb, u64 status, int n_owners, u64* __restrict__ out)
+{
+	const int o = (int)threadIdx.x;
+	if (o == 0)
+		out[0] = status;
+	if (o < n_owners)
+		out[1 + o] = status ? 0ull : ctl->fill[o * kCtlStride] - cb.fill[o];
+}
+
+hipError_t
+launch_gather_prep(const SeedBucketCtl* ctl, const SeedBucketBase& base, u64 status, int n_owners, u64* out, hipStream_t st)
+{
+	gather_prep_kernel<<<1, 64, 0, st>>>(ctl, base, status, n_owners, out);
+	return hipGetLastError();
+}
+
+__global__ void
+peer_pattern_kernel(const u64* __restrict__ src, u64* __restrict__ dst, int n, u64 salt)
+{
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (i < n)
+		dst[i] = src[i] ^ salt ^ (u64)i;
+}
+
+hipError_t
+launch_peer_pattern(const u64* src, u64* dst, int n, u64 salt, hipStream_t st)
+{
+	peer_pattern_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(src, dst, n, salt);
+	return hipGetLastError();
+}
+
 long
 seed_bucket_chunks(long n_reads)
 {

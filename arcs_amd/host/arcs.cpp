@@ -63,6 +63,7 @@ struct Params
 	                            // lanes inside a process when there are fewer files than ranks
 	int index_sharded = 0;      // --index-sharded[=N] (this build only): the seed table hash-sharded over N ranks of this
 	                            // process (arks_exchange, BASELINE configs[3]); 0 = replicas
+	bool share_devices = false; // --share-devices (this build only): more GPU ranks than visible devices is not an error
 	int lanes = 1;              // GPU lanes of THIS process (set by run_arks): device + 0 .. lanes - 1
 };
 
@@ -86,7 +87,8 @@ enum
 	OPT_DEVICE,
 	OPT_INDEX_SHARDS,
 	OPT_RANKS,
-	OPT_INDEX_SHARDED
+	OPT_INDEX_SHARDED,
+	OPT_SHARE_DEVICES
 };
 
 const char shortopts[] = "f:a:B:s:c:Dl:z:b:g:m:d:e:r:vt:u:j:k:P";
@@ -129,6 +131,7 @@ const struct option longopts[] = {
 	{ "index-shards", required_argument, NULL, OPT_INDEX_SHARDS },
 	{ "ranks", required_argument, NULL, OPT_RANKS },
 	{ "index-sharded", optional_argument, NULL, OPT_INDEX_SHARDED },
+	{ "share-devices", no_argument, NULL, OPT_SHARE_DEVICES },
 	{ NULL, 0, NULL, 0 }
 };
 
@@ -172,6 +175,8 @@ const char USAGE[] =
             "                         batches of a file are dealt to the GPUs of its process; outputs as with one [1]\n"
             "       --index-sharded[=N]  the index's seed table hash-sharded over N GPUs (default: --ranks, else all)\n"
             "                         instead of replicated: a read's seeds are answered by the GPUs that own them\n"
+            "       --share-devices   let GPU ranks share a device when --ranks / --index-sharded ask for more of them than\n"
+            "                         there are devices (an error otherwise: ranks that share a GPU add nothing; tests)\n"
             "       --device=N        GPU ordinal [0]\n";
 
 void
@@ -442,9 +447,11 @@ build_contig_index(std::vector<CI>& contigRecord, ContigToLength& contigToLength
 					if (rc != ARKS_OK)
 						die_arks(rc, "building a shard of the contig k-mer index");
 					by_lane[(size_t)lane].push_back(idx);
-					st.total_kmers += part.total_kmers, st.null_kmers += part.null_kmers, st.short_ends += part.short_ends;
-					st.recorded += part.recorded, st.collisions += part.collisions, st.removed_dup += part.removed_dup;
-					st.unique += part.unique;
+					if (lane == 0) { // (only lane 0 collects counters; the lanes of other devices run in threads of their own)
+						st.total_kmers += part.total_kmers, st.null_kmers += part.null_kmers, st.short_ends += part.short_ends;
+						st.recorded += part.recorded, st.collisions += part.collisions, st.removed_dup += part.removed_dup;
+						st.unique += part.unique;
+					}
 				}
 				return;
 			}
@@ -1288,8 +1295,29 @@ run_arks(const std::vector<std::string>& filenames)
 		}
 		int ndev = 0;
 		if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
-			params.device = (params.device + first_lane) % ndev;
+			// Which device every GPU rank of this process got, said out loud (stderr: stdout is the reference's log), and no
+			// silent doubling up: N ranks on fewer than N devices map nothing faster than the devices alone would, and a run
+			// that was meant for eight GPUs and found one should say so -- unless it was asked for (--share-devices: tests
+			// on a one-GPU box).
+			const int asked = params.index_sharded > 0 ? params.index_sharded : std::max(1, params.ranks);
+			if (asked > ndev && !params.share_devices) {
+				if (g_rank == 0)
+					std::cerr << PROGRAM ": error: " << asked << " GPU ranks asked for ("
+					          << (params.index_sharded > 0 ? "--index-sharded" : "--ranks") << "), " << ndev
+					          << " gfx950 device(s) visible; ranks that share a device add nothing (--share-devices to allow it).\n";
+				exit(EXIT_FAILURE);
+			}
+			const int base = params.device;
+			params.device = (base + first_lane) % ndev;
 			(void)hipSetDevice(params.device);
+			if (asked > 1)
+				for (int l = 0; l < std::max(1, params.lanes); ++l) {
+					const int dev = (params.device + l) % ndev;
+					hipDeviceProp_t pr;
+					const bool named = hipGetDeviceProperties(&pr, dev) == hipSuccess;
+					std::fprintf(stderr, "%s: GPU rank %d (process %d, lane %d) -> device %d%s%s%s\n", PROGRAM, first_lane + l, g_rank, l, dev,
+					             named ? " (" : "", named ? pr.name : "", named ? ")" : "");
+				}
 		}
 	}
 	{
@@ -1528,6 +1556,7 @@ main(int argc, char** argv)
 		case OPT_DEVICE: arg >> params.device; break;
 		case OPT_INDEX_SHARDS: arg >> params.index_shards; break;
 		case OPT_RANKS: arg >> params.ranks; break;
+		case OPT_SHARE_DEVICES: params.share_devices = true; break;
 		case OPT_INDEX_SHARDED:
 			params.index_sharded = -1; // (resolved in run_arks)
 			if (optarg != NULL)

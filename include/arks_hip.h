@@ -352,6 +352,8 @@ typedef struct
 	uint64_t sent;     /* ... of which asked of other ranks (8 B out, 16 B back each) */
 	uint64_t received; /* seeds other ranks asked of this one */
 	uint64_t reruns;   /* batches so far that did not fit the send buffer's regions and were bucketed again, larger */
+	uint64_t stream_syncs; /* hipStreamSynchronize calls arks_exchange_complete has made so far (0: the host never waits
+	                        * for a stream -- the counts all-gather of the RCCL transport is enqueued at submit, round 5) */
 } arks_exchange_stats;
 
 /* rank 0: a fresh id for arks_exchange_create on every rank (ncclGetUniqueId) */
@@ -373,8 +375,11 @@ int arks_exchange_last_stats(const arks_exchange* x, arks_exchange_stats* out);
 /* bestContig (Arcs/Arcs.cpp:939-1014) of this rank's reads against the sharded seed table, in two steps -- the
  * same results and counters as arks_map_reads_device against the whole index (the reads are independent,
  * Arcs.cpp:1169; the index is only read, :969-971):
- *   arks_exchange_submit    NOT collective.  On `stream`: the batch's seeds listed and bucketed by owner (one
- *                           kernel), the per-owner counts copied to the host.  At most two batches may be
+ *   arks_exchange_submit    On `stream`: the batch's seeds listed and bucketed by owner (one kernel), the
+ *                           per-owner counts copied to the host.  Does not wait for anybody; with the RCCL transport
+ *                           it also ENQUEUES the all-gather of the counts behind the kernel (round 5; complete() did
+ *                           it until then, and waited for the stream), so every rank submits its batches in the same
+ *                           order -- which the collective complete() asks for anyway.  At most two batches may be
  *                           submitted and not yet completed; the arrays must stay valid until the batch's
  *                           results have been consumed.
  *   arks_exchange_complete  COLLECTIVE: every rank calls it, in the same order, for its oldest submitted batch

@@ -60,3 +60,22 @@ def test_bench_sharded_index_over_the_exchange(arks, gpu):
     ex = sh["config"]["last_batch_of_rank0"]
     assert ex["seeds"] > 0 and 0 < ex["sent"] < ex["seeds"] and ex["received"] > 0
     assert max(sh["config"]["shard_bytes"]) > 0
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_dry_run(arks, gpu):
+    """What the driver will run the day an 8-GPU node appears -- `python bench.py --gpus 8` -- as a dry run on the one
+    GPU (ARKS_BENCH_BACKEND=gloo: eight processes share it): the same control flow (rendezvous, blocks dealt to eight
+    ranks, max-over-ranks timing, summed counters, one JSON line), counters equal to one rank's, and a wall-time
+    budget: eight processes generate the draft and build their index replicas side by side on the box's CPU quota,
+    which must stay far inside the driver's limit."""
+    import time
+    one = _bench([])
+    t0 = time.time()
+    many = _bench(["--gpus", "8"], {"ARKS_BENCH_BACKEND": "gloo"})
+    wall = time.time() - t0
+    assert many["n_gpus"] == 8 and many["scaling"] == "strong"
+    assert many["config"]["pairs_job"] == 400000
+    assert many["counters"] == one["counters"] and many["stored_pairs"] == one["stored_pairs"]
+    assert "x8" in many["config"]["parallelism"]
+    assert wall < 600, wall

@@ -208,9 +208,12 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
         tag = f"ranks{n_ranks}"
         argsr[argsr.index("-b") + 1] = str(tmp_path / tag)
         argsr[argsr.index("--barcode-counts") + 1] = str(tmp_path / (tag + "_counts"))
-        resr = subprocess.run(argsr + ["--ranks", str(n_ranks)] + [str(x) for x in paths], capture_output=True,
+        resr = subprocess.run(argsr + ["--ranks", str(n_ranks), "--share-devices"] + [str(x) for x in paths], capture_output=True,
                               text=True, timeout=300)
         assert resr.returncode == 0, resr.stderr[-2000:]
+        # every GPU rank says which device it got (stderr; here they share the box's GPU, which has to be asked for)
+        said = [ln for ln in resr.stderr.split("\n") if ln.startswith("arcs: GPU rank ")]
+        assert len(said) == n_ranks and all("-> device " in ln for ln in said), resr.stderr[-2000:]
         for suffix in ("_original.gv", "_pair.tsv", "_main.tsv", ".dist.gv"):
             assert open(str(tmp_path / tag) + suffix).read() == open(str(tmp_path / "multi") + suffix).read(), suffix
         assert open(str(tmp_path / (tag + "_counts.tsv"))).read() == open(str(tmp_path / "counts2.tsv")).read()
@@ -219,9 +222,16 @@ def test_arcs_cli_end_to_end(arks, gpu, oracle, tmp_path, use_mult_file, k, extr
     # are not even started: the reference's sequence -- the files in front of it, then the message -- is rank 0's)
     bad_paths = [str(paths[0]), str(tmp_path / "no_such_reads.fq"), str(paths[2])]
     one = subprocess.run(args2 + bad_paths, capture_output=True, text=True, timeout=300)
-    two = subprocess.run(args2 + ["--ranks", "2"] + bad_paths, capture_output=True, text=True, timeout=300)
+    two = subprocess.run(args2 + ["--ranks", "2", "--share-devices"] + bad_paths, capture_output=True, text=True, timeout=300)
     assert one.returncode == two.returncode and one.returncode != 0
-    assert "no_such_reads.fq" in one.stderr and one.stderr == two.stderr
+    two_err = "\n".join(ln for ln in two.stderr.split("\n") if not ln.startswith("arcs: GPU rank "))
+    assert "no_such_reads.fq" in one.stderr and one.stderr == two_err
+    # more GPU ranks than devices is an error unless it is asked for: a run meant for eight GPUs that finds one says so
+    import torch as _torch
+    if _torch.cuda.device_count() == 1:
+        for extra in (["--ranks", "2"], ["--index-sharded=2"]):
+            refused = subprocess.run(args2 + extra + [str(x) for x in paths], capture_output=True, text=True, timeout=300)
+            assert refused.returncode != 0 and "--share-devices" in refused.stderr, (extra, refused.stderr[-500:])
     assert _norm(one.stdout, "multi", "counts2") == _norm(two.stdout, "multi", "counts2")
     # ---- the contig k-mer index in three parts (--index-shards): per batch the votes of every part,
     #      their maximum, then the j_index test -- same files, same stored pairs ----------------------
@@ -581,14 +591,16 @@ def test_one_reads_file_many_gpus(arks, gpu, tmp_path, kind):
     assert "Stored read pairs: " in one.stdout and "Stored read pairs: 0\n" not in one.stdout
     for tag, extra in (("r2", ["--ranks", "2"]), ("r3", ["--ranks", "3"]), ("s2", ["--index-sharded=2"]),
                        ("s3", ["--index-sharded", "--ranks", "3"])):
-        res = run(tag, extra)
+        res = run(tag, extra + ["--share-devices"])
+        said = [ln for ln in res.stderr.split("\n") if ln.startswith("arcs: GPU rank ")]
+        assert len(said) == int(extra[-1][-1]), (tag, res.stderr[-1000:])
         assert _norm_log(res.stdout, tag) == _norm_log(one.stdout, "one"), tag
         for suffix in ("_original.gv", "_pair.tsv", "_main.tsv", ".dist.gv"):
             assert open(str(tmp_path / tag) + suffix).read() == open(str(tmp_path / "one") + suffix).read(), (tag, suffix)
     if kind == "fq":
         # two k in one pass over a sharded seed table (an exchange group per k), and the pipe of arcs-make:305
         base = run("k2", [], k="40,60")
-        res = run("k2s", ["--index-sharded=3"], k="40,60")
+        res = run("k2s", ["--index-sharded=3", "--share-devices"], k="40,60")
         assert _norm_log(res.stdout, "k2s") == _norm_log(base.stdout, "k2")
         for kk in (40, 60):
             for suffix in ("_original.gv", "_main.tsv"):
@@ -596,7 +608,7 @@ def test_one_reads_file_many_gpus(arks, gpu, tmp_path, kind):
                 assert len(a) == 1, (kk, suffix, a)
                 assert open(tmp_path / a[0]).read() == open(tmp_path / a[0].replace("k2s", "k2", 1)).read()
         args = [exe, "--arks", "-f", str(fa), "-c", "3", "-m", "8-10000", "-k", "60", "-t", "4", "-b", str(tmp_path / "pipe"),
-                "--batch-pairs", "700", "--ranks", "3", "/dev/stdin"]
+                "--batch-pairs", "700", "--ranks", "3", "--share-devices", "/dev/stdin"]
         with open(fq, "rb") as src:
             res = subprocess.run(args, stdin=src, capture_output=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]

@@ -143,6 +143,8 @@ def test_rccl_code_path_over_the_mock_transport(arks, gpu, oracle, mock_rccl, k,
         assert dict(zip(STAT_NAMES, np.sum(stats, axis=0).tolist())) == st.as_dict()
         ex = [x.last_stats() for x in xs]
         assert sum(e["sent"] for e in ex) == sum(e["received"] for e in ex) > 0
+        # complete() never waits for a stream: the counts all-gather is enqueued at submit
+        assert all(e["stream_syncs"] == 0 for e in ex), ex
         # 8 B per seed that travels and 16 B per answer, nothing else; one all-gather per rank; every group closed
         # (the batch is mapped twice, with and without counters)
         assert c1["bytes"] - c0["bytes"] == 2 * 24 * sum(e["sent"] for e in ex)
