@@ -543,6 +543,109 @@ def end_to_end_files(wl, dev, log, sub_mbp=20.0, n_pairs=2_000_000, threads=16):
             "same_stored_pairs": cli_stored == cpu_stored}
 
 
+def end_to_end_scale(wl, dev, local, log, port, n_files=8, pairs_per_file=4_000_000, threads=16):
+    """`end_to_end.from_fq_gz_at_scale`: the product's front end on a run of a size where start-up
+    no longer decides -- the WHOLE draft as FASTA (3 GB) and n_files gzipped interleaved FASTQ files of pairs_per_file
+    pairs drawn from all of it (32 M pairs, ~20 GB of text), `arcs --arks -v -t 16` as a whole process: draft read,
+    index build on the device (1.4 G keys), parallel gzip decode, parse, pack, H2D, kernels, graph, output files.  The
+    CPU port cannot hold the whole draft's map in a bench run, so its side is the rate it reached on the small
+    from_fq_gz leg (`port`: a sub-draft's map in host RAM, reads of that sub-draft, the same read shape) -- an
+    extrapolation, labelled as one: per pair the port's work does not depend on the draft (one hash probe per
+    window, out of cache in both).  Stored pairs are checked against the library path: the same reads mapped through
+    the C ABI from device arrays against the resident whole index."""
+    import re
+    import shutil
+    import tempfile
+    from arcs_amd import build as ab
+    exe = ab.build_host()
+    k, j = wl.k, wl.j
+    tmp = tempfile.mkdtemp(prefix="arks_e2e_scale_")
+    free = shutil.disk_usage(tmp).free
+    need = int(sum(len(c) for c in wl.contigs) * 1.02 + n_files * pairs_per_file * 130)
+    scaled = None
+    if free < 2 * need:            # (a small scratch disk: fewer pairs, and the record says so)
+        scaled = max(1, int(n_files * (free / (2.0 * need))))
+        log(f"end to end at scale: {free / 1e9:.1f} GB free in {tmp}, {need / 1e9:.1f} GB wanted: {scaled} files instead of {n_files}")
+        n_files = scaled
+    pairs_per_file -= pairs_per_file % 80
+    try:
+        t0 = time.time()
+        with open(os.path.join(tmp, "draft.fa"), "wb") as f:
+            for ci, c in enumerate(wl.contigs):
+                f.write(b">%d\n" % (ci + 1))
+                f.write(c.tobytes())
+                f.write(b"\n")
+        t_fa = time.time() - t0
+        t0 = time.time()
+        files, windows, lib_stored, gz_b, text_b, max_bid = [], 0, 0, 0, 0, 0
+        for fi in range(n_files):
+            batch = synth.make_read_pairs(wl.genome, pairs_per_file, seed=synth.SEED + 900 + fi, device=dev)
+            text = synth.fastq_bytes(batch, first_pair=fi * pairs_per_file)
+            fq = os.path.join(tmp, f"reads{fi}.fq.gz")
+            synth.write_gz_members(fq, text, threads=16, member_bytes=256 << 20)
+            files.append(fq)
+            gz_b += os.path.getsize(fq)
+            text_b += text.size
+            windows += int(torch.clamp(batch["lens"].to(torch.int64) - (k - 1), min=0).sum().item())
+            max_bid = max(max_bid, int(batch["barcode_id"].max().item()))
+            # the library path on the same reads (device arrays, the resident whole index): what the CLI must store
+            reads = arcs_amd.PackedReads.from_arrays_device(batch["ascii"], batch["offsets"], batch["lens"], device=local)
+            _, pr = arcs_amd.map_pairs_packed(wl.index, reads, j, pair_ok=batch["pair_ok"])
+            lib_stored += int(((pr != 0) & (batch["pair_ok"] != 0)).sum().item())
+            del batch, text, reads, pr
+        with open(os.path.join(tmp, "mult.tsv"), "w") as f:
+            for b in range(max_bid + 1):
+                v, name = b, []
+                for _ in range(16):
+                    name.append("ACGT"[v % 4])
+                    v //= 4
+                f.write("".join(reversed(name)) + "-1\t160\n")
+        n_pairs = n_files * pairs_per_file
+        log(f"end to end at scale: draft FASTA in {t_fa:.1f}s, {n_pairs} pairs as {n_files} .fq.gz ({gz_b / 1e9:.1f} GB, "
+            f"{text_b / 1e9:.1f} GB of text) in {time.time() - t0:.1f}s")
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        res = subprocess.run([exe, "--arks", "-v", "-f", os.path.join(tmp, "draft.fa"), "-u", os.path.join(tmp, "mult.tsv"),
+                              "-k", str(k), "-j", str(j), "-c", "5", "-m", "50-10000", "-e", "30000", "-z", "500",
+                              "-t", str(threads), "-b", os.path.join(tmp, "out")] + files,
+                             capture_output=True, text=True, env=dict(os.environ, ARKS_TIMING="1"))
+        cli_s = time.time() - t0
+        assert res.returncode == 0, res.stderr[-2000:]
+        m = re.findall(r"Stored read pairs: (\d+)", res.stdout)      # (per file: chromiumRead's locals, Arcs.cpp:1143-1146, 1322)
+        cli_stored = sum(int(x) for x in m) if m else -1
+        stages = {}
+        for ln in res.stderr.splitlines():
+            mm = re.match(r"\[timing\] +([^:]+): (\d+) ms", ln)
+            if mm:
+                stages[mm.group(1).strip()] = stages.get(mm.group(1).strip(), 0) + int(mm.group(2))
+        rd = [v for kk, v in stages.items() if "read files" in kk]
+        read_ms = float(rd[0]) if rd else None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    port_pairs_s = port["pairs_per_s"]
+    whole = n_pairs / cli_s
+    read_stage = (n_pairs / (read_ms * 1e-3)) if read_ms else None
+    return {"input": f"{n_files} gzipped interleaved FASTQ files of {pairs_per_file} pairs ({gz_b / 1e9:.1f} GB; {text_b / 1e9:.1f} GB of "
+                     f"text), reads drawn from the whole {sum(len(c) for c in wl.contigs) / 1e6:.0f} Mbp draft (FASTA, {len(wl.contigs)} contigs)"
+                     + (f" [scaled down from 8 files: scratch disk]" if scaled else ""),
+            "pairs": n_pairs, "windows": windows,
+            "gpu_cli": {"seconds": cli_s, "pairs_per_s": whole, "value": windows / cli_s, "unit": "k-mers/s",
+                        "read_stage_ms": read_ms, "read_stage_pairs_per_s": read_stage,
+                        "read_stage_kmers_per_s": (windows / (read_ms * 1e-3)) if read_ms else None,
+                        "stage_ms": stages, "threads": threads, "stored_pairs": cli_stored,
+                        "what": "arcs --arks -v, whole process: start-up, the 3 Gbp draft FASTA, index build on the device, the read "
+                                "stage (one decoding thread per .gz file, parse, pack, H2D, kernels), graph and output files"},
+            "library_stored_pairs": lib_stored, "same_stored_pairs_as_library": cli_stored == lib_stored,
+            "cpu_port_pairs_per_s": port_pairs_s,
+            "cpu_port_note": "the port's rate on the from_fq_gz leg (a sub-draft's map, reads of that sub-draft, the same read "
+                             "shape, the same host cores): an EXTRAPOLATION to this input -- the whole draft's map does not fit a bench run",
+            "cli_over_port_whole_process": whole / port_pairs_s,
+            "cli_read_stage_over_port": (read_stage / port_pairs_s) if read_stage else None,
+            "bound": (f"whole process {cli_s:.1f}s, of which the read stage {read_ms / 1e3:.1f}s: the rest is start-up (draft FASTA, "
+                      f"index build, graph, outputs); the read stage runs on the container's CPU quota "
+                      f"({cpu_quota()} CPUs): gzip inflate is what its threads do") if read_ms else None}
+
+
 def end_to_end(wl, dev, local, n_batches=8, pairs=2_000_000):
     """packed batches start in pinned HOST memory; per batch H2D (codes, N mask, offsets,
     lengths, class, pair_ok, barcode ids) -> gate / map / pair rule -> D2H (pair results), double-buffered
@@ -783,6 +886,11 @@ def main():
             out["end_to_end"] = end_to_end(wl, dev, local)
             if cpu_leg:
                 out["end_to_end"]["from_fq_gz"] = end_to_end_files(wl, dev, log)
+                if args.draft_mbp >= 1000 or os.environ.get("ARKS_BENCH_E2E_SCALE"):
+                    out["end_to_end"]["from_fq_gz_at_scale"] = end_to_end_scale(
+                        wl, dev, local, log, out["end_to_end"]["from_fq_gz"]["cpu_port"],
+                        n_files=int(os.environ.get("ARKS_BENCH_E2E_FILES", 8)),
+                        pairs_per_file=int(os.environ.get("ARKS_BENCH_E2E_PAIRS_PER_FILE", 4_000_000)))
             del wl
             torch.cuda.empty_cache()
             # BASELINE configs[1] (round 1's headline), same build, same box
@@ -806,6 +914,9 @@ def main():
             e2e = out["end_to_end"]["from_fq_gz"]
             assert e2e["gpu_cli"]["stored_pairs"] < 0 or e2e["same_stored_pairs"], \
                 "CLI and CPU port store different numbers of pairs"
+        if "from_fq_gz_at_scale" in out.get("end_to_end", {}):
+            e2s = out["end_to_end"]["from_fq_gz_at_scale"]
+            assert e2s["same_stored_pairs_as_library"], "CLI at scale and the library path store different numbers of pairs"
         if "configs2_repeats" in out:
             assert out["configs2_repeats"]["sample_parity"], "repeat-rich draft: GPU results differ from the CPU oracle"
         if "configs2_human_like" in out:
