@@ -140,13 +140,23 @@ struct GrowBuf
 {
 	void* p = nullptr;
 	size_t cap = 0;
+	// Contents are not kept.  Who may still touch the old block: the set's own kernels (its last map kernel reads slot,
+	// chunk_off and the answers) and, in a local group, the peers' probe kernels (they read `send` and write `ans_back`)
+	// -- and the set's stream has waited for every one of those (direct_finish: the owners' `probed` events) before its
+	// map kernel.  So the block is free once `user` -- the stream the set was last used on -- has drained: waited for
+	// HERE, explicitly (until round 4 this leaned on hipFree's device-wide wait, which also stalled the other
+	// batch in flight).
 	hipError_t
-	reserve(size_t bytes) // contents are not kept; hipFree waits for the device: nothing still reads the old block
+	reserve(size_t bytes, hipStream_t user)
 	{
 		if (bytes <= cap)
 			return hipSuccess;
-		if (p)
+		if (p) {
+			const hipError_t e = hipStreamSynchronize(user);
+			if (e != hipSuccess)
+				return e;
 			(void)hipFree(p);
+		}
 		p = nullptr;
 		cap = 0;
 		const size_t want = bytes + bytes / 8 + 4096;
@@ -633,10 +643,10 @@ exchange_bucket(arks_exchange* x, ExSet& s)
 		return ARKS_ERR_BAD_ARG;
 	}
 	s.cap = cap, s.slot_cap = slot_cap;
-	HIP_TRY(s.send.reserve(sizeof(u64) * (size_t)cap * (size_t)W));
-	HIP_TRY(s.ans_back.reserve(2 * sizeof(u64) * (size_t)cap * (size_t)W));
-	HIP_TRY(s.slot.reserve(sizeof(u32) * (size_t)slot_cap));
-	HIP_TRY(s.chunk_off.reserve(sizeof(u32) * (size_t)(arks::seed_bucket_chunks(s.n_reads) + 1)));
+	HIP_TRY(s.send.reserve(sizeof(u64) * (size_t)cap * (size_t)W, s.st));
+	HIP_TRY(s.ans_back.reserve(2 * sizeof(u64) * (size_t)cap * (size_t)W, s.st));
+	HIP_TRY(s.slot.reserve(sizeof(u32) * (size_t)slot_cap, s.st));
+	HIP_TRY(s.chunk_off.reserve(sizeof(u32) * (size_t)(arks::seed_bucket_chunks(s.n_reads) + 1), s.st));
 	// the map kernels' queues of this stream: made (or grown) here, so that the bucket launch can zero their scratch
 	// block on the side -- one launch less per batch
 	s.scratch_zeroed = false;
@@ -1053,9 +1063,9 @@ arks_exchange_complete(arks_exchange* x)
 	if (rccl && W > 1) {
 		// ---- 3. seeds to their owners; 4. the owner's answers; 5. answers back -------------------------------------
 		const u64 R = roff[(size_t)W];
-		hipError_t he = s.recv.reserve(sizeof(u64) * (size_t)(R + 1));
+		hipError_t he = s.recv.reserve(sizeof(u64) * (size_t)(R + 1), st);
 		if (he == hipSuccess)
-			he = s.ans_out.reserve(2 * sizeof(u64) * (size_t)(R + 1));
+			he = s.ans_out.reserve(2 * sizeof(u64) * (size_t)(R + 1), st);
 		if (he != hipSuccess) {
 			// the others are on their way into the exchange: they must not wait for this rank
 			rc = fail_hip(he, "hipMalloc(exchange receive buffers)");

@@ -26,6 +26,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <array>
 #include <chrono>
 #include <cstdarg>
 #include <cstring>
@@ -277,12 +278,29 @@ read_barcodes(const std::vector<std::string>& files, std::unordered_map<std::str
 bool
 check_contig_sequence(const std::string& seq)
 {
-	for (char ch : seq) {
-		const char c = (char)toupper((unsigned char)ch);
-		if (!strchr("ATGCNMRWSYKVHDB", c) || c == '\0') {
-			std::cout << c << std::endl;
-			return false;
+	// (the reference's toupper + strchr per character is 2 ns a base: 7 s of a -v run's start-up on a 3 Gbp draft,
+	// profiles/r09_bench.json; the same rule as a table, 64 characters at a time, first offender printed as before)
+	static const std::array<unsigned char, 256> bad = [] {
+		std::array<unsigned char, 256> t{};
+		for (int ch = 0; ch < 256; ++ch) {
+			const char c = (char)toupper(ch);
+			t[(size_t)ch] = (!strchr("ATGCNMRWSYKVHDB", c) || c == '\0') ? 1 : 0;
 		}
+		return t;
+	}();
+	const unsigned char* p = reinterpret_cast<const unsigned char*>(seq.data());
+	const size_t n = seq.size();
+	for (size_t i = 0; i < n; i += 64) {
+		const size_t e = i + 64 < n ? i + 64 : n;
+		unsigned char any = 0;
+		for (size_t x = i; x < e; ++x)
+			any |= bad[p[x]];
+		if (any)
+			for (size_t x = i; x < e; ++x)
+				if (bad[p[x]]) {
+					std::cout << (char)toupper(p[x]) << std::endl;
+					return false;
+				}
 	}
 	return true;
 }
