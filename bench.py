@@ -5,7 +5,7 @@ One "step" = one pass of the hot path (pair gate -> per-read k-mer window keys -
 index lookup -> per-read vote -> pair rule + (barcode, contig end) accumulation) over the whole
 resident read set.  Workload at N=1: BASELINE.json configs[2] -- synthetic 3 Gbp draft + 500 M
 linked-read pairs (R1 128 bp / R2 151 bp), k=60, j=0.55, everything resident in HBM (packed reads
-~55 GB, seed index ~46 GB); the read set is mapped in launches of 100 M pairs.  The read set is a
+~55 GB, seed index ~46 GB); the read set is mapped in launches of 250 M pairs.  The read set is a
 function of the global pair number alone (generated in 40 blocks, block b from seed SEED+1+b), so
 the same 500 M pairs are mapped whatever the number of ranks.  With N > 1 every rank holds a replica
 of the index and the blocks are dealt to the ranks (strong scaling: fixed total work, no data-path
@@ -718,9 +718,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=500_000_000, help="read pairs in total (per GPU with --weak)")
-    ap.add_argument("--chunk", type=int, default=100_000_000,
-                    help="read pairs per launch (100 M: 5 launches per pass; launches of 20 M pairs -- rounds 1-2's "
-                         "default -- cost 3-4 %% more per pair in fixed per-launch work)")
+    ap.add_argument("--chunk", type=int, default=250_000_000,
+                    help="read pairs per launch (250 M: 2 launches per pass; the general kernels behind the hot one are a "
+                         "latency-bound tail of every launch: 100 M -- rounds 2-4's default -- costs 2.6 %% more per pair, "
+                         "20 M another 3-4 %%; ONE launch of 500 M is slower again, profiles/r09h_chunk.txt)")
     ap.add_argument("--draft-mbp", type=float, default=3000.0)
     ap.add_argument("--k", type=int, default=60)
     ap.add_argument("--j", type=float, default=0.55)

@@ -9,7 +9,7 @@ import bench
 tag = sys.argv[1]
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=500_000_000)
-ap.add_argument("--chunk", type=int, default=100_000_000)  # bench.py's default
+ap.add_argument("--chunk", type=int, default=250_000_000)  # bench.py's default
 ap.add_argument("--draft-mbp", type=float, default=3000.0)
 ap.add_argument("--k", type=int, default=60)
 ap.add_argument("--repeats", action="store_true")
@@ -55,7 +55,10 @@ except OSError:
 # kernel on this workload's kind of reads.
 cal, factor = None, 1.0
 try:
-    cal = json.load(open(os.path.join("profiles", "r04_traffic_classes.json")))
+    cal_path = os.path.join("profiles", "r09_traffic_classes.json")          # (this round's kernel; round 4's otherwise)
+    if not os.path.exists(cal_path):
+        cal_path = os.path.join("profiles", "r04_traffic_classes.json")
+    cal = json.load(open(cal_path))
     factor = float(cal["read_factor_corrected_over_FETCH_SIZE"])
 except (OSError, KeyError, ValueError):
     cal = None
@@ -69,7 +72,7 @@ out = {"workload": wk,
        "hbm_bytes_per_launch": (f * factor + w) * 1024.0,
        "traffic_calibration": {
            "read_factor": factor,
-           "source": ("profiles/r04_traffic_classes.json (per-pair bytes by class: " +
+           "source": (cal_path + " (per-pair bytes by class: " +
                       json.dumps({k: round(v, 1) for k, v in cal["per_pair_bytes_corrected"].items()}) +
                       " corrected, " + json.dumps({k: round(v, 1) for k, v in cal["per_pair_bytes_counted"].items()}) +
                       " as FETCH_SIZE counts them); class factors from profiles/r04_fetch_calibration.json, "
