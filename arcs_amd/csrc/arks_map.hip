@@ -1966,6 +1966,13 @@ struct SeedTileLds
 	int sbase[sTR];            // tile seed h of read j is seed sbase[j] + h of the chunk
 	unsigned char rorig[sTR];  // read j of the tile is read c0 + rorig[j] of the batch
 	unsigned char perm[64];
+	// reads for the medium queue, collected per wave and handed over 47 or more at a time with ONE global atomic (round 5).
+	// Until then every flagged read's lane did `mqueue[atomicAdd(queue_count + 2, 1)] = r`: a dependent round trip per
+	// tile on a counter that every wave of the launch adds to -- nothing on the headline's draft (15 k of 40 M reads), the
+	// hot kernel's whole difference on a repeat-rich one: 16.0 -> 8.4 ms per 20 M pairs on the human-like draft
+	// (profiles/r09i_retry_kernels.txt found it by accident: a variant that pushed once per chunk instead of per tile)
+	u32 mqb[64];
+	u32 mqn;
 };
 
 #ifndef ARKS_SEED_WAVES
@@ -2039,6 +2046,30 @@ map_reads_s_kernel(
 	const bool skip_dead = kSkipDead && !(bx.has_img && !(k & 1));
 	if (STATS && lane_id < 8)
 		S.wstats[lane_id] = 0;
+	if (lane_id == 0)
+		S.mqn = 0u;
+	// the collected reads -> the medium queue: one atomic for all of them, their numbers by the lanes
+	auto flush_mq = [&]() {
+		ARKS_WAVE_SYNC();
+		const u32 nq = S.mqn;
+		if (nq != 0u) {
+			int cl = lane_id; // (opaque: see the chunk's metadata below)
+			asm volatile("" : "+v"(cl));
+			u32 qb = 0;
+			if (cl == 0)
+				qb = atomicAdd(queue_count + 2, nq);
+			qb = (u32)__builtin_amdgcn_readfirstlane((int)qb);
+			if ((u32)cl < nq)
+				mqueue[qb + (u32)cl] = S.mqb[cl];
+			ARKS_WAVE_SYNC();
+			if (cl == 0) {
+				u32 z;
+				asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+				S.mqn = z;
+			}
+			ARKS_WAVE_SYNC();
+		}
+	};
 	u32* const work_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kWorkCtrOffset);
 	u32 ctr = blockIdx.x & (u32)(kCounters - 1), misses = 0;
 	bool first_grab = true;
@@ -2244,6 +2275,8 @@ map_reads_s_kernel(
 		while (cur < nchunk_c) {
 			int lane = lane_id;
 			asm volatile("" : "+v"(lane));
+			if (S.mqn > 46u) // (a tile adds 16 at most, a read beyond a tile one: never more than 64)
+				flush_mq();
 			// ---- S0: tile = reads [cur, nxt) ---------------------------------------------------------
 			const u64 base_w = lane_value_u64(pos, cur);
 			const int gbase = __builtin_amdgcn_readlane(gex, cur);
@@ -2260,10 +2293,11 @@ map_reads_s_kernel(
 					if (rl < 0)
 						put_none<RAW>(out_conreci, r);
 					else if (wcnt <= kSW)
-						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)r;
+						S.mqb[atomicAdd(&S.mqn, 1u)] = (u32)r;
 					else
 						queue[atomicAdd(queue_count, 1u)] = (u32)r;
 				}
+				ARKS_WAVE_SYNC();
 				cur++;
 				continue;
 			}
@@ -2620,7 +2654,7 @@ map_reads_s_kernel(
 					// matches on one diagonal that belong to different contig ends: general path
 					medium = medium || (rec_a && S.rmax[j][0] != own_a) || (rec_b && S.rmax[j][1] != own_b);
 					if (medium) {
-						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)r;
+						S.mqb[atomicAdd(&S.mqn, 1u)] = (u32)r;
 					} else {
 						int best = 0, best_cnt = 0;
 						if (rec_a > 0 && rec_b > 0 && own_a == own_b) {
@@ -2668,6 +2702,7 @@ map_reads_s_kernel(
 			cur = nxt;
 		}
 	}
+	flush_mq();
 #ifdef ARKS_PROFILE_SECTIONS
 	if (!STATS && !RAW && lane_id == 0)
 		for (int x = 0; x < 12; ++x)
