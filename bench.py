@@ -361,8 +361,9 @@ def repeats_key(args, k, j, dev, local, log, barrier):
     """Secondary key `configs2_repeats`: the same 3 Gbp draft with human-like repeat families planted
     (synth.plant_repeats: 1e5 copies of a 300-bp element at 10-15 % divergence, 1e3 of a 6-kbp element, satellite
     arrays) -- reads that touch them carry heavy seeds and leave the hot kernel for the general ones -- and
-    100 M read pairs in one launch; sample parity on 1 M pairs as for the headline."""
-    pairs = min(args.pairs, 100_000_000)
+    250 M read pairs in one launch (100 M until round 5, when the headline's launches were 100 M too); sample parity
+    on 1 M pairs as for the headline."""
+    pairs = min(args.pairs, 250_000_000)          # (one launch of the size the headline's are)
     wl = Workload(args.draft_mbp, pairs, pairs, k, j, dev, local, log, want_stats=False, keep_draft=True, repeats=True)
     el, l_ms, st, _ = wl.timed(max(2, args.steps // 2), 1, barrier)
     steps = max(2, args.steps // 2)
@@ -384,14 +385,14 @@ def repeats_key(args, k, j, dev, local, log, barrier):
 def human_like_key(args, k, j, dev, local, log, barrier):
     """Secondary key `configs2_human_like`: the 3 Gbp draft with a human-like repeat SPECTRUM --
     synth.plant_human_like: ~10 % SINE-like (families of 35 k copies of a 300-bp element, 5-20 % diverged) + ~10 %
-    LINE-like (families of 2.5 k copies of a 6-kbp element, 3-15 %, most truncated) + satellite arrays -- and 100 M
+    LINE-like (families of 2.5 k copies of a 6-kbp element, 3-15 %, most truncated) + satellite arrays -- and 250 M
     read pairs in one launch: k-mers/s, the reads the hot kernel leaves to the general kernels, the bytes of the exact
     table behind heavy seeds, the index build time.  Sample parity: the families have a FIXED size and their number
     scales with the draft, so a 100 Mbp draft of the same generator (one family of each class) shows a read the same
     multiplicities; 1 M pairs drawn from ALL of it, the GPU against the oracle over the WHOLE small draft (a sub-draft
     oracle of the 3 Gbp one would have to hold the windows around 1.1 M copies: 0.7 G keys)."""
     from oracle import pyoracle as O
-    pairs = min(args.pairs, 100_000_000)
+    pairs = min(args.pairs, 250_000_000)          # (one launch of the size the headline's are)
     wl = Workload(args.draft_mbp, pairs, pairs, k, j, dev, local, log, want_stats=False, repeats="human")
     steps = max(2, args.steps // 2)
     el, l_ms, st, _ = wl.timed(steps, 1, barrier)
