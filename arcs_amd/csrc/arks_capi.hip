@@ -2013,6 +2013,16 @@ arks_debug_queue_counts(const arks_index* idx, unsigned* out4)
 	return ARKS_OK;
 }
 
+#ifdef ARKS_MEDIUM_DIAG
+int
+arks_debug_medium_diag(unsigned long long* out16)
+{
+	(void)hipDeviceSynchronize();
+	arks::read_medium_diag(out16);
+	return ARKS_OK;
+}
+#endif
+
 #ifdef ARKS_PROFILE_SECTIONS
 int
 arks_debug_section_cycles(unsigned long long* out16)

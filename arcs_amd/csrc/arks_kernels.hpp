@@ -145,5 +145,8 @@ hipError_t launch_imap_compact(
 #ifdef ARKS_PROFILE_SECTIONS
 void read_section_cycles(unsigned long long* out16);
 #endif
+#ifdef ARKS_MEDIUM_DIAG
+void read_medium_diag(unsigned long long* out16);
+#endif
 
 } // namespace arks

@@ -363,6 +363,7 @@ constexpr int kTW = 32;          // tile capacity in packed words: two passes, o
 constexpr int kTR = 16;          // reads per tile
 constexpr int kNH = 128;         // run heads per tile that get a published entry list
 constexpr int kGrabF = 8;        // medium kernel: queued reads per grab at most (two tiles of 10x reads)
+constexpr int kExtraSeeds = 12;  // medium kernel, seed index: m-mers per read probed beside its group seeds (8: fewer proofs; 18: the same time)
 constexpr int kChunk = 48;       // reads handed out per grab of the work counter (lane l holds read l's metadata):
                                  // a multiple of the usual reads per tile (4, 6, 8, 12), small enough for an even
                                  // finish, large enough for the counter (same-address atomics serialise at ~12 ns:
@@ -420,6 +421,11 @@ struct TileLds
 	// of every read's first word, and the read's number
 	u64 rbase[FULL ? kTR : 1];
 	u32 rid[FULL ? kTR : 1];
+	// medium kernel, seed index: one bit per tile position -- the window there holds an m-mer that is in no visited
+	// window of the text (T5's seeds without an entry, T6e's probes), so it is absent whatever its own seed says
+	// absent[1]: ... unless it matches the text on one of the read's staged diagonals (a seed all of whose one or two
+	// entries lie there: looked at only for windows that were compared on both and did not match)
+	u32 absent[2][FULL ? kTP / 32 + 4 : 1];
 	u32 redo;
 	u32 redo2; // reads that need the general verification (hot instantiation only)
 	u64 wstats[8]; // hot instantiation: this wave's arks_map_stats counters (registers are scarce there)
@@ -450,6 +456,12 @@ tile_window_key(const u64* cw, int i, const KeyGeom& g)
 	return f;
 }
 
+#ifdef ARKS_MEDIUM_DIAG
+__device__ unsigned long long g_med_diag[16];
+#define ARKS_MD(slot, v) md[slot] += (unsigned long long)(v)
+#else
+#define ARKS_MD(slot, v) ((void)0)
+#endif
 #ifdef ARKS_PROFILE_SECTIONS
 __device__ unsigned long long g_sec_cycles[16];
 #define ARKS_SEC(nsec)                                                                             \
@@ -874,6 +886,9 @@ map_reads_b_kernel(
 	unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
+#ifdef ARKS_MEDIUM_DIAG
+	unsigned long long md[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
 	const u32 n_medium = FULL ? __hip_atomic_load(queue_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 	bool first_grab = true;
 	u32* const work_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kWorkCtrOffset);
@@ -1028,6 +1043,8 @@ map_reads_b_kernel(
 				S.redo = z;
 				S.redo2 = z;
 			}
+			if (FULL && DENSE && lane < 2 * (kTP / 32 + 4))
+				(&S.absent[0][0])[lane] = 0u;
 			if (!FULL) { // per-read counters of T6c' (S.b + 128 ..: clear of the T3 block minima and the owners)
 				S.b[128 + lane] = lane < 32 ? 0u : 0xFFFFFFFFu; // rcnt, rmin
 				if (lane < 32)
@@ -1106,7 +1123,6 @@ map_reads_b_kernel(
 				ARKS_ROW_ADD(incl, 0x112);
 				ARKS_ROW_ADD(incl, 0x114);
 				ARKS_ROW_ADD(incl, 0x118);
-#undef ARKS_ROW_ADD
 				nheads = __builtin_amdgcn_readlane(incl, nr - 1);
 				const int hb = incl - G;
 				if (FULL && lane < nr)
@@ -1118,6 +1134,37 @@ map_reads_b_kernel(
 						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)lane << 12));
 					}
 				}
+				if (FULL && kExtraSeeds > 0) {
+					// Medium kernel, round 5: EXTRA seeds.  A read is here mostly because its group seeds are heavy or
+					// have more than two entries (a read inside a copy of a repeat family): they propose no diagonal,
+					// and without one every window under a heavy seed is an exact-key probe of the fallback table
+					// (~70 per read).  The table holds EVERY m-mer position of the visited windows, so any other m-mer
+					// of the read may propose the diagonal just as well -- and inside an old enough copy a third of
+					// them have one or two entries.  Up to kExtraSeeds more m-mers per read, evenly spaced, are probed
+					// in the same round trip as the group seeds (the lanes beyond the 6-12 group seeds of a tile were
+					// idle); they only take part in the election of the diagonals (T6a), after the group seeds, and
+					// the windows are verified base for base against the text as before: any diagonal is exact.
+					// On the human-like draft four of five reads without a diagonal get one (profiles/tools/seedstat.py).
+					int E = nheads < 64 ? (64 - nheads) / nr : 0;
+					E = E > kExtraSeeds ? kExtraSeeds : E;
+					const int Ej = (lane < nr && nwin > 0) ? E : 0;
+					int xin = Ej;
+					ARKS_ROW_ADD(xin, 0x111);
+					ARKS_ROW_ADD(xin, 0x112);
+					ARKS_ROW_ADD(xin, 0x114);
+					ARKS_ROW_ADD(xin, 0x118);
+					const int xtot = __builtin_amdgcn_readlane(xin, nr - 1);
+					const int xb = nheads + xin - Ej;
+					// offsets (2 e + 1) * (L - MM) / (2 E) into the read, in 16.16 fixed point
+					const u32 step = Ej ? ((u32)(nwin - 1 + k - MM) << 16) / (u32)(2 * E) : 0u;
+					for (int e = 0; e < E; ++e)
+						if (e < Ej) {
+							const int o = (int)(((u32)(2 * e + 1) * step) >> 16);
+							S.heads[xb + e] = (unsigned short)(((u32)(rs + o) << 1) | ((u32)lane << 12));
+						}
+					nheads += xtot;
+				}
+#undef ARKS_ROW_ADD
 				if (FULL) {
 					// window records of the medium path: pending (seed position, seed strand, head)
 					for (int base = 0; base < n; base += 64) {
@@ -1300,6 +1347,11 @@ map_reads_b_kernel(
 			}
 			ARKS_WAVE_SYNC();
 			ARKS_SEC(4);
+			if (FULL) {
+				ARKS_MD(0, 1);
+				ARKS_MD(1, nr);
+				ARKS_MD(9, nheads);
+			}
 			// ---- T5: run heads walk the minimizer table ------------------------------------------------
 			const int nh = nheads < kNH ? nheads : kNH;
 			for (int h = lane; h < nh; h += 64) {
@@ -1434,6 +1486,45 @@ map_reads_b_kernel(
 					}
 				}
 				any_b = __ballot(has_b) != 0;
+				if (FULL) {
+					ARKS_MD(2, __popcll(__ballot(lane < nr && (S.pdiag[lane][0] >> 41))));
+					ARKS_MD(11, any_b ? 1 : 0);
+				}
+				if (FULL && DENSE) {
+					// Proofs of absence (round 5).  The seed table holds EVERY m-mer position of the visited windows (a
+					// heavy m-mer as a marker), so a window one of whose m-mers has NO entry is in no visited window of
+					// the text -- the rule T6c applies to a group's own seed holds for every seed probed in T5, the
+					// extra ones included.  Half of the reads that come here were drawn from a copy of a repeat family
+					// that lies OUTSIDE the indexed contig ends: every seed heavy or empty, no diagonal, none of their
+					// windows in the index -- each of them was an exact-key probe of the fallback table (~60 per read);
+					// now nine in ten of those windows hold an empty seed.  A seed with one or two entries proves the
+					// same for the windows that do not match the text there, when both entries lie on staged diagonals.
+					ARKS_WAVE_SYNC(); // (the stripped diagonals)
+					for (int h = lane; h < nh; h += 64) {
+						const u32 cnt = S.hn[h];
+						const u32 hv = S.heads[h];
+						const int jh = (int)(hv >> 12), q = (int)((hv >> 1) & 2047u);
+						bool proves = cnt == 0;
+						if (cnt == 1 || cnt == 2) {
+							int jx;
+							u64 dk0, dk1;
+							bool off;
+							proposals(h, jx, dk0, dk1, off);
+							const u64 dA = S.pdiag[jh][0], dB = S.pdiag[jh][1];
+							proves = (dk0 == dA || dk0 == dB) && (cnt == 1 || dk1 == dA || dk1 == dB);
+						}
+						if (proves) { // windows [a, b] of the tile hold the seed
+							const int rs = S.rstart[jh], rend = rs + S.rlen[jh];
+							int a = q - (k - MM), b = q;
+							a = a > rs ? a : rs;
+							b = b < rend - k ? b : rend - k;
+							for (int x = a >> 5; x <= (b >> 5); ++x) {
+								const int lo = a > 32 * x ? a - 32 * x : 0, hi = b < 32 * x + 31 ? b - 32 * x : 31;
+								atomicOr(&S.absent[cnt ? 1 : 0][x], (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo));
+							}
+						}
+					}
+				}
 			}
 			ARKS_WAVE_SYNC();
 			// stage the text words and their visited / ambiguous / owner words (one round trip): one lane
@@ -1441,6 +1532,23 @@ map_reads_b_kernel(
 			// that has one (lanes = slots x 2 needed a second, almost empty trip through this code)
 			{
 				const int ns = tw + nr;
+				if (FULL) {
+					// medium kernel: <= kSW words + kTR reads = 32 slots per diagonal -- both diagonals in ONE round trip,
+					// lanes = slots x 2 (with the extra seeds of round 5 three tiles in four have a second diagonal; as two
+					// passes that was a dependent round trip per tile)
+					static_assert(kSW + kTR <= 32, "staging slots of a medium tile");
+					const int d = lane >> 5, sl = lane & 31;
+					if (sl < ns && (d == 0 || any_b)) {
+						const int j = S.sread[sl];
+						if (S.pdiag[j][d] >> 41) {
+							const u64 tw_idx = (u64)S.tfirst[j][d] + (u64)(sl - ((S.rstart[j] >> 5) + j));
+							tcodes[d][sl] = bx.codes[tw_idx];
+							tvis[d][sl] = bx.visited[tw_idx];
+							tamb[d][sl] = bx.ambig[tw_idx];
+							town[d][sl] = bx.word_owner[tw_idx];
+						}
+					}
+				} else
 				for (int d = 0; d < (any_b ? 2 : 1); ++d)
 					for (int sl = lane; sl < ns; sl += 64) {
 						const int j = S.sread[sl];
@@ -1512,7 +1620,12 @@ map_reads_b_kernel(
 			for (int base = 0; base < n; base += 64) {
 				const int i = base + lane;
 				const int rv = rec[i];
-				const bool pending = rv <= -16;
+				bool pending = rv <= -16;
+				if (DENSE && pending && ((S.absent[0][i >> 5] >> (i & 31)) & 1u)) {
+					rec[i] = -1; // holds a seed that is in no visited window
+					pending = false;
+					ARKS_MD(6, 0x100000000ull);
+				}
 				if (__ballot(pending) == 0)
 					continue;
 				if (pending) {
@@ -1557,6 +1670,10 @@ map_reads_b_kernel(
 						}
 						if (val >= 0)
 							full = false;
+						else if (DENSE && ((S.absent[1][i >> 5] >> (i & 31)) & 1u)) {
+							full = false; // one of its m-mers occurs on the staged diagonals only, and the window did not match there
+							ARKS_MD(6, 1);
+						}
 						// (Tried on top, for the windows still open: one m-mer of the window, laid over its first mismatch on the
 						// staged diagonal, through the seed table -- no entry proves the window absent without an exact-key
 						// probe.  Correct, and 6.2 instead of 5.9 ms per 100 M pairs on the repeat-rich draft: inside a repeat
@@ -1629,6 +1746,24 @@ map_reads_b_kernel(
 					}
 					rec[i] = val;
 				}
+#ifdef ARKS_MEDIUM_DIAG
+				ARKS_MD(3, __popcll(__ballot(pending && rec[i] == kRecFallback)));
+				// ... of them in reads without a diagonal; in reads whose diagonal A differs from the read in > 8 bases
+				ARKS_MD(4, __popcll(__ballot(pending && rec[i] == kRecFallback && !(S.pdiag[S.wread[i >> 5]][0] >> 41))));
+				{
+					bool far = false;
+					if (pending && rec[i] == kRecFallback && (S.pdiag[S.wread[i >> 5]][0] >> 41)) {
+						const int j = S.wread[i >> 5];
+						int dif = 0;
+						for (int x = S.rstart[j] >> 5; x < (S.rstart[j + 1] >> 5); ++x) {
+							const int nb = S.rstart[j] + S.rlen[j] - 32 * x;
+							dif += __popc(mm32[0][x] & (nb >= 32 ? 0xFFFFFFFFu : (nb > 0 ? (1u << nb) - 1u : 0u)));
+						}
+						far = dif > 8;
+					}
+					ARKS_MD(5, __popcll(__ballot(far)));
+				}
+#endif
 			}
 			ARKS_WAVE_SYNC();
 			// ---- T6d: the windows under heavy seeds: exact keys into the fallback table.  Their positions are
@@ -1645,6 +1780,7 @@ map_reads_b_kernel(
 					const int i = base + lane;
 					const bool need = i < n && rec[i] == kRecFallback;
 					const u64 nb = __ballot(need);
+					ARKS_MD(7, __popcll(nb));
 					if (need)
 						flist[nlist + (int)mask_below(nb)] = (unsigned short)i;
 					nlist += __popcll(nb);
@@ -1672,6 +1808,8 @@ map_reads_b_kernel(
 						sl[u] = mulhi64(key_hash(c[u]), bx.fallback.cap);
 					}
 					while (__ballot(act[0] || act[1]) != 0) {
+						ARKS_MD(8, 1);
+						ARKS_MD(12, __popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
 						u64 w[2][kSlotWords];
 #pragma unroll
 						for (int u = 0; u < 2; ++u)
@@ -1870,6 +2008,14 @@ map_reads_b_kernel(
 	if (lane_id == 0)
 		for (int x = 0; x < 10; ++x)
 			atomicAdd(&g_sec_cycles[x], sec_acc[x]);
+#endif
+#ifdef ARKS_MEDIUM_DIAG
+	if (FULL)
+		for (int x = 0; x < 16; ++x) {
+			const bool per_lane = x == 6 || x >= 13;
+			if ((per_lane || lane_id == 0) && md[x])
+				atomicAdd(&g_med_diag[x], md[x]);
+		}
 #endif
 	if (STATS && !FULL) {
 		ARKS_WAVE_SYNC();
@@ -3183,6 +3329,16 @@ launch_pair_gate(const uint8_t* pair_ok, const uint8_t* read_class, long n_pairs
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }
+
+#ifdef ARKS_MEDIUM_DIAG
+void
+read_medium_diag(unsigned long long* out16)
+{
+	(void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_med_diag), sizeof(unsigned long long) * 16);
+	unsigned long long z[16] = { 0 };
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_med_diag), z, sizeof z);
+}
+#endif
 
 #ifdef ARKS_PROFILE_SECTIONS
 void

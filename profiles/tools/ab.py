@@ -96,6 +96,15 @@ for (name, L, h, codes, nmask, out, ev) in libs:
               "candidates without diagonal A", ad[7])
     except AttributeError:
         pass
+    try:   # a library built with -DARKS_MEDIUM_DIAG (quarantined diagnostic: counters of the medium kernel's tiles)
+        md = (C.c_ulonglong * 16)(); L.arks_debug_medium_diag.argtypes = [C.c_void_p]; L.arks_debug_medium_diag(md)
+        print("   medium kernel (all launches of this process): tiles", md[0], "reads", md[1], "with a diagonal", md[2], "seeds probed", md[9],
+              "tiles with a second diagonal", md[11], "| windows proven absent by a seed without entries", md[6] >> 32,
+              "by a seed whose entries are all staged", md[6] & 0xFFFFFFFF, "| windows left to the exact table", md[3],
+              "(in reads without a diagonal", md[4], ", in reads whose diagonal A differs in > 8 bases", md[5], ")",
+              "exact-table rounds", md[8], "slot reads", md[12])
+    except AttributeError:
+        pass
     dig = int((out.to(torch.int64) * (torch.arange(n, device=dev, dtype=torch.int64) % 1000003 + 1)).sum().item())
     print(f"{name:14s} digest {dig} nonzero {int((out != 0).sum().item())}")
     print(f"{name:14s} median {statistics.median(t):7.3f} ms  min {min(t):7.3f}  -> {windows / (statistics.median(t) * 1e-3) / 1e9:6.2f} G k-mers/s  same_as_first={same}")
