@@ -363,6 +363,7 @@ constexpr int kTW = 32;          // tile capacity in packed words: two passes, o
 constexpr int kTR = 16;          // reads per tile
 constexpr int kNH = 128;         // run heads per tile that get a published entry list
 constexpr int kGrabF = 8;        // medium kernel: queued reads per grab at most (two tiles of 10x reads)
+constexpr int kSettleMargin = 2; // medium kernel without counters: open windows probed beyond the number that settles a failing vote
 constexpr int kExtraSeeds = 12;  // medium kernel, seed index: m-mers per read probed beside its group seeds (8: fewer proofs; 18: the same time)
 constexpr int kChunk = 48;       // reads handed out per grab of the work counter (lane l holds read l's metadata):
                                  // a multiple of the usual reads per tile (4, 6, 8, 12), small enough for an even
@@ -370,6 +371,7 @@ constexpr int kChunk = 48;       // reads handed out per grab of the work counte
                                  // 24 reads per grab made the COUNTER the kernel's run time, 20 ms at C2)
 constexpr u32 kHnHeavy = 255, kHnOverflow = 254;
 constexpr int kRecFallback = -4; // window record of the medium kernel: "probe the fallback table" (between T6c and T6d)
+constexpr int kRecOverflow = -5; // likewise: "walk the entries of the window's seed" (a seed with 3-8 entries)
 
 // Bit b of the result: none of the positions [b, b + k) of the 128-bit vector m3:m2:m1:m0 (m0 = positions
 // 0..31) is set, for b in [0, 32) and k in [32, 96].  Such a span always reaches the end of m0, so: b lies
@@ -426,6 +428,7 @@ struct TileLds
 	// absent[1]: ... unless it matches the text on one of the read's staged diagonals (a seed all of whose one or two
 	// entries lie there: looked at only for windows that were compared on both and did not match)
 	u32 absent[2][FULL ? kTP / 32 + 4 : 1];
+	int vfail[FULL ? kTR : 1]; // medium kernel without counters: the largest vote count with which read j fails (T6d)
 	u32 redo;
 	u32 redo2; // reads that need the general verification (hot instantiation only)
 	u64 wstats[8]; // hot instantiation: this wave's arks_map_stats counters (registers are scarce there)
@@ -1254,7 +1257,7 @@ map_reads_b_kernel(
 					// wc[t] = minimizer of window t when that window exists (and has any valid m-mer), else ~0
 					const int tc = rem0 - k; // windows t <= tc exist
 					u32 wc[8];
-	#pragma unroll
+#pragma unroll
 					for (int t = 0; t < 8; ++t)
 						wc[t] = t <= tc ? wmin[t] : 0xFFFFFFFFu;
 					// the previous lane's last window: one DPP wave shift (lane 0 keeps the "no window" value)
@@ -1263,7 +1266,7 @@ map_reads_b_kernel(
 					// predecessor's.  Heads are numbered position-class-major (all t = 0 heads of the pass,
 					// then t = 1, ...): a ballot + mbcnt per class, no per-lane serial numbering.  Which run
 					// comes first only decides which two diagonals get staged -- any choice is exact.
-	#pragma unroll
+#pragma unroll
 					for (int t = 0; t < 8; ++t) {
 						const bool head = wc[t] != 0xFFFFFFFFu && wc[t] != (t ? wc[t - 1] : wprev);
 						const u64 hb = __ballot(head);
@@ -1273,7 +1276,7 @@ map_reads_b_kernel(
 						nheads += __popcll(hb);
 					}
 					if (bx.has_img && !(k & 1)) { // see the comment in the FULL path below
-	#pragma unroll
+#pragma unroll
 						for (int t = 0; t < 8; ++t) {
 							if (wc[t] != 0xFFFFFFFFu) {
 								const int q = (int)((wc[t] >> 1) & 2047u);
@@ -1728,10 +1731,11 @@ map_reads_b_kernel(
 							// would wait for its own probes -- the windows are listed and probed together below
 							val = kRecFallback;
 						} else if (hn == kHnOverflow) {
-							{ // (the window's place in the batch's packed arrays: its read's, not the tile's)
-								const int jr = S.wread[i >> 5];
-								val = bindex_lookup_serial<KW, MM>(bx, g, codes, S.rbase[jr] * 32ull + (u64)(i - S.rstart[jr]), f, r);
-							}
+							// the walk over the seed's 3-8 entries and the text behind each -- a chain of dependent global
+							// reads: not here, where the other 63 positions of the batch would wait for it (a third of the
+							// kernel's time on the human-like draft), but with the exact-key probes of T6d, all in flight
+							// together, and only for the windows the vote still needs
+							val = kRecOverflow;
 						} else {
 							const int off = q - i;
 							for (u32 c = 0; c < hn && val < 0; ++c) {
@@ -1766,6 +1770,7 @@ map_reads_b_kernel(
 #endif
 			}
 			ARKS_WAVE_SYNC();
+			ARKS_SEC(10);
 			// ---- T6d: the windows under heavy seeds: exact keys into the fallback table.  Their positions are
 			//      compacted (ballot + mbcnt) into the storage of the staged text, which is dead by now, and every
 			//      lane keeps TWO probes in flight per round trip (a repeat-rich draft sends ~70 windows of a read
@@ -1775,72 +1780,182 @@ map_reads_b_kernel(
 				// (tcodes_f, tvis_f, tamb_f, town_f lie one behind the other: 2000 bytes for <= kTP positions)
 				static_assert(!FULL || offsetof(TileLds<FULL>, mm32_f) - offsetof(TileLds<FULL>, tcodes_f) >=
 				                           sizeof(unsigned short) * (size_t)kTP, "window list");
+				static_assert(kTP <= 0x8000, "a list entry: position | entry walk << 15");
+				// the probes of a list of nlist windows
+				auto probe_list = [&](int nlist) {
+					for (int base = 0; base < nlist; base += 128) {
+						int wi[2];
+						bool act[2], ov[2];
+						Key<KW> c[2];
+						u64 sl[2];
+						int val[2] = { -1, -1 };
+#pragma unroll
+						for (int u = 0; u < 2; ++u) {
+							const int e = base + 64 * u + lane;
+							const u32 raw = e < nlist ? (u32)flist[e] : 0u;
+							ov[u] = (raw >> 15) != 0; // an entry walk, below
+							act[u] = e < nlist && !ov[u];
+							wi[u] = (int)(raw & 0x7FFFu);
+							const Key<KW> f = tile_window_key<KW>(S.cw, wi[u], g);
+							const Key<KW> r = key_revcomp(f, g);
+							const bool lt = key_less(f, r);
+#pragma unroll
+							for (int x = 0; x < KW; ++x)
+								c[u].w[x] = lt ? f.w[x] : r.w[x];
+							if (key_eq(f, r)) // a palindrome lives in the fallback table under its damaged key
+								c[u] = key_palindrome_quirk(f, g);
+							sl[u] = mulhi64(key_hash(c[u]), bx.fallback.cap);
+						}
+						while (__ballot(act[0] || act[1]) != 0) {
+							ARKS_MD(8, 1);
+							ARKS_MD(12, __popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
+							u64 w[2][kSlotWords];
+#pragma unroll
+							for (int u = 0; u < 2; ++u)
+								if (act[u]) {
+									const u64* slot = bx.fallback.slots + sl[u] * kSlotWords;
+#pragma unroll
+									for (int x = 0; x < kSlotWords; ++x)
+										w[u][x] = slot[x];
+								}
+							asm volatile("" : "+v"(w[0][0]), "+v"(w[1][0])); // both slots requested before either is looked at
+#pragma unroll
+							for (int u = 0; u < 2; ++u)
+								if (act[u]) {
+									const u32 st = (u32)w[u][3];
+									bool eq = true;
+#pragma unroll
+									for (int x = 0; x < KW; ++x)
+										eq = eq && w[u][x] == c[u].w[x];
+									if (st == kEmpty)
+										act[u] = false;
+									else if (eq) {
+										val[u] = (int)(st - 1u);
+										act[u] = false;
+									} else
+										sl[u] = (sl[u] + 1 == bx.fallback.cap) ? 0 : sl[u] + 1;
+								}
+						}
+#pragma unroll
+						for (int u = 0; u < 2; ++u)
+							if (ov[u]) { // (the window's place in the batch's packed arrays: its read's, not the tile's)
+								const Key<KW> f = tile_window_key<KW>(S.cw, wi[u], g);
+								const Key<KW> r = key_revcomp(f, g);
+								const int jr = S.wread[wi[u] >> 5];
+								val[u] = bindex_lookup_serial<KW, MM>(bx, g, codes, S.rbase[jr] * 32ull + (u64)(wi[u] - S.rstart[jr]), f, r);
+							}
+#pragma unroll
+						for (int u = 0; u < 2; ++u)
+							if (base + 64 * u + lane < nlist)
+								rec[wi[u]] = val[u];
+					}
+				};
+				// Without counters and with the vote's result as the only output, the windows need not ALL be looked up:
+				// a read FAILS the vote (output 0, Arcs.cpp:1006-1010) as soon as the windows that can still vote are too
+				// few -- no contig end can collect more than C + P votes (C = windows with a contig end so far, P = open
+				// windows), and F = the largest count with F / windows <= j is known.  So only C + P - F of a read's
+				// open windows (+ a margin of kSettleMargin) are probed first; if enough of them come back absent or
+				// ambiguous the rest is never looked up, else it is, in a second round.  The reads this pays for are
+				// the ones every seed of which is heavy (young copies of a repeat family, in the index or not): no
+				// diagonal, no proof of absence, ~50 open windows of ~80, of which 7-10 settle the vote -- two of three
+				// exact-key probes of the human-like draft.  With counters (-v) every window is looked up as before.
+				constexpr bool kSettle = FULL && !STATS && !RAW;
 				int nlist = 0;
-				for (int base = 0; base < n; base += 64) {
-					const int i = base + lane;
-					const bool need = i < n && rec[i] == kRecFallback;
-					const u64 nb = __ballot(need);
-					ARKS_MD(7, __popcll(nb));
-					if (need)
-						flist[nlist + (int)mask_below(nb)] = (unsigned short)i;
-					nlist += __popcll(nb);
+				u32 deferred = 0; // reads with open windows left for the second round
+				if (!kSettle) {
+					for (int base = 0; base < n; base += 64) {
+						const int i = base + lane;
+						const int rv = i < n ? rec[i] : -3;
+						const bool need = rv == kRecFallback || rv == kRecOverflow;
+						const u64 nb = __ballot(need);
+						ARKS_MD(7, __popcll(nb));
+						if (need)
+							flist[nlist + (int)mask_below(nb)] = (unsigned short)((u32)i | (rv == kRecOverflow ? 0x8000u : 0u));
+						nlist += __popcll(nb);
+					}
+				} else {
+					for (int j = 0; j < nr; ++j) {
+						const int nwin = S.rlen[j] - k + 1, p0 = S.rstart[j];
+						if (nwin <= 0)
+							continue;
+						int C = 0, P = 0;
+						for (int base = 0; base < nwin; base += 64) {
+							const int p = base + lane;
+							const int v = p < nwin ? rec[p0 + p] : -3;
+							C += __popcll(__ballot(v > 0));
+							P += __popcll(__ballot(v == kRecFallback || v == kRecOverflow));
+						}
+						if (P == 0)
+							continue;
+						// F: the largest count that fails `(double)count / (double)windows > j_index`
+						int F = (int)(j_index * (double)nwin);
+						F = F < 0 ? 0 : (F > nwin ? nwin : F);
+						while (F < nwin && !((double)(F + 1) / (double)nwin > j_index))
+							++F;
+						while (F > 0 && (double)F / (double)nwin > j_index)
+							--F;
+						const int s = ((S.redo >> j) & 1u) ? 0 : C + P - F; // (a read for the slow queue is decided there)
+						int take = s <= 0 ? 0 : s + kSettleMargin;
+						take = take > P ? P : take;
+						if (take > 0 && take < P) {
+							deferred |= 1u << j;
+							S.vfail[j] = F;
+						}
+						ARKS_MD(7, take);
+						int seen = 0;
+						for (int base = 0; base < nwin; base += 64) {
+							const int p = base + lane;
+							const int rv = p < nwin ? rec[p0 + p] : -3;
+							const bool need = rv == kRecFallback || rv == kRecOverflow;
+							const u64 nb = __ballot(need);
+							const int rank = seen + (int)mask_below(nb);
+							if (need) {
+								if (rank < take)
+									flist[nlist + rank] = (unsigned short)((u32)(p0 + p) | (rv == kRecOverflow ? 0x8000u : 0u));
+								else if (s <= 0)
+									rec[p0 + p] = -1; // settled: whatever these windows hold, the read fails
+							}
+							seen += __popcll(nb);
+						}
+						nlist += take;
+					}
 				}
 				ARKS_WAVE_SYNC();
-				for (int base = 0; base < nlist; base += 128) {
-					int wi[2];
-					bool act[2];
-					Key<KW> c[2];
-					u64 sl[2];
-					int val[2] = { -1, -1 };
-#pragma unroll
-					for (int u = 0; u < 2; ++u) {
-						const int e = base + 64 * u + lane;
-						act[u] = e < nlist;
-						wi[u] = act[u] ? (int)flist[e] : 0;
-						const Key<KW> f = tile_window_key<KW>(S.cw, wi[u], g);
-						const Key<KW> r = key_revcomp(f, g);
-						const bool lt = key_less(f, r);
-#pragma unroll
-						for (int x = 0; x < KW; ++x)
-							c[u].w[x] = lt ? f.w[x] : r.w[x];
-						if (key_eq(f, r)) // a palindrome lives in the fallback table under its damaged key
-							c[u] = key_palindrome_quirk(f, g);
-						sl[u] = mulhi64(key_hash(c[u]), bx.fallback.cap);
-					}
-					while (__ballot(act[0] || act[1]) != 0) {
-						ARKS_MD(8, 1);
-						ARKS_MD(12, __popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
-						u64 w[2][kSlotWords];
-#pragma unroll
-						for (int u = 0; u < 2; ++u)
-							if (act[u]) {
-								const u64* slot = bx.fallback.slots + sl[u] * kSlotWords;
-#pragma unroll
-								for (int x = 0; x < kSlotWords; ++x)
-									w[u][x] = slot[x];
+				ARKS_SEC(11);
+				probe_list(nlist);
+				if (kSettle && deferred) {
+					ARKS_WAVE_SYNC();
+					nlist = 0;
+					for (int j = 0; j < nr; ++j) {
+						if (!((deferred >> j) & 1u))
+							continue;
+						const int nwin = S.rlen[j] - k + 1, p0 = S.rstart[j];
+						int C = 0, P = 0;
+						for (int base = 0; base < nwin; base += 64) {
+							const int p = base + lane;
+							const int v = p < nwin ? rec[p0 + p] : -3;
+							C += __popcll(__ballot(v > 0));
+							P += __popcll(__ballot(v == kRecFallback || v == kRecOverflow));
+						}
+						const bool settled = C + P <= S.vfail[j];
+						ARKS_MD(10, settled ? 1 : 0);
+						ARKS_MD(7, settled ? 0 : P);
+						for (int base = 0; base < nwin; base += 64) {
+							const int p = base + lane;
+							const int rv = p < nwin ? rec[p0 + p] : -3;
+							const bool need = rv == kRecFallback || rv == kRecOverflow;
+							const u64 nb = __ballot(need);
+							if (need) {
+								if (settled)
+									rec[p0 + p] = -1;
+								else
+									flist[nlist + (int)mask_below(nb)] = (unsigned short)((u32)(p0 + p) | (rv == kRecOverflow ? 0x8000u : 0u));
 							}
-						asm volatile("" : "+v"(w[0][0]), "+v"(w[1][0])); // both slots requested before either is looked at
-#pragma unroll
-						for (int u = 0; u < 2; ++u)
-							if (act[u]) {
-								const u32 st = (u32)w[u][3];
-								bool eq = true;
-#pragma unroll
-								for (int x = 0; x < KW; ++x)
-									eq = eq && w[u][x] == c[u].w[x];
-								if (st == kEmpty)
-									act[u] = false;
-								else if (eq) {
-									val[u] = (int)(st - 1u);
-									act[u] = false;
-								} else
-									sl[u] = (sl[u] + 1 == bx.fallback.cap) ? 0 : sl[u] + 1;
-							}
+							nlist += settled ? 0 : __popcll(nb);
+						}
 					}
-#pragma unroll
-					for (int u = 0; u < 2; ++u)
-						if (base + 64 * u + lane < nlist)
-							rec[wi[u]] = val[u];
+					ARKS_WAVE_SYNC();
+					probe_list(nlist);
 				}
 			}
 			ARKS_WAVE_SYNC();
@@ -2005,8 +2120,11 @@ map_reads_b_kernel(
 		}
 	}
 #ifdef ARKS_PROFILE_SECTIONS
+#ifdef ARKS_PROFILE_MEDIUM // (the medium kernel's sections alone: -DARKS_PROFILE_SECTIONS -DARKS_PROFILE_MEDIUM)
+	if (FULL)
+#endif
 	if (lane_id == 0)
-		for (int x = 0; x < 10; ++x)
+		for (int x = 0; x < 12; ++x)
 			atomicAdd(&g_sec_cycles[x], sec_acc[x]);
 #endif
 #ifdef ARKS_MEDIUM_DIAG
@@ -2849,7 +2967,7 @@ map_reads_s_kernel(
 		}
 	}
 	flush_mq();
-#ifdef ARKS_PROFILE_SECTIONS
+#if defined(ARKS_PROFILE_SECTIONS) && !defined(ARKS_PROFILE_MEDIUM)
 	if (!STATS && !RAW && lane_id == 0)
 		for (int x = 0; x < 12; ++x)
 			atomicAdd(&g_sec_cycles[x], sec_acc[x]);
