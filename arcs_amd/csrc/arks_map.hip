@@ -2223,6 +2223,7 @@ struct SeedTileLds
 	u32 rmax[sTR][2];
 	u32 redo;  // reads for the slow queue
 	u32 redo2; // reads for the medium queue
+	u32 rempty[sTR]; // bit gi: seed gi of the read has no entry -- every window that holds it is absent (S6, flagged reads)
 	u64 wstats[8];
 	// REMOTE without counters: the reads none of whose seeds has an entry are settled before the tiles are made, the
 	// others move up into their places
@@ -2630,6 +2631,7 @@ map_reads_s_kernel(
 					S.rcnt[j][0] = 0u, S.rcnt[j][1] = 0u;
 					S.rmin[j][0] = 0xFFFFFFFFu, S.rmin[j][1] = 0xFFFFFFFFu;
 					S.rmax[j][0] = 0u, S.rmax[j][1] = 0u;
+					S.rempty[j] = 0u;
 				}
 				if (lane == 0) {
 					// (a zero made here: as a loop-invariant constant pair it was kept in -- and spilled from -- registers)
@@ -2727,6 +2729,8 @@ map_reads_s_kernel(
 					}
 				}
 				off = cnt == kHnHeavy || cnt == kHnOverflow;
+				if (!STATS && !RAW && cnt == 0 && lane < nh) // seed gi of its read (the last one sits at the last window, not at a multiple of w)
+					atomicOr(&S.rempty[jh], 1u << (((u32)(q - S.rstart[jh]) * wrecip) >> 16));
 				if (cnt >= 1 && cnt <= 2) {
 					const int o = q - S.rstart[jh]; // offset of the seed in the read
 					// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
@@ -2905,7 +2909,21 @@ map_reads_s_kernel(
 						// out to belong to any contig end.  If the leader among the found ones passes j_index on its own and
 						// leads the other by more than u, it is the answer whatever the open windows hold (Arcs.cpp:998-1010:
 						// the count only grows, nobody can catch up or tie); if even leader + u does not pass, the answer is 0.
-						const int u = nvalid - (rec_a + amb_a + rec_b + amb_b);
+						int u = nvalid - (rec_a + amb_a + rec_b + amb_b);
+						// ... less the windows that hold a seed WITHOUT an entry: the seed table has every m-mer position of the
+						// visited windows, so such a window is in no visited window whatever a heavy seed beside it says (round 5;
+						// a read drawn from a repeat copy outside the indexed contig ends: one seed heavy, the others empty --
+						// one flagged read in seven of the human-like draft ends here instead of in the medium kernel).  Seed gi
+						// < G - 1 answers for the w windows of its group, the last one for the w windows that end at the last.
+						if (const u32 em = S.rempty[j]) {
+							const int nw = L - k + 1;
+							const int G = (int)(((u32)(nw + w - 1) * wrecip) >> 16);
+							int gone = __popc(em & ((1u << (G - 1)) - 1u)) * w;
+							if ((em >> (G - 1)) & 1u)
+								gone += (G >= 2 && ((em >> (G - 2)) & 1u)) ? nw - (G - 1) * w : (nw < w ? nw : w);
+							gone -= nw - nvalid; // (windows with an invalid base are not among the nvalid: all of them may lie there)
+							u -= gone > 0 ? gone : 0;
+						}
 						int lead, other;
 						if (rec_a > 0 && rec_b > 0 && own_a == own_b)
 							lead = rec_a + rec_b, other = 0;
