@@ -718,7 +718,7 @@ __global__ void
 bfill_mtab_kernel(
     const u64* __restrict__ codes, const u32* __restrict__ is_min, u64 total_words,
     u64* __restrict__ ckeys, u32* __restrict__ ccnts, u64 ccap, u64* __restrict__ mtab, u64 mcap,
-    u32* __restrict__ heavy_min, u32 own, u32 n_own, int fill)
+    u32* __restrict__ heavy_min, u32 own, u32 n_own, int fill, u32 heavy_over)
 {
 	typedef typename Mmer<MM>::type mm_t;
 	const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -733,7 +733,7 @@ bfill_mtab_kernel(
 	u32* cnt = ctab_slot<MM>(ckeys, ccnts, ccap, cm, false);
 	const u32 c = *cnt;
 	u64 e;
-	if ((c & kCntForced) || (c & kCntMask) > (u32)kHeavy) {
+	if ((c & kCntForced) || (c & kCntMask) > heavy_over) {
 		atomicOr(heavy_min + word, 1u << (31 - (u32)(pos & 31)));
 		if (!fill || (atomicOr(cnt, kCntMarker) & kCntMarker))
 			return;
@@ -1201,17 +1201,17 @@ launch_bforce(
 hipError_t
 launch_bfill_mtab(
     int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab,
-    u64 mcap, u32* heavy_min, u32 own, u32 n_own, bool fill, hipStream_t st)
+    u64 mcap, u32* heavy_min, u32 own, u32 n_own, bool fill, u32 heavy_over, hipStream_t st)
 {
 	if (total_words == 0)
 		return hipSuccess;
 	const unsigned b = blocks_for(total_words * 32ull, 256);
 	if (mm == kMShort)
 		bfill_mtab_kernel<kMShort><<<b, 256, 0, st>>>(
-		    codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min, own, n_own, fill ? 1 : 0);
+		    codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min, own, n_own, fill ? 1 : 0, heavy_over);
 	else
 		bfill_mtab_kernel<kMLong><<<b, 256, 0, st>>>(
-		    codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min, own, n_own, fill ? 1 : 0);
+		    codes, is_min, total_words, ckeys, ccnts, ccap, mtab, mcap, heavy_min, own, n_own, fill ? 1 : 0, heavy_over);
 	ARKS_LAUNCH_CHECK();
 	return hipSuccess;
 }

@@ -521,6 +521,19 @@ arks_pack_reads_host(
 /* index                                                                                          */
 /* ---------------------------------------------------------------------------------------------- */
 
+// occurrences of an m-mer beyond which it is heavy (arks_device.hpp kHeavy; ARKS_HEAVY_OVER=2..8 for tests and A/B runs:
+// results never depend on it, the share of work between the seed table's entry lists and the fallback table does)
+static u32
+heavy_over()
+{
+	if (const char* e = std::getenv("ARKS_HEAVY_OVER")) {
+		const int v = std::atoi(e);
+		if (v >= 2 && v <= 8)
+			return (u32)v;
+	}
+	return (u32)kHeavy;
+}
+
 static int
 want_locality(int k)
 {
@@ -968,7 +981,7 @@ index_build_impl(
 				                      d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t, nullptr, 0, (u32)p_own, (u32)own_n, st));
 				HIP_TRY(launch_bfill_mtab(mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(),
 				                          ccap_t, mine ? *out_tab : nullptr, mcap_t, d_heavy.as<u32>(), (u32)p_own, (u32)own_n,
-				                          mine, st));
+				                          mine, heavy_over(), st));
 				if (mine)
 					HIP_TRY(launch_bforce(idx->kw, mm, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense_t,
 					                      d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t, *out_tab, mcap_t, (u32)p_own, (u32)own_n, st));

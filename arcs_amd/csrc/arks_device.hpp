@@ -363,7 +363,15 @@ constexpr int kMShort = 17; // minimizer length where k leaves no room for the l
 constexpr int kMLong = 21;  // the default: specific at any text size (a 15-mer has ~ text / 5.4e8 chance
                             // occurrences, and every chance occurrence is one more diagonal to rule out)
 constexpr u32 kFpMask = (1u << 30) - 1u;
-constexpr int kHeavy = 8;         // a minimizer with more text occurrences than this is "heavy"
+// An m-mer with more occurrences than this inside visited windows is "heavy": one marker in the table instead of its
+// positions, and every window that holds it lives in the exact fallback table.  2 = what a probe reads (up to two
+// entries): until round 5 it was 8, and a seed with 3-8 entries -- useless as a proposal of diagonals -- sent its
+// windows through a walk over the entries and the text behind each (a chain of ~7 dependent reads per window: a tenth
+// of the medium kernel on a human-like repeat spectrum) instead of one exact-key probe; the fallback table grows by 5 %
+// there (327 -> 344 M keys), not at all on a draft without repeat families.  ARKS_HEAVY_OVER=8 in the environment
+// builds an index the old way (tests: the walk stays reachable -- fingerprint collisions can still show a probe more
+// than two entries).
+constexpr int kHeavy = 2;
 constexpr int kFrontPadWords = 16; // the text starts 512 bases into its arrays (diagonals may underrun)
 constexpr u32 kHeavyPos = 0xFFFFFFFFu;
 

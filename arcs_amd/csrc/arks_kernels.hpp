@@ -103,7 +103,7 @@ hipError_t launch_bforce(
     bool dense, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab, u64 mcap, u32 own, u32 n_own, hipStream_t st);
 hipError_t launch_bfill_mtab(
     int mm, const u64* codes, const u32* is_min, u64 total_words, u64* ckeys, u32* ccnts, u64 ccap, u64* mtab,
-    u64 mcap, u32* heavy_min, u32 own, u32 n_own, bool fill, hipStream_t st);
+    u64 mcap, u32* heavy_min, u32 own, u32 n_own, bool fill, u32 heavy_over, hipStream_t st);
 hipError_t launch_bfallback(
     int kw, int mm, bool insert, const u64* codes, const u32* visited, const u32* ambig, const u32* is_pal,
     const u32* is_img, const u32* heavy_min, const u32* word_owner, u64 total_words, const KeyGeom& g,

@@ -362,7 +362,7 @@ constexpr int kTP = kSW * 32;    // ... in base positions
 constexpr int kTW = 32;          // tile capacity in packed words: two passes, one joint back half
 constexpr int kTR = 16;          // reads per tile
 constexpr int kNH = 128;         // run heads per tile that get a published entry list
-constexpr int kGrabF = 8;        // medium kernel: queued reads per grab at most (two tiles of 10x reads)
+constexpr int kGrabF = 12;       // medium kernel: queued reads per grab at most (four tiles of 10x reads; 8 until round 5: tiles of 3 + 3 + 2)
 constexpr int kSettleMargin = 2; // medium kernel without counters: open windows probed beyond the number that settles a failing vote
 constexpr int kExtraSeeds = 12;  // medium kernel, seed index: m-mers per read probed beside its group seeds (8: fewer proofs; 18: the same time)
 constexpr int kChunk = 48;       // reads handed out per grab of the work counter (lane l holds read l's metadata):

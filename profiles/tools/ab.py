@@ -80,6 +80,11 @@ for (name, L, h, codes, nmask, out, ev) in libs:
     t = times[name]
     same = bool((out == ref).all().item())
     try:
+        fs = (C.c_int64 * 2)(); L.arks_index_fallback_size.argtypes = [C.c_void_p, C.c_void_p]
+        if L.arks_index_fallback_size(h, fs) == 0: print("   exact table behind heavy seeds:", fs[0], "keys,", fs[1], "bytes")
+    except AttributeError:
+        pass
+    try:
         qc = (C.c_uint * 4)(); L.arks_debug_queue_counts.argtypes = [C.c_void_p, C.c_void_p]; L.arks_debug_queue_counts(h, qc); print("   queues: slow", qc[0], "medium", qc[2], "of", n, "reads")
     except AttributeError:
         pass

@@ -45,6 +45,12 @@ while time.time() < t_end:
         os.environ["ARKS_DEBUG_MEDIUM_BLOCKS"] = str(1 + seed % 5)
     else:
         os.environ.pop("ARKS_DEBUG_MEDIUM_BLOCKS", None)
+    # two cases in five: m-mers heavy beyond 8 occurrences instead of 2 (seeds with 3-8 entries, whose windows take the
+    # walk over the entries)
+    if seed % 5 < 2:
+        os.environ["ARKS_HEAVY_OVER"] = "8"
+    else:
+        os.environ.pop("ARKS_HEAVY_OVER", None)
     ix = arcs_amd.ArksIndex.build(ends, k, device=0)
     assert {f: ix.build_stats[f] for f in ox.stats.as_dict()} == ox.stats.as_dict(), (seed, k, "build stats")
     genome = "".join(ends)

@@ -22,11 +22,13 @@ def _ends_of(arks, contigs):
     return ends
 
 
-@pytest.mark.parametrize("sub_rate", [0.005, 0.02])
-def test_human_like_spectrum_against_the_whole_oracle(arks, gpu, oracle, sub_rate):
+@pytest.mark.parametrize("sub_rate,heavy_over", [(0.005, None), (0.02, None), (0.005, "8")])
+def test_human_like_spectrum_against_the_whole_oracle(arks, gpu, oracle, sub_rate, heavy_over, monkeypatch):
     import torch
     from arcs_amd import synth
     k, j = 60, 0.55
+    if heavy_over:   # the index of rounds 1-5: seeds with 3-8 entries, their windows walk the entries
+        monkeypatch.setenv("ARKS_HEAVY_OVER", heavy_over)
     sites = []
     contigs = synth.make_draft(100_000_000, seed=synth.SEED, repeats="human", repeat_sites=sites)
     assert len(sites) > 35_000
