@@ -892,6 +892,25 @@ map_reads_b_kernel(
 #ifdef ARKS_MEDIUM_DIAG
 	unsigned long long md[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
+	// F(windows) = the largest vote count that FAILS `(double)count / (double)windows > j_index` (Arcs.cpp:1006): the
+	// quotient grows with the count, so `count > F` is that test, without a double-precision division per read -- the
+	// two read lengths of a linked-read library are remembered
+	int fc_n0 = -1, fc_f0 = 0, fc_n1 = -1, fc_f1 = 0;
+	auto fail_count = [&](int nwin) -> int {
+		if (nwin == fc_n0)
+			return fc_f0;
+		if (nwin == fc_n1)
+			return fc_f1;
+		int F = (int)(j_index * (double)nwin);
+		F = F < 0 ? 0 : (F > nwin ? nwin : F);
+		while (F < nwin && !((double)(F + 1) / (double)nwin > j_index))
+			++F;
+		while (F > 0 && (double)F / (double)nwin > j_index)
+			--F;
+		fc_n1 = fc_n0, fc_f1 = fc_f0;
+		fc_n0 = nwin, fc_f0 = F;
+		return F;
+	};
 	const u32 n_medium = FULL ? __hip_atomic_load(queue_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 	bool first_grab = true;
 	u32* const work_ctr = reinterpret_cast<u32*>(reinterpret_cast<char*>(queue_count) + kWorkCtrOffset);
@@ -1200,9 +1219,8 @@ map_reads_b_kernel(
 							qr = qr < nw - 1 ? qr : nw - 1;
 							const int q = S.rstart[j] + qr;
 							const int hidx = S.hbase[j] + gi;
-							const typename Mmer<MM>::type mf = tile_mmer<MM>(S.cw, q);
-							const u32 strand = mf < mmer_rc<MM>(mf) ? 1u : 0u;
-							rv = -16 - (int)((u32)q | (strand << 11) | ((u32)hidx << 12));
+							// (the seed's strand is decided once per seed, in T5, and kept in S.heads: T6c reads it there)
+							rv = -16 - (int)((u32)q | ((u32)hidx << 12));
 							if (bx.has_img && !(k & 1)) { // see the minimizer path below: a necessary condition
 								const int qm = 2 * i + (k - MM) - q;
 								if (tile_canonical_mmer<MM>(S.cw, qm) == tile_canonical_mmer<MM>(S.cw, q))
@@ -1617,6 +1635,34 @@ map_reads_b_kernel(
 				}
 				ARKS_WAVE_SYNC();
 			}
+			u32 failmask = 0; // medium kernel without counters: reads whose vote fails whatever their open windows hold (T6d)
+			// medium kernel, seed index: the match of every 32-window word on both diagonals, one bit per window, as the
+			// hot kernels work it out (lanes = words x 2 diagonals, one pass) -- T6c then TESTS A BIT per window where it
+			// shifted four words of mismatch bits per window and diagonal (a fifth of the kernel's time on the human-like
+			// draft).  In the pad of S.a, which only the minimizer index's sliding minimum reads.
+			u32* const wok = S.a + kTP;       // [2][kSW] windows that face a visited text window, base for base
+			u32* const wamb = S.a + kTP + 32; // ... whose key is ambiguous (value 0)
+			u32* const wown = S.a + kTP + 64; // contig end of the others, ~0 when the word's windows span two
+			static_assert(2 * kSW <= 32, "word masks of a medium tile");
+			if (FULL && DENSE) {
+				const int d = lane >= 32 ? 1 : 0, wl = lane & 31;
+				if (wl < kSW) {
+					u32 ok = 0, amb = 0, own = 0;
+					if (wl < tw) {
+						const int j = S.wread[wl];
+						if (S.pdiag[j][d] >> 41) {
+							const u32 valid = word_valid_windows(S.nm, wl, S.rlen[j] - k + 1 - (wl * 32 - S.rstart[j]), k, has_n);
+							if (valid)
+								word_match(S.pdiag[j][d], mm32[d], tvis[d], tamb[d], town[d], wl, wl * 32 - S.rstart[j],
+								           (S.rstart[j] >> 5) + j, S.tfirst[j][d], k, valid, ok, amb, own);
+						}
+					}
+					wok[d * kSW + wl] = ok;
+					wamb[d * kSW + wl] = amb;
+					wown[d * kSW + wl] = own;
+				}
+				ARKS_WAVE_SYNC();
+			}
 			if (FULL) {
 			// ---- T6c: lanes = windows: an entry on one of the read's two staged diagonals only tests the
 			//      window's k mismatch bits; anything else needs the general verification ----------------
@@ -1634,7 +1680,7 @@ map_reads_b_kernel(
 				if (pending) {
 					const u32 pay = (u32)(-16 - rv);
 					const int q = (int)(pay & 2047u), hidx = (int)(pay >> 12);
-					const u32 rstrand = (pay >> 11) & 1u;
+					const u32 rstrand = DENSE ? (hidx < kNH ? (u32)S.heads[hidx] & 1u : 0u) : (pay >> 11) & 1u;
 					const u32 hn = hidx < kNH ? S.hn[hidx] : kHnOverflow;
 					int val = -1;
 					bool full = hn == kHnHeavy || hn == kHnOverflow;
@@ -1648,6 +1694,23 @@ map_reads_b_kernel(
 						const int p = i - S.rstart[j];
 						const int l = i & 31;
 						for (int d = 0; d < 2 && val < 0; ++d) {
+							if (DENSE) { // (the word masks above)
+								const int wx = d * kSW + (i >> 5);
+								if ((wok[wx] >> l) & 1u) {
+									const u32 own = wown[wx];
+									if ((wamb[wx] >> l) & 1u)
+										val = 0;
+									else if (own != 0xFFFFFFFFu)
+										val = (int)own;
+									else { // the word's windows span two contig ends: this window's text position says which
+										const u64 dk = S.pdiag[j][d];
+										const u64 D = dk & 0xFFFFFFFFFFull;
+										const u64 t = ((dk >> 40) & 1ull) ? D + (u64)p : D - (u64)(p + k - 1);
+										val = (int)town[d][(S.rstart[j] >> 5) + j + (int)((u32)(t >> 5) - S.tfirst[j][d])];
+									}
+								}
+								continue;
+							}
 							const u64 dk = S.pdiag[j][d];
 							if (!(dk >> 41))
 								continue;
@@ -1700,6 +1763,21 @@ map_reads_b_kernel(
 								full = true;
 								continue;
 							}
+							if (DENSE) { // (the word masks above)
+								const int wx = d * kSW + (i >> 5);
+								if ((wok[wx] >> l) & 1u) {
+									const u32 own = wown[wx];
+									if ((wamb[wx] >> l) & 1u)
+										val = 0;
+									else if (own != 0xFFFFFFFFu)
+										val = (int)own;
+									else {
+										const u64 t = same ? D + (u64)p : D - (u64)(p + k - 1);
+										val = (int)town[d][(S.rstart[j] >> 5) + j + (int)((u32)(t >> 5) - S.tfirst[j][d])];
+									}
+								}
+								continue;
+							}
 							const u32* mw = mm32[d] + (i >> 5);
 							const u64 m01 = (u64)mw[0] | ((u64)mw[1] << 32);
 							const u64 m23 = (u64)mw[2] | ((u64)mw[3] << 32);
@@ -1724,28 +1802,18 @@ map_reads_b_kernel(
 					if (full && !FULL)
 						atomicOr(&S.redo2, 1u << S.wread[i >> 5]);
 					if (full && FULL) {
-						const Key<KW> f = tile_window_key<KW>(S.cw, i, g);
-						const Key<KW> r = key_revcomp(f, g);
 						if (hn == kHnHeavy) {
 							// an exact-key probe of the fallback table: not here, where every batch of 64 windows
 							// would wait for its own probes -- the windows are listed and probed together below
 							val = kRecFallback;
-						} else if (hn == kHnOverflow) {
-							// the walk over the seed's 3-8 entries and the text behind each -- a chain of dependent global
-							// reads: not here, where the other 63 positions of the batch would wait for it (a third of the
-							// kernel's time on the human-like draft), but with the exact-key probes of T6d, all in flight
-							// together, and only for the windows the vote still needs
-							val = kRecOverflow;
 						} else {
-							const int off = q - i;
-							for (u32 c = 0; c < hn && val < 0; ++c) {
-								const u64 e = hc[hidx][c];
-								const bool same = ((u32)(e >> 62) & 1u) == rstrand;
-								const u64 t = same ? (u64)(u32)e - (u64)off : (u64)(u32)e - (u64)(k - MM - off);
-								const Key<KW> tk = window_key_at<KW>(bx.codes, t, g);
-								if (key_eq(tk, same ? f : r) && bit_at(bx.visited, t))
-									val = bit_at(bx.ambig, t) ? 0 : (int)bx.word_owner[t >> 5];
-							}
+							// the seed has more than two entries (only fingerprint collisions since round 5; 3-8 occurrences with
+							// ARKS_HEAVY_OVER=8), or one or two of which one lies on a diagonal that is not staged: the walk over
+							// the entries and the text behind each -- a chain of dependent global reads.  Not here, where the
+							// other 63 positions of the batch would wait for it (a third of the kernel's time on the human-like
+							// draft when it was), but with the exact-key probes of T6d, all in flight together, and only for the
+							// windows the vote still needs
+							val = kRecOverflow;
 						}
 					}
 					rec[i] = val;
@@ -1887,13 +1955,7 @@ map_reads_b_kernel(
 						}
 						if (P == 0)
 							continue;
-						// F: the largest count that fails `(double)count / (double)windows > j_index`
-						int F = (int)(j_index * (double)nwin);
-						F = F < 0 ? 0 : (F > nwin ? nwin : F);
-						while (F < nwin && !((double)(F + 1) / (double)nwin > j_index))
-							++F;
-						while (F > 0 && (double)F / (double)nwin > j_index)
-							--F;
+						const int F = fail_count(nwin);
 						const int s = ((S.redo >> j) & 1u) ? 0 : C + P - F; // (a read for the slow queue is decided there)
 						int take = s <= 0 ? 0 : s + kSettleMargin;
 						take = take > P ? P : take;
@@ -1902,19 +1964,19 @@ map_reads_b_kernel(
 							S.vfail[j] = F;
 						}
 						ARKS_MD(7, take);
+						if (s <= 0) {
+							failmask |= 1u << j; // settled: whatever the open windows hold, the read fails (T7 writes its 0)
+							continue;
+						}
 						int seen = 0;
-						for (int base = 0; base < nwin; base += 64) {
+						for (int base = 0; base < nwin && seen < take; base += 64) { // the first `take` open windows
 							const int p = base + lane;
 							const int rv = p < nwin ? rec[p0 + p] : -3;
 							const bool need = rv == kRecFallback || rv == kRecOverflow;
 							const u64 nb = __ballot(need);
 							const int rank = seen + (int)mask_below(nb);
-							if (need) {
-								if (rank < take)
-									flist[nlist + rank] = (unsigned short)((u32)(p0 + p) | (rv == kRecOverflow ? 0x8000u : 0u));
-								else if (s <= 0)
-									rec[p0 + p] = -1; // settled: whatever these windows hold, the read fails
-							}
+							if (need && rank < take)
+								flist[nlist + rank] = (unsigned short)((u32)(p0 + p) | (rv == kRecOverflow ? 0x8000u : 0u));
 							seen += __popcll(nb);
 						}
 						nlist += take;
@@ -1940,18 +2002,18 @@ map_reads_b_kernel(
 						const bool settled = C + P <= S.vfail[j];
 						ARKS_MD(10, settled ? 1 : 0);
 						ARKS_MD(7, settled ? 0 : P);
+						if (settled) {
+							failmask |= 1u << j;
+							continue;
+						}
 						for (int base = 0; base < nwin; base += 64) {
 							const int p = base + lane;
 							const int rv = p < nwin ? rec[p0 + p] : -3;
 							const bool need = rv == kRecFallback || rv == kRecOverflow;
 							const u64 nb = __ballot(need);
-							if (need) {
-								if (settled)
-									rec[p0 + p] = -1;
-								else
-									flist[nlist + (int)mask_below(nb)] = (unsigned short)((u32)(p0 + p) | (rv == kRecOverflow ? 0x8000u : 0u));
-							}
-							nlist += settled ? 0 : __popcll(nb);
+							if (need)
+								flist[nlist + (int)mask_below(nb)] = (unsigned short)((u32)(p0 + p) | (rv == kRecOverflow ? 0x8000u : 0u));
+							nlist += __popcll(nb);
 						}
 					}
 					ARKS_WAVE_SYNC();
@@ -2048,6 +2110,11 @@ map_reads_b_kernel(
 				if ((redo2_mask >> j) & 1u) {
 					if (lane == 0)
 						mqueue[atomicAdd(queue_count + 2, 1u)] = (u32)r;
+					continue;
+				}
+				if ((failmask >> j) & 1u) { // (only without counters)
+					if (lane == 0)
+						put_none<RAW>(out_conreci, r);
 					continue;
 				}
 				const int nwin = L - k + 1;
