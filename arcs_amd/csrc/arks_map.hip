@@ -460,6 +460,12 @@ tile_window_key(const u64* cw, int i, const KeyGeom& g)
 }
 
 #ifdef ARKS_MEDIUM_DIAG
+// quarantined diagnostic (-DARKS_MEDIUM_DIAG; arks_debug_medium_diag, printed by profiles/tools/ab.py): counters of the
+// medium kernel's tiles -- 0 tiles, 1 reads, 2 reads with a diagonal, 9 seeds probed, 11 tiles with a second diagonal,
+// 6 windows proven absent (high word: by a seed without entries; low: by a seed whose entries are all staged), 3 windows
+// left to T6d (4: of reads without a diagonal, 5: of reads whose diagonal A differs in > 8 bases), 7 windows listed,
+// 8 probe rounds, 12 slot reads, 13 reads settled before any lookup, 14 reads with a first round, 10 settled after it.
+// The counters cost half of the kernel's time: shares, not times.
 __device__ unsigned long long g_med_diag[16];
 #define ARKS_MD(slot, v) md[slot] += (unsigned long long)(v)
 #else
@@ -1966,8 +1972,10 @@ map_reads_b_kernel(
 						ARKS_MD(7, take);
 						if (s <= 0) {
 							failmask |= 1u << j; // settled: whatever the open windows hold, the read fails (T7 writes its 0)
+							ARKS_MD(13, 1);
 							continue;
 						}
+						ARKS_MD(14, take < P ? 1 : 0);
 						int seen = 0;
 						for (int base = 0; base < nwin && seen < take; base += 64) { // the first `take` open windows
 							const int p = base + lane;
@@ -2197,7 +2205,7 @@ map_reads_b_kernel(
 #ifdef ARKS_MEDIUM_DIAG
 	if (FULL)
 		for (int x = 0; x < 16; ++x) {
-			const bool per_lane = x == 6 || x >= 13;
+			const bool per_lane = x == 6;
 			if ((per_lane || lane_id == 0) && md[x])
 				atomicAdd(&g_med_diag[x], md[x]);
 		}

@@ -105,9 +105,10 @@ for (name, L, h, codes, nmask, out, ev) in libs:
         md = (C.c_ulonglong * 16)(); L.arks_debug_medium_diag.argtypes = [C.c_void_p]; L.arks_debug_medium_diag(md)
         print("   medium kernel (all launches of this process): tiles", md[0], "reads", md[1], "with a diagonal", md[2], "seeds probed", md[9],
               "tiles with a second diagonal", md[11], "| windows proven absent by a seed without entries", md[6] >> 32,
-              "by a seed whose entries are all staged", md[6] & 0xFFFFFFFF, "| windows left to the exact table", md[3],
+              "by a seed whose entries are all staged", md[6] & 0xFFFFFFFF, "| windows left to T6d", md[3],
               "(in reads without a diagonal", md[4], ", in reads whose diagonal A differs in > 8 bases", md[5], ")",
-              "exact-table rounds", md[8], "slot reads", md[12])
+              "| reads settled before any lookup", md[13], "with a first round", md[14], "settled after it", md[10],
+              "| windows looked up", md[7], "probe rounds", md[8], "slot reads", md[12])
     except AttributeError:
         pass
     dig = int((out.to(torch.int64) * (torch.arange(n, device=dev, dtype=torch.int64) % 1000003 + 1)).sum().item())
