@@ -362,6 +362,13 @@ constexpr int kTP = kSW * 32;    // ... in base positions
 constexpr int kTW = 32;          // tile capacity in packed words: two passes, one joint back half
 constexpr int kTR = 16;          // reads per tile
 constexpr int kNH = 128;         // run heads per tile that get a published entry list
+// waves per SIMD of the seed index's medium kernel at k <= 64 (7.7 KB of LDS, 96 VGPRs): 5; 4 until the end of
+// round 5 (9.3 KB, 112 VGPRs: 6.21 against 5.72 ms per 20 M pairs of the human-like draft) and still 4 for
+// longer keys (120-124 VGPRs)
+#ifndef ARKS_MEDIUM_WAVES
+#define ARKS_MEDIUM_WAVES 5
+#endif
+constexpr int kNHd = 64;         // ... in the medium kernel of the seed index (group seeds + extra seeds: one probe round)
 constexpr int kGrabF = 12;       // medium kernel: queued reads per grab at most (four tiles of 10x reads; 8 until round 5: tiles of 3 + 3 + 2)
 constexpr int kSettleMargin = 2; // medium kernel without counters: open windows probed beyond the number that settles a failing vote
 constexpr int kExtraSeeds = 12;  // medium kernel, seed index: m-mers per read probed beside its group seeds (8: fewer proofs; 18: the same time)
@@ -394,16 +401,19 @@ clear_spans32(u32 m0, u32 m1, u32 m2, u32 m3, int k)
 #define ARKS_TILE_WAVES 7 // 72 VGPRs: at 8 waves (64) the kernel keeps two or three registers in scratch memory -- no kernel of the library uses scratch (tests/test_abi.py)
 #endif
 
-template <bool FULL>
+// DMED = the medium kernel of the SEED index (FULL && DENSE): no sliding minimum (S.a holds the seeds' entry lists and
+// the per-word match masks only), seeds capped at kNHd per tile -- 7.7 KB instead of 9.3, which is what five waves per
+// SIMD need (round 5: the kernel's time is LDS-latency chains at four)
+template <bool FULL, bool DMED = false>
 struct TileLds
 {
-	u32 a[kTP + 96];
+	u32 a[DMED ? 4 * kNHd + 96 : kTP + 96];
 	// hot instantiation: the block minima of T3, then the per-word result bits (no window records)
-	u32 b[FULL ? kTP + 96 : 256];
+	u32 b[DMED ? kTP : (FULL ? kTP + 96 : 256)];
 	u64 cw[kTW + 4];
 	u32 nm[kTW + 4];
-	unsigned short heads[kNH]; // run heads: [0] minimizer strand, [11:1] its position, [15:12] read of the tile
-	unsigned char hn[kNH];
+	unsigned short heads[DMED ? kNHd : kNH]; // run heads: [0] minimizer strand, [11:1] its position, [15:12] read of the tile
+	unsigned char hn[DMED ? kNHd : kNH];
 	unsigned char wread[kTW + 4];
 	u32 wmeta[kTW + 4]; // per word: read index << 16 | local end position of that read (0 = none)
 	int rstart[kTR + 1];
@@ -851,7 +861,7 @@ tile_sliding_min(u32* pre_lds, u32* blk_lds, int l0, int lane, int w, const u32 
 //                kernel's time); 2-3 probes per 10x read instead of 5-6.  Exact for the same reason: a
 //                window that is in the index brings its seed's text position into the seed's entry list.
 template <int KW, bool STATS, bool FULL, int MM, bool RAW = false, bool DENSE = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FULL ? 4 : ARKS_TILE_WAVES)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FULL ? (DENSE && KW <= 2 ? ARKS_MEDIUM_WAVES : 4) : ARKS_TILE_WAVES)))
 map_reads_b_kernel(
     const u64* __restrict__ codes,
     const u32* __restrict__ nmask,
@@ -868,7 +878,9 @@ map_reads_b_kernel(
     u32* __restrict__ mqueue,      // medium queue
     u32* __restrict__ queue_count) // [0] slow length, [1] work counter, [2] medium length, [3] medium work counter
 {
-	__shared__ TileLds<FULL> S;
+	constexpr bool kDMed = FULL && DENSE;
+	constexpr int kNHx = kDMed ? kNHd : kNH; // seeds (run heads) of a tile that get an entry list
+	__shared__ TileLds<FULL, kDMed> S;
 	// entry lists of the run heads (T5 .. T6a; the medium kernel reads them again in T6c): S.a is free
 	// once the window minimizers are taken
 	u64 (*const hc)[2] = reinterpret_cast<u64(*)[2]>(S.a);
@@ -888,8 +900,9 @@ map_reads_b_kernel(
 		S.wstats[lane_id] = 0;
 	const int k = g.k, w = bx.w;
 	// the sliding minimum reads up to w - 1 + 7 positions past the tile: a constant pad
-	for (int x = lane_id; x < 96; x += 64)
-		S.a[kTP + x] = 0xFFFFFFFFu;
+	if (!kDMed)
+		for (int x = lane_id; x < 96; x += 64)
+			S.a[kTP + x] = 0xFFFFFFFFu;
 #ifdef ARKS_PROFILE_SECTIONS
 	unsigned long long sec_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	unsigned long long sec_t0 = __builtin_amdgcn_s_memtime();
@@ -934,12 +947,16 @@ map_reads_b_kernel(
 			// the first grab of a wave is the one with its block index: no atomic, and the (many) waves
 			// beyond the queue length leave without touching the shared counter -- thousands of idle
 			// waves queueing one atomic each on the same word cost 0.1 ms
-			const u32 per_wave = n_medium / gridDim.x;
+			// (the grid size as an opaque value: `gridDim.x * grab` is otherwise an invariant of the loop that the
+			// compiler forms once and, at five waves per SIMD, keeps in scratch memory)
+			u32 n_blocks = gridDim.x;
+			asm volatile("" : "+s"(n_blocks));
+			const u32 per_wave = n_medium / n_blocks;
 			const u32 grab = per_wave >= (u32)kGrabF ? (u32)kGrabF : (per_wave > 1u ? per_wave : 1u);
 			u32 qi = blockIdx.x * grab;
 			if (!first_grab) {
 				if (lane_id == 0)
-					qi = gridDim.x * grab + atomicAdd(queue_count + 3, grab);
+					qi = n_blocks * grab + atomicAdd(queue_count + 3, grab);
 				qi = (u32)__builtin_amdgcn_readfirstlane((int)qi);
 			}
 			first_grab = false;
@@ -1025,7 +1042,9 @@ map_reads_b_kernel(
 			// short sliding windows mean many runs per base: keep the tile's expected run count
 			// (64 / (w + 1) per word) within kNH by capping its words (never below one read)
 			// (seed index: one head per w windows and one more per read -- 7 w / 2 words stay within kNH)
-			const u64 wcap = DENSE ? (u64)(7 * w / 2 < kTW ? 7 * w / 2 : kTW)
+			// (its medium kernel: kNHd seeds -- 3 w / 2 words of windows and sixteen reads)
+			const u64 wcap = kDMed ? (u64)(3 * w / 2 < kTW ? (3 * w / 2 > 0 ? 3 * w / 2 : 1) : kTW)
+			               : DENSE ? (u64)(7 * w / 2 < kTW ? 7 * w / 2 : kTW)
 			                       : (u64)(7 * (w + 1) / 4 < kTW ? 7 * (w + 1) / 4 : kTW);
 			const u64 fit = __ballot(
 			    lane > cur && lane <= nchunk && wo - base_w <= (u64)kSW && lane - cur <= kTR &&
@@ -1156,7 +1175,7 @@ map_reads_b_kernel(
 				if (FULL && lane < nr)
 					S.hbase[lane] = hb;
 				for (int gi = 0; __ballot(gi < G) != 0; ++gi) {
-					if (gi < G && hb + gi < kNH) {
+					if (gi < G && hb + gi < kNHx) {
 						int q = (gi + 1) * w - 1;
 						q = q < nwin - 1 ? q : nwin - 1;
 						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)lane << 12));
@@ -1380,7 +1399,7 @@ map_reads_b_kernel(
 				ARKS_MD(9, nheads);
 			}
 			// ---- T5: run heads walk the minimizer table ------------------------------------------------
-			const int nh = nheads < kNH ? nheads : kNH;
+			const int nh = nheads < kNHx ? nheads : kNHx;
 			for (int h = lane; h < nh; h += 64) {
 				const u32 q = ((u32)S.heads[h] >> 1) & 2047u;
 				if (DENSE) {
@@ -1494,7 +1513,7 @@ map_reads_b_kernel(
 						proposals(h, jh, dk0, dk1, off);
 						flag(jh, dk0, dk1, off);
 					}
-					if (nheads > kNH && lane == 0) // more runs than the tile publishes: every read
+					if (nheads > kNHx && lane == 0) // more runs than the tile publishes: every read
 						atomicOr(&S.redo2, 0xFFFFFFFFu);
 					ARKS_WAVE_SYNC();
 				}
@@ -1646,9 +1665,10 @@ map_reads_b_kernel(
 			// hot kernels work it out (lanes = words x 2 diagonals, one pass) -- T6c then TESTS A BIT per window where it
 			// shifted four words of mismatch bits per window and diagonal (a fifth of the kernel's time on the human-like
 			// draft).  In the pad of S.a, which only the minimizer index's sliding minimum reads.
-			u32* const wok = S.a + kTP;       // [2][kSW] windows that face a visited text window, base for base
-			u32* const wamb = S.a + kTP + 32; // ... whose key is ambiguous (value 0)
-			u32* const wown = S.a + kTP + 64; // contig end of the others, ~0 when the word's windows span two
+			constexpr int kMaskAt = kDMed ? 4 * kNHd : kTP; // (behind the entry lists)
+			u32* const wok = S.a + kMaskAt;       // [2][kSW] windows that face a visited text window, base for base
+			u32* const wamb = S.a + kMaskAt + 32; // ... whose key is ambiguous (value 0)
+			u32* const wown = S.a + kMaskAt + 64; // contig end of the others, ~0 when the word's windows span two
 			static_assert(2 * kSW <= 32, "word masks of a medium tile");
 			if (FULL && DENSE) {
 				const int d = lane >= 32 ? 1 : 0, wl = lane & 31;
@@ -1686,8 +1706,8 @@ map_reads_b_kernel(
 				if (pending) {
 					const u32 pay = (u32)(-16 - rv);
 					const int q = (int)(pay & 2047u), hidx = (int)(pay >> 12);
-					const u32 rstrand = DENSE ? (hidx < kNH ? (u32)S.heads[hidx] & 1u : 0u) : (pay >> 11) & 1u;
-					const u32 hn = hidx < kNH ? S.hn[hidx] : kHnOverflow;
+					const u32 rstrand = DENSE ? (hidx < kNHx ? (u32)S.heads[hidx] & 1u : 0u) : (pay >> 11) & 1u;
+					const u32 hn = hidx < kNHx ? S.hn[hidx] : kHnOverflow;
 					int val = -1;
 					bool full = hn == kHnHeavy || hn == kHnOverflow;
 					if (full && FULL) {
@@ -1852,7 +1872,8 @@ map_reads_b_kernel(
 			{
 				unsigned short* const flist = reinterpret_cast<unsigned short*>(S.tcodes_f);
 				// (tcodes_f, tvis_f, tamb_f, town_f lie one behind the other: 2000 bytes for <= kTP positions)
-				static_assert(!FULL || offsetof(TileLds<FULL>, mm32_f) - offsetof(TileLds<FULL>, tcodes_f) >=
+				typedef TileLds<FULL, kDMed> Lds_t;
+				static_assert(!FULL || offsetof(Lds_t, mm32_f) - offsetof(Lds_t, tcodes_f) >=
 				                           sizeof(unsigned short) * (size_t)kTP, "window list");
 				static_assert(kTP <= 0x8000, "a list entry: position | entry walk << 15");
 				// the probes of a list of nlist windows
