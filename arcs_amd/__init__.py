@@ -8,10 +8,10 @@ gfx950 device every compute call raises.
 from . import api  # noqa: F401
 from ._lib import ArksError, lib, lib_path  # noqa: F401
 from .api import (ArksIndex, ImapAccumulator, PackedReads, PairStep, SeedExchange, contig_ends, device_count,  # noqa: F401
-                  count_votes, end_cutoff, key_bytes, map_pairs_packed, map_reads_packed, map_votes_packed, max_votes,
+                  count_votes, end_cutoff, key_bytes, map_pairs_fused, map_pairs_packed, map_reads_packed, map_votes_packed, max_votes,
                   pack_reads_host, pair_gate, pairs_rule, queue_counts, resolve_votes, shard_of_ends)
 
 __all__ = ["ArksError", "ArksIndex", "ImapAccumulator", "PackedReads", "SeedExchange", "contig_ends",
-           "device_count", "end_cutoff", "key_bytes", "lib", "lib_path", "map_pairs_packed",
+           "device_count", "end_cutoff", "key_bytes", "lib", "lib_path", "map_pairs_fused", "map_pairs_packed",
            "count_votes", "map_reads_packed", "map_votes_packed", "max_votes", "pack_reads_host", "pair_gate", "pairs_rule",
            "queue_counts", "resolve_votes", "shard_of_ends"]

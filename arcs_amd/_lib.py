@@ -79,6 +79,7 @@ SYMBOLS = {
     "arks_pack_reads_device": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _I, _VP]),
     "arks_pack_reads_host": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP]),
     "arks_map_reads_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
+    "arks_map_pairs_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
     "arks_map_votes_device": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP]),
     "arks_votes_max_device": (_I, [_VP, _VP, _I64, _I, _VP]),
     "arks_votes_resolve_device": (_I, [_VP, _VP, _I64, _I, _D, _VP, _I, _VP]),

@@ -325,6 +325,25 @@ def map_reads_packed(index, reads, j_index, eval_mask=None, stats=None, out=None
     return out[:n]
 
 
+def map_pairs_fused(index, reads, j_index, pair_ok=None, eval_scratch=None, stats=None, out=None):
+    """arks_map_pairs_device on the current torch stream: the pair gate worked out inside the map kernel (reads 2p,
+    2p + 1 are mates; n_reads even).  eval_scratch: uint8[n_reads] the call may write (allocated when None).
+    Returns the int32 conreci tensor."""
+    torch = _torch()
+    n = reads.n_reads
+    assert n % 2 == 0, "arks_map_pairs_device wants whole pairs"
+    if out is None:
+        out = torch.empty(max(n, 1), dtype=torch.int32, device=reads.codes.device)
+    if eval_scratch is None:
+        eval_scratch = torch.empty(max(n, 1), dtype=torch.uint8, device=reads.codes.device)
+    check(lib().arks_map_pairs_device(
+        index.handle, reads.codes.data_ptr(), reads.nmask.data_ptr(), reads.word_off.data_ptr(),
+        reads.lens.data_ptr(), pair_ok.data_ptr() if pair_ok is not None else None, reads.read_class.data_ptr(),
+        eval_scratch.data_ptr(), n, float(j_index), out.data_ptr(), stats.data_ptr() if stats is not None else None,
+        _stream_ptr(reads.device)), "arks_map_pairs_device")
+    return out[:n]
+
+
 def seed_counts(index, reads, eval_mask=None):
     """arks_seed_counts_device: int32[n_reads], the seeds each read asks of the seed table"""
     torch = _torch()
@@ -667,19 +686,24 @@ class ImapAccumulator:
 
 
 def map_pairs_packed(index, reads, j_index, pair_ok=None, barcode_id=None, imap=None,
-                     stats=None, stored=None):
+                     stats=None, stored=None, fused=True):
     """The per-pair flow of chromiumRead (Arcs/Arcs.cpp:1264-1292) for a resident batch whose
     reads 2p, 2p+1 are mates: gate -> bestContig of both mates -> pair rule -> imap update.
+    fused (round 5): the gate inside the map kernel (arks_map_pairs_device) instead of a launch of its own
+    (arks_pair_gate_device + arks_map_reads_device; what an odd number of reads takes anyway).
     Returns (conreci int32[n_reads], pair int32[n_pairs])."""
     torch = _torch()
     dev = reads.codes.device
     n_pairs = reads.n_reads // 2
     sp = _stream_ptr(reads.device)
     ev = torch.empty(max(2 * n_pairs, 1), dtype=torch.uint8, device=dev)
-    check(lib().arks_pair_gate_device(pair_ok.data_ptr() if pair_ok is not None else None,
-                                      reads.read_class.data_ptr(), n_pairs, ev.data_ptr(),
-                                      reads.device, sp), "arks_pair_gate_device")
-    conreci = map_reads_packed(index, reads, j_index, eval_mask=ev, stats=stats)
+    if fused and reads.n_reads % 2 == 0:
+        conreci = map_pairs_fused(index, reads, j_index, pair_ok=pair_ok, eval_scratch=ev, stats=stats)
+    else:
+        check(lib().arks_pair_gate_device(pair_ok.data_ptr() if pair_ok is not None else None,
+                                          reads.read_class.data_ptr(), n_pairs, ev.data_ptr(),
+                                          reads.device, sp), "arks_pair_gate_device")
+        conreci = map_reads_packed(index, reads, j_index, eval_mask=ev, stats=stats)
     pair = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=dev)
     check(lib().arks_pairs_device(conreci.data_ptr(),
                                   pair_ok.data_ptr() if pair_ok is not None else None,
@@ -692,11 +716,13 @@ def map_pairs_packed(index, reads, j_index, pair_ok=None, barcode_id=None, imap=
 
 class PairStep:
     """One pass of the hot path over a resident batch with every buffer preallocated (what
-    bench.py times): pair gate -> map_reads -> pair rule + imap update."""
+    bench.py times): pair gate -> map_reads -> pair rule + imap update; the gate inside the map kernel
+    (arks_map_pairs_device) unless fused=False."""
 
-    def __init__(self, index, reads, j_index, pair_ok=None, barcode_id=None, imap=None):
+    def __init__(self, index, reads, j_index, pair_ok=None, barcode_id=None, imap=None, fused=True):
         torch = _torch()
         dev = reads.codes.device
+        self.fused = bool(fused) and reads.n_reads % 2 == 0
         self.index, self.reads, self.j = index, reads, float(j_index)
         self.pair_ok, self.barcode_id, self.imap = pair_ok, barcode_id, imap
         self.n_pairs = reads.n_reads // 2
@@ -708,12 +734,17 @@ class PairStep:
         L = lib()
         r = self.reads
         sp = _stream_ptr(r.device)
-        check(L.arks_pair_gate_device(self.pair_ok.data_ptr() if self.pair_ok is not None else None,
-                                      r.read_class.data_ptr(), self.n_pairs, self.eval.data_ptr(),
-                                      r.device, sp), "arks_pair_gate_device")
-        if map_events is not None:
-            map_events[0].record()
-        map_reads_packed(self.index, r, self.j, eval_mask=self.eval, stats=stats, out=self.conreci)
+        if self.fused:      # the gate worked out by the map kernel (arks_map_pairs_device)
+            if map_events is not None:
+                map_events[0].record()
+            map_pairs_fused(self.index, r, self.j, pair_ok=self.pair_ok, eval_scratch=self.eval, stats=stats, out=self.conreci)
+        else:
+            check(L.arks_pair_gate_device(self.pair_ok.data_ptr() if self.pair_ok is not None else None,
+                                          r.read_class.data_ptr(), self.n_pairs, self.eval.data_ptr(),
+                                          r.device, sp), "arks_pair_gate_device")
+            if map_events is not None:
+                map_events[0].record()
+            map_reads_packed(self.index, r, self.j, eval_mask=self.eval, stats=stats, out=self.conreci)
         if map_events is not None:
             map_events[1].record()
         check(L.arks_pairs_device(self.conreci.data_ptr(),

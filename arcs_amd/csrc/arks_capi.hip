@@ -1420,6 +1420,52 @@ done:
 }
 
 int
+arks_map_pairs_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_pair_ok,
+    const uint8_t* d_read_class,
+    uint8_t* d_eval_out,
+    int64_t n_reads,
+    double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream)
+{
+	if (!idx || n_reads < 0 || n_reads > 0xFFFFFFFFll || (n_reads & 1))
+		return ARKS_ERR_BAD_ARG;
+	if (n_reads == 0)
+		return ARKS_OK;
+	if (!d_codes || !d_nmask || !d_word_off || !d_lens || !d_read_class || !d_eval_out || !d_out_conreci)
+		return ARKS_ERR_BAD_ARG;
+	if (idx->seed_ranks > 1)
+		return ARKS_ERR_BAD_ARG; // a shard of the seed table: arks_exchange_submit_pairs
+	if (idx->kind != 2) {
+		// only the seed index's tile kernel works the gate out itself: the other layouts take the two launches
+		int rc2 = arks_pair_gate_device(d_pair_ok, d_read_class, n_reads / 2, d_eval_out, idx->device, stream);
+		if (rc2 != ARKS_OK)
+			return rc2;
+		return arks_map_reads_device(idx, d_codes, d_nmask, d_word_off, d_lens, d_eval_out, n_reads, j_index, d_out_conreci,
+		                             d_stats, stream);
+	}
+	DeviceGuard guard(idx->device);
+	arks_index::QueueSet qs;
+	int rc = ensure_queue(idx, stream, n_reads, &qs);
+	if (rc != ARKS_OK)
+		return rc;
+	HIP_TRY(poison_lds(idx->n_cu, static_cast<hipStream_t>(stream)));
+	HIP_TRY(launch_map_reads(
+	    idx->kw, (const u64*)d_codes, d_nmask, (const u64*)d_word_off, d_lens, nullptr, (long)n_reads,
+	    j_index, idx->geom, idx->table, idx->bx, d_out_conreci, reinterpret_cast<u64*>(d_stats),
+	    qs.queue, qs.queue_count, idx->n_cu, static_cast<hipStream_t>(stream), false, d_read_class, d_pair_ok));
+done:
+	return rc;
+}
+
+int
 arks_map_votes_device(
     const arks_index* idx,
     const uint64_t* d_codes,

@@ -2364,7 +2364,12 @@ map_reads_s_kernel(
     const u64* __restrict__ ans = nullptr,       // REMOTE only
     const u32* __restrict__ seed_slot = nullptr, // REMOTE only, may be NULL: the answer of seed s is ans[2 seed_slot[s]]
                                                  // (arks_exchange: answers lie in send-buffer order) instead of ans[2 s]
-    const u32* __restrict__ chunk_off = nullptr) // REMOTE only, instead of seed_off: first seed of chunk c0 / sChunk
+    const u32* __restrict__ chunk_off = nullptr, // REMOTE only, instead of seed_off: first seed of chunk c0 / sChunk
+    // the pair gate of chromiumRead (Arcs.cpp:1264-1268) worked out here instead of read from `eval` (round 5: the
+    // gate launch -- a pass over three arrays of the batch -- was 1.6 % of a step): gate_class != NULL: reads 2p, 2p + 1
+    // are mates, read r is evaluated iff gate_ok[r / 2] (NULL: yes) and both mates' class has bit 0; class bit 1 = ACGT only
+    const uint8_t* __restrict__ gate_class = nullptr,
+    const uint8_t* __restrict__ gate_ok = nullptr)
 {
 	typedef typename Mmer<MM>::type mm_t;
 	__shared__ SeedTileLds S;
@@ -2479,7 +2484,14 @@ map_reads_s_kernel(
 			if (cl < nchunk) {
 				rl = (int)lens[c0 + cl];
 				may_n = true; // (without an eval array nothing is known: the masks are fetched)
-				if (eval) {
+				if (gate_class) { // (arks_pair_gate_device's rule; n_reads is even)
+					const long r = c0 + cl;
+					const uint8_t c_me = gate_class[r], c_mate = gate_class[r ^ 1];
+					const uint8_t p_ok = gate_ok ? gate_ok[r >> 1] : (uint8_t)1;
+					if (!(p_ok && (c_me & 1) && (c_mate & 1)))
+						rl = -1;
+					may_n = !(c_me & 2);
+				} else if (eval) {
 					const uint8_t ev = eval[c0 + cl];
 					if (!ev)
 						rl = -1;
@@ -3279,10 +3291,12 @@ launch_map_reads(
     int kw, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens,
     const uint8_t* eval, long n_reads, double j_index, const KeyGeom& g, TableView t,
     const BIndexView& bx, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu, hipStream_t st,
-    bool raw)
+    bool raw, const uint8_t* gate_class, const uint8_t* gate_ok)
 {
 	if (n_reads <= 0)
 		return hipSuccess;
+	if (gate_class && (!bx.dense || raw || (n_reads & 1)))
+		return hipErrorInvalidValue; // (the caller falls back to the gate launch: only the seed tile kernel works it out)
 	if (raw && stats)
 		return hipErrorInvalidValue; // the window counters of a shard are not the reference's
 	// queue_count: 4 counters, then (64 bytes in) the partial rows of the statistics
@@ -3332,7 +3346,7 @@ launch_map_reads(
 			const u64 ress = (u64)(n_cu > 0 ? n_cu : 256) * 4ull * ARKS_SEED_WAVES;                \
 			map_reads_s_kernel<KWV, ST, MMV, RAWV><<<(unsigned)(wants < ress ? wants : ress), 64, 0, st>>>( \
 			    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,    \
-			    queue + n_reads, queue_count);                                                     \
+			    queue + n_reads, queue_count, nullptr, nullptr, nullptr, nullptr, gate_class, gate_ok); \
 		} else                                                                                     \
 			map_reads_b_kernel<KWV, ST, false, MMV, RAWV, false><<<bb, 64, 0, st>>>(               \
 			    codes, nmask, word_off, lens, eval, n_reads, j_index, g, bx, out, stats, queue,    \

@@ -269,6 +269,29 @@ int arks_map_reads_device(
     arks_map_stats* d_stats,
     void* stream);
 
+/* arks_map_reads_device for a batch of PAIRS (reads 2p, 2p + 1 are mates; n_reads even) with the gate of chromiumRead
+ * (Arcs/Arcs.cpp:1264-1268) folded in: what arks_pair_gate_device would write from d_read_class (arks_pack_reads_device
+ * / the host packer) and d_pair_ok (may be NULL = every pair) is worked out by the map kernel itself while it reads
+ * the batch's metadata -- one launch and one pass over three arrays less per batch (round 5: 1.6 % of a step of 500 M
+ * pairs).  Results are arks_pair_gate_device + arks_map_reads_device's, read for read and counter for counter.
+ * d_eval_out (n_reads bytes, required) is scratch the call MAY write: an index whose layout is not the seed index
+ * (arks_index_kind != 2) takes the two launches through it; with the seed index it is left untouched -- a caller that
+ * wants the gate's array (arks_gate_count_device) calls arks_pair_gate_device. */
+int arks_map_pairs_device(
+    const arks_index* idx,
+    const uint64_t* d_codes,
+    const uint32_t* d_nmask,
+    const uint64_t* d_word_off,
+    const uint32_t* d_lens,
+    const uint8_t* d_pair_ok,
+    const uint8_t* d_read_class,
+    uint8_t* d_eval_out,
+    int64_t n_reads,
+    double j_index,
+    int32_t* d_out_conreci,
+    arks_map_stats* d_stats,
+    void* stream);
+
 /* bestContig (Arcs/Arcs.cpp:939-1004) up to, not including, the j_index test, against ONE shard:
  * d_out_votes[r] = (count << 32) | ~conreci of the end that won the walk of :998-1004 in this shard
  * (0 = nothing recorded, or d_eval[r] == 0).  The unsigned 64-bit MAXIMUM of a read's votes over all
