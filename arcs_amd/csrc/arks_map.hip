@@ -2486,8 +2486,11 @@ map_reads_s_kernel(
 				may_n = true; // (without an eval array nothing is known: the masks are fetched)
 				if (gate_class) { // (arks_pair_gate_device's rule; n_reads is even)
 					const long r = c0 + cl;
-					const uint8_t c_me = gate_class[r], c_mate = gate_class[r ^ 1];
+					const uint8_t c_me = gate_class[r];
 					const uint8_t p_ok = gate_ok ? gate_ok[r >> 1] : (uint8_t)1;
+					// (the mate's class sits in the neighbouring lane: chunks start at even reads and hold whole pairs)
+					static_assert(sChunk % 2 == 0, "a chunk holds whole pairs");
+					const int c_mate = __builtin_amdgcn_update_dpp(0, (int)c_me, 0xB1, 0xF, 0xF, true); // quad_perm [1, 0, 3, 2]
 					if (!(p_ok && (c_me & 1) && (c_mate & 1)))
 						rl = -1;
 					may_n = !(c_me & 2);
