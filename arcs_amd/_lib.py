@@ -101,7 +101,7 @@ SYMBOLS = {
 _lib = None
 
 
-ABI_VERSION = 2          # include/arks_hip.h ARKS_ABI_VERSION
+ABI_VERSION = 3          # include/arks_hip.h ARKS_ABI_VERSION
 
 
 def lib_path():

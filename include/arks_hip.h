@@ -42,7 +42,7 @@ extern "C" {
  * arcs_amd/host/arcs.cpp) so that a caller built against another header fails there, not in a wild write.  A
  * calibration build of the library (-DARKS_CALIBRATION_BUILD: kernels with a memory phase taken out, results wrong by
  * design, profiles/tools/) reports the NEGATIVE number and is refused by both. */
-#define ARKS_ABI_VERSION 2
+#define ARKS_ABI_VERSION 3 /* 3 (end of round 5): arks_map_pairs_device added */
 
 /* status codes */
 #define ARKS_OK 0

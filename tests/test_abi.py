@@ -29,7 +29,7 @@ def test_header_and_library_agree(arks):
     out = subprocess.check_output(["nm", "-D", "--defined-only", arks.lib_path()]).decode()
     exported = set(re.findall(r" T (arks_[a-z0-9_]+)", out))
     assert set(names) <= exported
-    assert arks.lib().arks_abi_version() == 2
+    assert arks.lib().arks_abi_version() == 3
 
 
 def test_library_has_gfx950_code_object(arks):
