@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -29,7 +30,17 @@ def test_header_and_library_agree(arks):
     out = subprocess.check_output(["nm", "-D", "--defined-only", arks.lib_path()]).decode()
     exported = set(re.findall(r" T (arks_[a-z0-9_]+)", out))
     assert set(names) <= exported
-    assert arks.lib().arks_abi_version() == 3
+    assert arks.lib().arks_abi_version() == _lib.ABI_VERSION
+    hdr = open(os.path.join(ROOT, "include", "arks_hip.h")).read()
+    assert int(re.search(r"#define\s+ARKS_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.ABI_VERSION
+
+
+def test_driver_entry_build():
+    """__graft_entry__.build() is what the driver runs each round: it must survive an ABI bump (round 5's did not:
+    a literal version number in it went stale)"""
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stderr[-2000:]
 
 
 def test_library_has_gfx950_code_object(arks):
