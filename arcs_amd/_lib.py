@@ -38,6 +38,16 @@ class MapStats(C.Structure):
 
 MAP_STATS_FIELDS = [n for n, _ in MapStats._fields_]
 
+
+class BuildOptions(C.Structure):
+    """arks_build_options (include/arks_hip.h): the layout choices of an index build; results never depend on them"""
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in
+                ("index_kind", "heavy_over", "minimizer_len", "fallback_load_inv", "shard", "n_shards",
+                 "seed_rank", "seed_ranks")]
+
+
+INDEX_KINDS = {"auto": 0, "hash": 1, "minimizer": 2, "seeds": 3}        # ARKS_INDEX_*
+
 # name -> (restype, argtypes): every symbol include/arks_hip.h declares
 _VP, _I, _I64, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
 SYMBOLS = {
@@ -47,6 +57,7 @@ SYMBOLS = {
     "arks_device_count": (_I, []),
     "arks_key_bytes": (_I, [_I]),
     "arks_index_build": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, C.POINTER(BuildStats)]),
+    "arks_index_build_ex": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, C.POINTER(BuildOptions), C.POINTER(BuildStats)]),
     "arks_shard_of_ends": (_I, [_VP, _I64, _I, _VP]),
     "arks_index_build_shard": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I]),
     "arks_index_build_shard_stats": (_I, [C.POINTER(_VP), _I, _VP, _VP, _VP, _I64, _I, _I, _I, C.POINTER(BuildStats)]),
@@ -93,6 +104,7 @@ SYMBOLS = {
     "arks_imap_export_ordered": (_I, [_VP, _VP, _VP]),
     "arks_debug_queue_counts": (_I, [_VP, _VP]),
     "arks_exchange_debug_set_rccl": (_I, [_VP]),
+    "arks_debug_set_medium_blocks": (_I, [_I]),
     "arks_pair_gate_device": (_I, [_VP, _VP, _I64, _VP, _I, _VP]),
     "arks_gate_count_device": (_I, [_VP, _VP, _I64, _VP, _I, _VP]),
     "arks_pairs_device": (_I, [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _I, _VP]),
@@ -101,7 +113,7 @@ SYMBOLS = {
 _lib = None
 
 
-ABI_VERSION = 3          # include/arks_hip.h ARKS_ABI_VERSION
+ABI_VERSION = 4          # include/arks_hip.h ARKS_ABI_VERSION
 
 
 def lib_path():

@@ -6,7 +6,17 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BuildStats, MapStats, check, lib
+from ._lib import INDEX_KINDS, ArksError, BuildOptions, BuildStats, MapStats, check, lib
+
+# Layout choices (fields of arks_build_options) that every ArksIndex.build* of this process applies unless the call
+# says otherwise.  Tests and A/B runs set them here (tests/conftest.py index_layout): rounds 1-5 went through the
+# process environment, which the library read at every build; it reads no environment any more.
+BUILD_DEFAULTS = {}
+
+
+def set_medium_blocks(n):
+    """arks_debug_set_medium_blocks (include/arks_hip_debug.h): the medium kernel on at most n waves (0: no cap)"""
+    check(lib().arks_debug_set_medium_blocks(int(n)), "arks_debug_set_medium_blocks")
 
 
 def device_count():
@@ -91,46 +101,49 @@ class ArksIndex:
         self.build_stats = stats
 
     @classmethod
-    def build(cls, ends, k, device=0, want_stats=True):
+    def _build_ex(cls, ends, k, device, want_stats, **choice):
+        """arks_index_build_ex: every build goes through it; `choice` = fields of arks_build_options laid over
+        BUILD_DEFAULTS (layout choices only: results never depend on them)"""
         data, offsets, lens = _concat(ends)
         data = np.concatenate([data, np.zeros(1, np.uint8)])
+        opt = BuildOptions()
+        opt.struct_size = C.sizeof(BuildOptions)
+        merged = dict(BUILD_DEFAULTS)
+        merged.update({f: v for f, v in choice.items() if v is not None})
+        for f, v in merged.items():
+            if f == "index_kind" and isinstance(v, str):
+                v = INDEX_KINDS[v]
+            setattr(opt, f, int(v))
         h = C.c_void_p()
         st = BuildStats()
-        rc = lib().arks_index_build(C.byref(h), k, data.ctypes.data, offsets.ctypes.data,
-                                    lens.ctypes.data, len(lens), device,
-                                    C.byref(st) if want_stats else None)
-        check(rc, "arks_index_build")
+        rc = lib().arks_index_build_ex(C.byref(h), k, data.ctypes.data, offsets.ctypes.data, lens.ctypes.data,
+                                       len(lens), device, C.byref(opt), C.byref(st) if want_stats else None)
+        check(rc, "arks_index_build_ex")
         return cls(h, k, device, st.as_dict() if want_stats else None)
 
     @classmethod
-    def build_shard(cls, ends, k, shard, n_shards, device=0, want_stats=False):
+    def build(cls, ends, k, device=0, want_stats=True, index_kind=None, heavy_over=None, minimizer_len=None,
+              fallback_load_inv=None):
+        """arks_index_build; index_kind "auto" | "hash" | "minimizer" | "seeds" and the other layout choices of
+        arks_build_options default to BUILD_DEFAULTS (empty: the library's own defaults)"""
+        return cls._build_ex(ends, k, device, want_stats, index_kind=index_kind, heavy_over=heavy_over,
+                             minimizer_len=minimizer_len, fallback_load_inv=fallback_load_inv)
+
+    @classmethod
+    def build_shard(cls, ends, k, shard, n_shards, device=0, want_stats=False, **choice):
         """arks_index_build_shard(_stats): the k-mers of the ends that shard_of_ends gives to `shard`, keys
         shared with any other end of the list read 0; every shard is given the same list.  want_stats: the
         shard's share of the build counters (their sums over the shards are arks_index_build's)"""
-        data, offsets, lens = _concat(ends)
-        data = np.concatenate([data, np.zeros(1, np.uint8)])
-        h = C.c_void_p()
-        st = BuildStats()
-        rc = lib().arks_index_build_shard_stats(C.byref(h), k, data.ctypes.data, offsets.ctypes.data,
-                                                lens.ctypes.data, len(lens), shard, n_shards, device,
-                                                C.byref(st) if want_stats else None)
-        check(rc, "arks_index_build_shard_stats")
-        return cls(h, k, device, st.as_dict() if want_stats else None)
+        return cls._build_ex(ends, k, device, want_stats, shard=shard, n_shards=n_shards, **choice)
 
     @classmethod
-    def build_seed_shard(cls, ends, k, rank, n_ranks, device=0, want_stats=False):
+    def build_seed_shard(cls, ends, k, rank, n_ranks, device=0, want_stats=False, **choice):
         """arks_index_build_seed_shard: text, bitmaps and fallback table whole, the seed table's entries that
         rank `rank` of `n_ranks` owns (by a hash prefix of the m-mer), a replicated minimizer table for the
         general kernels; every rank is given the same list"""
-        data, offsets, lens = _concat(ends)
-        data = np.concatenate([data, np.zeros(1, np.uint8)])
-        h = C.c_void_p()
-        st = BuildStats()
-        rc = lib().arks_index_build_seed_shard(C.byref(h), k, data.ctypes.data, offsets.ctypes.data,
-                                               lens.ctypes.data, len(lens), rank, n_ranks, device,
-                                               C.byref(st) if want_stats else None)
-        check(rc, "arks_index_build_seed_shard")
-        return cls(h, k, device, st.as_dict() if want_stats else None)
+        if n_ranks < 1 or not 0 <= rank < n_ranks:
+            raise ArksError(6, "arks_index_build_seed_shard")
+        return cls._build_ex(ends, k, device, want_stats, seed_rank=rank, seed_ranks=n_ranks, **choice)
 
     @property
     def seed_ranks(self):

@@ -53,7 +53,11 @@ poison_lds_kernel(unsigned word)
 static hipError_t
 poison_lds(int n_cu, hipStream_t st)
 {
+#ifdef ARKS_DEBUG_KNOBS
 	static const char* e = std::getenv("ARKS_DEBUG_POISON_LDS");
+#else
+	static const char* e = nullptr; // the release build reads no environment (include/arks_hip.h, arks_build_options)
+#endif
 	if (!e)
 		return hipSuccess;
 	const unsigned word = (unsigned)std::strtoul(e, nullptr, 16);
@@ -80,7 +84,11 @@ fail_hip(hipError_t e, const char* what)
 	return e == hipErrorOutOfMemory ? ARKS_ERR_OOM : ARKS_ERR_HIP;
 }
 
+#ifdef ARKS_DEBUG_KNOBS
 static bool g_trace = std::getenv("ARKS_TRACE") != nullptr;
+#else
+constexpr bool g_trace = false;
+#endif
 static double
 trace_ms()
 {
@@ -521,39 +529,32 @@ arks_pack_reads_host(
 /* index                                                                                          */
 /* ---------------------------------------------------------------------------------------------- */
 
-// occurrences of an m-mer beyond which it is heavy (arks_device.hpp kHeavy; ARKS_HEAVY_OVER=2..8 for tests and A/B runs:
-// results never depend on it, the share of work between the seed table's entry lists and the fallback table does)
-static u32
-heavy_over()
+// The layout choices of a build (include/arks_hip.h arks_build_options), validated.  Results never depend on them.
+struct BuildChoice
 {
-	if (const char* e = std::getenv("ARKS_HEAVY_OVER")) {
-		const int v = std::atoi(e);
-		if (v >= 2 && v <= 8)
-			return (u32)v;
-	}
-	return (u32)kHeavy;
-}
+	int kind = ARKS_INDEX_AUTO;
+	u32 heavy = (u32)kHeavy; // occurrences of an m-mer beyond which it is heavy (arks_device.hpp kHeavy)
+	int mlen = 0;            // 0: by k
+	int fb_load_inv = 0;     // 0: by free memory
+};
 
 static int
-want_locality(int k)
+want_locality(int k, const BuildChoice& c)
 {
-	const char* e = std::getenv("ARKS_INDEX_KIND");
-	if (e && std::strcmp(e, "hash") == 0)
+	if (c.kind == ARKS_INDEX_HASH)
 		return 0;
 	return k >= 20; // below that the minimizer window degenerates; the hash table serves
 }
 
 // Seed index (every m-mer position in the table, fixed-position seeds on the read side) or minimizer
 // index (minimizer positions only, ~20x smaller table, the read side computes its minimizers)?  The
-// seed index is the fast one; it is chosen when its table fits comfortably: ARKS_INDEX_KIND=minimizer /
-// =seeds force one or the other.
+// seed index is the fast one; it is chosen when its table fits comfortably, unless the caller's options say which.
 static bool
-want_seeds(u64 text_positions, int device)
+want_seeds(u64 text_positions, int device, const BuildChoice& c)
 {
-	const char* e = std::getenv("ARKS_INDEX_KIND");
-	if (e && std::strcmp(e, "minimizer") == 0)
+	if (c.kind == ARKS_INDEX_MINIMIZER)
 		return false;
-	if (e && std::strcmp(e, "seeds") == 0)
+	if (c.kind == ARKS_INDEX_SEEDS)
 		return true;
 	size_t free_b = 0, total_b = 0;
 	(void)device;
@@ -682,7 +683,8 @@ index_build_impl(
     int device,
     arks_build_stats* stats,
     int seed_rank = 0,
-    int seed_ranks = 1)
+    int seed_ranks = 1,
+    const BuildChoice& choice = BuildChoice())
 {
 	if (!out || n_ends < 0 || (n_ends > 0 && (!h_bases || !h_offsets || !h_all_lens)) || n_shards < 1 ||
 	    shard < 0 || shard >= n_shards || seed_ranks < 1 || seed_rank < 0 || seed_rank >= seed_ranks)
@@ -750,15 +752,15 @@ index_build_impl(
 	}
 	// minimizer length: 21-mers stay specific at any text size (a 15-mer sees ~ text / 5.4e8 chance
 	// occurrences, and every chance occurrence is a third diagonal for the hot kernel); the short one
-	// (17) only where k leaves no room (k < 24).  ARKS_MINIMIZER_LEN overrides (tests).
+	// (17) only where k leaves no room (k < 24).  arks_build_options.minimizer_len overrides (tests).
 	mm = k >= kMLong + 3 ? kMLong : kMShort; // measured: from k = 24 on the 21-mer wins even with a 4-position window
-	if (const char* e = std::getenv("ARKS_MINIMIZER_LEN"))
-		mm = (std::atoi(e) >= 19 && k >= kMLong + 2) ? kMLong : kMShort;
+	if (choice.mlen)
+		mm = (choice.mlen >= 19 && k >= kMLong + 2) ? kMLong : kMShort;
 	// text positions are 32-bit in the minimizer table; and with the short minimizer (some 60 runs per
 	// read at k = 20) a text beyond ~2.5e8 positions proposes chance diagonals for nearly every read:
 	// measured at 1 Gbp, k = 20: 86 ms per 4 M pairs against 52 ms for the plain hash table
-	locality = want_locality(k) && alloc_words * 32ull < 0xFFFF0000ull &&
-	           !(mm == kMShort && alloc_words * 32ull > 250000000ull && !std::getenv("ARKS_MINIMIZER_LEN"));
+	locality = want_locality(k, choice) && alloc_words * 32ull < 0xFFFF0000ull &&
+	           !(mm == kMShort && alloc_words * 32ull > 250000000ull && !choice.mlen);
 	w = k - mm + 1;
 	bm_bytes = sizeof(u32) * alloc_words;
 
@@ -910,7 +912,7 @@ index_build_impl(
 	} else {
 		// (decided here, with the exact table of the build -- 64 B per visited window -- still allocated: what
 		// is free now is a lower bound of what the index may use)
-		dense = seed_ranks > 1 || want_seeds(visited_total + (u64)w * (u64)n_ends, device);
+		dense = seed_ranks > 1 || want_seeds(visited_total + (u64)w * (u64)n_ends, device, choice);
 		idx->kind = dense ? 2 : 1;
 		idx->seed_rank = seed_rank;
 		idx->seed_ranks = seed_ranks;
@@ -981,7 +983,7 @@ index_build_impl(
 				                      d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t, nullptr, 0, (u32)p_own, (u32)own_n, st));
 				HIP_TRY(launch_bfill_mtab(mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(),
 				                          ccap_t, mine ? *out_tab : nullptr, mcap_t, d_heavy.as<u32>(), (u32)p_own, (u32)own_n,
-				                          mine, heavy_over(), st));
+				                          mine, choice.heavy, st));
 				if (mine)
 					HIP_TRY(launch_bforce(idx->kw, mm, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense_t,
 					                      d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t, *out_tab, mcap_t, (u32)p_own, (u32)own_n, st));
@@ -1040,9 +1042,9 @@ index_build_impl(
 		{
 			size_t free_b = 0, total_b = 0;
 			const u64 want = 4 * n_fb + 64;
-			static const char* fl = std::getenv("ARKS_FALLBACK_LOAD");   // "2": the old load (A/B runs)
 			const bool roomy = hipMemGetInfo(&free_b, &total_b) == hipSuccess && want * 32ull < (u64)free_b / 4;
-			idx->table.cap = (roomy && !(fl && fl[0] == '2')) ? want : 2 * n_fb + 64;
+			// (arks_build_options.fallback_load_inv = 2: the old load, for A/B runs; = 4: whatever the room)
+			idx->table.cap = (choice.fb_load_inv == 4 || (roomy && choice.fb_load_inv != 2)) ? want : 2 * n_fb + 64;
 		}
 		{
 			void* p = nullptr;
@@ -1111,6 +1113,54 @@ arks_index_build(
     arks_build_stats* stats)
 {
 	return index_build_impl(out, k, h_bases, h_offsets, h_lens, n_ends, 0, 1, device, stats);
+}
+
+int
+arks_index_build_ex(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int device,
+    const arks_build_options* opt,
+    arks_build_stats* stats)
+{
+	arks_build_options o;
+	std::memset(&o, 0, sizeof o);
+	if (opt) {
+		// the caller's struct may be shorter (an older header) or longer (a newer one): the common prefix counts
+		if (opt->struct_size < 2 * sizeof(uint32_t))
+			return ARKS_ERR_BAD_ARG;
+		std::memcpy(&o, opt, opt->struct_size < sizeof o ? opt->struct_size : sizeof o);
+	}
+	BuildChoice c;
+	if (o.index_kind < ARKS_INDEX_AUTO || o.index_kind > ARKS_INDEX_SEEDS)
+		return ARKS_ERR_BAD_ARG;
+	c.kind = o.index_kind;
+	if (o.heavy_over) {
+		if (o.heavy_over < 2 || o.heavy_over > 8)
+			return ARKS_ERR_BAD_ARG;
+		c.heavy = (u32)o.heavy_over;
+	}
+	if (o.minimizer_len < 0 || o.minimizer_len > 32)
+		return ARKS_ERR_BAD_ARG;
+	c.mlen = o.minimizer_len;
+	if (o.fallback_load_inv && o.fallback_load_inv != 2 && o.fallback_load_inv != 4)
+		return ARKS_ERR_BAD_ARG;
+	c.fb_load_inv = o.fallback_load_inv;
+	const int n_shards = o.n_shards ? o.n_shards : 1, seed_ranks = o.seed_ranks ? o.seed_ranks : 1;
+	if (n_shards > 1 && seed_ranks > 1)
+		return ARKS_ERR_BAD_ARG; // one way of sharding at a time
+	const int rc = index_build_impl(
+	    out, k, h_bases, h_offsets, h_lens, n_ends, o.shard, n_shards, device, stats, o.seed_rank, seed_ranks, c);
+	if (rc == ARKS_OK && seed_ranks > 1 && (*out)->kind != 2) { // k < 20: no seed table to shard
+		arks_index_free(*out);
+		*out = nullptr;
+		return ARKS_ERR_K_UNSUPPORTED;
+	}
+	return rc;
 }
 
 int
@@ -2069,6 +2119,15 @@ arks_debug_queue_counts(const arks_index* idx, unsigned* out4)
 		if (q.first == idx->last_stream && q.second.queue_count)
 			return hipMemcpy(out4, q.second.queue_count, 4 * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess ? ARKS_OK : ARKS_ERR_HIP;
 	out4[0] = out4[1] = out4[2] = out4[3] = 0;
+	return ARKS_OK;
+}
+
+int
+arks_debug_set_medium_blocks(int n)
+{
+	if (n < 0)
+		return ARKS_ERR_BAD_ARG;
+	arks::set_medium_blocks_cap((unsigned)n);
 	return ARKS_OK;
 }
 

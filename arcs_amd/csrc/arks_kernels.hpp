@@ -31,6 +31,7 @@ hipError_t launch_map_reads(
     const BIndexView& bx, int* out, u64* stats, u32* queue, u32* queue_count, int n_cu,
     hipStream_t st, bool raw = false, // raw: out is u64[n_reads], the votes of put_result<true>
     const uint8_t* gate_class = nullptr, const uint8_t* gate_ok = nullptr); // the pair gate worked out by the seed tile kernel (bx.dense only)
+void set_medium_blocks_cap(unsigned n); // arks_debug_set_medium_blocks (0: no cap)
 hipError_t launch_seed_counts(const u32* lens, const uint8_t* eval, long n_reads, int k, int w, int* out, hipStream_t st);
 hipError_t launch_seeds_fill(
     int mm, const u64* codes, const u32* nmask, const u64* word_off, const u32* lens, const uint8_t* eval, long n_reads,

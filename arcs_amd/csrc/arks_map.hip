@@ -2,6 +2,7 @@
 // (Arcs/Arcs.cpp:939-1014) for a batch, the pair rule of chromiumRead (:1264-1292) and the
 // (barcode, contig end) accumulation.  Reference behaviour restated, never its code.
 #include "arks_kernels.hpp"
+#include <atomic>
 #include <cstddef>
 
 #include <cstdio>
@@ -3277,16 +3278,19 @@ fold_stats_kernel(const u64* __restrict__ rows, u64* __restrict__ stats)
 		atomicAdd(stats + c, v);
 }
 
-// ARKS_DEBUG_MEDIUM_BLOCKS=<n>: the medium kernel on n waves only, so that even a test's short queue gives every
-// wave several reads per grab (tiles of several gathered reads: the path a long queue takes); read per launch
+// arks_debug_set_medium_blocks(n) (include/arks_hip_debug.h): the medium kernel on n waves only, so that even a test's
+// short queue gives every wave several reads per grab (tiles of several gathered reads: the path a long queue takes)
+static std::atomic<unsigned> g_medium_blocks_cap{ 0 };
+void
+set_medium_blocks_cap(unsigned n)
+{
+	g_medium_blocks_cap.store(n, std::memory_order_relaxed);
+}
 static unsigned
 medium_blocks(unsigned bb)
 {
-	const char* e = std::getenv("ARKS_DEBUG_MEDIUM_BLOCKS");
-	if (!e)
-		return bb;
-	const long v = std::atol(e);
-	return v >= 1 && (unsigned long)v < bb ? (unsigned)v : bb;
+	const unsigned v = g_medium_blocks_cap.load(std::memory_order_relaxed);
+	return v >= 1 && v < bb ? v : bb;
 }
 
 hipError_t
@@ -3314,7 +3318,11 @@ launch_map_reads(
 	const u64 cap = (u64)(n_cu > 0 ? n_cu : 256) * 8ull;
 	const unsigned b = (unsigned)(want < cap ? want : cap);
 	const unsigned bs = (unsigned)(want < 256 ? want : 256); // slow path: the queue is short
+#ifdef ARKS_DEBUG_KNOBS
 	static const bool dbg_sync = std::getenv("ARKS_DEBUG_SYNC") != nullptr;
+#else
+	constexpr bool dbg_sync = false;
+#endif
 #define ARKS_DEBUG_STAGE(name)                                                                     \
 	do {                                                                                           \
 		if (dbg_sync) {                                                                            \

@@ -42,7 +42,8 @@ extern "C" {
  * arcs_amd/host/arcs.cpp) so that a caller built against another header fails there, not in a wild write.  A
  * calibration build of the library (-DARKS_CALIBRATION_BUILD: kernels with a memory phase taken out, results wrong by
  * design, profiles/tools/) reports the NEGATIVE number and is refused by both. */
-#define ARKS_ABI_VERSION 3 /* 3 (end of round 5): arks_map_pairs_device added */
+#define ARKS_ABI_VERSION 4 /* 3 (end of round 5): arks_map_pairs_device added; 4 (round 6): arks_index_build_ex +
+                           * arks_build_options -- the library no longer reads the caller's environment */
 
 /* status codes */
 #define ARKS_OK 0
@@ -113,6 +114,39 @@ int arks_index_build(
     const uint32_t* h_lens,
     int64_t n_ends,
     int device,
+    arks_build_stats* stats);
+
+/* Every build above and below is a case of this one.  The options choose the LAYOUT of the index and of its build --
+ * never a result: whatever they say, every map call returns what Arcs/Arcs.cpp:939-1014 returns.  opt == NULL or a
+ * zeroed struct with struct_size set = the defaults (what arks_index_build does).  Rounds 1-5 read these choices from
+ * the process environment on every build (ARKS_INDEX_KIND, ARKS_HEAVY_OVER, ARKS_MINIMIZER_LEN, ARKS_FALLBACK_LOAD):
+ * a shared library whose layout follows its host's environment is no drop-in, and getenv() under a host that calls
+ * setenv() from another thread is a data race; the release build of the library has no getenv in it (tests/test_abi.py). */
+#define ARKS_INDEX_AUTO 0      /* locality index where k >= 20, seed table where it fits the device, else minimizers */
+#define ARKS_INDEX_HASH 1      /* the exact hash table only (what k < 20 always gets) */
+#define ARKS_INDEX_MINIMIZER 2 /* locality index, minimizer table (~20x smaller than the seed table) */
+#define ARKS_INDEX_SEEDS 3     /* locality index, seed table (every m-mer position of a visited window) */
+typedef struct
+{
+	uint32_t struct_size;      /* sizeof(arks_build_options) of the caller: the struct may grow at its end */
+	int32_t index_kind;        /* ARKS_INDEX_*; a kind that k or the text size rules out falls back as AUTO does */
+	int32_t heavy_over;        /* occurrences beyond which an m-mer is "heavy" (its windows go to the exact table):
+	                              0 = the default (2), else 2..8 */
+	int32_t minimizer_len;     /* 0 = by k (the long one, 21, from k = 24 on, else the short one); >= 19: the long one
+	                              where k leaves room, 1..18: the short one */
+	int32_t fallback_load_inv; /* slots per key of the exact table: 0 = 4 where the device has room, else 2; 2; 4 */
+	int32_t shard, n_shards;   /* contig shards (arks_index_build_shard_stats): 0, 0|1 = every end */
+	int32_t seed_rank, seed_ranks; /* seed-table shards (arks_index_build_seed_shard): 0, 0|1 = the whole table */
+} arks_build_options;
+int arks_index_build_ex(
+    arks_index** out,
+    int k,
+    const char* h_bases,
+    const uint64_t* h_offsets,
+    const uint32_t* h_lens,
+    int64_t n_ends,
+    int device,
+    const arks_build_options* opt,
     arks_build_stats* stats);
 
 /* One shard of the index for a draft whose whole index should not (or cannot) live on one GPU --

@@ -17,6 +17,12 @@ extern "C" {
  * counters).  The reads the hot kernel of bestContig (Arcs/Arcs.cpp:939-1014) did not finish itself. */
 int arks_debug_queue_counts(const arks_index* idx, unsigned* out4);
 
+/* n >= 1: the medium kernel (map_reads_b_kernel) of every later map call of this process on at most n waves, so that
+ * even a test's short queue gives every wave several reads per grab (tiles of several gathered reads: the path a long
+ * queue takes); 0: as many as the launch wants.  (Rounds 1-5: the environment variable ARKS_DEBUG_MEDIUM_BLOCKS, read
+ * at every launch.) */
+int arks_debug_set_medium_blocks(int n);
+
 /* The RCCL entry points arks_exchange reaches (ncclSend / ncclRecv groups, ncclAllGather ...), with RCCL's own
  * signatures.  By default the table is filled from librccl.so.1 (dlopen).  A test installs stand-ins -- threads of
  * one process and device copies (tests/mock_rccl.cpp) -- and so runs the library's world > 1 code, which RCCL itself

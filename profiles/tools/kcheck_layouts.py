@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
-k = int(sys.argv[1]); os.environ["ARKS_INDEX_KIND"] = sys.argv[2]
+k = int(sys.argv[1]); import arcs_amd.api; arcs_amd.api.BUILD_DEFAULTS["index_kind"] = sys.argv[2]
 import arcs_amd
 from arcs_amd import synth
 from oracle import pyoracle as O

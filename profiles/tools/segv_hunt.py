@@ -39,7 +39,6 @@ while time.time() < t_end and deaths < 4:
         env = dict(os.environ, FUZZ_SHARDS="1", FUZZ_SEED_SHARDS="1", FUZZ_TRACE=os.path.join(wd, "case"),
                    PYTHONPATH=ROOT + ":" + os.path.join(ROOT, "tests"), LD_PRELOAD=so,
                    SEGV_TRACE_FILE=os.path.join(wd, "native.txt"), FUZZ_ROOT=ROOT, **extra)
-        env.pop("ARKS_INDEX_KIND", None)
         procs.append((wd, subprocess.Popen([sys.executable, "-X", "faulthandler", os.path.join(ROOT, "tests", "fuzz_open_ended.py"),
                                             secs, str(base + 1_000_000 * p)], cwd=ROOT, env=env,
                                            stdout=open(os.path.join(wd, "out"), "w"), stderr=open(os.path.join(wd, "err"), "w"))))

@@ -77,9 +77,17 @@ def gpu(arks):
     return 0
 
 
+@pytest.fixture
+def medium_blocks(arks):
+    """arks_debug_set_medium_blocks for the length of one test (the cap is process-wide)"""
+    yield arks.api.set_medium_blocks
+    arks.api.set_medium_blocks(0)
+
+
 @pytest.fixture(params=["seeds", "minimizer"])
 def index_layout(request, monkeypatch):
     """both layouts of the locality index: the seed index (every m-mer position in the table, fixed seeds
     on the read side; arks_index_kind 2) and the minimizer index (kind 1); results must be identical"""
-    monkeypatch.setenv("ARKS_INDEX_KIND", request.param)
+    from arcs_amd import api
+    monkeypatch.setitem(api.BUILD_DEFAULTS, "index_kind", request.param)      # arks_build_options.index_kind
     return request.param

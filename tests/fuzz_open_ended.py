@@ -37,20 +37,15 @@ while time.time() < t_end:
         ends.append("".join(s))
     ends.append(base)
     ox = oracle.OracleIndex(k).build(ends)
-    # both layouts of the locality index take turns (the library reads the variable at every build)
-    os.environ["ARKS_INDEX_KIND"] = "seeds" if seed % 3 else "minimizer"
+    # both layouts of the locality index take turns (arks_build_options through api.BUILD_DEFAULTS: the library reads no
+    # environment any more, and this process no longer calls setenv with the HIP runtime's threads alive)
+    arcs_amd.api.BUILD_DEFAULTS["index_kind"] = "seeds" if seed % 3 else "minimizer"
     # every other case: the medium kernel on a few waves only, so that its (short) queue is taken several reads per
     # grab -- tiles of several gathered reads
-    if seed % 2:
-        os.environ["ARKS_DEBUG_MEDIUM_BLOCKS"] = str(1 + seed % 5)
-    else:
-        os.environ.pop("ARKS_DEBUG_MEDIUM_BLOCKS", None)
+    arcs_amd.api.set_medium_blocks(1 + seed % 5 if seed % 2 else 0)
     # two cases in five: m-mers heavy beyond 8 occurrences instead of 2 (seeds with 3-8 entries, whose windows take the
     # walk over the entries)
-    if seed % 5 < 2:
-        os.environ["ARKS_HEAVY_OVER"] = "8"
-    else:
-        os.environ.pop("ARKS_HEAVY_OVER", None)
+    arcs_amd.api.BUILD_DEFAULTS["heavy_over"] = 8 if seed % 5 < 2 else 0
     ix = arcs_amd.ArksIndex.build(ends, k, device=0)
     assert {f: ix.build_stats[f] for f in ox.stats.as_dict()} == ox.stats.as_dict(), (seed, k, "build stats")
     genome = "".join(ends)

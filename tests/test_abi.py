@@ -43,6 +43,37 @@ def test_driver_entry_build():
     assert out.returncode == 0, out.stderr[-2000:]
 
 
+def test_library_reads_no_environment(arks):
+    """the release build has no getenv in it: index layout and launch shape come through arks_build_options
+    (arks_index_build_ex) and arks_debug_set_medium_blocks, never from the host process's environment"""
+    out = subprocess.check_output(["nm", "-D", "--undefined-only", arks.lib_path()]).decode()
+    assert not re.search(r"\b(secure_)?getenv\b", out), [l for l in out.splitlines() if "getenv" in l]
+    for f in ("arks_capi.hip", "arks_map.hip", "arks_build.hip", "arks_shard.hip", "arks_imap.hip", "arks_exchange.hpp"):
+        text = open(os.path.join(ROOT, "arcs_amd", "csrc", f)).read()
+        text = re.sub(r"#ifdef ARKS_DEBUG_KNOBS.*?#e(lse|ndif)", "", text, flags=re.S)
+        assert "getenv" not in text, f
+
+
+def test_build_options_are_validated(arks):
+    """arks_index_build_ex refuses nonsense before it touches a device"""
+    from arcs_amd._lib import BuildOptions
+    L = arks.lib()
+    h = C.c_void_p()
+    data = np.frombuffer(b"ACGT" * 40 + b"\0", dtype=np.uint8)
+    offs, lens = np.zeros(1, np.uint64), np.array([160], np.uint32)
+    def call(**kw):
+        o = BuildOptions(); o.struct_size = C.sizeof(BuildOptions)
+        for f, v in kw.items():
+            setattr(o, f, v)
+        return L.arks_index_build_ex(C.byref(h), 30, data.ctypes.data, offs.ctypes.data, lens.ctypes.data, 1, 0, C.byref(o), None)
+    for bad in (dict(index_kind=7), dict(index_kind=-1), dict(heavy_over=1), dict(heavy_over=9), dict(minimizer_len=40),
+                dict(fallback_load_inv=3), dict(struct_size=4), dict(n_shards=2, seed_ranks=2), dict(shard=2, n_shards=2)):
+        assert call(**bad) == 6, bad                      # ARKS_ERR_BAD_ARG
+    assert call() in (0, 5)                               # fine: builds (GPU box) or ARKS_ERR_NO_DEVICE (here)
+    if h:
+        L.arks_index_free(h)
+
+
 def test_library_has_gfx950_code_object(arks):
     """the .so carries a gfx950 code object (what the GPU box will load)"""
     data = open(arks.lib_path(), "rb").read()

@@ -18,16 +18,16 @@ def rc(s):
 
 
 @pytest.mark.parametrize("first_seed", [1, 5000, 90000, 130000])
-def test_fuzz_vs_oracle(arks, gpu, oracle, first_seed, index_layout, monkeypatch):
+def test_fuzz_vs_oracle(arks, gpu, oracle, first_seed, index_layout, monkeypatch, medium_blocks):
     arcs_amd = arks
     if first_seed in (5000, 130000):
         # the medium kernel on three waves: its queue, short in these cases, then gives every wave several reads per
         # grab -- tiles of several gathered reads, the path a long queue (a repeat-rich draft) takes
-        monkeypatch.setenv("ARKS_DEBUG_MEDIUM_BLOCKS", "3")
+        medium_blocks(3)
     if first_seed in (90000, 130000):
         # m-mers heavy beyond 8 occurrences instead of 2 (the index of rounds 1-5): seeds with 3-8 entries exist and
         # their windows take the walk over the entries, a path that only fingerprint collisions reach otherwise
-        monkeypatch.setenv("ARKS_HEAVY_OVER", "8")
+        monkeypatch.setitem(arcs_amd.api.BUILD_DEFAULTS, "heavy_over", 8)
     seed = first_seed
     for _case in range(60):
         rng = np.random.Generator(np.random.PCG64(seed)); seed += 1
@@ -89,7 +89,6 @@ def test_many_processes_share_the_device(arks, gpu, oracle):
     import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FUZZ_SHARDS="1", FUZZ_SEED_SHARDS="1")
-    env.pop("ARKS_INDEX_KIND", None)                     # the fuzz alternates the layouts itself
     procs = []
     with tempfile.TemporaryDirectory() as tmp:
         for p in range(12):

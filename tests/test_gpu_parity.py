@@ -259,8 +259,8 @@ def test_reads_across_adjacent_text_sequences(arks, gpu, oracle):
 
 
 def test_hash_kind_still_exact(arks, gpu, oracle, golden_mini, monkeypatch):
-    """ARKS_INDEX_KIND=hash forces the plain hash-table index (design A): same results"""
-    monkeypatch.setenv("ARKS_INDEX_KIND", "hash")
+    """index_kind "hash" (arks_build_options) forces the plain hash-table index (design A): same results"""
+    monkeypatch.setitem(arks.api.BUILD_DEFAULTS, "index_kind", "hash")
     cs, reads = golden_mini["contigs"], golden_mini["reads"]
     ends = arks.contig_ends(cs, golden_mini["params"]["min_size"], golden_mini["params"]["end_length"])
     case = golden_mini["cases"]["k60_j0.55"]
@@ -277,9 +277,9 @@ def test_hash_kind_still_exact(arks, gpu, oracle, golden_mini, monkeypatch):
 
 @pytest.mark.parametrize("k,mlen", [(24, 21), (30, 15), (60, 15), (64, 15), (96, 15), (40, 21)])
 def test_minimizer_length_variants(arks, gpu, oracle, golden_mini, monkeypatch, k, mlen):
-    """ARKS_MINIMIZER_LEN forces the other minimizer length (default: 21-mers from k = 24 on, the short
+    """arks_build_options.minimizer_len forces the other minimizer length (default: 21-mers from k = 24 on, the short
     17-mers below; any value < 19 selects the short one): identical results, incl. the exception paths"""
-    monkeypatch.setenv("ARKS_MINIMIZER_LEN", str(mlen))
+    monkeypatch.setitem(arks.api.BUILD_DEFAULTS, "minimizer_len", mlen)
     cs, reads = golden_mini["contigs"], golden_mini["reads"]
     ends = arks.contig_ends(cs, golden_mini["params"]["min_size"], golden_mini["params"]["end_length"])
     ix = arks.ArksIndex.build(ends, k, device=gpu)

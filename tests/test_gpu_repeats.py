@@ -28,7 +28,7 @@ def test_human_like_spectrum_against_the_whole_oracle(arks, gpu, oracle, sub_rat
     from arcs_amd import synth
     k, j = 60, 0.55
     if heavy_over:   # the index of rounds 1-5: seeds with 3-8 entries, their windows walk the entries
-        monkeypatch.setenv("ARKS_HEAVY_OVER", heavy_over)
+        monkeypatch.setitem(arks.api.BUILD_DEFAULTS, "heavy_over", int(heavy_over))
     sites = []
     contigs = synth.make_draft(100_000_000, seed=synth.SEED, repeats="human", repeat_sites=sites)
     assert len(sites) > 35_000

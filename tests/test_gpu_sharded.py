@@ -167,9 +167,9 @@ def test_shards_equal_whole_index(arks, gpu, oracle, k, n_shards):
 
 
 def test_hash_layout_shards(arks, gpu, oracle, monkeypatch):
-    """the exact hash table layout (ARKS_INDEX_KIND=hash) shards the same way"""
+    """the exact hash table layout (index_kind "hash") shards the same way"""
     import torch
-    monkeypatch.setenv("ARKS_INDEX_KIND", "hash")
+    monkeypatch.setitem(arks.api.BUILD_DEFAULTS, "index_kind", "hash")
     k, n_shards = 40, 3
     cs = _draft(k, 77)
     ends = arks.contig_ends(cs, 500, 1500)
