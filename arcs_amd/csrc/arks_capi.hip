@@ -210,6 +210,7 @@ struct arks_index
 		u32* queue = nullptr;
 		u32* queue_count = nullptr;
 		int64_t cap = 0;
+		u64 gen = 0; // ensure_queue calls on this set so far: who holds a copy sees whether anybody else has used it since
 	};
 	mutable std::mutex queue_m;
 	mutable std::vector<std::pair<void*, QueueSet>> queues; // (stream, its set): a handful at most
@@ -1429,6 +1430,7 @@ ensure_queue(const arks_index* idx, void* stream, int64_t n_reads, arks_index::Q
 		qs->queue = static_cast<u32*>(p);
 		qs->cap = cap;
 	}
+	++qs->gen;
 	*out = *qs;
 	return ARKS_OK;
 }

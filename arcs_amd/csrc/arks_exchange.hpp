@@ -147,11 +147,12 @@ struct GrowBuf
 	// HERE, explicitly (until round 4 this leaned on hipFree's device-wide wait, which also stalled the other
 	// batch in flight).
 	hipError_t
-	reserve(size_t bytes, hipStream_t user)
+	reserve(size_t bytes, hipStream_t user, u64* drains)
 	{
 		if (bytes <= cap)
 			return hipSuccess;
 		if (p) {
+			++*drains; // (arks_exchange_stats::stream_syncs)
 			const hipError_t e = hipStreamSynchronize(user);
 			if (e != hipSuccess)
 				return e;
@@ -234,7 +235,7 @@ struct arks_exchange
 	// seeds per read the regions are sized for: per owner, and in all (raised when a batch does not fit)
 	// (first guess: a 10x read pair has 2 + 3 seeds at k = 60; a batch of another shape does not fit, says what it needs,
 	// and is bucketed again -- once per shape; 3.3 until round 4: 30 % of the buffers of a 10x batch were never used)
-	u64 stream_syncs = 0; // hipStreamSynchronize calls made by complete() (arks_exchange_stats)
+	u64 stream_syncs = 0; // times the host drained a stream (arks_exchange_stats): a buffer grew, a set changed streams
 	double per_read_owner = 0, per_read_all = 2.65;
 	long largest_batch = 0;
 	u64 reruns = 0;
@@ -643,10 +644,10 @@ exchange_bucket(arks_exchange* x, ExSet& s)
 		return ARKS_ERR_BAD_ARG;
 	}
 	s.cap = cap, s.slot_cap = slot_cap;
-	HIP_TRY(s.send.reserve(sizeof(u64) * (size_t)cap * (size_t)W, s.st));
-	HIP_TRY(s.ans_back.reserve(2 * sizeof(u64) * (size_t)cap * (size_t)W, s.st));
-	HIP_TRY(s.slot.reserve(sizeof(u32) * (size_t)slot_cap, s.st));
-	HIP_TRY(s.chunk_off.reserve(sizeof(u32) * (size_t)(arks::seed_bucket_chunks(s.n_reads) + 1), s.st));
+	HIP_TRY(s.send.reserve(sizeof(u64) * (size_t)cap * (size_t)W, s.st, &x->stream_syncs));
+	HIP_TRY(s.ans_back.reserve(2 * sizeof(u64) * (size_t)cap * (size_t)W, s.st, &x->stream_syncs));
+	HIP_TRY(s.slot.reserve(sizeof(u32) * (size_t)slot_cap, s.st, &x->stream_syncs));
+	HIP_TRY(s.chunk_off.reserve(sizeof(u32) * (size_t)(arks::seed_bucket_chunks(s.n_reads) + 1), s.st, &x->stream_syncs));
 	// the map kernels' queues of this stream: made (or grown) here, so that the bucket launch can zero their scratch
 	// block on the side -- one launch less per batch
 	s.scratch_zeroed = false;
@@ -701,8 +702,10 @@ exchange_submit(
 	DeviceGuard guard(x->device);
 	// the buffers of the set's last batch (its map kernel may still be reading them) are reused in stream order: a
 	// batch on another stream waits for the old one first
-	if (s.used && s.st != st)
+	if (s.used && s.st != st) {
+		++x->stream_syncs;
 		(void)hipStreamSynchronize(s.st);
+	}
 	s.st = st, s.used = true;
 	s.codes = reinterpret_cast<const u64*>(d_codes), s.nmask = d_nmask, s.word_off = reinterpret_cast<const u64*>(d_word_off);
 	s.lens = d_lens, s.eval = d_eval, s.n_reads = (long)n_reads, s.j_index = j_index, s.out = d_out_conreci, s.stats = d_stats;
@@ -870,8 +873,19 @@ ex_map(arks_exchange* x, ExSet& s)
 	const arks_index* idx = x->idx;
 	int rc = ARKS_OK;
 	if (s.n_reads > 0) {
-		// (the queues were made at submit; their scratch block was zeroed by the bucket launch, in front of this one on
-		// the stream.  With the gate folded in, the map kernels read the eval the bucket kernel wrote.)
+		// The queues were made at submit and their scratch block was zeroed by the bucket launch, in front of this one on
+		// the stream -- unless somebody else has mapped on this (index, stream) since: the other batch in flight when the
+		// caller gave both the same stream (order bucket A, bucket B, map A, map B: A dirties what B's bucket zeroed,
+		// and a larger B has replaced A's queues), or a plain map call on the shard.  The set's generation tells: it
+		// must stand exactly one past what the bucket step saw.  Otherwise: the fresh pointers, and the memset.
+		arks_index::QueueSet now;
+		rc = ensure_queue(idx, s.st, s.n_reads, &now);
+		if (rc != ARKS_OK)
+			return rc;
+		const bool untouched = s.scratch_zeroed && now.gen == s.qs.gen + 1 && now.queue_count == s.qs.queue_count && now.queue == s.qs.queue;
+		s.qs = now;
+		s.scratch_zeroed = untouched;
+		// (with the gate folded in, the map kernels read the eval the bucket kernel wrote)
 		EX_TRY(launch_map_reads_seeded(
 		    idx->kw, s.codes, s.nmask, s.word_off, s.lens, s.read_class ? s.eval_out : s.eval, s.n_reads, s.j_index, idx->geom, idx->bx,
 		    idx->bxg, nullptr, s.ans_back.as<u64>(), s.out, reinterpret_cast<u64*>(s.stats), s.qs.queue, s.qs.queue_count, idx->n_cu,
@@ -1063,9 +1077,9 @@ arks_exchange_complete(arks_exchange* x)
 	if (rccl && W > 1) {
 		// ---- 3. seeds to their owners; 4. the owner's answers; 5. answers back -------------------------------------
 		const u64 R = roff[(size_t)W];
-		hipError_t he = s.recv.reserve(sizeof(u64) * (size_t)(R + 1), st);
+		hipError_t he = s.recv.reserve(sizeof(u64) * (size_t)(R + 1), st, &x->stream_syncs);
 		if (he == hipSuccess)
-			he = s.ans_out.reserve(2 * sizeof(u64) * (size_t)(R + 1), st);
+			he = s.ans_out.reserve(2 * sizeof(u64) * (size_t)(R + 1), st, &x->stream_syncs);
 		if (he != hipSuccess) {
 			// the others are on their way into the exchange: they must not wait for this rank
 			rc = fail_hip(he, "hipMalloc(exchange receive buffers)");

@@ -2841,8 +2841,13 @@ map_reads_s_kernel(
 					}
 				}
 				off = cnt == kHnHeavy || cnt == kHnOverflow;
-				if (!STATS && !RAW && cnt == 0 && lane < nh) // seed gi of its read (the last one sits at the last window, not at a multiple of w)
-					atomicOr(&S.rempty[jh], 1u << (((u32)(q - S.rstart[jh]) * wrecip) >> 16));
+				if (!STATS && !RAW && cnt == 0 && lane < nh) { // seed gi of its read (the last one sits at the last window, not at a multiple of w)
+					// (a read of more than 32 seeds -- w = 4 at k = 20 and 24, tile reads reach 512 bases -- keeps the first 32
+					// only: a shift by 32 or more is undefined, and on gfx950 wraps onto another seed's bit)
+					const u32 gi = ((u32)(q - S.rstart[jh]) * wrecip) >> 16;
+					if (gi < 32u)
+						atomicOr(&S.rempty[jh], 1u << gi);
+				}
 				if (cnt >= 1 && cnt <= 2) {
 					const int o = q - S.rstart[jh]; // offset of the seed in the read
 					// same strand: read base x <-> text D + x ; opposite: read base x <-> text D - x
@@ -3030,8 +3035,10 @@ map_reads_s_kernel(
 						if (const u32 em = S.rempty[j]) {
 							const int nw = L - k + 1;
 							const int G = (int)(((u32)(nw + w - 1) * wrecip) >> 16);
-							int gone = __popc(em & ((1u << (G - 1)) - 1u)) * w;
-							if ((em >> (G - 1)) & 1u)
+							// (G > 32: bits 0..31 are seeds that are not the last one, each answers for its w windows; the seeds
+							// beyond have no bit and count as present)
+							int gone = G > 32 ? __popc(em) * w : __popc(em & ((1u << (G - 1)) - 1u)) * w;
+							if (G <= 32 && ((em >> (G - 1)) & 1u))
 								gone += (G >= 2 && ((em >> (G - 2)) & 1u)) ? nw - (G - 1) * w : (nw < w ? nw : w);
 							gone -= nw - nvalid; // (windows with an invalid base are not among the nvalid: all of them may lie there)
 							u -= gone > 0 ? gone : 0;

@@ -409,8 +409,10 @@ typedef struct
 	uint64_t sent;     /* ... of which asked of other ranks (8 B out, 16 B back each) */
 	uint64_t received; /* seeds other ranks asked of this one */
 	uint64_t reruns;   /* batches so far that did not fit the send buffer's regions and were bucketed again, larger */
-	uint64_t stream_syncs; /* hipStreamSynchronize calls arks_exchange_complete has made so far (0: the host never waits
-	                        * for a stream -- the counts all-gather of the RCCL transport is enqueued at submit, round 5) */
+	uint64_t stream_syncs; /* times the exchange has drained a stream from the host so far: a buffer of a set had to grow
+	                        * (its old block may still be read), or a set was handed a batch on another stream than its
+	                        * last.  A run of batches of one shape on fixed streams adds none: the host then waits for
+	                        * the batch's counts (an event) and for nothing else */
 } arks_exchange_stats;
 
 /* rank 0: a fresh id for arks_exchange_create on every rank (ncclGetUniqueId) */

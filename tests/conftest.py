@@ -14,6 +14,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
 
 
+# Order of the GPU suite: the committed golden fixtures and the demo-log counters first (configs[0] on the HIP path,
+# the vote rules), then the oracle comparisons of the other kernels, the long full-size runs after them, the
+# many-process stress test last.  `pytest -x` (the driver's flags) then stops at the most specific failure.
+_ORDER = ["test_gpu_parity", "test_gpu_imap", "test_gpu_repeats", "test_gpu_sharded", "test_gpu_seed_shards",
+          "test_gpu_exchange", "test_gpu_fuzz", "test_gpu_cli", "test_gpu_bench", "test_gpu_full_size", "test_zz_gpu_stress"]
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(name) if name in _ORDER else -1          # CPU tests: in front, in their own order
+    items.sort(key=rank)                                             # (stable: the order inside a file stays)
+
+
 def read_fasta(path):
     seqs, name, cur = [], None, []
     with open(path) as fh:

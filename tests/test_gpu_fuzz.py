@@ -75,31 +75,3 @@ def test_fuzz_vs_oracle(arks, gpu, oracle, first_seed, index_layout, monkeypatch
             assert not bad, (seed - 1, k, j, bad[:5], [len(reads[i]) for i in bad[:5]])
             assert gst == st.as_dict(), (seed - 1, k, j, gst, st.as_dict())
         ix.close()
-
-
-def test_many_processes_share_the_device(arks, gpu, oracle):
-    """Stress: 12 processes on the one device at once, each building a small index and mapping against it case after
-    case (tests/fuzz_open_ended.py: all index layouts, the contig-sharded and the seed-sharded paths) for 45 s -- what
-    `arcs --ranks` and a shared node do to the library.  Every process must end with `fuzz ok` (a GPU memory fault
-    kills the process: round 2 saw two such deaths in a 40-minute run of 24 processes, before the kernels lost their
-    scratch use)."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FUZZ_SHARDS="1", FUZZ_SEED_SHARDS="1")
-    procs = []
-    with tempfile.TemporaryDirectory() as tmp:
-        for p in range(12):
-            e = dict(env, FUZZ_TRACE=os.path.join(tmp, f"seed{p}"))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "fuzz_open_ended.py"), "45",
-                                           str(700_000_000 + 1_000_000 * p)], cwd=root, env=e,
-                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-        outs = [p.communicate(timeout=600) for p in procs]
-        last = [open(os.path.join(tmp, f"seed{p}")).read() if os.path.exists(os.path.join(tmp, f"seed{p}")) else "?"
-                for p in range(12)]
-    for p, (proc, (out, err)) in enumerate(zip(procs, outs)):
-        assert proc.returncode == 0 and "fuzz ok" in out, (p, proc.returncode, "case under way: " + last[p], err[-2000:])
-    cases = sum(int(o.split("fuzz ok:")[1].split("cases")[0]) for o, _ in outs)
-    assert cases >= 200, cases
