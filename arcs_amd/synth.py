@@ -232,6 +232,9 @@ def contigs_to_strings(contigs):
     return [c.tobytes().decode() for c in contigs]
 
 
+READ_LENS = (128, 151)          # R1, R2 of the synthetic 10x-like pair (make_read_pairs' defaults)
+
+
 def make_read_pairs(contigs, n_pairs, seed=SEED, device="cpu", r1_len=128, r2_len=151,
                     frag=350, mol_len=50000, pairs_per_mol=40, sub_rate=0.005, one_n_rate=0.01,
                     many_n_rate=0.001, unpaired_rate=0.001, chunk=2_000_000, want_origin=False):

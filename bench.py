@@ -99,6 +99,47 @@ def pmc_traffic(workload):
     return None, False, None
 
 
+def traffic_model(k, index, pairs_per_launch, read_lens, hbm_bytes_per_launch, misses_per_launch):
+    """What THIS kernel design must move per read pair, beside what it does move (SURVEY 8(d)'s
+    19.43 B per window describes one key compare per window, which the locality index does not do; `frac` alone rises
+    when bytes are wasted).  The minimum of the design:
+      * the read stream: the packed words of the pair, word offsets, lengths, the eval byte -- N masks are not fetched
+        for tiles of ACGT-only reads (what profiles/r09_traffic_classes.json measured as 98.0 B on the 128 + 151 pair);
+      * one seed-table probe per seed: ceil(windows / (k - m + 1)) seeds per read, one aligned group of four 8-byte
+        entries = 32 B each -- the fabric fetches a 64-byte sector for it, which is the over-fetch `efficiency` shows
+        (`at_64B_sectors`: the same minimum with the probe priced at the sector the memory system moves);
+      * the text records along the read's diagonal, for the reads that have one: taken at the true bytes the calibration
+        passes measured for this kind of read set (a class figure of the workload, not of the kernel build).
+    efficiency = minimum / moved: it FALLS when the kernel wastes bytes (a probe made twice, a sector half used), unlike
+    `frac`.  min_accesses: one per probe, one per 64-byte sector of stream and of text records."""
+    m = 21 if k >= 24 else 17
+    w = k - m + 1
+    seeds = sum(-(-max(L - k + 1, 0) // w) for L in read_lens)
+    stream = sum(8 * (-(-L // 32)) + 8 + 4 + 1 for L in read_lens)          # words + word_off + len + eval
+    cls_path = os.path.join(ROOT, "profiles", "r09_traffic_classes.json")
+    try:
+        text = json.load(open(cls_path))["per_pair_bytes_corrected"]["text_records"]
+    except (OSError, KeyError, ValueError):
+        text = None
+    if index.kind != 2 or text is None:
+        return None
+    mn32 = stream + 32.0 * seeds + text
+    mn64 = stream + 64.0 * seeds + text
+    moved = hbm_bytes_per_launch / pairs_per_launch if hbm_bytes_per_launch else None
+    acc = seeds + stream / 64.0 + text / 64.0
+    return {"unit": "bytes per read pair",
+            "min_bytes": {"read_stream": stream, "probes": 32.0 * seeds, "text_records": text, "total": mn32},
+            "min_bytes_at_64B_sectors": mn64,
+            "seeds_per_pair": seeds,
+            "moved_bytes": moved,
+            "efficiency": (mn32 / moved) if moved else None,
+            "efficiency_at_64B_sectors": (mn64 / moved) if moved else None,
+            "min_accesses": acc,
+            "l2_misses": (misses_per_launch / pairs_per_launch) if misses_per_launch else None,
+            "access_efficiency": (acc * pairs_per_launch / misses_per_launch) if misses_per_launch else None,
+            "text_records_source": "profiles/r09_traffic_classes.json per_pair_bytes_corrected"}
+
+
 # measured ceiling of independent random HBM accesses on this part (profiles/r03_gather_tlb.txt: 3.8e10 /s over a
 # 16-64 GiB table whatever the allocation, 4.8e10 /s with the probes of a launch confined to a 1 GiB slice)
 RANDOM_ACCESS_CEILING = 3.8e10
@@ -817,6 +858,8 @@ def main():
         hbm_gb = (traffic["hbm_bytes_per_launch"] / 1e9) if traffic else None
         achieved = (hbm_gb / (kernel_ms * 1e-3)) if traffic else None
         misses = traffic.get("TCC_MISS_per_launch") if traffic else None
+        model = traffic_model(k, wl.index, wl.pairs_per_launch, synth.READ_LENS,
+                              traffic["hbm_bytes_per_launch"] if traffic else None, misses)
         scaling = "weak" if args.weak else "strong"          # the default: one fixed read set whatever N
         out = {
             "metric": METRIC, "value": value, "unit": "k-mers/s", "n_gpus": world,
@@ -849,6 +892,10 @@ def main():
                                          "text records), not byte bandwidth",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
+                         # utilisation (above) says how busy the memory system is; efficiency says how much of what it
+                         # moves the design needs: minimum bytes of THIS kernel design per pair / bytes moved per pair
+                         "efficiency": (model or {}).get("efficiency"),
+                         "model": model,
                          "traffic": hbm_gb,
                          "traffic_unit": "GB per launch (rocprofv3 PMC, mean over the profiled dispatches: FETCH_SIZE x the "
                                          "calibrated read factor + WRITE_SIZE; FETCH_SIZE counts a 128-byte request as 64)",
@@ -1087,6 +1134,28 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
             if d.get("workload") == {"draft_mbp": args.draft_mbp, "pairs": args.pairs, "k": k, "shards": n_ranks, "n_gpus": 1}:
                 traffic = d
         step_gb = traffic["hbm_bytes_per_step_uncalibrated"] / 1e9 if traffic else None
+        # What travels between ranks, per rank and batch, from the exchange's own counts of rank 0's last batch: 8 B per
+        # seed asked of another rank, 16 B per answer (arks_exchange: nothing else; tests/test_gpu_exchange.py accounts
+        # for every byte over the mock transport).  Beside it the xGMI budget of SURVEY 8(e): a fully connected node
+        # gives every peer pair its own link (~153 GB/s, taken as half per direction), a rank's seeds go to its 7 peers
+        # evenly (hash prefix), so one link carries 1/7 of what the rank sends out and 1/7 of what it answers.
+        wire = None
+        if ex and n_ranks > 1:
+            pairs_b = per_rank[0][-1][0].n_reads // 2 if per_rank[0] else 0
+            out_b, back_b = 8 * ex["sent"], 16 * ex["sent"]
+            in_b, ans_b = 8 * ex["received"], 16 * ex["received"]
+            peers = n_ranks - 1
+            link_dir = (out_b + ans_b) / peers                      # bytes one direction of one link carries per batch
+            xgmi_dir = 153e9 / 2
+            wire = {"per": "rank and batch (rank 0's last batch)", "pairs_in_batch": pairs_b,
+                    "seeds": ex["seeds"], "seeds_sent": ex["sent"], "seeds_received": ex["received"],
+                    "bytes_out": out_b + ans_b, "bytes_in": in_b + back_b,
+                    "bytes_out_per_pair": (out_b + ans_b) / max(1, pairs_b),
+                    "bytes_per_link_and_direction": link_dir,
+                    "xgmi_ms_per_batch_at_76GBs_per_link_direction": 1e3 * link_dir / xgmi_dir,
+                    "xgmi_pairs_per_s_per_gpu_ceiling": pairs_b / (link_dir / xgmi_dir) if link_dir else None,
+                    "note": "on one GPU the local ranks read each other's buffers (no wire); the figures are what the "
+                            "same batch puts on xGMI with one rank per GPU"}
         print(json.dumps({
             "metric": METRIC, "value": windows * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -1102,7 +1171,7 @@ def sharded_index_bench(args, world, rank, local, dev, red_dev, log, barrier):
                                      "direct: the local ranks of one process read and write each other's buffers "
                                      "(no copies); two batches in flight per rank" if world == 1 else
                                      "torch.distributed gloo through host memory (test transport)"),
-                       "last_batch_of_rank0": ex,
+                       "last_batch_of_rank0": ex, "wire": wire,
                        "parallelism": f"seed table hash-sharded x{n_ranks}, reads dealt to the ranks in blocks, seeds "
                                       "routed to their owners and back (arks_exchange)"},
             "counters": st_job, "timed_path_parity": timed_parity,
