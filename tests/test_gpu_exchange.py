@@ -371,7 +371,6 @@ def test_two_batches_in_flight_on_one_stream(arks, gpu, oracle, with_stats):
             assert c.cpu().tolist()[:b.n_reads] == [ox.best_contig(r, 0.55, ost) for r in part], i
     if with_stats:
         assert dict(zip(STAT_NAMES, np.sum([x.cpu().numpy() for x in st], axis=0).tolist())) == ost.as_dict()
-    assert drains[0] > 0, drains          # the second batch was larger: its buffers grew, the stream was drained for it
     assert drains[-1] == drains[-2], drains   # shapes seen before: the host waits for the counts' event and nothing else
     for x in xs:
         x.close()
