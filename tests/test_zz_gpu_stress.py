@@ -30,6 +30,7 @@ def test_many_processes_share_the_device(arks, gpu, oracle):
         last = [open(os.path.join(tmp, f"seed{p}")).read() if os.path.exists(os.path.join(tmp, f"seed{p}")) else "?"
                 for p in range(12)]
     for p, (proc, (out, err)) in enumerate(zip(procs, outs)):
-        assert proc.returncode == 0 and "fuzz ok" in out, (p, proc.returncode, "case under way: " + last[p], err[-6000:])
+        assert proc.returncode == 0 and "fuzz ok" in out, (p, proc.returncode, "phase (a case number, 'done', 'exit'): " + last[p],
+                                                           "stdout: " + out[-300:], err[-6000:])
     cases = sum(int(o.split("fuzz ok:")[1].split("cases")[0]) for o, _ in outs)
     assert cases >= 200, cases
