@@ -349,3 +349,64 @@ def test_reads_without_seed_entries_in_every_pattern(arks, gpu, oracle, index_la
     assert x.map_reads(packed, j).cpu().tolist() == want
     assert x.map_reads(packed, j, stats=st).cpu().tolist() == want
     x.close()
+
+
+@pytest.mark.parametrize("k", [20, 24, 31])
+def test_long_reads_with_more_than_32_seeds(arks, gpu, oracle, k):
+    """Reads of 300-512 bases at k = 20 and 24 have a seed every 4 windows -- up to ~120 per read -- and the hot kernel's
+    mask of "seeds without an entry" has 32 bits (shifts by the seed number wrapped onto other seeds' bits).
+    Reads that are flagged for the medium queue (a heavy seed: a planted repeat) and hold stretches that are in no
+    contig end (seeds without entries, anywhere in the read), kernels without counters: the early-settle count of the
+    flagged reads is what the mask feeds.  Against the oracle, for several j."""
+    rng = np.random.default_rng(1000 + k)
+
+    def rnd(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    rep = rnd(90)                                           # its m-mers occur more than twice: heavy seeds
+    ends = []
+    for e in range(6):
+        s = rnd(1500) + rep + rnd(1500)
+        if e % 2:
+            s = s[:700] + rep + s[700:]
+        ends.append(s)
+    ox = oracle.OracleIndex(k).build(ends)
+    ix = arks.ArksIndex.build(ends, k, device=gpu, index_kind="seeds")
+    assert ix.kind == 2
+    reads = []
+    for i in range(600):
+        L = int(rng.choice([300, 350, 400, 450, 500, 511, 512]))
+        e = ends[int(rng.integers(len(ends)))]
+        parts, n = [], 0
+        while n < L:                                         # pieces: from an end, novel sequence, the repeat
+            kind = int(rng.integers(0, 5))
+            m = int(rng.integers(20, 160))
+            if kind <= 2:
+                a = int(rng.integers(0, len(e) - m))
+                p = e[a:a + m]
+            elif kind == 3:
+                p = rnd(m)
+            else:
+                a = int(rng.integers(0, 40))
+                p = rep[a:a + min(m, 50)]
+            parts.append(p)
+            n += len(p)
+        r = "".join(parts)[:L]
+        reads.append(_rc(r) if i % 2 else r)
+    # ... and reads that lie in an end whole, over the planted repeat (flagged, every window found or absent)
+    for i in range(200):
+        e = ends[int(rng.integers(len(ends)))]
+        L = int(rng.choice([300, 400, 512]))
+        a = int(rng.integers(1200, 1600))
+        r = list(e[a:a + L])
+        if i % 3 == 0:
+            r[int(rng.integers(len(r)))] = "N"
+        reads.append("".join(r))
+    for j in (0.0, 0.2, 0.55, 0.8):
+        st = oracle.MapStats()
+        want = [ox.best_contig(r, j, st) for r in reads]
+        got, gst = map_reads_both_ways(ix, reads, j)
+        bad = [i for i, (a, b) in enumerate(zip(got.tolist(), want)) if a != b]
+        assert not bad, (k, j, bad[:5])
+        assert gst == st.as_dict(), (k, j)
+    assert any(w for w in want)
+    ix.close()
