@@ -653,6 +653,8 @@ def end_to_end_scale(wl, dev, local, log, port, n_files=8, pairs_per_file=4_000_
                              capture_output=True, text=True, env=dict(os.environ, ARKS_TIMING="1"))
         cli_s = time.time() - t0
         assert res.returncode == 0, res.stderr[-2000:]
+        if os.environ.get("ARKS_BENCH_E2E_STDERR"):     # (profiling runs: the front end's own timing / ingest profile lines)
+            open(os.environ["ARKS_BENCH_E2E_STDERR"], "w").write(res.stderr)
         m = re.findall(r"Stored read pairs: (\d+)", res.stdout)      # (per file: chromiumRead's locals, Arcs.cpp:1143-1146, 1322)
         cli_stored = sum(int(x) for x in m) if m else -1
         stages = {}
