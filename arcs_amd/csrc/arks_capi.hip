@@ -155,6 +155,71 @@ struct DevBuf
 	}
 };
 
+// The big buffers of an index build behind ONE address range (HIP's virtual-memory API): the exact table of the build
+// (64 B per visited window: 90 GB for a 3 Gbp draft) dies before the seed table (32 B per position, 45 GB, kept) and its
+// count table (24 B per position, scratch) are made.  Freed and allocated anew, those 79 GB cost seconds -- a large
+// hipMalloc that follows a large hipFree waits for the driver's wipe of released VRAM (profiles/r13_alloc_cost.txt:
+// 4-6 s for 45-90 GB; the CLI's index build spent 5.5 of its 6.7 s in such calls) -- so the range is made of two
+// physical blocks: HEAD, sized for the seed table, which the index keeps, and TAIL, which takes the count table and goes
+// back at the end of the build.  Any call of the API failing = the classic path (hipMalloc per buffer).
+struct VmArena
+{
+	char* va = nullptr;
+	size_t head = 0, tail = 0; // bytes of the two blocks (multiples of kGran)
+	hipMemGenericAllocationHandle_t h[2] = {};
+	bool have[2] = { false, false }, mapped[2] = { false, false };
+	static constexpr size_t kGran = (size_t)2 << 20;
+	static size_t up(size_t b) { return (b + kGran - 1) / kGran * kGran; }
+	bool ok() const { return va != nullptr; }
+	// head_bytes + tail_bytes >= what the exact table needs; false = nothing is held
+	bool create(size_t head_bytes, size_t tail_bytes, int device)
+	{
+		head = up(head_bytes), tail = up(tail_bytes);
+		hipMemAllocationProp prop = {};
+		prop.type = hipMemAllocationTypePinned;
+		prop.location.type = hipMemLocationTypeDevice;
+		prop.location.id = device;
+		hipMemAccessDesc acc = {};
+		acc.location = prop.location;
+		acc.flags = hipMemAccessFlagsProtReadWrite;
+		void* p = nullptr;
+		bool good = hipMemAddressReserve(&p, head + tail, kGran, nullptr, 0) == hipSuccess && p;
+		va = good ? static_cast<char*>(p) : nullptr;
+		const size_t sz[2] = { head, tail };
+		for (int b = 0; b < 2 && good; ++b) {
+			good = hipMemCreate(&h[b], sz[b], &prop, 0) == hipSuccess;
+			have[b] = good;
+			if (good) {
+				good = hipMemMap(va + (b ? head : 0), sz[b], 0, h[b], 0) == hipSuccess;
+				mapped[b] = good;
+			}
+		}
+		good = good && hipMemSetAccess(va, head + tail, &acc, 1) == hipSuccess;
+		if (!good) {
+			(void)hipGetLastError();
+			release_all();
+		}
+		return good;
+	}
+	void release_block(int b)
+	{
+		if (mapped[b])
+			(void)hipMemUnmap(va + (b ? head : 0), b ? tail : head);
+		if (have[b])
+			(void)hipMemRelease(h[b]);
+		mapped[b] = have[b] = false;
+	}
+	void release_all()
+	{
+		release_block(1);
+		release_block(0);
+		if (va)
+			(void)hipMemAddressFree(va, head + tail);
+		va = nullptr;
+	}
+	~VmArena() { release_all(); }
+};
+
 struct DeviceGuard
 {
 	int prev = -1;
@@ -190,6 +255,11 @@ struct arks_index
 	u32* ambig = nullptr;
 	u32* word_owner = nullptr;
 	u64* mtab = nullptr;
+	// mtab lies in the head block of the build's arena (VmArena) instead of in a hipMalloc block of its own: the
+	// address range [mtab_va, + mtab_va_bytes) is reserved, its first mtab_map_bytes are mapped to mtab_handle
+	char* mtab_va = nullptr;
+	size_t mtab_va_bytes = 0, mtab_map_bytes = 0;
+	hipMemGenericAllocationHandle_t mtab_handle = {};
 	u64* trec = nullptr; // seed index: text records (BIndexView::trec)
 	// seed table sharded over ranks (arks_index_build_seed_shard): `mtab` holds the seeds this rank owns, the
 	// hot kernel gets its probes answered by their owners; the general kernels (medium, slow) work from a
@@ -729,6 +799,7 @@ index_build_impl(
 	std::vector<uint64_t> word_off((size_t)n_ends + 1, 0), offs((size_t)n_ends + 1, 0);
 	uint64_t total_bases = 0;
 	DevBuf d_ascii, d_offs, d_lens, d_woff, d_nmask, d_counters, d_full;
+	VmArena arena; // (locality index with the whole seed table: the exact table, then the seed table + its count table)
 	DevBuf d_ismin, d_ispal, d_isimg, d_heavy, d_ckeys, d_ccnts, d_wown;
 	u64 text_words = 0, alloc_words = 0, counters[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	u64 visited_total = 0, n_min = 0, n_pal = 0, n_fb = 0, ccap = 0, mcap = 0;
@@ -817,8 +888,21 @@ index_build_impl(
 
 	// the full exact table: load factor <= 0.5 over the visited windows (>= the distinct keys)
 	full.cap = std::max<u64>(1024, visited_total * 2 + 64);
-	HIP_TRY(d_full.alloc(full.cap * kSlotWords * sizeof(u64)));
-	full.slots = d_full.as<u64>();
+	{
+		const size_t full_bytes = full.cap * kSlotWords * sizeof(u64);
+		// head = what the seed table may need (every m-mer position of the visited windows: at most one per visited
+		// window + w per end, palindromes' extras in the slack); a table that turns out larger gets a block of its own
+		const size_t seed_bytes = sizeof(u64) * (size_t)ARKS_SEED_LOAD_INV * (size_t)(visited_total + (u64)(k - kMShort + 1) * (u64)n_ends);
+		const size_t head_want = seed_bytes + seed_bytes / 64 + ((size_t)4 << 20);
+		if (locality && seed_ranks == 1 && n_shards == 1 && full_bytes >= ((size_t)8 << 20) && head_want < full_bytes)
+			(void)arena.create(head_want, full_bytes - VmArena::up(head_want) + VmArena::kGran, device);
+		if (arena.ok())
+			full.slots = reinterpret_cast<u64*>(arena.va);
+		else {
+			HIP_TRY(d_full.alloc(full_bytes));
+			full.slots = d_full.as<u64>();
+		}
+	}
 	ARKS_TRACE_STEP("exact table allocated");
 	HIP_TRY(hipMemsetAsync(full.slots, 0, full.cap * kSlotWords * sizeof(u64), st));
 	ARKS_TRACE_STEP("exact table cleared");
@@ -949,8 +1033,10 @@ index_build_impl(
 		n_min = counters[0];
 		n_pal = counters[1];
 		idx->bx.has_img = counters[2] != 0;
-		// the full table is no longer needed: every position now carries its value bits
-		(void)hipFree(d_full.p);
+		// the full table is no longer needed: every position now carries its value bits (in the arena its memory is taken
+		// over by the tables below; a block of its own goes back now)
+		if (d_full.p)
+			(void)hipFree(d_full.p);
 		d_full.p = nullptr;
 		// One table = count the occurrences of every registered m-mer (heavy ones get one marker instead
 		// of their positions), decree the m-mers of the quirk images heavy, fill.  With the seed table
@@ -965,30 +1051,55 @@ index_build_impl(
 				const u64 npos = own_n > 1 ? pos_per_owner[p_own] : n_pos_total;
 				const bool mine = own_n == 1 || p_own == own_r;
 				const u64 ccap_t = 2 * (npos + pal_extra) + 64;
-				HIP_TRY(d_ckeys.alloc(sizeof(u64) * ccap_t));
-				HIP_TRY(d_ccnts.alloc(sizeof(u32) * ccap_t));
-				HIP_TRY(hipMemsetAsync(d_ckeys.p, 0, sizeof(u64) * ccap_t, st));
-				HIP_TRY(hipMemsetAsync(d_ccnts.p, 0, sizeof(u32) * ccap_t, st));
 				u64 mcap_t = 0;
-				if (mine) {
+				if (mine)
 					mcap_t = ((u64)(dense_t ? ARKS_SEED_LOAD_INV : ARKS_MTAB_LOAD_INV) * (npos + pal_extra) + 64 + 3) & ~3ull; // whole groups of 4 (mtab_home)
-					void* p = nullptr;
-					HIP_TRY(hipMalloc(&p, sizeof(u64) * mcap_t));
-					*out_tab = static_cast<u64*>(p);
+				// in the arena (own_n == 1 there): the table in the head block -- which the index keeps --, the count table in
+				// the tail block; whichever does not fit gets a block of its own
+				const size_t ck_bytes = (sizeof(u64) * ccap_t + 255) & ~(size_t)255, cc_bytes = sizeof(u32) * ccap_t;
+				// (the head block was sized for a seed table: a minimizer table is 20x smaller and must not pin it)
+				const bool tab_in_arena = arena.ok() && mine && dense_t && out_tab == &idx->mtab && sizeof(u64) * mcap_t <= arena.head &&
+				                          2 * sizeof(u64) * mcap_t >= arena.head;
+				const bool cnt_in_arena = arena.ok() && ck_bytes + cc_bytes <= arena.tail;
+				u64* ck = nullptr;
+				u32* cc = nullptr;
+				if (cnt_in_arena) {
+					ck = reinterpret_cast<u64*>(arena.va + arena.head);
+					cc = reinterpret_cast<u32*>(arena.va + arena.head + ck_bytes);
+				} else {
+					HIP_TRY(d_ckeys.alloc(sizeof(u64) * ccap_t));
+					HIP_TRY(d_ccnts.alloc(sizeof(u32) * ccap_t));
+					ck = d_ckeys.as<u64>(), cc = d_ccnts.as<u32>();
+				}
+				HIP_TRY(hipMemsetAsync(ck, 0, sizeof(u64) * ccap_t, st));
+				HIP_TRY(hipMemsetAsync(cc, 0, sizeof(u32) * ccap_t, st));
+				if (mine) {
+					if (tab_in_arena)
+						*out_tab = reinterpret_cast<u64*>(arena.va);
+					else {
+						void* p = nullptr;
+						HIP_TRY(hipMalloc(&p, sizeof(u64) * mcap_t));
+						*out_tab = static_cast<u64*>(p);
+					}
 					*out_cap = mcap_t;
 					HIP_TRY(hipMemsetAsync(*out_tab, 0, sizeof(u64) * mcap_t, st));
 				}
-				HIP_TRY(launch_bcount(mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t,
-				                      (u32)p_own, (u32)own_n, st));
-				HIP_TRY(launch_bforce(idx->kw, mm, 0, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense_t,
-				                      d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t, nullptr, 0, (u32)p_own, (u32)own_n, st));
-				HIP_TRY(launch_bfill_mtab(mm, idx->codes, d_ismin.as<u32>(), text_words, d_ckeys.as<u64>(), d_ccnts.as<u32>(),
-				                          ccap_t, mine ? *out_tab : nullptr, mcap_t, d_heavy.as<u32>(), (u32)p_own, (u32)own_n,
-				                          mine, choice.heavy, st));
+				HIP_TRY(launch_bcount(mm, idx->codes, d_ismin.as<u32>(), text_words, ck, cc, ccap_t, (u32)p_own, (u32)own_n, st));
+				HIP_TRY(launch_bforce(idx->kw, mm, 0, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense_t, ck, cc, ccap_t,
+				                      nullptr, 0, (u32)p_own, (u32)own_n, st));
+				HIP_TRY(launch_bfill_mtab(mm, idx->codes, d_ismin.as<u32>(), text_words, ck, cc, ccap_t, mine ? *out_tab : nullptr,
+				                          mcap_t, d_heavy.as<u32>(), (u32)p_own, (u32)own_n, mine, choice.heavy, st));
 				if (mine)
-					HIP_TRY(launch_bforce(idx->kw, mm, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense_t,
-					                      d_ckeys.as<u64>(), d_ccnts.as<u32>(), ccap_t, *out_tab, mcap_t, (u32)p_own, (u32)own_n, st));
+					HIP_TRY(launch_bforce(idx->kw, mm, 1, idx->codes, d_ispal.as<u32>(), text_words, idx->geom, w, dense_t, ck, cc, ccap_t,
+					                      *out_tab, mcap_t, (u32)p_own, (u32)own_n, st));
 				HIP_TRY(hipStreamSynchronize(st));
+				if (tab_in_arena) {
+					// the head block is the index's from here on: the tail goes back, the range stays reserved until the index is freed
+					arena.release_block(1);
+					idx->mtab_va = arena.va, idx->mtab_va_bytes = arena.head + arena.tail, idx->mtab_map_bytes = arena.head;
+					idx->mtab_handle = arena.h[0];
+					arena.va = nullptr, arena.have[0] = arena.mapped[0] = false; // (ownership moved: arks_index_free unmaps and releases)
+				}
 			}
 		done:
 			return rc;
@@ -1027,6 +1138,7 @@ index_build_impl(
 			if (rc != ARKS_OK)
 				goto done;
 		}
+		arena.release_all(); // (whatever of it the index did not take over)
 		ARKS_TRACE_STEP("table");
 		HIP_TRY(hipMemsetAsync(d_counters.p, 0, sizeof(counters), st));
 		HIP_TRY(launch_bfallback(
@@ -1253,7 +1365,11 @@ arks_index_free(arks_index* idx)
 		(void)hipFree(idx->ambig);
 	if (idx->word_owner)
 		(void)hipFree(idx->word_owner);
-	if (idx->mtab)
+	if (idx->mtab_va) {
+		(void)hipMemUnmap(idx->mtab_va, idx->mtab_map_bytes);
+		(void)hipMemRelease(idx->mtab_handle);
+		(void)hipMemAddressFree(idx->mtab_va, idx->mtab_va_bytes);
+	} else if (idx->mtab)
 		(void)hipFree(idx->mtab);
 	if (idx->trec)
 		(void)hipFree(idx->trec);
