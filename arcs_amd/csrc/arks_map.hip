@@ -2298,6 +2298,9 @@ constexpr int sNH = 64;               // seeds per tile (= lanes of S2)
 constexpr int sChunk = 56;            // reads per grab of the work counter: four tiles of 10x reads
 constexpr int sSlots = sTW + sTR + 2; // staging slots: one more than its words per read
 
+#ifndef ARKS_PARK_FIRST
+#define ARKS_PARK_FIRST 1
+#endif
 struct SeedTileLds
 {
 	u64 cw[sTW + 4];
@@ -2321,6 +2324,14 @@ struct SeedTileLds
 	u32 redo;  // reads for the slow queue
 	u32 redo2; // reads for the medium queue
 	u32 rempty[sTR]; // bit gi: seed gi of the read has no entry -- every window that holds it is absent (S6, flagged reads)
+#if ARKS_PARK_FIRST
+	// the answer the chunk's pre-pass (S-1) got for a read's FIRST seed, kept for the tile when it is the usual one -- exactly
+	// one entry: its text position, and in ppark bit 0 "there is one", bit 1 its strand.  The tile then does not probe that
+	// seed again (one probe in three of a kept 151-base read, one in two of a 128-base one).  280 of the 320 bytes that 32
+	// waves per CU leave beside the tile.
+	u32 ppos[sChunk];
+	unsigned char ppark[sChunk];
+#endif
 	u64 wstats[8];
 	// REMOTE without counters: the reads none of whose seeds has an entry are settled before the tiles are made, the
 	// others move up into their places
@@ -2340,6 +2351,7 @@ struct SeedTileLds
 #ifndef ARKS_SEED_WAVES
 #define ARKS_SEED_WAVES 8
 #endif
+
 // REMOTE = true: the seed table is sharded over the ranks of a node (arks_index_build_seed_shard): the probes
 //                of S2 were answered by the seeds' owners before the launch (arks_seeds_fill_device -> all-to-all
 //                -> arks_seeds_probe_device -> all-to-all); seed_off[r] = index of read r's first seed,
@@ -2520,6 +2532,7 @@ map_reads_s_kernel(
 		u64 pos = wo;
 		int gexo = gex;      // the read's first seed among the chunk's (answers are numbered with every read in place)
 		int rorig = lane_id; // the read this lane holds is read c0 + rorig
+		u32 park_pos = 0, park_code = 0; // (ARKS_PARK_FIRST) the first seed's one entry, if that is what the pre-pass found
 		int nchunk_c = nchunk;
 		if (kSkipDead && skip_dead) {
 			bool keep = lane_id < nchunk && rl >= 0 && G > 0;
@@ -2573,6 +2586,32 @@ map_reads_s_kernel(
 							const u32 fp = mmer_fp<MM>(cm[gi]);
 							const u64 e[4] = { h[gi][0].x, h[gi][0].y, h[gi][1].x, h[gi][1].y };
 							bool ended = false, hit = false;
+#if ARKS_PARK_FIRST
+							// (the whole group is looked at, as probe_minimizer_table does: how many entries, not just whether)
+							u32 n_ent = 0;
+							u64 first = 0;
+#pragma unroll
+							for (int x = 0; x < 4; ++x) {
+								if (ended)
+									continue;
+								if (!(e[x] >> 63))
+									ended = true; // an empty slot ends the probe sequence
+								else if (((u32)(e[x] >> 32) & kFpMask) == fp) {
+									hit = true;
+									if ((u32)e[x] == kHeavyPos)
+										ended = true, n_ent = 3; // the "heavy" mark
+									else {
+										if (n_ent == 0)
+											first = e[x];
+										++n_ent;
+									}
+								}
+							}
+							if (gi == 0 && ended && n_ent == 1) {
+								park_pos = (u32)first;
+								park_code = 1u | (((u32)(first >> 62) & 1u) << 1);
+							}
+#else
 #pragma unroll
 							for (int x = 0; x < 4; ++x) {
 								if (ended)
@@ -2582,7 +2621,8 @@ map_reads_s_kernel(
 								else if (((u32)(e[x] >> 32) & kFpMask) == fp)
 									hit = ended = true; // an entry, or the "heavy" mark
 							}
-							if (!ended) { // (a full group without the m-mer: rare -- the whole sequence)
+#endif
+							if (!ended && !hit) { // (a full group without the m-mer: rare -- the whole sequence)
 								u64 e2[2];
 								hit = probe_minimizer_table<MM>(bx, cm[gi], e2) != 0;
 							}
@@ -2631,11 +2671,20 @@ map_reads_s_kernel(
 			// reads that stay are exactly the sources of the reads that move up)
 			const int p_wcnt = __builtin_amdgcn_ds_bpermute(sel, wcnt);
 			const int p_rl = __builtin_amdgcn_ds_bpermute(sel, rl);
-			const int p_mn = __builtin_amdgcn_ds_bpermute(sel, (int)may_n);
+			const int p_mn = __builtin_amdgcn_ds_bpermute(sel, (int)may_n | (REMOTE ? 0 : (int)(park_code << 1)));
+#if ARKS_PARK_FIRST
+			if (!REMOTE) {
+				const int p_pp = __builtin_amdgcn_ds_bpermute(sel, (int)park_pos);
+				if (have) {
+					S.ppos[lane_id] = (u32)p_pp;
+					S.ppark[lane_id] = (unsigned char)((u32)p_mn >> 1);
+				}
+			}
+#endif
 			gexo = __builtin_amdgcn_ds_bpermute(sel, gex);
 			wcnt = have ? p_wcnt : 0;
 			rl = have ? p_rl : 0;
-			may_n = have && p_mn != 0;
+			may_n = have && (p_mn & 1) != 0;
 			nwin_l = rl - k + 1;
 			G = have && nwin_l > 0 ? (int)(((u32)(nwin_l + w - 1) * wrecip) >> 16) : 0;
 			gex = wave_incl_scan_i32(G) - G;
@@ -2736,7 +2785,13 @@ map_reads_s_kernel(
 					for (int gi = 0; gi < G; ++gi) {
 						int q = (gi + 1) * w - 1;
 						q = q < nwin_l - 1 ? q : nwin_l - 1;
+#if ARKS_PARK_FIRST
+						// bit 0: this is the read's first seed and the pre-pass parked its answer (lane = the read's place in the chunk)
+						const u32 pk = (kSkipDead && skip_dead && !REMOTE && gi == 0) ? (u32)(S.ppark[lane] & 1u) : 0u;
+						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)j << 12) | pk);
+#else
 						S.heads[hb + gi] = (unsigned short)(((u32)(rs + q) << 1) | ((u32)j << 12));
+#endif
 					}
 					S.pdiag[j][0] = ~0ull;
 					S.pdiag[j][1] = ~0ull;
@@ -2813,10 +2868,12 @@ map_reads_s_kernel(
 			bool off = false;
 			{
 				int q = 0;
+				bool parked = false;
 				if (lane < nh) {
 					const u32 hv = S.heads[lane];
 					q = (int)((hv >> 1) & 2047u);
 					jh = (int)(hv >> 12);
+					parked = ARKS_PARK_FIRST && !REMOTE && (hv & 1u) != 0;
 				}
 				u64 ent[2];
 				u32 cnt = 0;
@@ -2834,6 +2891,12 @@ map_reads_s_kernel(
 							ent[0] = a[0], ent[1] = a[1];
 							cnt = seed_answer_count(ent[0], ent[1]);
 						}
+#if ARKS_PARK_FIRST
+					} else if (parked) {
+						// (the pre-pass of the chunk probed this seed and found its one entry: read j of the tile is read cur + j of the chunk)
+						ent[0] = mtab_entry(0u, (u32)(S.ppark[cur + jh] >> 1) & 1u, S.ppos[cur + jh]);
+						cnt = 1;
+#endif
 					} else {
 #ifndef ARKS_CAL_NO_PROBE
 						cnt = probe_minimizer_table<MM>(bx, mf < mr ? mf : mr, ent);
