@@ -1102,6 +1102,9 @@ index_build_impl(
 				}
 			}
 		done:
+			// (a table that lies in the arena and was not handed over: the arena releases it, the index must not hipFree it)
+			if (rc != ARKS_OK && arena.ok() && *out_tab == reinterpret_cast<u64*>(arena.va))
+				*out_tab = nullptr;
 			return rc;
 		};
 		if (seed_ranks > 1) {
